@@ -1,0 +1,148 @@
+"""Deterministic inputs and weights shared by the golden-vector generator, the
+tests, `__graft_entry__.smoke()` and `bench.py`.
+
+TEST INFRASTRUCTURE.  Nothing in the product path (`iccv2025-gdl_amd/`) imports
+this module.  Everything here is numpy-only (PCG64 streams are identical on
+every machine), so the GPU box regenerates bit-identical inputs without the
+reference being present.
+
+The weight fill follows the *shape* of the reference's initialisation
+(`utils/utils.py:15-23`: conv kaiming-normal fan_out, linear xavier-normal) but
+keys every tensor's random stream on its state_dict name, and deliberately uses
+non-trivial BatchNorm gamma/beta and running statistics so that a wrong
+scale/shift/momentum path cannot hide behind gamma=1, beta=0.
+"""
+import zlib
+
+import numpy as np
+
+N_CLASSES = {"VGGSound": 309, "KineticSound": 34, "kinect400": 400, "CREMAD": 6, "AVE": 28}
+# /root/reference/models/basic_model.py:15-26
+
+
+def _rng(name, salt=0):
+    return np.random.default_rng([zlib.crc32(name.encode()), salt])
+
+
+def named_tensor(name, shape):
+    """Deterministic float32 tensor for state_dict entry `name`."""
+    shape = tuple(int(s) for s in shape)
+    r = _rng(name)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, dtype=np.int64)
+    if leaf == "running_mean":
+        return (0.05 * r.standard_normal(shape)).astype(np.float32)
+    if leaf == "running_var":
+        return (1.0 + 0.1 * np.abs(r.standard_normal(shape))).astype(np.float32)
+    if len(shape) == 4:  # conv weight [K, C, R, S]; kaiming_normal_(fan_out, relu)
+        k, c, rr, ss = shape
+        std = np.sqrt(2.0 / (k * rr * ss))
+        return (std * r.standard_normal(shape)).astype(np.float32)
+    if len(shape) == 2:  # linear weight [out, in]; xavier_normal_
+        std = np.sqrt(2.0 / (shape[0] + shape[1]))
+        return (std * r.standard_normal(shape)).astype(np.float32)
+    # 1-D: BN gamma / beta, or a linear bias
+    is_bn = ("bn" in name) or ("downsample.1" in name)
+    if leaf == "weight" and is_bn:
+        return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
+    if leaf == "bias" and is_bn:
+        return (0.1 * r.standard_normal(shape)).astype(np.float32)
+    return (0.01 * r.standard_normal(shape)).astype(np.float32)
+
+
+def make_state(shapes):
+    """`shapes`: ordered {name: shape} -> ordered {name: ndarray}."""
+    return {k: named_tensor(k, v) for k, v in shapes.items()}
+
+
+def make_batch(seed, batch, spec_hw, frames, image_hw, n_classes):
+    """Synthetic batch with the layout the reference datasets emit
+    (`dataset/CramedDataset.py:57-110`): spec [B,F,T'] f32, image [B,3,T,H,W] f32,
+    label [B] int64.  N(0,1) values as BASELINE.md section 4 prescribes."""
+    r = np.random.default_rng([1234, seed])
+    spec = r.standard_normal((batch,) + tuple(spec_hw), dtype=np.float32)
+    image = r.standard_normal((batch, 3, frames) + tuple(image_hw), dtype=np.float32)
+    label = r.integers(0, n_classes, size=(batch,), dtype=np.int64)
+    return spec, image, label
+
+
+# ---------------------------------------------------------------- ResNet18 topology
+def resnet18_param_shapes(prefix, in_ch):
+    """Ordered parameter shapes of the reference encoder
+    (`models/backbone.py:75-156`), in `named_parameters()` order."""
+    out = {}
+    out[prefix + "conv1.weight"] = (64, in_ch, 7, 7)
+    out[prefix + "bn1.weight"] = (64,)
+    out[prefix + "bn1.bias"] = (64,)
+    inpl = 64
+    for li, planes in enumerate((64, 128, 256, 512), start=1):
+        for bi in range(2):
+            p = f"{prefix}layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            out[p + "conv1.weight"] = (planes, inpl, 3, 3)
+            out[p + "bn1.weight"] = (planes,)
+            out[p + "bn1.bias"] = (planes,)
+            out[p + "conv2.weight"] = (planes, planes, 3, 3)
+            out[p + "bn2.weight"] = (planes,)
+            out[p + "bn2.bias"] = (planes,)
+            if stride != 1 or inpl != planes:
+                out[p + "downsample.0.weight"] = (planes, inpl, 1, 1)
+                out[p + "downsample.1.weight"] = (planes,)
+                out[p + "downsample.1.bias"] = (planes,)
+            inpl = planes
+    return out
+
+
+def resnet18_buffer_shapes(prefix):
+    out = {}
+
+    def bn(p, c):
+        out[p + "running_mean"] = (c,)
+        out[p + "running_var"] = (c,)
+        out[p + "num_batches_tracked"] = ()
+
+    bn(prefix + "bn1.", 64)
+    inpl = 64
+    for li, planes in enumerate((64, 128, 256, 512), start=1):
+        for bi in range(2):
+            p = f"{prefix}layer{li}.{bi}."
+            stride = 2 if (bi == 0 and li > 1) else 1
+            bn(p + "bn1.", planes)
+            bn(p + "bn2.", planes)
+            if stride != 1 or inpl != planes:
+                bn(p + "downsample.1.", planes)
+            inpl = planes
+    return out
+
+
+def model_param_shapes(n_classes, fusion="concat_dgl"):
+    """`AVClassifier_DGL.named_parameters()` order: fusion head first, then
+    audio_net, then visual_net (`models/basic_model.py:29-44`)."""
+    out = {}
+    if fusion == "concat_dgl":  # fusion_modules.py:45-49
+        out["fusion_module.fc_out.weight"] = (n_classes, 1024)
+        out["fusion_module.fc_out.bias"] = (n_classes,)
+        out["fusion_module.fc_auxi.weight"] = (n_classes, 1024)
+        out["fusion_module.fc_auxi.bias"] = (n_classes,)
+    elif fusion == "concat":  # fusion_modules.py:33-36
+        out["fusion_module.fc_out.weight"] = (n_classes, 1024)
+        out["fusion_module.fc_out.bias"] = (n_classes,)
+    else:
+        raise NotImplementedError(fusion)
+    out.update(resnet18_param_shapes("audio_net.", 1))
+    out.update(resnet18_param_shapes("visual_net.", 3))
+    return out
+
+
+def model_buffer_shapes():
+    out = {}
+    out.update(resnet18_buffer_shapes("audio_net."))
+    out.update(resnet18_buffer_shapes("visual_net."))
+    return out
+
+
+def model_state(n_classes, fusion="concat_dgl"):
+    ps = make_state(model_param_shapes(n_classes, fusion))
+    bs = make_state(model_buffer_shapes())
+    return ps, bs

@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the reference
+(`/root/reference`, PyTorch CPU fp32) in the BUILD container.
+
+Run once here:  python tests/golden/make_golden.py
+The reference never travels to the GPU box; only the .npz outputs do.  Inputs
+and weights are regenerated on both sides by `oracle/fixtures.py`.
+
+What is restated around the imported model is the step body of
+`main_dgl.py:97-154` (the script itself hard-codes cuda:0 and imports
+librosa/torchvision, so it cannot run here): zero_grad, forward, three CE
+losses, `((loss_a+loss_v)*alpha).backward(retain_graph=True)`, drop of the
+fusion-head grads, `loss_f.backward()`, `clip_grad_norm_(.., 40, 2)`, the two
+logged `sum(mean(abs(grad)))`, `optimizer.step()` with SGD(momentum .9, wd 1e-4).
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from oracle import fixtures as fx  # noqa: E402
+
+REF = "/root/reference"
+
+
+def _import_reference():
+    # timm is absent here; models/swin_transformer.py:11 needs three symbols.
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    tl.DropPath = DropPath
+    tl.to_2tuple = lambda x: (x, x)
+    tl.trunc_normal_ = nn.init.trunc_normal_
+    sys.modules["timm"] = timm
+    sys.modules["timm.models"] = tm
+    sys.modules["timm.models.layers"] = tl
+    sys.path.insert(0, REF)
+    import models.basic_model as bm  # noqa
+    import models.backbone as bb  # noqa
+    import models.fusion_modules as fm  # noqa
+
+    return bm, bb, fm
+
+
+def _load(model, n_classes, fusion):
+    ps, bs = fx.model_state(n_classes, fusion)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in {**ps, **bs}.items()}
+    missing = model.load_state_dict(sd, strict=True)
+    return missing
+
+
+class _ConcatAV(nn.Module):
+    """BASELINE config 1: the reference's `AVClassifier` (non-DGL) class is
+    missing from models/basic_model.py; its math is the two
+    imported encoders + imported `ConcatFusion` with the pooling glue of
+    basic_model.py:73-82 and a single CE loss (main.py:161-175)."""
+
+    def __init__(self, bb, fm, n_classes):
+        super().__init__()
+        self.fusion_module = fm.ConcatFusion(output_dim=n_classes)
+        self.audio_net = bb.resnet18(modality="audio", args=None)
+        self.visual_net = bb.resnet18(modality="visual", args=None)
+
+    def forward(self, audio, visual):
+        import torch.nn.functional as F
+
+        a = self.audio_net(audio)
+        v = self.visual_net(visual)
+        (_, C, H, W) = v.size()
+        B = a.size()[0]
+        v = v.view(B, -1, C, H, W).permute(0, 2, 1, 3, 4)
+        a = torch.flatten(F.adaptive_avg_pool2d(a, 1), 1)
+        v = torch.flatten(F.adaptive_avg_pool3d(v, 1), 1)
+        _, _, out = self.fusion_module(a, v)
+        return out, a, v
+
+
+def _summ(t):
+    a = t.detach().double().flatten()
+    return np.array([a.sum().item(), a.abs().sum().item()], dtype=np.float64)
+
+
+def run_step_case(name, bm, bb, fm, dataset, spec_hw, frames, image_hw, batch, alpha, steps, mode="dgl", seed=0,
+                  lr=2e-3):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    n_classes = fx.N_CLASSES[dataset]
+    if mode == "dgl":
+        args = argparse.Namespace(fusion_method="concat", dataset=dataset, modality="full", batch_size=batch)
+        model = bm.AVClassifier_DGL(args)
+        _load(model, n_classes, "concat_dgl")
+    else:
+        model = _ConcatAV(bb, fm, n_classes)
+        _load(model, n_classes, "concat")
+    # main_dgl.py:244 wraps in DataParallel, which supplies the 'module.' prefix
+    # that the grad-drop filter (main_dgl.py:114-119) keys on; on CPU we mimic the prefix.
+    named = [("module." + n, p) for n, p in model.named_parameters()]
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)  # main_dgl.py:249
+    crit = nn.CrossEntropyLoss()  # main_dgl.py:71
+    out_d = {}
+    cfg = dict(name=name, dataset=dataset, n_classes=n_classes, spec_hw=list(spec_hw), frames=frames,
+               image_hw=list(image_hw), batch=batch, alpha=alpha, steps=steps, mode=mode, seed=seed, lr=lr,
+               momentum=0.9, weight_decay=1e-4, max_norm=40.0, torch=torch.__version__)
+    out_d["config"] = np.array(json.dumps(cfg))
+    model.train()
+    for st in range(steps):
+        spec, image, label = fx.make_batch(seed + st, batch, spec_hw, frames, image_hw, n_classes)
+        spec, image, label = torch.from_numpy(spec), torch.from_numpy(image), torch.from_numpy(label)
+        opt.zero_grad()  # main_dgl.py:97
+        pre = f"s{st}."
+        if mode == "dgl":
+            out, out_a, out_v = model(spec.unsqueeze(1).float(), image.float())  # :100
+            loss_v = crit(out_v, label)
+            loss_a = crit(out_a, label)
+            loss_f = crit(out, label)
+            loss_unimodal = (loss_a + loss_v) * alpha  # :108
+            loss_unimodal.backward(retain_graph=True)  # :110
+            dropped = 0.0
+            for n, p in named:  # :114-119
+                layer = str(n).split(".")[1]
+                if "fusion" in layer:
+                    if p.grad is not None:
+                        dropped += float(p.grad.double().pow(2).sum())
+                    p.grad = None
+            loss_f.backward()  # :122
+            out_d[pre + "out_a"] = out_a.detach().numpy()
+            out_d[pre + "out_v"] = out_v.detach().numpy()
+            out_d[pre + "loss_a"] = np.float64(loss_a.item())
+            out_d[pre + "loss_v"] = np.float64(loss_v.item())
+            out_d[pre + "dropped_head_gradnorm"] = np.float64(dropped ** 0.5)
+        else:
+            out, fa, fv = model(spec.unsqueeze(1).float(), image.float())
+            loss_f = crit(out, label)
+            loss_f.backward()
+        out_d[pre + "out"] = out.detach().numpy()
+        out_d[pre + "loss_f"] = np.float64(loss_f.item())
+        total = nn.utils.clip_grad_norm_(model.parameters(), max_norm=40, norm_type=2)  # :129
+        out_d[pre + "total_norm"] = np.float64(total.item())
+        a_sum = sum(torch.abs(p.grad).mean().item() for p in model.audio_net.parameters())  # :132-137
+        v_sum = sum(torch.abs(p.grad).mean().item() for p in model.visual_net.parameters())  # :139-143
+        out_d[pre + "audio_grad_sum"] = np.float64(a_sum)
+        out_d[pre + "visual_grad_sum"] = np.float64(v_sum)
+        names, gn, gam, gh8, isnone = [], [], [], [], []
+        for n, p in model.named_parameters():
+            names.append(n)
+            if p.grad is None:
+                isnone.append(1)
+                gn.append(0.0)
+                gam.append(0.0)
+                gh8.append(np.zeros(8, np.float32))
+                continue
+            isnone.append(0)
+            g = p.grad.detach()
+            gn.append(float(g.double().norm()))
+            gam.append(float(g.abs().double().mean()))
+            h = g.flatten()[:8].numpy()
+            gh8.append(np.pad(h, (0, 8 - len(h))))
+            if g.numel() <= 10000:
+                out_d[pre + "grad." + n] = g.numpy().copy()
+        out_d[pre + "grad_names"] = np.array(names)
+        out_d[pre + "grad_norm"] = np.array(gn)
+        out_d[pre + "grad_absmean"] = np.array(gam)
+        out_d[pre + "grad_head8"] = np.stack(gh8)
+        out_d[pre + "grad_is_none"] = np.array(isnone, dtype=np.int8)
+        opt.step()  # :154
+        ps, ph8, ms = [], [], []
+        for n, p in model.named_parameters():
+            ps.append(_summ(p))
+            h = p.detach().flatten()[:8].numpy()
+            ph8.append(np.pad(h, (0, 8 - len(h))))
+            buf = opt.state.get(p, {}).get("momentum_buffer", None)
+            ms.append(_summ(buf) if buf is not None else np.zeros(2))
+        out_d[pre + "param_sums"] = np.stack(ps)
+        out_d[pre + "param_head8"] = np.stack(ph8)
+        out_d[pre + "momentum_sums"] = np.stack(ms)
+        for n, b in model.named_buffers():
+            out_d[pre + "buf." + n] = b.detach().numpy().copy()
+    # eval-mode forward after the last step (valid(), main_dgl.py:185-204)
+    model.eval()
+    with torch.no_grad():
+        spec, image, label = fx.make_batch(seed + 1000, batch, spec_hw, frames, image_hw, n_classes)
+        o = model(torch.from_numpy(spec).unsqueeze(1).float(), torch.from_numpy(image).float())
+        out_d["eval.out"] = o[0].numpy()
+        if mode == "dgl":
+            out_d["eval.out_a"] = o[1].numpy()
+            out_d["eval.out_v"] = o[2].numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out_d)
+    print(name, "loss_f", out_d[f"s{steps-1}.loss_f"], "total_norm", out_d[f"s{steps-1}.total_norm"])
+
+
+def run_encoder_case(name, bb, modality, in_shape, seed=0):
+    """Full feature map + parameter grads of one imported `resnet18`
+    (backbone.py:255) on a tiny input, for a fixed upstream gradient."""
+    net = bb.resnet18(modality=modality, args=None)
+    prefix = ""
+    ps = fx.make_state(fx.resnet18_param_shapes(prefix, 1 if modality == "audio" else 3))
+    bs = fx.make_state(fx.resnet18_buffer_shapes(prefix))
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in {**ps, **bs}.items()}, strict=True)
+    r = np.random.default_rng([77, seed])
+    x = r.standard_normal(in_shape, dtype=np.float32)
+    net.train()
+    y = net(torch.from_numpy(x))
+    dy = np.random.default_rng([78, seed]).standard_normal(tuple(y.shape), dtype=np.float32)
+    y.backward(torch.from_numpy(dy))
+    d = {"x": x, "y": y.detach().numpy(), "dy": dy}
+    for n, p in net.named_parameters():
+        g = p.grad.numpy()
+        if g.size <= 10000:
+            d["grad." + n] = g.copy()
+        else:  # big conv weights: L2 norm, mean|g| and a strided sample (every 997th element)
+            d["gradstat." + n] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum()), np.abs(g).mean()])
+            d["gradsample." + n] = g.reshape(-1)[::997].copy()
+    for n, b in net.named_buffers():
+        d["buf." + n] = b.detach().numpy().copy()
+    net.eval()
+    with torch.no_grad():
+        d["y_eval"] = net(torch.from_numpy(x)).numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, d["y"].shape, float(np.abs(d["y"]).mean()))
+
+
+def run_head_case(name, fm, cls, n_classes, batch=4):
+    """Isolated fusion head (fusion_modules.py:33-59) forward + both backward
+    phases of main_dgl.py:110-122."""
+    head = getattr(fm, cls)(output_dim=n_classes)
+    shapes = {"fc_out.weight": (n_classes, 1024), "fc_out.bias": (n_classes,)}
+    if cls == "ConcatFusion_DGL":
+        shapes.update({"fc_auxi.weight": (n_classes, 1024), "fc_auxi.bias": (n_classes,)})
+    st = fx.make_state({"fusion_module." + k: v for k, v in shapes.items()})
+    head.load_state_dict({k[len("fusion_module."):]: torch.from_numpy(v.copy()) for k, v in st.items()})
+    r = np.random.default_rng([91, n_classes])
+    x = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    y = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    g = [r.standard_normal((batch, n_classes), dtype=np.float32) for _ in range(3)]
+    o = head(x, y)
+    d = {"x": x.detach().numpy(), "y": y.detach().numpy()}
+    if cls == "ConcatFusion_DGL":
+        x_out, y_out, out = o
+        d.update(x_out=x_out.detach().numpy(), y_out=y_out.detach().numpy(), out=out.detach().numpy())
+        (x_out * torch.from_numpy(g[0])).sum().add((y_out * torch.from_numpy(g[1])).sum()).backward(retain_graph=True)
+        d.update(g_x_out=g[0], g_y_out=g[1], g_out=g[2], dx=x.grad.numpy().copy(), dy=y.grad.numpy().copy(),
+                 dW_uni=head.fc_out.weight.grad.numpy().copy(), db_uni=head.fc_out.bias.grad.numpy().copy())
+        head.fc_out.weight.grad = None
+        head.fc_out.bias.grad = None
+        x.grad = None
+        y.grad = None
+        (out * torch.from_numpy(g[2])).sum().backward()
+        d.update(dW_f=head.fc_out.weight.grad.numpy().copy(), db_f=head.fc_out.bias.grad.numpy().copy(),
+                 dx_after_f=np.zeros(1) if x.grad is None else x.grad.numpy().copy(),
+                 auxi_grad_is_none=np.int8(head.fc_auxi.weight.grad is None))
+    else:
+        _, _, out = o
+        d.update(out=out.detach().numpy(), g_out=g[2])
+        (out * torch.from_numpy(g[2])).sum().backward()
+        d.update(dx=x.grad.numpy().copy(), dy=y.grad.numpy().copy(), dW=head.fc_out.weight.grad.numpy().copy(),
+                 db=head.fc_out.bias.grad.numpy().copy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "ok")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    bm, bb, fm = _import_reference()
+    cases = {
+        "head_dgl_c6": lambda: run_head_case("head_dgl_c6", fm, "ConcatFusion_DGL", 6),
+        "head_dgl_c34": lambda: run_head_case("head_dgl_c34", fm, "ConcatFusion_DGL", 34),
+        "head_concat_c6": lambda: run_head_case("head_concat_c6", fm, "ConcatFusion", 6),
+        "enc_audio_tiny": lambda: run_encoder_case("enc_audio_tiny", bb, "audio", (2, 1, 65, 47)),
+        "enc_visual_tiny": lambda: run_encoder_case("enc_visual_tiny", bb, "visual", (2, 3, 2, 64, 64)),
+        "dgl_tiny_b4": lambda: run_step_case("dgl_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2),
+        "dgl_tiny_t1_b2": lambda: run_step_case("dgl_tiny_t1_b2", bm, bb, fm, "CREMAD", (65, 47), 1, (64, 64), 2, 5.0,
+                                                1),
+        "dgl_cremad_b2": lambda: run_step_case("dgl_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224), 2,
+                                               4.0, 1),
+        "dgl_ks_b2": lambda: run_step_case("dgl_ks_b2", bm, bb, fm, "KineticSound", (129, 626), 3, (224, 224), 2, 2.0,
+                                           1),
+        "concat_cremad_b2": lambda: run_step_case("concat_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224),
+                                                  2, 0.0, 1, mode="concat"),
+    }
+    for k, f in cases.items():
+        if a.only and a.only not in k:
+            continue
+        f()
+
+
+if __name__ == "__main__":
+    main()
