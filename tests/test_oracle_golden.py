@@ -1,0 +1,158 @@
+"""Pins the CPU oracle (oracle/) against golden vectors captured from the
+imported reference (tests/golden/make_golden.py).  CPU-only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fixtures as fx
+from oracle import oracle as orc
+
+RTOL, ATOL = 2e-4, 2e-5  # fp32 vs fp32, different summation orders
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name,ncls", [("head_dgl_c6", 6), ("head_dgl_c34", 34)])
+def test_head_dgl(golden_dir, name, ncls):
+    g = _load(golden_dir, name)
+    st = fx.make_state({"fusion_module.fc_out.weight": (ncls, 1024), "fusion_module.fc_out.bias": (ncls,)})
+    W, b = st["fusion_module.fc_out.weight"], st["fusion_module.fc_out.bias"]
+    x_out, y_out, out = orc.concat_dgl_fwd(g["x"], g["y"], W, b)
+    np.testing.assert_allclose(x_out, g["x_out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(y_out, g["y_out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out, g["out"], rtol=RTOL, atol=ATOL)
+    dx, dy, dW, db = orc.concat_dgl_bwd(g["x"], g["y"], W, g["g_x_out"], g["g_y_out"], None)
+    np.testing.assert_allclose(dx, g["dx"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(dy, g["dy"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(dW, g["dW_uni"], rtol=RTOL, atol=1e-4)
+    np.testing.assert_allclose(db, g["db_uni"], rtol=RTOL, atol=1e-4)
+    dx2, dy2, dW2, db2 = orc.concat_dgl_bwd(g["x"], g["y"], W, None, None, g["g_out"])
+    assert not dx2.any() and not dy2.any()  # detached input: no gradient reaches the encoders
+    np.testing.assert_allclose(dW2, g["dW_f"], rtol=RTOL, atol=1e-4)
+    np.testing.assert_allclose(db2, g["db_f"], rtol=RTOL, atol=1e-4)
+    assert int(g["auxi_grad_is_none"]) == 1
+
+
+def test_head_concat(golden_dir):
+    g = _load(golden_dir, "head_concat_c6")
+    st = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
+    W, b = st["fusion_module.fc_out.weight"], st["fusion_module.fc_out.bias"]
+    np.testing.assert_allclose(orc.concat_fwd(g["x"], g["y"], W, b), g["out"], rtol=RTOL, atol=ATOL)
+    dx, dy, dW, db = orc.concat_bwd(g["x"], g["y"], W, g["g_out"])
+    for a, k in ((dx, "dx"), (dy, "dy"), (dW, "dW"), (db, "db")):
+        np.testing.assert_allclose(a, g[k], rtol=RTOL, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,modality", [("enc_audio_tiny", "audio"), ("enc_visual_tiny", "visual")])
+def test_encoder(golden_dir, name, modality):
+    g = _load(golden_dir, name)
+    P = fx.make_state(fx.resnet18_param_shapes("", 1 if modality == "audio" else 3))
+    Bf = fx.make_state(fx.resnet18_buffer_shapes(""))
+    net = orc.ResNet18(P, Bf, "", modality)
+    y = net.forward(g["x"], train=True)
+    np.testing.assert_allclose(y, g["y"], rtol=1e-3, atol=1e-4)
+    G = net.backward(g["dy"])
+    for k in P:
+        if "grad." + k in g.files:
+            ref = g["grad." + k]
+            # norm-wise.  Measured when this fixture was made: against an fp64 run of the reference
+            # the oracle agrees to 5e-6 on every tensor, while the fp32 golden itself is 2.7e-3 off
+            # for everything upstream of layer2.0.bn1 (one ReLU sign decided differently in fp32).
+            # The bound therefore has to admit one such flip: 1 %.
+            rel = np.linalg.norm((G[k] - ref).astype(np.float64)) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30)
+            assert rel < 1e-2, (k, rel)
+        else:
+            st = g["gradstat." + k]
+            got = np.array([np.sqrt((G[k].astype(np.float64) ** 2).sum()), np.abs(G[k]).mean()])
+            np.testing.assert_allclose(got, st, rtol=1e-3, err_msg=k)
+            ref = g["gradsample." + k]
+            smp = G[k].reshape(-1)[::997]
+            rel = np.linalg.norm((smp - ref).astype(np.float64)) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30)
+            assert rel < 1e-2, (k, rel)
+    for k in Bf:
+        np.testing.assert_allclose(np.asarray(Bf[k], dtype=np.float64), g["buf." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    net2 = orc.ResNet18(P, Bf, "", modality)
+    np.testing.assert_allclose(net2.forward(g["x"], train=False), g["y_eval"], rtol=1e-3, atol=1e-4)
+
+
+def check_step_against_golden(g, model_step, cfg, steps, rtol_logits=1e-3, rtol_norm=2e-3, rtol_gn=5e-3):
+    """Shared by the oracle test here and the GPU parity tests: `model_step(st)` -> result dict."""
+    base = (rtol_logits, rtol_norm, rtol_gn)
+    for st in range(steps):
+        r = model_step(st)
+        pre = f"s{st}."
+        # After an update the tiny fixtures (BatchNorm over 16-24 samples in layer4) amplify the
+        # step-0 ReLU-flip noise chaotically (measured: logits 3e-3, grad norms 3e-2 at step 1 with
+        # step 0 agreeing to 5e-6 / 2e-3); later steps only pin the update rule, loosely.
+        rtol_logits, rtol_norm, rtol_gn = base if st == 0 else (1e-2, 1e-2, 6e-2)
+        np.testing.assert_allclose(r["out"], g[pre + "out"], rtol=rtol_logits, atol=rtol_logits)
+        np.testing.assert_allclose(r["loss_f"], g[pre + "loss_f"], rtol=rtol_logits, atol=rtol_logits)
+        if cfg["mode"] == "dgl":
+            np.testing.assert_allclose(r["out_a"], g[pre + "out_a"], rtol=rtol_logits, atol=rtol_logits)
+            np.testing.assert_allclose(r["out_v"], g[pre + "out_v"], rtol=rtol_logits, atol=rtol_logits)
+            np.testing.assert_allclose(r["loss_a"], g[pre + "loss_a"], rtol=rtol_logits, atol=rtol_logits)
+            np.testing.assert_allclose(r["loss_v"], g[pre + "loss_v"], rtol=rtol_logits, atol=rtol_logits)
+        np.testing.assert_allclose(r["total_norm"], g[pre + "total_norm"], rtol=rtol_norm)
+        np.testing.assert_allclose(r["audio_grad_sum"], g[pre + "audio_grad_sum"], rtol=rtol_gn)
+        np.testing.assert_allclose(r["visual_grad_sum"], g[pre + "visual_grad_sum"], rtol=rtol_gn)
+        names = [str(n) for n in g[pre + "grad_names"]]
+        gn, isnone = g[pre + "grad_norm"], g[pre + "grad_is_none"]
+        for i, n in enumerate(names):
+            if isnone[i]:
+                assert n not in r["grads"], n  # fc_auxi: grad stays None
+                continue
+            got = float(np.sqrt((r["grads"][n].astype(np.float64) ** 2).sum()))
+            assert abs(got - gn[i]) <= rtol_gn * gn[i] + 1e-6 * float(g[pre + "total_norm"]), (n, got, gn[i])
+
+
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "concat_cremad_b2"])
+def test_step(golden_dir, name):
+    g = _load(golden_dir, name)
+    cfg = json.loads(str(g["config"]))
+    fusion = "concat_dgl" if cfg["mode"] == "dgl" else "concat"
+    P, Bf = fx.model_state(cfg["n_classes"], fusion)
+    model = orc.AVModel(P, Bf, cfg["mode"])
+
+    def step(st):
+        spec, image, label = fx.make_batch(cfg["seed"] + st, cfg["batch"], cfg["spec_hw"], cfg["frames"],
+                                           cfg["image_hw"], cfg["n_classes"])
+        return model.train_step(spec, image, label, cfg["alpha"], cfg["lr"])
+
+    check_step_against_golden(g, step, cfg, cfg["steps"])
+    last = f"s{cfg['steps'] - 1}."
+    names = [str(n) for n in g[last + "grad_names"]]
+    ps = g[last + "param_sums"]
+    for i, n in enumerate(names):
+        got = np.array([P[n].astype(np.float64).sum(), np.abs(P[n].astype(np.float64)).sum()])
+        np.testing.assert_allclose(got[1], ps[i][1], rtol=1e-5 if cfg["steps"] == 1 else 5e-4, err_msg=n)
+        np.testing.assert_allclose(P[n].reshape(-1)[:8], g[last + "param_head8"][i][:min(8, P[n].size)], rtol=1e-4,
+                                   atol=5e-5 if cfg["steps"] == 1 else 2e-4, err_msg=n)
+    for k in Bf:
+        np.testing.assert_allclose(np.asarray(Bf[k], dtype=np.float64), g[last + "buf." + k], rtol=1e-3,
+                                   atol=1e-5 if cfg["steps"] == 1 else 1e-3, err_msg=k)
+    spec, image, label = fx.make_batch(cfg["seed"] + 1000, cfg["batch"], cfg["spec_hw"], cfg["frames"],
+                                       cfg["image_hw"], cfg["n_classes"])
+    o = model.forward(spec, image, train=False)
+    tol = 1e-3 if cfg["steps"] == 1 else 1e-2
+    np.testing.assert_allclose(o[0], g["eval.out"], rtol=tol, atol=tol)
+
+
+def test_sgd_matches_torch():
+    """orc_sgd against torch.optim.SGD (the third-party arithmetic behind main_dgl.py:249) over 3 steps."""
+    import torch
+
+    r = np.random.default_rng(5)
+    p0 = r.standard_normal(1000).astype(np.float32)
+    gs = [r.standard_normal(1000).astype(np.float32) for _ in range(3)]
+    tp = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.SGD([tp], lr=2e-3, momentum=0.9, weight_decay=1e-4)
+    p, buf = p0.copy(), np.zeros_like(p0)
+    for i, g in enumerate(gs):
+        tp.grad = torch.from_numpy(g.copy())
+        opt.step()
+        orc.sgd_(p, g, buf, 2e-3, 0.9, 1e-4, i == 0)
+        np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-6, atol=1e-7)
