@@ -1,0 +1,161 @@
+// api.cpp -- the C ABI of libgdl_hip.so (see include/gdl_hip.h) over the internal launchers.
+#include "ops.h"
+
+using namespace gdl;
+
+extern "C" {
+
+const char* gdl_last_error(void) { return last_error(); }
+int gdl_version(void) { return 100; }
+
+int gdl_device_info(int* cu_count, char* name, int name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return check_hip(e, "hipGetDevice");
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return check_hip(e, "hipGetDeviceProperties");
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    return GDL_OK;
+}
+
+static bool dt_ok(int dtype) { return dtype == GDL_F32 || dtype == GDL_BF16; }
+
+int gdl_conv_bn_tiles(int dtype, int N, int P, int Q, int K) { return conv_tiles_m(dtype, N * P * Q, K); }
+
+int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, int N, int H, int W, int C, int K,
+                 int R, int S, int stride, int pad, void* stream) {
+    GDL_REQUIRE(x && w_krsc && y, "conv_fwd: null pointer");
+    return conv_fwd(dtype, x, w_krsc, y, bn_partial, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+}
+int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H, int W, int C,
+                   int K, int R, int S, int stride, int pad, void* stream) {
+    GDL_REQUIRE(dy && w_crsk && dx, "conv_dgrad: null pointer");
+    return conv_dgrad(dtype, dy, w_crsk, dx, addend, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+}
+size_t gdl_conv_wgrad_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    (void)dtype;
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    return conv_wgrad_ws_bytes(N * P * Q, C, K, R * S);
+}
+int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int R, int S,
+                   int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    GDL_REQUIRE(dy && x && dw, "conv_wgrad: null pointer");
+    return conv_wgrad(dtype, dy, x, dw, N, H, W, C, K, R, S, stride, pad, C, ws, ws_bytes, (hipStream_t)stream);
+}
+int gdl_pack_weight(int dtype, const float* w, void* w_krsc, void* w_crsk, int K, int C, int R, int S, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && w, "pack_weight: bad arguments");
+    return pack_weight(dtype, w, w_krsc, w_crsk, K, C, R, S, (hipStream_t)stream);
+}
+int gdl_stem_kp(int cin, int dtype) { return stem_kp(cin, dtype); }
+int gdl_stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && col, "stem_im2col: bad arguments");
+    return stem_im2col(dtype, x, col, B, Cin, T, H, W, (hipStream_t)stream);
+}
+int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && w && wp, "pack_stem_weight: bad arguments");
+    return pack_stem_weight(dtype, w, wp, Cin, (hipStream_t)stream);
+}
+int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, int M, int Cin, void* ws, size_t ws_bytes,
+                   void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && col && dw, "stem_wgrad: bad arguments");
+    return conv_wgrad(dtype, dy, col, dw, M, 1, 1, stem_kp(Cin, dtype), 64, 1, 1, 1, 0, Cin * 49, ws, ws_bytes,
+                      (hipStream_t)stream);
+}
+int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && y, "nhwc_to_nchw: bad arguments");
+    return nhwc_to_nchw_f32(dtype, x, y, N, H, W, C, (hipStream_t)stream);
+}
+int gdl_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && y, "nchw_to_nhwc: bad arguments");
+    return nchw_f32_to_nhwc(dtype, x, y, N, H, W, C, (hipStream_t)stream);
+}
+
+int gdl_bn_stats_tiles(int M) { return bn_stats_tiles(M); }
+int gdl_bn_stats(int dtype, const void* y, float* partial, int M, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && y && partial, "bn_stats: bad arguments");
+    return bn_stats(dtype, y, partial, M, C, (hipStream_t)stream);
+}
+int gdl_bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                          float* save_mean, float* save_rstd, float* scale, float* shift, void* stream) {
+    GDL_REQUIRE(partial && gamma && beta && save_mean && save_rstd && scale && shift, "bn_finalize_train: null pointer");
+    return bn_finalize_train(partial, tiles, C, count, gamma, beta, eps, momentum, running_mean, running_var, nbt,
+                             save_mean, save_rstd, scale, shift, (hipStream_t)stream);
+}
+int gdl_bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                         const float* running_var, float* scale, float* shift, void* stream) {
+    GDL_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, "bn_finalize_eval: null pointer");
+    return bn_finalize_eval(C, gamma, beta, eps, running_mean, running_var, scale, shift, (hipStream_t)stream);
+}
+int gdl_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+               const float* res_shift, int relu, void* out, size_t M, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && y && scale && shift && out, "bn_act: bad arguments");
+    return bn_act(dtype, y, scale, shift, res, res_scale, res_shift, relu, out, M, C, (hipStream_t)stream);
+}
+int gdl_bn_bwd_blocks(size_t M) { return bn_bwd_blocks(M); }
+int gdl_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift,
+                      const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M, int C,
+                      void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && g && y && save_mean && save_rstd && partial, "bn_bwd_reduce: bad arguments");
+    return bn_bwd_reduce(dtype, g, y, scale, shift, save_mean, save_rstd, relu_mask, partial, M, C, (hipStream_t)stream);
+}
+int gdl_bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
+                        void* stream) {
+    GDL_REQUIRE(partial && dgamma && dbeta && coef, "bn_bwd_finalize: null pointer");
+    return bn_bwd_finalize(partial, blocks, C, count, dgamma, dbeta, coef, (hipStream_t)stream);
+}
+int gdl_bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift,
+                     const float* save_mean, const float* save_rstd, const float* gamma, const float* coef, int relu_mask,
+                     void* dy, size_t M, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && g && y && save_mean && save_rstd && gamma && coef && dy, "bn_bwd_apply: bad arguments");
+    return bn_bwd_apply(dtype, g, y, scale, shift, save_mean, save_rstd, gamma, coef, relu_mask, dy, M, C,
+                        (hipStream_t)stream);
+}
+int gdl_relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && out && dx, "relu_bwd: bad arguments");
+    return relu_bwd(dtype, dy, out, dx, n, (hipStream_t)stream);
+}
+
+int gdl_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx,
+                            int N, int H, int W, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && y && scale && shift && out && idx, "bn_relu_maxpool_fwd: bad arguments");
+    return bn_relu_maxpool_fwd(dtype, y, scale, shift, out, idx, N, H, W, C, (hipStream_t)stream);
+}
+int gdl_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dout && idx && dx, "maxpool_bwd: bad arguments");
+    return maxpool_bwd(dtype, dout, idx, dx, N, H, W, C, (hipStream_t)stream);
+}
+int gdl_avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && feat, "avgpool_fwd: bad arguments");
+    return avgpool_fwd(dtype, x, feat, B, T, HW, C, (hipStream_t)stream);
+}
+int gdl_avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dfeat && dx, "avgpool_bwd: bad arguments");
+    return avgpool_bwd(dtype, dfeat, dx, B, T, HW, C, (hipStream_t)stream);
+}
+
+int gdl_head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out,
+                        float* y_out, int B, int n_classes, void* stream) {
+    GDL_REQUIRE(x && y && W && b && out && B > 0 && n_classes > 0, "head_concat_fwd: bad arguments");
+    return head_concat_fwd(x, y, W, b, out, x_out, y_out, B, n_classes, (hipStream_t)stream);
+}
+int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
+                        const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db,
+                        int B, int n_classes, void* stream) {
+    GDL_REQUIRE(x && y && W && B > 0 && n_classes > 0, "head_concat_bwd: bad arguments");
+    GDL_REQUIRE((dx != nullptr) == (dy != nullptr) && (dW != nullptr) == (db != nullptr),
+                "head_concat_bwd: dx/dy and dW/db come in pairs");
+    return head_concat_bwd(x, y, W, g_x_out, g_y_out, g_out, out_reaches_xy, uni_in_dw, dx, dy, dW, db, B, n_classes,
+                           (hipStream_t)stream);
+}
+int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
+                   int n_classes, void* stream) {
+    GDL_REQUIRE(logits && labels && loss && B > 0 && n_classes > 0, "softmax_ce: bad arguments");
+    return softmax_ce(logits, labels, scale, loss, dlogits, B, n_classes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// bn.hip -- BatchNorm2d (+ReLU, +residual add) forward / backward on NHWC tensors.
+//
+// Replaces nn.BatchNorm2d (train + eval), nn.ReLU(inplace) and `out += identity` of
+// /root/reference/models/backbone.py:45-48,57,62-66,104-105,144.  All of these are HBM
+// bound: every kernel here streams 16-byte vectors, keeps per-channel statistics in fp32
+// (finalised in double), and reduces deterministically (fixed-order trees, no atomics).
+//
+// Channel of a vector: with NHWC storage the flat element index modulo C; a thread that
+// strides by a multiple of C keeps the same channels for its whole loop, so its scale /
+// shift / partial sums live in registers.
+#include "common.h"
+
+namespace gdl {
+
+constexpr int BN_THREADS = 256;
+
+// ---------------------------------------------------------------- statistics of an existing tensor
+// grid.x = tiles; block handles rows [tile*rows_per_tile, ...).  partial[tile][C][2].
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ y, float* __restrict__ partial, int M,
+                                                              int C, int rows_per_tile) {
+    constexpr int EPC = TT<T>::EPC;
+    extern __shared__ float red[];  // [BN_THREADS/cpr][C][2]
+    const int cpr = C / EPC;        // vectors per row
+    const int rpp = BN_THREADS / cpr;
+    const int vc = threadIdx.x % cpr, vr = threadIdx.x / cpr;
+    const int r0 = blockIdx.x * rows_per_tile, r1 = min(M, r0 + rows_per_tile);
+    float s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.f;
+    if (vr < rpp)
+        for (int r = r0 + vr; r < r1; r += rpp) {
+            float f[EPC];
+            unpack16<T>(*(const uint4*)(y + (size_t)r * C + vc * EPC), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s[e] += f[e];
+                q[e] += f[e] * f[e];
+            }
+        }
+    if (vr < rpp) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[((size_t)vr * C + vc * EPC + e) * 2 + 0] = s[e];
+            red[((size_t)vr * C + vc * EPC + e) * 2 + 1] = q[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 2; i += BN_THREADS) {
+        float a = 0.f;
+        for (int r = 0; r < rpp; ++r) a += red[(size_t)r * C * 2 + i];
+        partial[(size_t)blockIdx.x * C * 2 + i] = a;
+    }
+}
+
+constexpr int BN_STATS_ROWS = 1024;
+int bn_stats_tiles(int M) { return ceil_div(M, BN_STATS_ROWS); }
+
+int bn_stats(int dtype, const void* y, float* partial, int M, int C, hipStream_t st) {
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    GDL_REQUIRE(C % epc == 0 && C / epc <= BN_THREADS && BN_THREADS % (C / epc) == 0, "bn_stats: C=%d unsupported", C);
+    const int rpp = BN_THREADS / (C / epc);
+    const size_t sh = (size_t)rpp * C * 2 * sizeof(float);
+    const int tiles = bn_stats_tiles(M);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16>, dim3(tiles), dim3(BN_THREADS), sh, st, (const bf16*)y, partial, M, C,
+                           BN_STATS_ROWS);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(tiles), dim3(BN_THREADS), sh, st, (const float*)y, partial, M, C,
+                           BN_STATS_ROWS);
+    GDL_CHECK_LAUNCH("bn_stats_kernel");
+    return GDL_OK;
+}
+
+// ---------------------------------------------------------------- finalize (one block per channel)
+__device__ __forceinline__ double block_sum_double(double v, double* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if (t < o) sh[t] += sh[t + o];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(128) void bn_finalize_train_kernel(const float* __restrict__ partial, int tiles, int C,
+                                                                double count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, float momentum,
+                                                                float* running_mean, float* running_var, int64_t* nbt,
+                                                                float* save_mean, float* save_rstd, float* scale,
+                                                                float* shift) {
+    __shared__ double sh[128];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+        s += (double)partial[((size_t)t * C + c) * 2 + 0];
+        q += (double)partial[((size_t)t * C + c) * 2 + 1];
+    }
+    s = block_sum_double(s, sh);
+    q = block_sum_double(q, sh);
+    if (threadIdx.x == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;  // biased
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const float sc = (float)((double)gamma[c] * rstd);
+        save_mean[c] = (float)mean;
+        save_rstd[c] = (float)rstd;
+        scale[c] = sc;
+        shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
+        if (running_mean) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        }
+        if (nbt && c == 0) *nbt += 1;
+    }
+}
+int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
+                      float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(128), 0, st, partial, tiles, C, count, gamma, beta, eps,
+                       momentum, rm, rv, nbt, save_mean, save_rstd, scale, shift);
+    GDL_CHECK_LAUNCH("bn_finalize_train_kernel");
+    return GDL_OK;
+}
+
+__global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                        const float* __restrict__ rm, const float* __restrict__ rv, float* scale,
+                                        float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)rv[c] + (double)eps);
+    scale[c] = (float)((double)gamma[c] * rstd);
+    shift[c] = (float)((double)beta[c] - (double)rm[c] * (double)gamma[c] * rstd);
+}
+int bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, const float* rm, const float* rv,
+                     float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, C, gamma, beta, eps, rm, rv,
+                       scale, shift);
+    GDL_CHECK_LAUNCH("bn_finalize_eval_kernel");
+    return GDL_OK;
+}
+
+// ---------------------------------------------------------------- forward apply
+// out = [relu]( y*scale+shift + residual ),  RES: 0 none, 1 raw tensor, 2 tensor*res_scale+res_shift
+template <typename T, int RES, bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const T* __restrict__ res,
+                                                            const float* __restrict__ rscale,
+                                                            const float* __restrict__ rshift, T* __restrict__ out,
+                                                            size_t nvec, int C, size_t stride_vec) {
+    constexpr int EPC = TT<T>::EPC;
+    size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
+    if (i >= nvec) return;
+    const int c0 = (int)((i * EPC) % C);  // stride_vec*EPC is a multiple of C: channels are loop invariant
+    float sc[EPC], sf[EPC], rsc[EPC], rsf[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale[c0 + e];
+        sf[e] = shift[c0 + e];
+        if (RES == 2) {
+            rsc[e] = rscale[c0 + e];
+            rsf[e] = rshift[c0 + e];
+        }
+    }
+    for (; i < nvec; i += stride_vec) {
+        float f[EPC], g[EPC];
+        unpack16<T>(*(const uint4*)(y + i * EPC), f);
+        if (RES) unpack16<T>(*(const uint4*)(res + i * EPC), g);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float v = f[e] * sc[e] + sf[e];
+            if (RES == 1) v += g[e];
+            if (RES == 2) v += g[e] * rsc[e] + rsf[e];
+            if (RELU) v = v > 0.f ? v : 0.f;
+            f[e] = v;
+        }
+        *(uint4*)(out + i * EPC) = pack16<T>(f);
+    }
+}
+
+// grid sizing for channel-invariant grid-stride loops: total threads is a multiple of C/EPC
+static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec) {
+    // threads = blocks*256 must be a multiple of cpr (cpr divides 256 or is a multiple of it handled by lcm)
+    size_t want = (nvec + BN_THREADS - 1) / BN_THREADS;
+    if (want > 4096) want = 4096;
+    if (want < 1) want = 1;
+    // make blocks*256 % cpr == 0
+    size_t unit = 1;
+    while ((unit * BN_THREADS) % (size_t)cpr) ++unit;
+    want = (want + unit - 1) / unit * unit;
+    blocks = (int)want;
+    stride_vec = want * BN_THREADS;
+}
+
+template <typename T>
+static int bn_act_t(const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+                    const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st) {
+    constexpr int EPC = TT<T>::EPC;
+    GDL_REQUIRE(C % EPC == 0, "bn_act: C=%d not a multiple of %d", C, EPC);
+    const size_t nvec = M * (size_t)C / EPC;
+    int blocks;
+    size_t stride;
+    ew_grid(nvec, C / EPC, blocks, stride);
+    const int resmode = res ? (rscale ? 2 : 1) : 0;
+#define BN_ACT_LAUNCH(RM, RL)                                                                                        \
+    hipLaunchKernelGGL((bn_act_kernel<T, RM, RL>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale, shift, \
+                       (const T*)res, rscale, rshift, (T*)out, nvec, C, stride)
+    if (resmode == 0 && relu) BN_ACT_LAUNCH(0, true);
+    if (resmode == 0 && !relu) BN_ACT_LAUNCH(0, false);
+    if (resmode == 1 && relu) BN_ACT_LAUNCH(1, true);
+    if (resmode == 1 && !relu) BN_ACT_LAUNCH(1, false);
+    if (resmode == 2 && relu) BN_ACT_LAUNCH(2, true);
+    if (resmode == 2 && !relu) BN_ACT_LAUNCH(2, false);
+#undef BN_ACT_LAUNCH
+    GDL_CHECK_LAUNCH("bn_act_kernel");
+    return GDL_OK;
+}
+int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st) {
+    if (dtype == GDL_BF16) return bn_act_t<bf16>(y, scale, shift, res, rscale, rshift, relu, out, M, C, st);
+    return bn_act_t<float>(y, scale, shift, res, rscale, rshift, relu, out, M, C, st);
+}
+
+// ---------------------------------------------------------------- backward
+// pass 1: partial[block][C][2] = { sum g', sum g'*xhat },  g' = MASK ? g*(y*scale+shift>0) : g
+template <typename T, bool MASK>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd,
+                                                                   float* __restrict__ partial, size_t nvec, int C,
+                                                                   size_t stride_vec) {
+    constexpr int EPC = TT<T>::EPC;
+    extern __shared__ float red[];  // [rpp][C][2]
+    const int cpr = C / EPC;
+    size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
+    const int c0 = (int)((i * EPC) % C);
+    float sc[EPC], sf[EPC], mu[EPC], rs[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        mu[e] = mean[c0 + e];
+        rs[e] = rstd[c0 + e];
+        if (MASK) {
+            sc[e] = scale[c0 + e];
+            sf[e] = shift[c0 + e];
+        }
+        s1[e] = s2[e] = 0.f;
+    }
+    for (; i < nvec; i += stride_vec) {
+        float gv[EPC], yv[EPC];
+        unpack16<T>(*(const uint4*)(g + i * EPC), gv);
+        unpack16<T>(*(const uint4*)(y + i * EPC), yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float gg = gv[e];
+            if (MASK) gg = (yv[e] * sc[e] + sf[e] > 0.f) ? gg : 0.f;
+            s1[e] += gg;
+            s2[e] += gg * ((yv[e] - mu[e]) * rs[e]);
+        }
+    }
+    // 256 % cpr == 0: thread t holds channel vector t % cpr of row-lane t / cpr
+    const int rpp = BN_THREADS / cpr, vr = threadIdx.x / cpr;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[((size_t)vr * C + c0 + e) * 2 + 0] = s1[e];
+        red[((size_t)vr * C + c0 + e) * 2 + 1] = s2[e];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * 2; k += BN_THREADS) {
+        float a = 0.f;
+        for (int r = 0; r < rpp; ++r) a += red[(size_t)r * C * 2 + k];
+        partial[(size_t)blockIdx.x * C * 2 + k] = a;
+    }
+}
+
+int bn_bwd_blocks(size_t M) {
+    size_t b = (M + 511) / 512;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <typename T>
+static int bn_bwd_reduce_t(const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                           const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    GDL_REQUIRE(C % EPC == 0 && cpr <= BN_THREADS && BN_THREADS % cpr == 0, "bn_bwd: C=%d unsupported", C);
+    const size_t nvec = M * (size_t)C / EPC;
+    const int blocks = bn_bwd_blocks(M);
+    const size_t stride = (size_t)blocks * BN_THREADS;  // multiple of cpr since 256 % cpr == 0
+    const size_t sh = (size_t)(BN_THREADS / cpr) * C * 2 * sizeof(float);
+    if (relu_mask)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)g,
+                           (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)g,
+                           (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride);
+    GDL_CHECK_LAUNCH("bn_bwd_reduce_kernel");
+    return GDL_OK;
+}
+int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                  const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st) {
+    if (dtype == GDL_BF16) return bn_bwd_reduce_t<bf16>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, st);
+    return bn_bwd_reduce_t<float>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, st);
+}
+
+// dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M
+__global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                              double count, float* dgamma, float* dbeta, float* coef) {
+    __shared__ double sh[128];
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
+        a += (double)partial[((size_t)t * C + c) * 2 + 0];
+        b += (double)partial[((size_t)t * C + c) * 2 + 1];
+    }
+    a = block_sum_double(a, sh);
+    b = block_sum_double(b, sh);
+    if (threadIdx.x == 0) {
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+        coef[c] = (float)(a / count);
+        coef[C + c] = (float)(b / count);
+    }
+}
+int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(128), 0, st, partial, blocks, C, count, dgamma, dbeta, coef);
+    GDL_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    return GDL_OK;
+}
+
+// pass 2: dy = gamma*rstd*(g' - coef0 - xhat*coef1)
+template <typename T, bool MASK>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ coef, T* __restrict__ dy,
+                                                                  size_t nvec, int C, size_t stride_vec) {
+    constexpr int EPC = TT<T>::EPC;
+    size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
+    if (i >= nvec) return;
+    const int c0 = (int)((i * EPC) % C);
+    float sc[EPC], sf[EPC], mu[EPC], rs[EPC], gr[EPC], k1[EPC], k2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        mu[e] = mean[c0 + e];
+        rs[e] = rstd[c0 + e];
+        gr[e] = gamma[c0 + e] * rs[e];
+        k1[e] = coef[c0 + e];
+        k2[e] = coef[C + c0 + e];
+        if (MASK) {
+            sc[e] = scale[c0 + e];
+            sf[e] = shift[c0 + e];
+        }
+    }
+    for (; i < nvec; i += stride_vec) {
+        float gv[EPC], yv[EPC];
+        unpack16<T>(*(const uint4*)(g + i * EPC), gv);
+        unpack16<T>(*(const uint4*)(y + i * EPC), yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float gg = gv[e];
+            if (MASK) gg = (yv[e] * sc[e] + sf[e] > 0.f) ? gg : 0.f;
+            gv[e] = gr[e] * (gg - k1[e] - (yv[e] - mu[e]) * rs[e] * k2[e]);
+        }
+        *(uint4*)(dy + i * EPC) = pack16<T>(gv);
+    }
+}
+template <typename T>
+static int bn_bwd_apply_t(const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, const float* gamma, const float* coef, int relu_mask, void* dy, size_t M,
+                          int C, hipStream_t st) {
+    constexpr int EPC = TT<T>::EPC;
+    const size_t nvec = M * (size_t)C / EPC;
+    int blocks;
+    size_t stride;
+    ew_grid(nvec, C / EPC, blocks, stride);
+    if (relu_mask)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)g, (const T*)y,
+                           scale, shift, mean, rstd, gamma, coef, (T*)dy, nvec, C, stride);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)g,
+                           (const T*)y, scale, shift, mean, rstd, gamma, coef, (T*)dy, nvec, C, stride);
+    GDL_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return GDL_OK;
+}
+int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                 const float* rstd, const float* gamma, const float* coef, int relu_mask, void* dy, size_t M, int C,
+                 hipStream_t st) {
+    if (dtype == GDL_BF16)
+        return bn_bwd_apply_t<bf16>(g, y, scale, shift, mean, rstd, gamma, coef, relu_mask, dy, M, C, st);
+    return bn_bwd_apply_t<float>(g, y, scale, shift, mean, rstd, gamma, coef, relu_mask, dy, M, C, st);
+}
+
+// ---------------------------------------------------------------- relu backward: dx = dy * (out > 0)
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ out,
+                                                              T* __restrict__ dx, size_t nvec) {
+    constexpr int EPC = TT<T>::EPC;
+    for (size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x; i < nvec; i += (size_t)gridDim.x * BN_THREADS) {
+        float d[EPC], o[EPC];
+        unpack16<T>(*(const uint4*)(dy + i * EPC), d);
+        unpack16<T>(*(const uint4*)(out + i * EPC), o);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        *(uint4*)(dx + i * EPC) = pack16<T>(d);
+    }
+}
+int relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, hipStream_t st) {
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    GDL_REQUIRE(n % epc == 0, "relu_bwd: n not a multiple of %d", epc);
+    const size_t nvec = n / epc;
+    size_t blocks = (nvec + BN_THREADS - 1) / BN_THREADS;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(relu_bwd_kernel<bf16>, dim3((int)blocks), dim3(BN_THREADS), 0, st, (const bf16*)dy,
+                           (const bf16*)out, (bf16*)dx, nvec);
+    else
+        hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3((int)blocks), dim3(BN_THREADS), 0, st, (const float*)dy,
+                           (const float*)out, (float*)dx, nvec);
+    GDL_CHECK_LAUNCH("relu_bwd_kernel");
+    return GDL_OK;
+}
+
+}  // namespace gdl

@@ -1,0 +1,142 @@
+// common.h -- shared device/host helpers for libgdl_hip (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gdl_hip.h"
+
+namespace gdl {
+
+// ---------------------------------------------------------------- storage types
+// Activations are NHWC in one of two storage types: float (parity mode, exact f32
+// MFMA) or bf16 (the benchmark configuration; fp32 accumulate / statistics).
+struct bf16 {
+    uint16_t v;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+template <typename T>
+struct TT;
+template <>
+struct TT<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    static constexpr int DT = GDL_F32;
+};
+template <>
+struct TT<bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int DT = GDL_BF16;
+};
+
+// 16 bytes of T  <->  EPC floats
+template <typename T>
+__device__ __forceinline__ void unpack16(const uint4& v, float* f);
+template <>
+__device__ __forceinline__ void unpack16<float>(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x);
+    f[1] = __uint_as_float(v.y);
+    f[2] = __uint_as_float(v.z);
+    f[3] = __uint_as_float(v.w);
+}
+template <>
+__device__ __forceinline__ void unpack16<bf16>(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16);
+    f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16);
+    f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16);
+    f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16);
+    f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack16(const float* f);
+template <>
+__device__ __forceinline__ uint4 pack16<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <>
+__device__ __forceinline__ uint4 pack16<bf16>(const float* f) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+// value as it will be read back from storage
+template <typename T>
+__device__ __forceinline__ float roundT(float f);
+template <>
+__device__ __forceinline__ float roundT<float>(float f) {
+    return f;
+}
+template <>
+__device__ __forceinline__ float roundT<bf16>(float f) {
+    return bf2f(f2bf(f));
+}
+template <typename T>
+__device__ __forceinline__ float loadT(const T* p);
+template <>
+__device__ __forceinline__ float loadT<float>(const float* p) {
+    return *p;
+}
+template <>
+__device__ __forceinline__ float loadT<bf16>(const bf16* p) {
+    return bf2f(p->v);
+}
+template <typename T>
+__device__ __forceinline__ void storeT(T* p, float f);
+template <>
+__device__ __forceinline__ void storeT<float>(float* p, float f) {
+    *p = f;
+}
+template <>
+__device__ __forceinline__ void storeT<bf16>(bf16* p, float f) {
+    p->v = f2bf(f);
+}
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define GDL_CHECK_LAUNCH(name)                                  \
+    do {                                                        \
+        hipError_t e__ = hipGetLastError();                     \
+        if (e__ != hipSuccess) return gdl::check_hip(e__, name); \
+    } while (0)
+
+#define GDL_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            gdl::set_error(__VA_ARGS__); \
+            return GDL_ERR_ARG;           \
+        }                                 \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// exact n / d for 0 <= n < 2^24 via float reciprocal + one correction step
+__device__ __forceinline__ int fdiv_small(int n, int d, float rcp) {
+    int q = (int)((float)n * rcp);
+    int r = n - q * d;
+    if (r < 0) {
+        --q;
+    } else if (r >= d) {
+        ++q;
+    }
+    return q;
+}
+
+}  // namespace gdl

@@ -1,0 +1,400 @@
+// conv_igemm.hip -- implicit-GEMM convolution forward / data-gradient on MFMA (gfx950).
+//
+// Replaces nn.Conv2d forward and its input-gradient for the shapes the reference
+// encoder uses (/root/reference/models/backbone.py:20-28 conv3x3 / conv1x1, and
+// the stem after im2col).  GEMM view: M = N*OH*OW output pixels, Ngemm = OC
+// output channels, Kgemm = R*S*IC; NHWC activations make every K-step a
+// contiguous 128-byte slice of one input pixel (fixed tap, 64 bf16 / 32 f32
+// channels) and the [OC][R][S][IC] weight layout makes the matching weight slice
+// contiguous too, so both operands load as 16-byte chunks straight into the MFMA
+// fragment order.
+//
+// Block = 256 threads (4 waves), tile BM pixels x BN channels, BK = 128 bytes.
+// Two LDS stages, register-staged (the gather needs per-row predication / zero
+// fill for padding), one barrier per K-step.  LDS rows are 128 B with a 16-byte
+// chunk XOR swizzle chunk ^= (row>>1)&7, conflict-free for the ds_read_b128
+// fragment reads.  Operands are swapped (weights = MFMA "A", pixels = MFMA "B")
+// so a lane ends up with 4 consecutive output channels of one pixel.  The
+// epilogue stages the tile through LDS, then streams full rows: optional addend
+// (dgrad accumulation), optional per-channel sum / sum-of-squares of the STORED
+// values (BatchNorm statistics), 16-byte coalesced stores.
+#include "common.h"
+
+namespace gdl {
+
+struct ConvArgs {
+    const void* in;      // gather source, NHWC [N][IH][IW][IC]
+    const void* wt;      // [OC][R][S][IC]
+    void* out;           // NHWC [N][OH][OW][OC]
+    const void* addend;  // optional, like out
+    float* stats;        // optional [mtiles][OC][2]
+    int N, IH, IW, IC, OH, OW, OC, R, S, stride, pad;
+    int M;       // N*OH*OW
+    int mtiles;  // ceil(M/BM)
+    int ohow;
+    float rcp_ohow, rcp_ow;
+};
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16> {
+    // one 16-byte chunk per lane = 8 bf16 = the whole K=32 operand of one 16x16x32 MFMA
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0,
+                                                    0, 0);
+    }
+};
+template <>
+struct Mma<float> {
+    // one 16-byte chunk per lane = 4 floats = the operands of four 16x16x4 MFMAs
+    static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+template <int BM, int BN, typename T>
+struct ConvSmem {
+    static constexpr int STAGE = (BM + BN) * 128;
+    static constexpr int MAIN = 2 * STAGE;
+    static constexpr int PITCH = BN * (int)sizeof(T) + 16;
+    static constexpr int CS = BM * PITCH;
+    static constexpr int RED = 4 * BN * 2 * 4;
+    static constexpr int BYTES = (MAIN > CS + RED) ? MAIN : (CS + RED);
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using SM = ConvSmem<BM, BN, T>;
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int BKE = 8 * EPC;  // elements per K-step
+    constexpr int AROWS = BM / 32, BROWS = BN / 32;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+    static_assert(WM * WN == 4, "4 waves");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+
+    // ---- tile mapping: consecutive M-tiles stay on one XCD (block b runs on XCD b%8), all
+    // N-tiles of an M-tile are neighbours on that XCD, so the input halo and the A panel hit L2
+    const int ntn = a.OC / BN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int mt_per_xcd = (a.mtiles + 7) >> 3;
+    const int mtile = xcd * mt_per_xcd + j / ntn;
+    const int ntile = j % ntn;
+    if (mtile >= a.mtiles) return;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    // ---- per-thread gather bookkeeping for the A (pixel) rows
+    const int chunk = tid & 7, row0 = tid >> 3;
+    int a_base[AROWS], a_hs[AROWS], a_ws[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        if (m < a.M) {
+            const int n = fdiv_small(m, a.ohow, a.rcp_ohow);
+            const int rem = m - n * a.ohow;
+            const int oh = fdiv_small(rem, a.OW, a.rcp_ow);
+            const int ow = rem - oh * a.OW;
+            a_base[i] = n * a.IH * a.IW;
+            if (MODE == MODE_FWD) {
+                a_hs[i] = oh * a.stride - a.pad;
+                a_ws[i] = ow * a.stride - a.pad;
+            } else {
+                a_hs[i] = oh + a.pad;
+                a_ws[i] = ow + a.pad;
+            }
+        } else {
+            a_base[i] = -1;
+            a_hs[i] = 0;
+            a_ws[i] = 0;
+        }
+    }
+    const int kpt = a.IC / BKE;  // K-steps per tap
+    const int nk = a.R * a.S * kpt;
+    const T* __restrict__ gin = (const T*)a.in;
+    const T* __restrict__ gw = (const T*)a.wt;
+    const int sshift = (a.stride == 2) ? 1 : 0;
+
+    uint4 va[AROWS], vb[BROWS];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / kpt;
+        const int c0 = (kt - tap * kpt) * BKE + chunk * EPC;
+        const int r = tap / a.S, s = tap - r * a.S;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            int ih, iw;
+            bool ok = a_base[i] >= 0;
+            if (MODE == MODE_FWD) {
+                ih = a_hs[i] + r;
+                iw = a_ws[i] + s;
+            } else {
+                const int th = a_hs[i] - r, tw = a_ws[i] - s;
+                ok = ok && th >= 0 && tw >= 0 && (((th | tw) & sshift) == 0);
+                ih = th >> sshift;
+                iw = tw >> sshift;
+            }
+            ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+            if (ok) {
+                const size_t off = (size_t)(a_base[i] + ih * a.IW + iw) * a.IC + c0;
+                va[i] = *(const uint4*)(gin + off);
+            } else {
+                va[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int oc = n0 + row0 + 32 * i;
+            const size_t off = ((size_t)oc * (a.R * a.S) + tap) * a.IC + c0;
+            vb[i] = *(const uint4*)(gw + off);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* As = smem + buf * SM::STAGE;
+        unsigned char* Bs = As + BM * 128;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int row = row0 + 32 * i;
+            *(uint4*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = va[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) {
+            const int row = row0 + 32 * i;
+            *(uint4*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = vb[i];
+        }
+    };
+
+    f32x4_t acc[NI][MI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int m = 0; m < MI; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = tilebase + (lane&15), logical chunk = kk*4 + (lane>>4)
+    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const int off_kk0 = frow * 128 + (((0 + fg) ^ fswz) << 4);
+    const int off_kk1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const unsigned char* As = smem + buf * SM::STAGE + (wm * WTM) * 128;
+        const unsigned char* Bs = smem + buf * SM::STAGE + BM * 128 + (wn * WTN) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int off = kk ? off_kk1 : off_kk0;
+            uint4 px[MI], wf[NI];
+#pragma unroll
+            for (int m = 0; m < MI; ++m) px[m] = *(const uint4*)(As + m * 16 * 128 + off);
+#pragma unroll
+            for (int n = 0; n < NI; ++n) wf[n] = *(const uint4*)(Bs + n * 16 * 128 + off);
+#pragma unroll
+            for (int n = 0; n < NI; ++n)
+#pragma unroll
+                for (int m = 0; m < MI; ++m) Mma<T>::run(wf[n], px[m], acc[n][m]);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS tile [BM][BN] of T.
+    // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
+    unsigned char* Cs = smem;
+    {
+        const int px_row = wm * WTM + (lane & 15);
+        const int ch = wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+            for (int m = 0; m < MI; ++m) {
+                unsigned char* p = Cs + (px_row + m * 16) * SM::PITCH + (ch + n * 16) * (int)sizeof(T);
+                if (sizeof(T) == 2) {
+                    *(uint2*)p = make_uint2(pack2bf(acc[n][m][0], acc[n][m][1]), pack2bf(acc[n][m][2], acc[n][m][3]));
+                } else {
+                    *(float4*)p = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+                }
+            }
+    }
+    __syncthreads();
+    constexpr int CH = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
+    constexpr int RPI = 256 / CH;                  // rows per pass
+    const int ec = tid % CH, er0 = tid / CH;
+    float ssum[EPC], ssq[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) ssum[e] = ssq[e] = 0.f;
+    T* __restrict__ gout = (T*)a.out;
+    const T* __restrict__ gadd = (const T*)a.addend;
+    for (int row = er0; row < BM; row += RPI) {
+        const int m = m0 + row;
+        if (m >= a.M) break;
+        uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
+        const size_t goff = (size_t)m * a.OC + n0 + ec * EPC;
+        if (gadd) {
+            float f[EPC], g[EPC];
+            unpack16<T>(v, f);
+            const uint4 w = *(const uint4*)(gadd + goff);
+            unpack16<T>(w, g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            v = pack16<T>(f);
+        }
+        if (a.stats) {
+            float f[EPC];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                ssum[e] += f[e];
+                ssq[e] += f[e] * f[e];
+            }
+        }
+        *(uint4*)(gout + goff) = v;
+    }
+    if (a.stats) {
+        // lanes with equal (lane % CH) hold the same channels: fold them, then fold the 4 waves in fixed order
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            for (int msk = CH; msk < 64; msk <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], msk);
+                ssq[e] += __shfl_xor(ssq[e], msk);
+            }
+        }
+        float* red = (float*)(smem + SM::CS);  // [4 waves][BN][2]
+        if (CH >= 64 || lane < CH) {
+            // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
+            const int c = (lane % CH) * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                red[(wave * BN + c + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + c + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int c = tid >> 1, w = tid & 1;
+            const float s = ((red[(0 * BN + c) * 2 + w] + red[(1 * BN + c) * 2 + w]) + red[(2 * BN + c) * 2 + w]) +
+                            red[(3 * BN + c) * 2 + w];
+            a.stats[((size_t)mtile * a.OC + n0 + c) * 2 + w] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct TileCfg {
+    int bm, bn;
+};
+
+static TileCfg pick_cfg(int M, int OC, int dtype) {
+    (void)dtype;
+    if (OC == 64) return {256, 64};
+    // 128x128 while it still yields >= 2 blocks per CU's worth of tiles, else 64x64
+    const long blocks = (long)((M + 127) / 128) * (OC / 128);
+    if (OC % 128 == 0 && blocks >= 384) return {128, 128};
+    return {64, 64};
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
+static int launch_one(ConvArgs& a, hipStream_t st) {
+    using SM = ConvSmem<BM, BN, T>;
+    a.mtiles = ceil_div(a.M, BM);
+    auto kfn = conv_igemm_kernel<T, BM, BN, WM, WN, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_igemm)");
+        attr_set = true;
+    }
+    const int ntn = a.OC / BN;
+    const int grid = ((a.mtiles + 7) / 8) * 8 * ntn;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, a);
+    GDL_CHECK_LAUNCH("conv_igemm_kernel");
+    return GDL_OK;
+}
+
+template <typename T, int MODE>
+static int launch_mode(ConvArgs& a, int dtype, hipStream_t st) {
+    const TileCfg c = pick_cfg(a.M, a.OC, dtype);
+    if (c.bm == 256) return launch_one<T, 256, 64, 4, 1, MODE>(a, st);
+    if (c.bm == 128) return launch_one<T, 128, 128, 2, 2, MODE>(a, st);
+    return launch_one<T, 64, 64, 2, 2, MODE>(a, st);
+}
+
+int conv_tiles_m(int dtype, int M, int OC) {
+    const TileCfg c = pick_cfg(M, OC, dtype);
+    return ceil_div(M, c.bm);
+}
+
+static int fill_common(ConvArgs& a, int dtype) {
+    const int bke = (dtype == GDL_BF16) ? 64 : 32;
+    GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
+    GDL_REQUIRE(a.IC % bke == 0, "conv: gather channels %d not a multiple of %d", a.IC, bke);
+    GDL_REQUIRE(a.OC % 64 == 0, "conv: output channels %d not a multiple of 64", a.OC);
+    GDL_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride %d unsupported", a.stride);
+    GDL_REQUIRE((long)a.N * a.OH * a.OW < (1L << 24), "conv: M = %ld exceeds 2^24", (long)a.N * a.OH * a.OW);
+    GDL_REQUIRE((size_t)a.N * a.IH * a.IW * (size_t)a.IC < (1UL << 31), "conv: input too large for 32-bit pixel index");
+    a.M = a.N * a.OH * a.OW;
+    a.ohow = a.OH * a.OW;
+    a.rcp_ohow = 1.0f / (float)a.ohow;
+    a.rcp_ow = 1.0f / (float)a.OW;
+    return GDL_OK;
+}
+
+int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, int N, int H, int W, int C, int K, int R,
+             int S, int stride, int pad, hipStream_t st) {
+    ConvArgs a{};
+    a.in = x;
+    a.wt = w;
+    a.out = y;
+    a.addend = nullptr;
+    a.stats = bn_partial;
+    a.N = N;
+    a.IH = H;
+    a.IW = W;
+    a.IC = C;
+    a.OH = (H + 2 * pad - R) / stride + 1;
+    a.OW = (W + 2 * pad - S) / stride + 1;
+    a.OC = K;
+    a.R = R;
+    a.S = S;
+    a.stride = stride;
+    a.pad = pad;
+    int rc = fill_common(a, dtype);
+    if (rc) return rc;
+    if (dtype == GDL_BF16) return launch_mode<bf16, MODE_FWD>(a, dtype, st);
+    return launch_mode<float, MODE_FWD>(a, dtype, st);
+}
+
+int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H, int W, int C,
+               int K, int R, int S, int stride, int pad, hipStream_t st) {
+    ConvArgs a{};
+    a.in = dy;
+    a.wt = w_crsk;
+    a.out = dx;
+    a.addend = addend;
+    a.stats = nullptr;
+    a.N = N;
+    a.IH = (H + 2 * pad - R) / stride + 1;  // P
+    a.IW = (W + 2 * pad - S) / stride + 1;  // Q
+    a.IC = K;
+    a.OH = H;
+    a.OW = W;
+    a.OC = C;
+    a.R = R;
+    a.S = S;
+    a.stride = stride;
+    a.pad = pad;
+    int rc = fill_common(a, dtype);
+    if (rc) return rc;
+    if (dtype == GDL_BF16) return launch_mode<bf16, MODE_DGRAD>(a, dtype, st);
+    return launch_mode<float, MODE_DGRAD>(a, dtype, st);
+}
+
+}  // namespace gdl

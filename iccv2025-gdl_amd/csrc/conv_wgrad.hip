@@ -1,0 +1,364 @@
+// conv_wgrad.hip -- convolution weight-gradient on MFMA (gfx950).
+//
+// Replaces the weight-gradient of nn.Conv2d (/root/reference/models/backbone.py:20-28,
+// 96-101) for NHWC activations:  dw[k][r][s][c] = sum_m dy[m][k] * x[gather(m,r,s)][c].
+// GEMM view per tap: rows i = k (output channels), cols j = c (input channels),
+// reduction over the M = N*P*Q output pixels.  Both operands are stored pixel-major
+// ([pixel][channel]), i.e. the reduction index is the slow one, so the MFMA fragments
+// (8 consecutive reduction elements per lane) are produced by the gfx950 LDS transpose
+// read ds_read_b64_tr_b16 for bf16; the f32 MFMA takes one element per lane and needs
+// no transpose.
+//
+// Block = 256 threads (2x2 waves), tile TK x TC output channels for ONE tap and ONE
+// slice of the pixel range (split-K); LDS stages of 64 pixels, double buffered,
+// register staged.  Partial tiles go to a workspace [split][K][R*S][C] f32; a second
+// kernel folds the splits in a fixed order and writes the reference's [K][C][R][S]
+// gradient layout.  Tap is the fastest-varying index among blocks that share an XCD,
+// so the 9 taps of one pixel slice reuse dy / x from that XCD's L2.
+#include "common.h"
+
+namespace gdl {
+
+struct WgradArgs {
+    const void* dy;  // [N][P][Q][K]
+    const void* x;   // [N][H][W][C]
+    float* partial;  // [nsplit][K][RS][C]
+    int N, H, W, C, P, Q, K, R, S, stride, pad;
+    int M, pq;
+    float rcp_pq, rcp_q;
+    int nsplit, chunk;  // pixels per split (multiple of 64)
+    int tiles_k, tiles_c;
+};
+
+constexpr int WG_BP = 64;  // pixels per LDS stage
+
+// ds_read_b64_tr_b16: within each 16-lane group the 16 lanes' 8-byte reads form a 4x16 block of
+// 16-bit elements (lane i supplies row i>>2, columns (i&3)*4..+3); lane i receives column i.
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    return __builtin_bit_cast(uint2, v);
+}
+
+// 32-byte granule swizzle of a [pixel][channel] LDS tile (see DESIGN.md "wgrad LDS image")
+template <int PITCH>
+__device__ __forceinline__ int wg_swz(int row) {
+    if (PITCH == 128) return ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    return (row & 3) | (((row >> 3) & 1) << 2);
+}
+
+template <typename T, int TK, int TC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int PK = TK * (int)sizeof(T), PC = TC * (int)sizeof(T);  // row pitches (bytes)
+    constexpr int STAGE = WG_BP * (PK + PC);
+    constexpr int CPR_K = PK / 16, CPR_C = PC / 16;                    // 16-byte chunks per row
+    constexpr int LK = WG_BP * CPR_K / 256, LC = WG_BP * CPR_C / 256;  // loads per thread
+    constexpr int WTK = TK / 2, WTC = TC / 2, FK = WTK / 16, FC = WTC / 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 1, wc = wave >> 1;
+
+    // block -> (slice, tap, ktile, ctile); blocks b, b+8, b+16.. share an XCD: keep the taps and
+    // channel tiles of one pixel slice on it
+    const int RS = a.R * a.S;
+    const int per_slice = RS * a.tiles_k * a.tiles_c;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slices_per_xcd = (a.nsplit + 7) >> 3;
+    const int slice = xcd * slices_per_xcd + j / per_slice;
+    if (slice >= a.nsplit) return;
+    int rem = j % per_slice;
+    const int tap = rem % RS;
+    rem /= RS;
+    const int kt = rem % a.tiles_k, ct = rem / a.tiles_k;
+    const int k0 = kt * TK, c0 = ct * TC;
+    const int r = tap / a.S, s = tap - r * a.S;
+
+    const int m_begin = slice * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int nst = (m_end - m_begin + WG_BP - 1) / WG_BP;
+
+    const T* __restrict__ gdy = (const T*)a.dy;
+    const T* __restrict__ gx = (const T*)a.x;
+
+    uint4 vk[LK], vc[LC];
+    auto load_stage = [&](int st) {
+        const int mb = m_begin + st * WG_BP;
+#pragma unroll
+        for (int i = 0; i < LK; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_K, ch = idx % CPR_K;
+            const int m = mb + row;
+            if (m < m_end)
+                vk[i] = *(const uint4*)(gdy + (size_t)m * a.K + k0 + ch * EPC);
+            else
+                vk[i] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < LC; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_C, ch = idx % CPR_C;
+            const int m = mb + row;
+            bool ok = m < m_end;
+            size_t off = 0;
+            if (ok) {
+                const int n = fdiv_small(m, a.pq, a.rcp_pq);
+                const int rm = m - n * a.pq;
+                const int p = fdiv_small(rm, a.Q, a.rcp_q);
+                const int q = rm - p * a.Q;
+                const int ih = p * a.stride - a.pad + r, iw = q * a.stride - a.pad + s;
+                ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                off = ((size_t)(n * a.H + ih) * a.W + iw) * a.C + c0 + ch * EPC;
+            }
+            vc[i] = ok ? *(const uint4*)(gx + off) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        unsigned char* Ks = smem + buf * STAGE;
+        unsigned char* Cs = Ks + WG_BP * PK;
+#pragma unroll
+        for (int i = 0; i < LK; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_K, ch = idx % CPR_K;
+            const int pch = (((ch >> 1) ^ wg_swz<PK>(row)) << 1) | (ch & 1);
+            *(uint4*)(Ks + row * PK + pch * 16) = vk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LC; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_C, ch = idx % CPR_C;
+            const int pch = (((ch >> 1) ^ wg_swz<PC>(row)) << 1) | (ch & 1);
+            *(uint4*)(Cs + row * PC + pch * 16) = vc[i];
+        }
+    };
+
+    f32x4_t acc[FK][FC];
+#pragma unroll
+    for (int i = 0; i < FK; ++i)
+#pragma unroll
+        for (int jj = 0; jj < FC; ++jj) acc[i][jj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15;
+
+    if (nst > 0) {
+        load_stage(0);
+        store_stage(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(st + 1);
+        const unsigned char* Ks = smem + buf * STAGE;
+        const unsigned char* Cs = Ks + WG_BP * PK;
+        if (sizeof(T) == 2) {
+            // bf16: K-step = 32 pixels; lane group g owns pixels ks*32 + g*8 + {0..7}, fetched as two
+            // transposed 4x16 blocks: lane li supplies row (li>>2), columns (li&3)*4.. and receives
+            // column li of the block (verified on gfx950 by csrc/probe).
+#pragma unroll
+            for (int ks = 0; ks < WG_BP / 32; ++ks) {
+                uint4 fa[FK], fb[FC];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = ks * 32 + g * 8 + h * 4 + (li >> 2);
+#pragma unroll
+                    for (int i = 0; i < FK; ++i) {
+                        const int chb = (wk * WTK + i * 16 + (li & 3) * 4) * 2;  // byte offset in row
+                        const int addr = row * PK + ((((chb >> 5) ^ wg_swz<PK>(row)) << 5) | (chb & 31));
+                        const uint2 u = lds_tr16(Ks + addr);
+                        if (h == 0) {
+                            fa[i].x = u.x;
+                            fa[i].y = u.y;
+                        } else {
+                            fa[i].z = u.x;
+                            fa[i].w = u.y;
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < FC; ++jj) {
+                        const int chb = (wc * WTC + jj * 16 + (li & 3) * 4) * 2;
+                        const int addr = row * PC + ((((chb >> 5) ^ wg_swz<PC>(row)) << 5) | (chb & 31));
+                        const uint2 u = lds_tr16(Cs + addr);
+                        if (h == 0) {
+                            fb[jj].x = u.x;
+                            fb[jj].y = u.y;
+                        } else {
+                            fb[jj].z = u.x;
+                            fb[jj].w = u.y;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FK; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < FC; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
+                                                                           __builtin_bit_cast(bf16x8_t, fb[jj]),
+                                                                           acc[i][jj], 0, 0, 0);
+            }
+        } else {
+            // f32: 16x16x4 MFMA, A[i = li][k = g], B[k = g][j = li]: one float per lane, pixel = ks*4 + g
+#pragma unroll 4
+            for (int ks = 0; ks < WG_BP / 4; ++ks) {
+                const int row = ks * 4 + g;
+                float fa[FK], fb[FC];
+#pragma unroll
+                for (int i = 0; i < FK; ++i) {
+                    const int chb = (wk * WTK + i * 16 + li) * 4;
+                    fa[i] = *(const float*)(Ks + row * PK + ((((chb >> 5) ^ wg_swz<PK>(row)) << 5) | (chb & 31)));
+                }
+#pragma unroll
+                for (int jj = 0; jj < FC; ++jj) {
+                    const int chb = (wc * WTC + jj * 16 + li) * 4;
+                    fb[jj] = *(const float*)(Cs + row * PC + ((((chb >> 5) ^ wg_swz<PC>(row)) << 5) | (chb & 31)));
+                }
+#pragma unroll
+                for (int i = 0; i < FK; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < FC; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nst) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i][j]: i = k channel = g*4 + reg, j = c channel = li
+    float* part = a.partial + (size_t)slice * a.K * RS * a.C;
+#pragma unroll
+    for (int i = 0; i < FK; ++i)
+#pragma unroll
+        for (int jj = 0; jj < FC; ++jj) {
+            const int c = c0 + wc * WTC + jj * 16 + li;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + wk * WTK + i * 16 + g * 4 + e;
+                part[((size_t)k * RS + tap) * a.C + c] = acc[i][jj][e];
+            }
+        }
+}
+
+// out[k][c][r][s] = sum_split partial[split][k][rs][c], c < Cout (Cout <= C drops im2col padding)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nsplit, int K, int RS,
+                                    int C, int Cout) {
+    const size_t total = (size_t)K * RS * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int rs = (int)(t % RS);
+        const int k = (int)(t / RS);
+        if (c >= Cout) continue;
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * total + i];
+        out[((size_t)k * Cout + c) * RS + rs] = s;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct WgradPlan {
+    int tk, tc, nsplit, chunk;
+};
+
+static WgradPlan plan_wgrad(int M, int C, int K, int RS) {
+    WgradPlan p;
+    p.tk = (K % 128 == 0) ? 128 : 64;
+    p.tc = (C % 128 == 0) ? 128 : 64;
+    const int tiles = (K / p.tk) * (C / p.tc) * RS;
+    // aim at ~2048 blocks, at least 2 stages of work per block, split count a multiple of 8
+    int ns = (2048 + tiles - 1) / tiles;
+    const int max_ns = (M + 2 * WG_BP - 1) / (2 * WG_BP);
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    ns = (ns + 7) / 8 * 8;
+    int chunk = (M + ns - 1) / ns;
+    chunk = (chunk + WG_BP - 1) / WG_BP * WG_BP;
+    p.nsplit = (M + chunk - 1) / chunk;
+    p.chunk = chunk;
+    return p;
+}
+
+size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS) {
+    const WgradPlan p = plan_wgrad(M, C, K, RS);
+    return (size_t)p.nsplit * K * RS * C * sizeof(float);
+}
+
+template <typename T, int TK, int TC>
+static int launch_wg(WgradArgs& a, hipStream_t st) {
+    constexpr int BYTES = 2 * WG_BP * (TK + TC) * (int)sizeof(T);
+    auto kfn = conv_wgrad_kernel<T, TK, TC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad)");
+        attr_set = true;
+    }
+    const int per_slice = a.R * a.S * a.tiles_k * a.tiles_c;
+    const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, a);
+    GDL_CHECK_LAUNCH("conv_wgrad_kernel");
+    return GDL_OK;
+}
+
+// Cout: number of leading input channels kept in dw (== C except for the padded stem im2col)
+int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int R, int S,
+               int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    WgradArgs a{};
+    a.dy = dy;
+    a.x = x;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.C = C;
+    a.K = K;
+    a.R = R;
+    a.S = S;
+    a.stride = stride;
+    a.pad = pad;
+    a.P = (H + 2 * pad - R) / stride + 1;
+    a.Q = (W + 2 * pad - S) / stride + 1;
+    GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "wgrad: bad dtype %d", dtype);
+    GDL_REQUIRE(C % 64 == 0 && K % 64 == 0, "wgrad: C=%d K=%d must be multiples of 64", C, K);
+    GDL_REQUIRE((long)N * a.P * a.Q < (1L << 24), "wgrad: M exceeds 2^24");
+    GDL_REQUIRE((size_t)N * H * W < (1UL << 31), "wgrad: too many input pixels");
+    a.M = N * a.P * a.Q;
+    a.pq = a.P * a.Q;
+    a.rcp_pq = 1.0f / (float)a.pq;
+    a.rcp_q = 1.0f / (float)a.Q;
+    const WgradPlan p = plan_wgrad(a.M, C, K, R * S);
+    a.nsplit = p.nsplit;
+    a.chunk = p.chunk;
+    a.tiles_k = K / p.tk;
+    a.tiles_c = C / p.tc;
+    const size_t need = (size_t)p.nsplit * K * R * S * C * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        set_error("wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDL_ERR_WORKSPACE;
+    }
+    a.partial = (float*)ws;
+    int rc;
+    if (dtype == GDL_BF16) {
+        if (p.tk == 128 && p.tc == 128)
+            rc = launch_wg<bf16, 128, 128>(a, st);
+        else if (p.tk == 128)
+            rc = launch_wg<bf16, 128, 64>(a, st);
+        else if (p.tc == 128)
+            rc = launch_wg<bf16, 64, 128>(a, st);
+        else
+            rc = launch_wg<bf16, 64, 64>(a, st);
+    } else {
+        if (p.tk == 128 && p.tc == 128)
+            rc = launch_wg<float, 128, 128>(a, st);
+        else if (p.tk == 128)
+            rc = launch_wg<float, 128, 64>(a, st);
+        else if (p.tc == 128)
+            rc = launch_wg<float, 64, 128>(a, st);
+        else
+            rc = launch_wg<float, 64, 64>(a, st);
+    }
+    if (rc) return rc;
+    const size_t total = (size_t)K * R * S * C;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, a.partial, dw, p.nsplit, K, R * S, C, Cout);
+    GDL_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return GDL_OK;
+}
+
+}  // namespace gdl

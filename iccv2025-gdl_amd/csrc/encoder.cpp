@@ -1,0 +1,443 @@
+// encoder.cpp -- ResNet18 encoder engine: a planned sequence of libgdl_hip kernels on ONE stream.
+//
+// Mirrors `resnet18(modality, args)` / `ResNet.forward` of /root/reference/models/backbone.py
+// (:75-156 topology, :158-201 forward, BasicBlock.forward :52-68) plus the pooling glue of
+// AVClassifier_DGL.forward (/root/reference/models/basic_model.py:73-82).  No autograd tape:
+// the engine keeps exactly the tensors its own backward needs in a caller-provided workspace
+// (sized for 288 GB HBM: nothing is recomputed, the stem im2col matrix is kept for wgrad).
+//
+// Per BasicBlock forward:   y1 = conv1(x) [+BN stats in the conv epilogue]; a1 = relu(bn1(y1));
+//                           y2 = conv2(a1); [yd = convd(x)]; z = relu(bn2(y2) + (bnd(yd) | x)).
+// Backward:  do2 = dz*(z>0); bn2/bnd backward (two passes each); wgrad; dgrad with the identity /
+//            downsample gradient accumulated in the dgrad epilogue.
+#include <vector>
+
+#include "ops.h"
+
+using namespace gdl;
+
+namespace {
+
+struct Conv {
+    int cin, cout, r, s, stride, pad;
+    int h, w, p, q;  // input / output spatial size
+    int pidx;        // index of the weight in the 60-parameter table
+    void* w_krsc = nullptr;
+    void* w_crsk = nullptr;
+};
+struct BN {
+    int c;
+    int pidx;  // gamma index (beta = pidx + 1)
+    int bidx;  // 0..19
+    float *scale = nullptr, *shift = nullptr, *mean = nullptr, *rstd = nullptr, *coef = nullptr;
+};
+struct Block {
+    Conv c1, c2, cd;
+    BN b1, b2, bd;
+    bool has_ds = false;
+    int n, h, w, p, q, cin, cout;
+    void *y1 = nullptr, *a1 = nullptr, *y2 = nullptr, *yd = nullptr, *z = nullptr;
+    const void* xin = nullptr;
+};
+
+struct Bump {
+    size_t off = 0;
+    unsigned char* base = nullptr;
+    void* take(size_t bytes) {
+        off = align_up(off, 256);
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+}  // namespace
+
+struct gdl_encoder {
+    int modality, dtype, B, T, H, W, cin, n_img;
+    int esz;  // bytes per activation element
+    // stem
+    int h0, w0, h1, w1, kp;
+    long m0;  // n_img*h0*w0
+    BN bn0;
+    void *col = nullptr, *w0p = nullptr, *y0 = nullptr, *x1 = nullptr;
+    uint8_t* idx = nullptr;
+    std::vector<Block> blocks;
+    int hf, wf;  // final map
+    // scratch
+    void *gA = nullptr, *gB = nullptr, *gC = nullptr, *gD = nullptr, *gE = nullptr, *g0 = nullptr;
+    float *bn_partial = nullptr, *bnb_partial = nullptr, *dw0p = nullptr;
+    void* wg_ws = nullptr;
+    size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
+    size_t ws_bytes = 0;
+    void* ws = nullptr;
+    // bound tables
+    const float* params[GDL_ENC_NPARAMS] = {nullptr};
+    float* rmean[GDL_ENC_NBN] = {nullptr};
+    float* rvar[GDL_ENC_NBN] = {nullptr};
+    int64_t* nbt[GDL_ENC_NBN] = {nullptr};
+    bool params_set = false;
+    int64_t serial = 0;
+    bool have_train_fwd = false;
+    int64_t numel[GDL_ENC_NPARAMS];
+
+    size_t plan(unsigned char* base);
+};
+
+// lays out every buffer in the workspace; with base == nullptr only measures
+size_t gdl_encoder::plan(unsigned char* base) {
+    Bump b;
+    b.base = base;
+    const size_t e = (size_t)esz;
+    col = b.take((size_t)m0 * kp * e);
+    w0p = b.take((size_t)64 * kp * e);
+    y0 = b.take((size_t)m0 * 64 * e);
+    x1 = b.take((size_t)n_img * h1 * w1 * 64 * e);
+    idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
+    dw0p = (float*)b.take((size_t)64 * kp * sizeof(float));
+    auto bn_alloc = [&](BN& n) {
+        n.scale = (float*)b.take(sizeof(float) * n.c);
+        n.shift = (float*)b.take(sizeof(float) * n.c);
+        n.mean = (float*)b.take(sizeof(float) * n.c);
+        n.rstd = (float*)b.take(sizeof(float) * n.c);
+        n.coef = (float*)b.take(sizeof(float) * 2 * n.c);
+    };
+    auto conv_alloc = [&](Conv& c) {
+        const size_t n = (size_t)c.cout * c.cin * c.r * c.s * e;
+        c.w_krsc = b.take(n);
+        c.w_crsk = b.take(n);
+    };
+    bn_alloc(bn0);
+    size_t max_act = (size_t)n_img * h1 * w1 * 64;  // elements
+    size_t max_tiles_c = (size_t)conv_tiles_m(dtype, (int)m0, 64) * 64;
+    size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0) * 64;
+    size_t wg = conv_wgrad_ws_bytes((int)m0, kp, 64, 1);
+    const void* prev = x1;
+    for (Block& k : blocks) {
+        const size_t out_el = (size_t)k.n * k.p * k.q * k.cout;
+        k.xin = prev;
+        k.y1 = b.take(out_el * e);
+        k.a1 = b.take(out_el * e);
+        k.y2 = b.take(out_el * e);
+        k.z = b.take(out_el * e);
+        conv_alloc(k.c1);
+        conv_alloc(k.c2);
+        bn_alloc(k.b1);
+        bn_alloc(k.b2);
+        if (k.has_ds) {
+            k.yd = b.take(out_el * e);
+            conv_alloc(k.cd);
+            bn_alloc(k.bd);
+        }
+        const size_t in_el = (size_t)k.n * k.h * k.w * k.cin;
+        if (out_el > max_act) max_act = out_el;
+        if (in_el > max_act) max_act = in_el;
+        const int M = k.n * k.p * k.q;
+        const size_t tc = (size_t)conv_tiles_m(dtype, M, k.cout) * k.cout;
+        if (tc > max_tiles_c) max_tiles_c = tc;
+        const size_t bb = (size_t)bn_bwd_blocks((size_t)M) * k.cout;
+        if (bb > max_bnb) max_bnb = bb;
+        size_t w1 = conv_wgrad_ws_bytes(M, k.cin, k.cout, 9);
+        size_t w2 = conv_wgrad_ws_bytes(M, k.cout, k.cout, 9);
+        size_t w3 = k.has_ds ? conv_wgrad_ws_bytes(M, k.cin, k.cout, 1) : 0;
+        if (w1 > wg) wg = w1;
+        if (w2 > wg) wg = w2;
+        if (w3 > wg) wg = w3;
+        prev = k.z;
+    }
+    gA = b.take(max_act * e);
+    gB = b.take(max_act * e);
+    gC = b.take(max_act * e);
+    gD = b.take(max_act * e);
+    gE = b.take(max_act * e);
+    g0 = b.take((size_t)m0 * 64 * e);
+    bn_partial_floats = max_tiles_c * 2;
+    bnb_partial_floats = max_bnb * 2;
+    bn_partial = (float*)b.take(bn_partial_floats * sizeof(float));
+    bnb_partial = (float*)b.take(bnb_partial_floats * sizeof(float));
+    wg_ws_bytes = wg;
+    wg_ws = b.take(wg);
+    return align_up(b.off, 256);
+}
+
+extern "C" {
+
+int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int T, int H, int W) {
+    GDL_REQUIRE(out, "encoder_create: null out");
+    GDL_REQUIRE(modality == GDL_AUDIO || modality == GDL_VISUAL, "encoder_create: modality %d", modality);
+    GDL_REQUIRE(dtype == GDL_F32 || dtype == GDL_BF16, "encoder_create: dtype %d", dtype);
+    GDL_REQUIRE(B > 0 && T > 0 && H >= 7 && W >= 7, "encoder_create: bad shape B=%d T=%d H=%d W=%d", B, T, H, W);
+    GDL_REQUIRE(modality == GDL_VISUAL || T == 1, "encoder_create: audio takes T=1");
+    gdl_encoder* e = new gdl_encoder();
+    e->modality = modality;
+    e->dtype = dtype;
+    e->B = B;
+    e->T = T;
+    e->H = H;
+    e->W = W;
+    e->cin = modality == GDL_AUDIO ? 1 : 3;  // backbone.py:96-101
+    e->n_img = B * T;
+    e->esz = dtype == GDL_BF16 ? 2 : 4;
+    e->h0 = (H + 6 - 7) / 2 + 1;
+    e->w0 = (W + 6 - 7) / 2 + 1;
+    e->h1 = (e->h0 - 1) / 2 + 1;  // MaxPool2d(3,2,1)
+    e->w1 = (e->w0 - 1) / 2 + 1;
+    e->kp = stem_kp(e->cin, dtype);
+    e->m0 = (long)e->n_img * e->h0 * e->w0;
+    if (e->m0 >= (1L << 24)) {
+        set_error("encoder_create: stem output has %ld pixels (limit 2^24); lower the batch", e->m0);
+        delete e;
+        return GDL_ERR_ARG;
+    }
+    int pi = 0, bi = 0;
+    e->numel[pi] = (int64_t)64 * e->cin * 49;
+    pi++;  // conv1.weight
+    e->bn0.c = 64;
+    e->bn0.pidx = pi;
+    e->bn0.bidx = bi++;
+    e->numel[pi] = 64;
+    e->numel[pi + 1] = 64;
+    pi += 2;
+    int inpl = 64, h = e->h1, w = e->w1;
+    const int planes_of[4] = {64, 128, 256, 512};
+    for (int li = 0; li < 4; ++li) {  // _make_layer, backbone.py:134-156
+        for (int bk = 0; bk < 2; ++bk) {
+            Block k;
+            const int planes = planes_of[li];
+            const int stride = (bk == 0 && li > 0) ? 2 : 1;
+            k.has_ds = (stride != 1 || inpl != planes);
+            k.n = e->n_img;
+            k.h = h;
+            k.w = w;
+            k.cin = inpl;
+            k.cout = planes;
+            k.p = (h + 2 - 3) / stride + 1;
+            k.q = (w + 2 - 3) / stride + 1;
+            k.c1 = Conv{inpl, planes, 3, 3, stride, 1, h, w, k.p, k.q, pi};
+            e->numel[pi] = (int64_t)planes * inpl * 9;
+            k.b1.c = planes;
+            k.b1.pidx = pi + 1;
+            k.b1.bidx = bi++;
+            e->numel[pi + 1] = e->numel[pi + 2] = planes;
+            k.c2 = Conv{planes, planes, 3, 3, 1, 1, k.p, k.q, k.p, k.q, pi + 3};
+            e->numel[pi + 3] = (int64_t)planes * planes * 9;
+            k.b2.c = planes;
+            k.b2.pidx = pi + 4;
+            k.b2.bidx = bi++;
+            e->numel[pi + 4] = e->numel[pi + 5] = planes;
+            pi += 6;
+            if (k.has_ds) {
+                k.cd = Conv{inpl, planes, 1, 1, stride, 0, h, w, k.p, k.q, pi};
+                e->numel[pi] = (int64_t)planes * inpl;
+                k.bd.c = planes;
+                k.bd.pidx = pi + 1;
+                k.bd.bidx = bi++;
+                e->numel[pi + 1] = e->numel[pi + 2] = planes;
+                pi += 3;
+            }
+            e->blocks.push_back(k);
+            inpl = planes;
+            h = k.p;
+            w = k.q;
+        }
+    }
+    e->hf = h;
+    e->wf = w;
+    if (pi != GDL_ENC_NPARAMS || bi != GDL_ENC_NBN) {
+        delete e;
+        set_error("encoder_create: internal topology error (%d params, %d bn)", pi, bi);
+        return GDL_ERR_STATE;
+    }
+    e->ws_bytes = e->plan(nullptr);
+    *out = e;
+    return GDL_OK;
+}
+
+void gdl_encoder_destroy(gdl_encoder_t* e) { delete e; }
+
+size_t gdl_encoder_workspace_bytes(const gdl_encoder_t* e) { return e ? e->ws_bytes : 0; }
+
+int gdl_encoder_param_numel(const gdl_encoder_t* e, int64_t* numel) {
+    GDL_REQUIRE(e && numel, "encoder_param_numel: null");
+    for (int i = 0; i < GDL_ENC_NPARAMS; ++i) numel[i] = e->numel[i];
+    return GDL_OK;
+}
+
+int gdl_encoder_out_shape(const gdl_encoder_t* e, int* n_img, int* h, int* w) {
+    GDL_REQUIRE(e, "encoder_out_shape: null");
+    if (n_img) *n_img = e->n_img;
+    if (h) *h = e->hf;
+    if (w) *w = e->wf;
+    return GDL_OK;
+}
+
+int gdl_encoder_bind(gdl_encoder_t* e, void* workspace, size_t bytes) {
+    GDL_REQUIRE(e && workspace, "encoder_bind: null");
+    if (bytes < e->ws_bytes) {
+        set_error("encoder_bind: workspace %zu < %zu bytes", bytes, e->ws_bytes);
+        return GDL_ERR_WORKSPACE;
+    }
+    GDL_REQUIRE(((uintptr_t)workspace & 255) == 0, "encoder_bind: workspace must be 256-byte aligned");
+    e->ws = workspace;
+    e->plan((unsigned char*)workspace);
+    e->have_train_fwd = false;
+    return GDL_OK;
+}
+
+int gdl_encoder_set_params(gdl_encoder_t* e, const float* const* params, float* const* running_mean,
+                           float* const* running_var, int64_t* const* num_batches_tracked) {
+    GDL_REQUIRE(e && params && running_mean && running_var, "encoder_set_params: null");
+    for (int i = 0; i < GDL_ENC_NPARAMS; ++i) {
+        GDL_REQUIRE(params[i], "encoder_set_params: params[%d] is null", i);
+        e->params[i] = params[i];
+    }
+    for (int i = 0; i < GDL_ENC_NBN; ++i) {
+        GDL_REQUIRE(running_mean[i] && running_var[i], "encoder_set_params: running stats[%d] null", i);
+        e->rmean[i] = running_mean[i];
+        e->rvar[i] = running_var[i];
+        e->nbt[i] = num_batches_tracked ? num_batches_tracked[i] : nullptr;
+    }
+    e->params_set = true;
+    return GDL_OK;
+}
+
+int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e) { return e ? e->serial : -1; }
+
+#define RC(x)                 \
+    do {                      \
+        int rc__ = (x);       \
+        if (rc__) return rc__; \
+    } while (0)
+
+static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double count, hipStream_t st) {
+    const float* gamma = e->params[n.pidx];
+    const float* beta = e->params[n.pidx + 1];
+    if (training)
+        return bn_finalize_train(e->bn_partial, tiles, n.c, count, gamma, beta, 1e-5f, 0.1f, e->rmean[n.bidx],
+                                 e->rvar[n.bidx], e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift, st);
+    return bn_finalize_eval(n.c, gamma, beta, 1e-5f, e->rmean[n.bidx], e->rvar[n.bidx], n.scale, n.shift, st);
+}
+
+static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st) {
+    RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? e->bn_partial : nullptr, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s,
+                c.stride, c.pad, st));
+    const int M = nimg * c.p * c.q;
+    return bn_finalize(e, n, training, conv_tiles_m(e->dtype, M, c.cout), (double)M, st);
+}
+
+int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* feat_out, float* fmap_nchw,
+                        void* stream) {
+    GDL_REQUIRE(e && x, "encoder_forward: null");
+    GDL_REQUIRE(e->ws, "encoder_forward: no workspace bound");
+    GDL_REQUIRE(e->params_set, "encoder_forward: parameters not set");
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = e->dtype;
+    if (!training) e->have_train_fwd = false;  // an eval pass overwrites the saved activations
+    // weights -> kernel layouts (float32 master copies stay with the caller)
+    RC(pack_stem_weight(dt, e->params[0], e->w0p, e->cin, st));
+    for (Block& k : e->blocks) {
+        RC(pack_weight(dt, e->params[k.c1.pidx], k.c1.w_krsc, training ? k.c1.w_crsk : nullptr, k.c1.cout, k.c1.cin, 3, 3,
+                       st));
+        RC(pack_weight(dt, e->params[k.c2.pidx], k.c2.w_krsc, training ? k.c2.w_crsk : nullptr, k.c2.cout, k.c2.cin, 3, 3,
+                       st));
+        if (k.has_ds)
+            RC(pack_weight(dt, e->params[k.cd.pidx], k.cd.w_krsc, training ? k.cd.w_crsk : nullptr, k.cd.cout, k.cd.cin, 1,
+                           1, st));
+    }
+    // stem: conv1 (7x7/2) as im2col + GEMM, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
+    RC(stem_im2col(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
+    RC(conv_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0,
+                st));
+    RC(bn_finalize(e, e->bn0, training, conv_tiles_m(dt, (int)e->m0, 64), (double)e->m0, st));
+    RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, e->n_img, e->h0, e->w0, 64, st));
+    // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
+    for (Block& k : e->blocks) {
+        const size_t Mo = (size_t)k.n * k.p * k.q;
+        RC(conv_bn(e, k.c1, k.b1, k.xin, k.y1, k.n, training, st));
+        RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st));
+        RC(conv_bn(e, k.c2, k.b2, k.a1, k.y2, k.n, training, st));
+        if (k.has_ds) {
+            RC(conv_bn(e, k.cd, k.bd, k.xin, k.yd, k.n, training, st));
+            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st));
+        } else {
+            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.xin, nullptr, nullptr, 1, k.z, Mo, k.cout, st));
+        }
+    }
+    const Block& last = e->blocks.back();
+    if (feat_out) RC(avgpool_fwd(dt, last.z, feat_out, e->B, e->T, e->hf * e->wf, 512, st));
+    if (fmap_nchw) RC(nhwc_to_nchw_f32(dt, last.z, fmap_nchw, e->n_img, e->hf, e->wf, 512, st));
+    if (training) {
+        e->serial++;
+        e->have_train_fwd = true;
+    }
+    return GDL_OK;
+}
+
+static int bn_backward(gdl_encoder* e, BN& n, const void* g, const void* y, int relu_mask, void* dy, size_t M,
+                       float* const* grads, hipStream_t st) {
+    const int blocks = bn_bwd_blocks(M);
+    RC(bn_bwd_reduce(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, st));
+    RC(bn_bwd_finalize(e->bnb_partial, blocks, n.c, (double)M, grads[n.pidx], grads[n.pidx + 1], n.coef, st));
+    return bn_bwd_apply(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, relu_mask, dy, M, n.c,
+                        st);
+}
+
+int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfmap_nchw, float* const* grads,
+                         void* stream) {
+    GDL_REQUIRE(e && grads, "encoder_backward: null");
+    GDL_REQUIRE((dfeat != nullptr) != (dfmap_nchw != nullptr), "encoder_backward: pass exactly one of dfeat / dfmap_nchw");
+    if (!e->have_train_fwd) {
+        set_error("encoder_backward: no training-mode forward to differentiate");
+        return GDL_ERR_STATE;
+    }
+    for (int i = 0; i < GDL_ENC_NPARAMS; ++i) GDL_REQUIRE(grads[i], "encoder_backward: grads[%d] null", i);
+    hipStream_t st = (hipStream_t)stream;
+    const int dt = e->dtype;
+    // upstream gradient on the layer4 map -> gA
+    if (dfeat)
+        RC(avgpool_bwd(dt, dfeat, e->gA, e->B, e->T, e->hf * e->wf, 512, st));
+    else
+        RC(nchw_f32_to_nhwc(dt, dfmap_nchw, e->gA, e->n_img, e->hf, e->wf, 512, st));
+    void* dz = e->gA;    // gradient w.r.t. the current block's output
+    void* spare = e->gE;  // receives the gradient w.r.t. the block's input
+    for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
+        Block& k = e->blocks[bi];
+        const size_t Mo = (size_t)k.n * k.p * k.q;
+        const size_t out_el = Mo * k.cout;
+        // do2 = dz * (z > 0), in place                                  (relu of backbone.py:66)
+        RC(relu_bwd(dt, dz, k.z, dz, out_el, st));
+        void* do2 = dz;
+        // bn2 / conv2
+        RC(bn_backward(e, k.b2, do2, k.y2, 0, e->gB, Mo, grads, st));  // gB = dy2
+        RC(conv_wgrad(dt, e->gB, k.a1, grads[k.c2.pidx], k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout, e->wg_ws,
+                      e->wg_ws_bytes, st));
+        RC(conv_dgrad(dt, e->gB, k.c2.w_crsk, e->gC, nullptr, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, st));  // gC = da1
+        // relu + bn1 / conv1
+        RC(bn_backward(e, k.b1, e->gC, k.y1, 1, e->gC, Mo, grads, st));  // gC = dy1 (in place)
+        RC(conv_wgrad(dt, e->gC, k.xin, grads[k.c1.pidx], k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1, k.cin,
+                      e->wg_ws, e->wg_ws_bytes, st));
+        void* dxin;
+        if (k.has_ds) {
+            RC(bn_backward(e, k.bd, do2, k.yd, 0, e->gD, Mo, grads, st));  // gD = dyd
+            RC(conv_wgrad(dt, e->gD, k.xin, grads[k.cd.pidx], k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0, k.cin,
+                          e->wg_ws, e->wg_ws_bytes, st));
+            RC(conv_dgrad(dt, e->gD, k.cd.w_crsk, spare, nullptr, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0, st));
+            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, spare, spare, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1, st));
+            dxin = spare;
+            spare = dz;  // the old dz buffer is free now
+        } else {
+            // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
+            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, do2, do2, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
+            dxin = do2;
+        }
+        dz = dxin;
+    }
+    // stem: maxpool -> relu -> bn1 -> conv1 weight gradient (the input needs no gradient)
+    RC(maxpool_bwd(dt, dz, e->idx, e->g0, e->n_img, e->h0, e->w0, 64, st));
+    RC(bn_backward(e, e->bn0, e->g0, e->y0, 1, e->g0, (size_t)e->m0, grads, st));
+    RC(conv_wgrad(dt, e->g0, e->col, grads[0], (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0, e->cin * 49, e->wg_ws,
+                  e->wg_ws_bytes, st));
+    return GDL_OK;
+}
+
+}  // extern "C"

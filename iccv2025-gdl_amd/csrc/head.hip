@@ -1,0 +1,162 @@
+// head.hip -- gradient-truncated fusion head and cross-entropy, float32.
+//
+// ConcatFusion_DGL.forward (/root/reference/models/fusion_modules.py:51-59):
+//   output = fc_out(cat(x, y).detach());  x_out = fc_out(cat(x, 0));  y_out = fc_out(cat(0, y))
+// ConcatFusion.forward (:38-42): output = fc_out(cat(x, y)).
+// nn.CrossEntropyLoss (main_dgl.py:71,102-104).
+// The reference spends ~20 tiny launches here (3 cats, 2 zero fills, 3 GEMMs and their
+// backwards); the three logit sets share the two half dot-products W[:, :512].x and
+// W[:, 512:].y, so one launch produces all of them.  Sizes are tiny (B x 1024 x n_classes):
+// latency bound, no MFMA.
+#include "common.h"
+
+namespace gdl {
+
+constexpr int HD = 512;  // features per modality
+
+// grid = B; each wave handles classes j = wave, wave+4, ...; lanes split the 512-long dots.
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ out, float* __restrict__ x_out,
+                                                       float* __restrict__ y_out, int n) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float xv[8], yv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xv[i] = x[(size_t)b * HD + lane + 64 * i];
+        yv[i] = y[(size_t)b * HD + lane + 64 * i];
+    }
+    for (int j = wave; j < n; j += 4) {
+        const float* w = W + (size_t)j * 2 * HD;
+        float pa = 0.f, pv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pa += w[lane + 64 * i] * xv[i];
+            pv += w[HD + lane + 64 * i] * yv[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pa += __shfl_xor(pa, o);
+            pv += __shfl_xor(pv, o);
+        }
+        if (lane == 0) {
+            const float bj = bias[j];
+            out[(size_t)b * n + j] = pa + pv + bj;
+            if (x_out) x_out[(size_t)b * n + j] = pa + bj;
+            if (y_out) y_out[(size_t)b * n + j] = pv + bj;
+        }
+    }
+}
+int head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out,
+                    int B, int n, hipStream_t st) {
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, st, x, y, W, b, out, x_out, y_out, n);
+    GDL_CHECK_LAUNCH("head_fwd_kernel");
+    return GDL_OK;
+}
+
+// dx[b][i] = sum_j gx[b][j] * W[j][i]  (gx = g_x_out (+ g_out)), same for dy with W[j][512+i]
+__global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float* __restrict__ W, const float* __restrict__ g_x_out,
+                                                            const float* __restrict__ g_y_out,
+                                                            const float* __restrict__ g_out, int out_reaches_xy,
+                                                            float* __restrict__ dx, float* __restrict__ dy, int n) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * HD; i += 256) {
+        const bool is_y = i >= HD;
+        const float* gu = is_y ? g_y_out : g_x_out;
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float g = gu ? gu[(size_t)b * n + j] : 0.f;
+            if (out_reaches_xy && g_out) g += g_out[(size_t)b * n + j];
+            s += g * W[(size_t)j * 2 * HD + i];
+        }
+        if (is_y)
+            dy[(size_t)b * HD + (i - HD)] = s;
+        else
+            dx[(size_t)b * HD + i] = s;
+    }
+}
+// dW[j][i] = sum_b gw[b][j] * feat[b][i]; gw = g_out (+ g_x_out on the x half, + g_y_out on the y half if uni_in_dw)
+// db[j] = sum_b (g_out + uni*(g_x_out + g_y_out))[b][j].   grid = n classes.
+__global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ g_x_out,
+                                                         const float* __restrict__ g_y_out, const float* __restrict__ g_out,
+                                                         int uni_in_dw, float* __restrict__ dW, float* __restrict__ db,
+                                                         int B, int n) {
+    const int j = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * HD; i += 256) {
+        const bool is_y = i >= HD;
+        const float* feat = is_y ? y : x;
+        const float* gu = is_y ? g_y_out : g_x_out;
+        const int fi = is_y ? i - HD : i;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float g = g_out ? g_out[(size_t)b * n + j] : 0.f;
+            if (uni_in_dw && gu) g += gu[(size_t)b * n + j];
+            s += g * feat[(size_t)b * HD + fi];
+        }
+        dW[(size_t)j * 2 * HD + i] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float g = g_out ? g_out[(size_t)b * n + j] : 0.f;
+            if (uni_in_dw) {
+                if (g_x_out) g += g_x_out[(size_t)b * n + j];
+                if (g_y_out) g += g_y_out[(size_t)b * n + j];
+            }
+            s += g;
+        }
+        db[j] = s;
+    }
+}
+int head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
+                    const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db,
+                    int B, int n, hipStream_t st) {
+    if (dx && dy) {
+        hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(B), dim3(256), 0, st, W, g_x_out, g_y_out, g_out, out_reaches_xy, dx,
+                           dy, n);
+        GDL_CHECK_LAUNCH("head_bwd_feat_kernel");
+    }
+    if (dW && db) {
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dW, db, B,
+                           n);
+        GDL_CHECK_LAUNCH("head_bwd_w_kernel");
+    }
+    return GDL_OK;
+}
+
+// loss = mean_b ( logsumexp(l_b) - l_b[label_b] ); dlogits = scale*(softmax - onehot)/B.  One block.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         float scale, float* __restrict__ loss, float* __restrict__ dlogits,
+                                                         int B, int n) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* l = logits + (size_t)b * n;
+        float mx = l[0];
+        for (int j = 1; j < n; ++j) mx = fmaxf(mx, l[j]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += expf(l[j] - mx);
+        const float lse = mx + logf(se);
+        const int lab = (int)labels[b];
+        acc += lse - l[lab];
+        if (dlogits)
+            for (int j = 0; j < n; ++j)
+                dlogits[(size_t)b * n + j] = scale * (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)B;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
+               hipStream_t st) {
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, scale, loss, dlogits, B, n);
+    GDL_CHECK_LAUNCH("softmax_ce_kernel");
+    return GDL_OK;
+}
+
+}  // namespace gdl

@@ -1,0 +1,171 @@
+// layout.hip -- weight packing, stem im2col and NHWC<->NCHW conversion (HBM-bound helpers).
+//
+// The reference keeps conv weights as float32 [K][C][R][S] (nn.Conv2d, backbone.py:20-28,
+// 96-101) and activations NCHW.  Inside the library activations are NHWC `dtype`, weights
+// are [K][R][S][C] for forward / wgrad and [C][R][S][K] for the data gradient.
+#include "common.h"
+
+namespace gdl {
+
+// one thread per (k, rs, c) element: reads follow the source order along c? No: the source is
+// [K][C][RS]; each thread gathers one element.  Total traffic is 2 * 11 M elements per encoder.
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ krsc, T* __restrict__ crsk, int K, int C,
+                                   int RS) {
+    const size_t total = (size_t)K * C * RS;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // i enumerates the destination krsc order: ((k*RS)+rs)*C + c
+        const int c = (int)(i % C);
+        const size_t t = i / C;
+        const int rs = (int)(t % RS);
+        const int k = (int)(t / RS);
+        const float v = w[((size_t)k * C + c) * RS + rs];
+        if (krsc) storeT<T>(krsc + i, v);
+        if (crsk) storeT<T>(crsk + ((size_t)c * RS + rs) * K + k, v);
+    }
+}
+
+int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C, int R, int S, hipStream_t st) {
+    const size_t total = (size_t)K * C * R * S;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid), dim3(256), 0, st, w, (bf16*)krsc, (bf16*)crsk, K, C, R * S);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)krsc, (float*)crsk, K, C,
+                           R * S);
+    GDL_CHECK_LAUNCH("pack_weight_kernel");
+    return GDL_OK;
+}
+
+// ---------------------------------------------------------------- stem
+int stem_kp(int cin, int dtype) {
+    const int bke = (dtype == GDL_BF16) ? 64 : 32;
+    int kp = (cin * 49 + bke - 1) / bke * bke;
+    if (kp % 64) kp = (kp + 63) / 64 * 64;  // wgrad tiles are 64 wide
+    return kp;
+}
+
+// float32 [64][Cin*49] -> T [64][Kp], zero padded
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restrict__ wp, int kin, int kp) {
+    const int total = 64 * kp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i / kp, j = i - k * kp;
+        storeT<T>(wp + i, j < kin ? w[k * kin + j] : 0.f);
+    }
+}
+int pack_stem_weight(int dtype, const float* w, void* wp, int cin, hipStream_t st) {
+    const int kp = stem_kp(cin, dtype);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(pack_stem_weight_kernel<bf16>, dim3(48), dim3(256), 0, st, w, (bf16*)wp, cin * 49, kp);
+    else
+        hipLaunchKernelGGL(pack_stem_weight_kernel<float>, dim3(48), dim3(256), 0, st, w, (float*)wp, cin * 49, kp);
+    GDL_CHECK_LAUNCH("pack_stem_weight_kernel");
+    return GDL_OK;
+}
+
+// im2col of the 7x7 / stride 2 / pad 3 stem.  x float32 [B][Cin][T][H][W] (the reference's own
+// input tensor; image n = b*T + t, backbone.py:162-164).  col [M][Kp], M = B*T*P*Q,
+// column j = (c*7 + r)*7 + s.  One thread produces one 16-byte chunk of one row; the 7x7 windows
+// of neighbouring pixels overlap, so the gathers are served by L1/L2 and HBM sees the input once.
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int Cin, int Tn, int H, int W,
+                                   int P, int Q, int kp) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = kp / EPC;
+    const size_t total = (size_t)B * Tn * P * Q * cpr;
+    const int kin = Cin * 49;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        size_t m = i / cpr;
+        const int q = (int)(m % Q);
+        m /= Q;
+        const int p = (int)(m % P);
+        m /= P;
+        const int t = (int)(m % Tn);
+        const int b = (int)(m / Tn);
+        float f[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int j = ch * EPC + e;
+            float v = 0.f;
+            if (j < kin) {
+                const int c = j / 49, rs = j - c * 49;
+                const int r = rs / 7, s = rs - r * 7;
+                const int ih = p * 2 - 3 + r, iw = q * 2 - 3 + s;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                    v = x[((((size_t)b * Cin + c) * Tn + t) * H + ih) * W + iw];
+            }
+            f[e] = v;
+        }
+        *(uint4*)((unsigned char*)col + i * 16) = pack16<T>(f);
+    }
+}
+int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, hipStream_t st) {
+    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1;
+    const int kp = stem_kp(Cin, dtype);
+    const size_t total = (size_t)B * T * P * Q * (kp / (dtype == GDL_BF16 ? 8 : 4));
+    const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(stem_im2col_kernel<bf16>, dim3(grid), dim3(256), 0, st, x, (bf16*)col, B, Cin, T, H, W, P, Q, kp);
+    else
+        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)col, B, Cin, T, H, W, P, Q,
+                           kp);
+    GDL_CHECK_LAUNCH("stem_im2col_kernel");
+    return GDL_OK;
+}
+
+// ---------------------------------------------------------------- NHWC <-> NCHW (module boundary)
+// Tiled through LDS: a block transposes a [32 pixels][32 channels] patch.
+template <typename T, bool TO_NCHW>
+__global__ void transpose_kernel(const void* __restrict__ src, void* __restrict__ dst, int HW, int C) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    if (TO_NCHW) {
+        const T* s = (const T*)src + (size_t)n * HW * C;
+        float* d = (float*)dst + (size_t)n * C * HW;
+        for (int r = ty; r < 32; r += 8) {
+            const int p = p0 + r, c = c0 + tx;
+            tile[r][tx] = (p < HW && c < C) ? loadT<T>(s + (size_t)p * C + c) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, p = p0 + tx;
+            if (p < HW && c < C) d[(size_t)c * HW + p] = tile[tx][r];
+        }
+    } else {
+        const float* s = (const float*)src + (size_t)n * C * HW;
+        T* d = (T*)dst + (size_t)n * HW * C;
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, p = p0 + tx;
+            tile[r][tx] = (p < HW && c < C) ? s[(size_t)c * HW + p] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int p = p0 + r, c = c0 + tx;
+            if (p < HW && c < C) storeT<T>(d + (size_t)p * C + c, tile[tx][r]);
+        }
+    }
+}
+int nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, hipStream_t st) {
+    const dim3 grid(ceil_div(H * W, 32), ceil_div(C, 32), N);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16, true>), grid, dim3(256), 0, st, x, (void*)y, H * W, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<float, true>), grid, dim3(256), 0, st, x, (void*)y, H * W, C);
+    GDL_CHECK_LAUNCH("transpose_kernel(nhwc->nchw)");
+    return GDL_OK;
+}
+int nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, int C, hipStream_t st) {
+    const dim3 grid(ceil_div(H * W, 32), ceil_div(C, 32), N);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16, false>), grid, dim3(256), 0, st, (const void*)x, y, H * W, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<float, false>), grid, dim3(256), 0, st, (const void*)x, y, H * W, C);
+    GDL_CHECK_LAUNCH("transpose_kernel(nchw->nhwc)");
+    return GDL_OK;
+}
+
+}  // namespace gdl

@@ -1,0 +1,61 @@
+// ops.h -- internal (C++) launch interface of the kernels; the C ABI in api.cpp and the encoder
+// engine in encoder.cpp are thin layers over these.
+#pragma once
+#include "common.h"
+
+namespace gdl {
+
+const char* last_error();
+
+// conv_igemm.hip
+int conv_tiles_m(int dtype, int M, int OC);
+int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, int N, int H, int W, int C, int K,
+             int R, int S, int stride, int pad, hipStream_t st);
+int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H, int W, int C,
+               int K, int R, int S, int stride, int pad, hipStream_t st);
+// conv_wgrad.hip
+size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS);
+int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int R, int S,
+               int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+// layout.hip
+int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C, int R, int S, hipStream_t st);
+int stem_kp(int cin, int dtype);
+int pack_stem_weight(int dtype, const float* w, void* wp, int cin, hipStream_t st);
+int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, hipStream_t st);
+int nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, hipStream_t st);
+int nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, int C, hipStream_t st);
+// bn.hip
+int bn_stats_tiles(int M);
+int bn_stats(int dtype, const void* y, float* partial, int M, int C, hipStream_t st);
+int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
+                      float* scale, float* shift, hipStream_t st);
+int bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, const float* rm, const float* rv,
+                     float* scale, float* shift, hipStream_t st);
+int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
+           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st);
+int bn_bwd_blocks(size_t M);
+int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                  const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
+int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
+                    hipStream_t st);
+int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                 const float* rstd, const float* gamma, const float* coef, int relu_mask, void* dy, size_t M, int C,
+                 hipStream_t st);
+int relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, hipStream_t st);
+// pool.hip
+int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
+                        int H, int W, int C, hipStream_t st);
+int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, hipStream_t st);
+int avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int C, hipStream_t st);
+int avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, int C, hipStream_t st);
+// head.hip
+int head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out,
+                    int B, int n, hipStream_t st);
+int head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
+                    const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db,
+                    int B, int n, hipStream_t st);
+int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
+               hipStream_t st);
+
+}  // namespace gdl

@@ -1,0 +1,260 @@
+// optim.hip -- fused multi-tensor gradient statistics, clipping and SGD over flat arenas.
+//
+// Replaces, for the step of /root/reference/main_dgl.py:
+//   nn.utils.clip_grad_norm_(model.parameters(), max_norm=40, norm_type=2)      (:129)
+//   sum_p torch.abs(p.grad).mean() over audio_net / visual_net parameters        (:132-143)
+//   optim.SGD(lr, momentum=0.9, weight_decay=1e-4).step()                        (:249,154)
+// which the reference runs as ~370 small launches and 120 host syncs.  Here: one pass over
+// the gradient arena (sum of squares + sum of |g| per parameter, fixed-order reduction in
+// double), one tiny finalise kernel that leaves {total_norm, clip_coef, audio_sum,
+// visual_sum, per-parameter norms} on the device, and one streaming update kernel.
+#include "common.h"
+
+#include <vector>
+
+struct gdl_optim {
+    int nseg = 0;
+    int64_t total = 0;
+    int nchunks = 0;
+    std::vector<int64_t> offs;
+    std::vector<int32_t> group;
+    // device tables (owned): chunk descriptors and per-segment chunk ranges
+    void* d_chunks = nullptr;    // ChunkDesc[nchunks]
+    void* d_segrange = nullptr;  // int32[nseg][4] = {first_chunk, n_chunks, group, 0}
+    void* d_segnumel = nullptr;  // double[nseg]
+};
+
+namespace gdl {
+
+constexpr int OPT_CHUNK = 8192;
+
+struct ChunkDesc {
+    int64_t start;
+    int32_t len;
+    int32_t seg;
+};
+
+__global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict__ g, const ChunkDesc* __restrict__ chunks,
+                                                         double* __restrict__ partial) {
+    __shared__ double sh[2][256];
+    const ChunkDesc c = chunks[blockIdx.x];
+    const float* p = g + c.start;
+    float s2 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < c.len; i += 256) {
+        const float v = p[i];
+        s2 += v * v;
+        s1 += fabsf(v);
+    }
+    sh[0][threadIdx.x] = (double)s2;
+    sh[1][threadIdx.x] = (double)s1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[(size_t)blockIdx.x * 2 + 0] = sh[0][0];
+        partial[(size_t)blockIdx.x * 2 + 1] = sh[1][0];
+    }
+}
+
+// stats[0] total_norm (pre-clip, after grad_scale), [1] clip_coef, [2] audio_sum, [3] visual_sum,
+// [4+s] post-clip L2 norm of segment s, [4+nseg+s] post-clip mean|g| of segment s.
+__global__ __launch_bounds__(256) void grad_stats_final_kernel(const double* __restrict__ partial,
+                                                               const int32_t* __restrict__ segrange,
+                                                               const double* __restrict__ segnumel, int nseg,
+                                                               float max_norm, float grad_scale, float* __restrict__ stats,
+                                                               double* __restrict__ segsum /*[nseg][2] scratch*/) {
+    __shared__ double sh[3][256];
+    double tot = 0.0;
+    for (int s = threadIdx.x; s < nseg; s += 256) {
+        const int first = segrange[s * 4 + 0], cnt = segrange[s * 4 + 1];
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < cnt; ++k) {
+            a += partial[(size_t)(first + k) * 2 + 0];
+            b += partial[(size_t)(first + k) * 2 + 1];
+        }
+        segsum[s * 2 + 0] = a;
+        segsum[s * 2 + 1] = b;
+        tot += a;
+    }
+    sh[0][threadIdx.x] = tot;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+        __syncthreads();
+    }
+    const double norm = sqrt(sh[0][0]) * (double)grad_scale;
+    // torch: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1 (float arithmetic there; double here)
+    double coef = (double)max_norm / (norm + 1e-6);
+    if (coef > 1.0) coef = 1.0;
+    __syncthreads();
+    double au = 0.0, vi = 0.0;
+    for (int s = threadIdx.x; s < nseg; s += 256) {
+        const double l2 = sqrt(segsum[s * 2 + 0]) * (double)grad_scale * coef;
+        const double am = segsum[s * 2 + 1] / segnumel[s] * (double)grad_scale * coef;
+        stats[4 + s] = (float)l2;
+        stats[4 + nseg + s] = (float)am;
+        const int grp = segrange[s * 4 + 2];
+        if (grp == 1) au += am;
+        if (grp == 2) vi += am;
+    }
+    sh[1][threadIdx.x] = au;
+    sh[2][threadIdx.x] = vi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        stats[0] = (float)norm;
+        stats[1] = (float)coef;
+        stats[2] = (float)sh[1][0];
+        stats[3] = (float)sh[2][0];
+    }
+}
+
+// g *= coef*grad_scale (stored back: p.grad is clipped in place by the reference);
+// d = g + wd*p; m = mu*m + d; p -= lr*m
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                  const float* __restrict__ stats, float grad_scale, float lr, float mu,
+                                                  float wd, int64_t n) {
+    const float k = (stats ? stats[1] : 1.f) * grad_scale;
+    const int64_t nv = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float4 pv = ((float4*)p)[i], gv = ((float4*)g)[i], mv = ((float4*)m)[i];
+        gv.x *= k;
+        gv.y *= k;
+        gv.z *= k;
+        gv.w *= k;
+        mv.x = mu * mv.x + (gv.x + wd * pv.x);
+        mv.y = mu * mv.y + (gv.y + wd * pv.y);
+        mv.z = mu * mv.z + (gv.z + wd * pv.z);
+        mv.w = mu * mv.w + (gv.w + wd * pv.w);
+        pv.x -= lr * mv.x;
+        pv.y -= lr * mv.y;
+        pv.z -= lr * mv.z;
+        pv.w -= lr * mv.w;
+        ((float4*)g)[i] = gv;
+        ((float4*)m)[i] = mv;
+        ((float4*)p)[i] = pv;
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += 256) {
+            const float gg = g[i] * k;
+            const float mm = mu * m[i] + (gg + wd * p[i]);
+            g[i] = gg;
+            m[i] = mm;
+            p[i] -= lr * mm;
+        }
+    }
+}
+
+}  // namespace gdl
+
+using namespace gdl;
+
+extern "C" {
+
+int gdl_optim_create(gdl_optim_t** out, const int64_t* seg_offsets, const int32_t* seg_group, int nseg) {
+    GDL_REQUIRE(out && seg_offsets && seg_group && nseg > 0, "optim_create: bad arguments");
+    GDL_REQUIRE(seg_offsets[0] == 0, "optim_create: arena must start at offset 0");
+    gdl_optim* o = new gdl_optim();
+    o->nseg = nseg;
+    o->offs.assign(seg_offsets, seg_offsets + nseg + 1);
+    o->group.assign(seg_group, seg_group + nseg);
+    o->total = seg_offsets[nseg];
+    std::vector<ChunkDesc> chunks;
+    std::vector<int32_t> segrange(nseg * 4);
+    std::vector<double> numel(nseg);
+    for (int s = 0; s < nseg; ++s) {
+        const int64_t b = seg_offsets[s], e = seg_offsets[s + 1];
+        if (e <= b) {
+            delete o;
+            set_error("optim_create: empty or unordered segment %d", s);
+            return GDL_ERR_ARG;
+        }
+        segrange[s * 4 + 0] = (int32_t)chunks.size();
+        for (int64_t c = b; c < e; c += OPT_CHUNK) {
+            ChunkDesc d;
+            d.start = c;
+            d.len = (int32_t)((e - c) < OPT_CHUNK ? (e - c) : OPT_CHUNK);
+            d.seg = s;
+            chunks.push_back(d);
+        }
+        segrange[s * 4 + 1] = (int32_t)chunks.size() - segrange[s * 4 + 0];
+        segrange[s * 4 + 2] = seg_group[s];
+        segrange[s * 4 + 3] = 0;
+        numel[s] = (double)(e - b);
+    }
+    o->nchunks = (int)chunks.size();
+    hipError_t e1 = hipMalloc(&o->d_chunks, chunks.size() * sizeof(ChunkDesc));
+    hipError_t e2 = hipMalloc(&o->d_segrange, segrange.size() * sizeof(int32_t));
+    hipError_t e3 = hipMalloc(&o->d_segnumel, numel.size() * sizeof(double));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        gdl_optim_destroy(o);
+        return check_hip(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "optim_create: hipMalloc");
+    }
+    hipMemcpy(o->d_chunks, chunks.data(), chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+    hipMemcpy(o->d_segrange, segrange.data(), segrange.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipMemcpy(o->d_segnumel, numel.data(), numel.size() * sizeof(double), hipMemcpyHostToDevice);
+    *out = o;
+    return GDL_OK;
+}
+
+void gdl_optim_destroy(gdl_optim_t* o) {
+    if (!o) return;
+    if (o->d_chunks) (void)hipFree(o->d_chunks);
+    if (o->d_segrange) (void)hipFree(o->d_segrange);
+    if (o->d_segnumel) (void)hipFree(o->d_segnumel);
+    delete o;
+}
+
+size_t gdl_optim_workspace_bytes(const gdl_optim_t* o) {
+    if (!o) return 0;
+    return ((size_t)o->nchunks * 2 + (size_t)o->nseg * 2) * sizeof(double);
+}
+
+int gdl_optim_stats_len(const gdl_optim_t* o) { return o ? 4 + 2 * o->nseg : 0; }
+
+int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, float grad_scale, float* stats, void* ws,
+                         size_t ws_bytes, void* stream) {
+    GDL_REQUIRE(o && grads && stats && ws, "optim_grad_stats: null argument");
+    if (ws_bytes < gdl_optim_workspace_bytes(o)) {
+        set_error("optim_grad_stats: workspace %zu < %zu", ws_bytes, gdl_optim_workspace_bytes(o));
+        return GDL_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)ws;
+    double* segsum = partial + (size_t)o->nchunks * 2;
+    hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)o->d_chunks, partial);
+    GDL_CHECK_LAUNCH("grad_stats_kernel");
+    hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial,
+                       (const int32_t*)o->d_segrange, (const double*)o->d_segnumel, o->nseg, max_norm, grad_scale, stats,
+                       segsum);
+    GDL_CHECK_LAUNCH("grad_stats_final_kernel");
+    return GDL_OK;
+}
+
+int gdl_optim_sgd_step(gdl_optim_t* o, float* params, float* grads, float* momentum, const float* stats, float grad_scale,
+                       float lr, float mu, float wd, void* stream) {
+    GDL_REQUIRE(o && params && grads && momentum, "optim_sgd_step: null argument");
+    GDL_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)momentum) & 15) == 0,
+                "optim_sgd_step: arenas must be 16-byte aligned");
+    const int64_t nv = o->total >> 2;
+    int64_t blocks = (nv + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum, stats,
+                       grad_scale, lr, mu, wd, o->total);
+    GDL_CHECK_LAUNCH("sgd_kernel");
+    return GDL_OK;
+}
+
+}  // extern "C"

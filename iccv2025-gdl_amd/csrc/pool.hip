@@ -1,0 +1,235 @@
+// pool.hip -- stem max-pool (fused with BN+ReLU) and the global average pools, NHWC.
+//
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1): /root/reference/models/backbone.py:106,
+// applied to relu(bn1(conv1(x))) (:166-173).  F.adaptive_avg_pool2d(a,1) /
+// F.adaptive_avg_pool3d(v,1): /root/reference/models/basic_model.py:73-82.
+#include "common.h"
+
+namespace gdl {
+
+// out[n,p,q,c] = max_{window} relu(y*scale+shift); idx = first maximum in row-major window
+// order (ATen's CPU kernel updates on strict '>'); windows never are empty (pad 1 < kernel 3).
+// One thread = one 16-byte channel vector of one output pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, T* __restrict__ out,
+                                                              uint8_t* __restrict__ idx, int N, int H, int W, int C, int P,
+                                                              int Q) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    const size_t total = (size_t)N * P * Q * cpr;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int vc = (int)(i % cpr);
+        size_t t = i / cpr;
+        const int q = (int)(t % Q);
+        t /= Q;
+        const int p = (int)(t % P);
+        const int n = (int)(t / P);
+        float sc[EPC], sf[EPC], best[EPC];
+        int bi[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = scale[vc * EPC + e];
+            sf[e] = shift[vc * EPC + e];
+            best[e] = -INFINITY;
+            bi[e] = -1;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = p * 2 - 1 + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int iw = q * 2 - 1 + s;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float f[EPC];
+                unpack16<T>(*(const uint4*)(y + (((size_t)n * H + ih) * W + iw) * C + vc * EPC), f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    float v = f[e] * sc[e] + sf[e];
+                    v = roundT<T>(v > 0.f ? v : 0.f);
+                    if (v > best[e] || bi[e] < 0) {
+                        best[e] = v;
+                        bi[e] = r * 3 + s;
+                    }
+                }
+            }
+        }
+        *(uint4*)(out + i * EPC) = pack16<T>(best);
+        uint8_t* ip = idx + i * EPC;
+        if (EPC == 8) {
+            *(uint2*)ip = make_uint2((uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24),
+                                     (uint32_t)bi[4 % EPC] | ((uint32_t)bi[5 % EPC] << 8) | ((uint32_t)bi[6 % EPC] << 16) |
+                                         ((uint32_t)bi[7 % EPC] << 24));
+        } else {
+            *(uint32_t*)ip = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        }
+    }
+}
+int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
+                        int H, int W, int C, hipStream_t st) {
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    GDL_REQUIRE(C % epc == 0, "maxpool: C=%d", C);
+    const size_t total = (size_t)N * P * Q * (C / epc);
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, scale, shift,
+                           (bf16*)out, idx, N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, scale, shift,
+                           (float*)out, idx, N, H, W, C, P, Q);
+    GDL_CHECK_LAUNCH("bn_relu_maxpool_kernel");
+    return GDL_OK;
+}
+
+// dx[n,h,w,c] = sum over the <= 2x2 windows (p,q) that contain (h,w) and whose idx names it.
+// Window (p,q) covers rows 2p-1..2p+1: h belongs to p = floor(h/2) (r = h-2p+1 in {1,2}) and,
+// if h is odd, also to p = (h+1)/2 (r = 0).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int P, int Q) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    const size_t total = (size_t)N * H * W * cpr;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int vc = (int)(i % cpr);
+        size_t t = i / cpr;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int n = (int)(t / H);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int p = (h >> 1) + a;
+            if (a == 1 && !(h & 1)) continue;
+            if (p >= P) continue;
+            const int r = h - (2 * p - 1);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int q = (w >> 1) + b;
+                if (b == 1 && !(w & 1)) continue;
+                if (q >= Q) continue;
+                const int s = w - (2 * q - 1);
+                const int code = r * 3 + s;
+                const size_t o = (((size_t)n * P + p) * Q + q) * C + vc * EPC;
+                float d[EPC];
+                unpack16<T>(*(const uint4*)(dout + o), d);
+                uint8_t ix[EPC];
+                if (EPC == 8) {
+                    const uint2 u = *(const uint2*)(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ix[e] = (u.x >> (8 * e)) & 0xff;
+                        ix[(4 + e) % EPC] = (u.y >> (8 * e)) & 0xff;
+                    }
+                } else {
+                    const uint32_t u = *(const uint32_t*)(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ix[e] = (u >> (8 * e)) & 0xff;
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (ix[e] == code) acc[e] += d[e];
+            }
+        }
+        *(uint4*)(dx + i * EPC) = pack16<T>(acc);
+    }
+}
+int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, hipStream_t st) {
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    const size_t total = (size_t)N * H * W * (C / epc);
+    const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H,
+                           W, C, P, Q);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, idx, (float*)dx, N,
+                           H, W, C, P, Q);
+    GDL_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return GDL_OK;
+}
+
+// ---------------------------------------------------------------- global average pools
+// x [B*T][HW][C] -> feat[b][c] = mean over t, hw.  One block per (b, 16-byte channel vector group).
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ feat, int T_, int HW,
+                                                          int C) {
+    constexpr int EPC = TT<T>::EPC;
+    extern __shared__ float red[];  // [rpp][C]
+    const int cpr = C / EPC;
+    const int b = blockIdx.x;
+    const int rows = T_ * HW;
+    const T* xb = x + (size_t)b * rows * C;
+    const int rpp = 256 / cpr > 0 ? 256 / cpr : 1;
+    for (int v0 = 0; v0 < cpr; v0 += 256) {  // cpr <= 256 in practice (C = 512: 64 / 128 vectors)
+        const int vc = v0 + threadIdx.x % (cpr < 256 ? cpr : 256);
+        const int vr = threadIdx.x / (cpr < 256 ? cpr : 256);
+        float s[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+        if (vc < cpr)
+            for (int r = vr; r < rows; r += rpp) {
+                float f[EPC];
+                unpack16<T>(*(const uint4*)(xb + (size_t)r * C + vc * EPC), f);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) s[e] += f[e];
+            }
+        if (vc < cpr) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) red[(size_t)vr * C + vc * EPC + e] = s[e];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f;
+            for (int r = 0; r < rpp; ++r) a += red[(size_t)r * C + c];
+            feat[(size_t)b * C + c] = a / (float)rows;
+        }
+        __syncthreads();
+    }
+}
+int avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int C, hipStream_t st) {
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    const int cpr = C / epc;
+    GDL_REQUIRE(C % epc == 0 && cpr <= 256 && 256 % cpr == 0, "avgpool: C=%d unsupported", C);
+    const size_t sh = (size_t)(256 / cpr) * C * sizeof(float);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, dim3(B), dim3(256), sh, st, (const bf16*)x, feat, T, HW, C);
+    else
+        hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(B), dim3(256), sh, st, (const float*)x, feat, T, HW, C);
+    GDL_CHECK_LAUNCH("avgpool_fwd_kernel");
+    return GDL_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ dx, int rows,
+                                                          int C, size_t nvec) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    const float inv = 1.0f / (float)rows;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const int vc = (int)(i % cpr);
+        const size_t b = (i / cpr) / rows;
+        float f[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = dfeat[b * C + vc * EPC + e] * inv;
+        *(uint4*)(dx + i * EPC) = pack16<T>(f);
+    }
+}
+int avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, int C, hipStream_t st) {
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    const size_t nvec = (size_t)B * T * HW * (C / epc);
+    const int grid = (int)((nvec + 255) / 256 > 4096 ? 4096 : (nvec + 255) / 256);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, dfeat, (bf16*)dx, T * HW, C, nvec);
+    else
+        hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, dfeat, (float*)dx, T * HW, C, nvec);
+    GDL_CHECK_LAUNCH("avgpool_bwd_kernel");
+    return GDL_OK;
+}
+
+}  // namespace gdl

@@ -1,0 +1,136 @@
+"""ctypes binding of libgdl_hip.so (the C ABI declared in include/gdl_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this
+raises.  PyTorch is used only as the owner of device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "build", "libgdl_hip.so")
+
+GDL_F32, GDL_BF16 = 0, 1
+GDL_AUDIO, GDL_VISUAL = 0, 1
+ENC_NPARAMS, ENC_NBN = 60, 20
+
+_C = {"i": ctypes.c_int, "p": ctypes.c_void_p, "z": ctypes.c_size_t, "f": ctypes.c_float, "d": ctypes.c_double,
+      "l": ctypes.c_int64, "s": ctypes.c_char_p}
+
+# name -> (restype code, argtypes codes); mirrors include/gdl_hip.h one to one
+SIGNATURES = {
+    "gdl_last_error": ("s", ""),
+    "gdl_version": ("i", ""),
+    "gdl_device_info": ("i", "ppi"),
+    "gdl_conv_bn_tiles": ("i", "iiiii"),
+    "gdl_conv_fwd": ("i", "ipppp" + "iiiiiiiii" + "p"),
+    "gdl_conv_dgrad": ("i", "ipppp" + "iiiiiiiii" + "p"),
+    "gdl_conv_wgrad_workspace_bytes": ("z", "iiiiiiiiii"),
+    "gdl_conv_wgrad": ("i", "ippp" + "iiiiiiiii" + "pzp"),
+    "gdl_pack_weight": ("i", "ippp" + "iiii" + "p"),
+    "gdl_stem_kp": ("i", "ii"),
+    "gdl_stem_im2col": ("i", "ipp" + "iiiii" + "p"),
+    "gdl_pack_stem_weight": ("i", "ippip"),
+    "gdl_stem_wgrad": ("i", "ippp" + "ii" + "pzp"),
+    "gdl_nhwc_to_nchw_f32": ("i", "ipp" + "iiii" + "p"),
+    "gdl_nchw_f32_to_nhwc": ("i", "ipp" + "iiii" + "p"),
+    "gdl_bn_stats_tiles": ("i", "i"),
+    "gdl_bn_stats": ("i", "ippiip"),
+    "gdl_bn_finalize_train": ("i", "pii" + "d" + "pp" + "ff" + "ppp" + "pppp" + "p"),
+    "gdl_bn_finalize_eval": ("i", "ippf" + "pppp" + "p"),
+    "gdl_bn_act": ("i", "ippp" + "ppp" + "i" + "p" + "zi" + "p"),
+    "gdl_bn_bwd_blocks": ("i", "z"),
+    "gdl_bn_bwd_reduce": ("i", "ipppppp" + "i" + "p" + "zi" + "p"),
+    "gdl_bn_bwd_finalize": ("i", "pii" + "d" + "ppp" + "p"),
+    "gdl_bn_bwd_apply": ("i", "ipppppppp" + "i" + "p" + "zi" + "p"),
+    "gdl_relu_bwd": ("i", "ipppzp"),
+    "gdl_bn_relu_maxpool_fwd": ("i", "ippppp" + "iiii" + "p"),
+    "gdl_maxpool_bwd": ("i", "ippp" + "iiii" + "p"),
+    "gdl_avgpool_fwd": ("i", "ipp" + "iiii" + "p"),
+    "gdl_avgpool_bwd": ("i", "ipp" + "iiii" + "p"),
+    "gdl_head_concat_fwd": ("i", "ppppppp" + "ii" + "p"),
+    "gdl_head_concat_bwd": ("i", "pppppp" + "ii" + "pppp" + "ii" + "p"),
+    "gdl_softmax_ce": ("i", "ppf" + "pp" + "ii" + "p"),
+    "gdl_optim_create": ("i", "pppi"),
+    "gdl_optim_destroy": (None, "p"),
+    "gdl_optim_workspace_bytes": ("z", "p"),
+    "gdl_optim_stats_len": ("i", "p"),
+    "gdl_optim_grad_stats": ("i", "ppffp" + "pzp"),
+    "gdl_optim_sgd_step": ("i", "ppppp" + "ffff" + "p"),
+    "gdl_encoder_create": ("i", "piiiiii"),
+    "gdl_encoder_destroy": (None, "p"),
+    "gdl_encoder_workspace_bytes": ("z", "p"),
+    "gdl_encoder_param_numel": ("i", "pp"),
+    "gdl_encoder_out_shape": ("i", "pppp"),
+    "gdl_encoder_bind": ("i", "ppz"),
+    "gdl_encoder_set_params": ("i", "ppppp"),
+    "gdl_encoder_forward": ("i", "ppippp"),
+    "gdl_encoder_backward": ("i", "ppppp"),
+    "gdl_encoder_forward_serial": ("l", "p"),
+}
+
+_lib = None
+
+
+class GdlError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgdl_hip.so; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise GdlError(f"libgdl_hip.so not found at {SO_PATH}: build it with `make -C iccv2025-gdl_amd/csrc` "
+                       "(or __graft_entry__.build()); there is no fallback path")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = _C[res] if res else None
+        fn.argtypes = [_C[a] for a in args]
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().gdl_last_error().decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise GdlError(f"{what}: {last_error()} (code {rc})")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise GdlError on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise GdlError(f"{name}: {last_error()} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "gdl: tensor must be contiguous"
+    return t.data_ptr()
+
+
+def cur_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(name):
+    if name in ("bf16", "bfloat16", GDL_BF16):
+        return GDL_BF16
+    if name in ("f32", "fp32", "float32", GDL_F32):
+        return GDL_F32
+    raise ValueError(f"gdl: unknown dtype {name!r} (use 'bf16' or 'f32')")
+
+
+def torch_dtype(code):
+    import torch
+
+    return torch.bfloat16 if code == GDL_BF16 else torch.float32

@@ -1,0 +1,200 @@
+"""Native DGL training step: the whole body of /root/reference/main_dgl.py:97-154 as one
+sequence of gfx950 kernels on three HIP streams, without an autograd tape.
+
+Per step (all asynchronous, nothing is read back unless `read()` is called):
+  audio encoder forward  (stream A)  ||  visual encoder forward (stream V)
+  fusion head forward, 3x cross-entropy, head backward with the DGL truncation   (main stream)
+      - encoders receive only alpha * d(CE(a_out) + CE(v_out))      (main_dgl.py:108-110)
+      - fc_out receives only d CE(out) on detached features          (:114-122)
+      - fc_auxi never receives a gradient and is skipped by SGD      
+  audio encoder backward (stream A)  ||  visual encoder backward (stream V)
+      [+ per-bucket RCCL all-reduce as soon as a bucket is final]
+  fused grad statistics (total norm -> clip coefficient, per-encoder sum mean|g|)  (:129-143)
+  fused clip + SGD(momentum, weight decay) over the flat parameter arena               (:154)
+
+The result is numerically the reference's two-phase backward: SURVEY section 0 shows the
+single-pass form is bit-identical in exact arithmetic, and tests/test_step_gpu.py checks it
+against golden vectors of the reference.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from .encoder import EncoderEngine
+
+
+class DGLTrainer:
+    def __init__(self, model, lr, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, mode="dgl", dtype=None,
+                 process_group=None):
+        self.lib = L.load()
+        self.model = model
+        self.mode = mode
+        self.lr, self.alpha, self.mu, self.wd, self.max_norm = float(lr), float(alpha), float(momentum), \
+            float(weight_decay), float(max_norm)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+
+            self.dist = dist
+            self.world = dist.get_world_size(process_group)
+        self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
+        head = model.fusion_module
+        self.device = head.fc_out.weight.device
+        if self.device.type != "cuda":
+            raise L.GdlError("DGLTrainer: the model must live on an MI355X (cuda) device; there is no CPU path")
+        self.n_classes = head.fc_out.weight.shape[0]
+        # ---- flat arenas: [fc_out.weight, fc_out.bias | audio_net (60) | visual_net (60)]
+        named = [("fusion_module.fc_out.weight", head.fc_out.weight), ("fusion_module.fc_out.bias", head.fc_out.bias)]
+        named += [("audio_net." + n, p) for n, p in model.audio_net.named_parameters()]
+        named += [("visual_net." + n, p) for n, p in model.visual_net.named_parameters()]
+        self.names = [n for n, _ in named]
+        offs, o = [0], 0
+        for _, p in named:
+            o += p.numel()
+            offs.append(o)
+        self.offsets = offs
+        self.total = o
+        group = [0, 0] + [1] * 60 + [2] * 60
+        self.params = torch.empty(o, device=self.device)
+        self.grads = torch.zeros(o, device=self.device)
+        self.momentum = torch.zeros(o, device=self.device)
+        self.pviews, self.gviews = [], []
+        for i, (_, p) in enumerate(named):
+            v = self.params[offs[i]:offs[i + 1]].view(p.shape)
+            v.copy_(p.data)
+            p.data = v  # the module now aliases the arena: state_dict / eval see the trained weights
+            self.pviews.append(v)
+            self.gviews.append(self.grads[offs[i]:offs[i + 1]].view(p.shape))
+        self.bucket = {"fusion": (0, offs[2]), "audio": (offs[2], offs[62]), "visual": (offs[62], offs[122])}
+        h = ctypes.c_void_p()
+        so = (ctypes.c_int64 * len(offs))(*offs)
+        sg = (ctypes.c_int32 * len(group))(*group)
+        L.call("gdl_optim_create", ctypes.byref(h), so, sg, len(group))
+        self.opt = h
+        self.opt_ws_bytes = self.lib.gdl_optim_workspace_bytes(h)
+        self.opt_ws = torch.empty(max(self.opt_ws_bytes, 8), dtype=torch.uint8, device=self.device)
+        self.stats = torch.zeros(self.lib.gdl_optim_stats_len(h), device=self.device)
+        self.losses = torch.zeros(3, device=self.device)  # loss_f, loss_a, loss_v
+        self.s_a = torch.cuda.Stream(device=self.device)
+        self.s_v = torch.cuda.Stream(device=self.device)
+        self.eng_a = self.eng_v = None
+        self.steps = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "opt", None):
+                self.lib.gdl_optim_destroy(self.opt)
+                self.opt = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ setup per batch shape
+    def _prepare(self, spec, image):
+        B, F_, T_ = spec.shape
+        Bv, C, T, H, W = image.shape
+        if Bv != B or C != 3:
+            raise L.GdlError("DGLTrainer.step: spec must be [B,F,T'] and image [B,3,T,H,W]")
+        key = (B, F_, T_, T, H, W)
+        if getattr(self, "_key", None) == key:
+            return
+        self._key = key
+        self.eng_a = EncoderEngine("audio", self.dtype, B, 1, F_, T_, self.device)
+        self.eng_v = EncoderEngine("visual", self.dtype, B, T, H, W, self.device)
+        n, d = self.n_classes, self.device
+        self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
+        self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
+        self.out, self.out_a, self.out_v = (torch.empty((B, n), device=d) for _ in range(3))
+        self.g_f, self.g_a, self.g_v = (torch.empty((B, n), device=d) for _ in range(3))
+        self.B = B
+
+    def _bind(self):
+        m = self.model
+        for eng, net in ((self.eng_a, m.audio_net), (self.eng_v, m.visual_net)):
+            bns = net._bn_layers()
+            eng.set_params([p.data for p in net.parameters()], [b.running_mean for b in bns],
+                           [b.running_var for b in bns], [b.num_batches_tracked for b in bns])
+
+    # ------------------------------------------------------------------ the step
+    def step(self, spec, image, label):
+        """spec [B,F,T'] float, image [B,3,T,H,W] float, label [B] int64 -- all resident on the device."""
+        self._prepare(spec, image)
+        self._bind()
+        main = torch.cuda.current_stream(self.device)
+        audio = spec.unsqueeze(1)  # main_dgl.py:100
+        label = label.contiguous()
+        B, n = self.B, self.n_classes
+        W, b = self.pviews[0], self.pviews[1]
+        ev = main.record_event()
+        self.s_a.wait_event(ev)
+        self.s_v.wait_event(ev)
+        with torch.cuda.stream(self.s_a):
+            self.eng_a.forward(audio, True, feat_out=self.fa)
+        with torch.cuda.stream(self.s_v):
+            self.eng_v.forward(image, True, feat_out=self.fv)
+        main.wait_stream(self.s_a)
+        main.wait_stream(self.s_v)
+        st = main.cuda_stream
+        dgl = self.mode == "dgl"
+        L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), L.ptr(b), L.ptr(self.out),
+               L.ptr(self.out_a) if dgl else None, L.ptr(self.out_v) if dgl else None, B, n, st)
+        lp = self.losses.data_ptr()
+        L.call("gdl_softmax_ce", L.ptr(self.out), L.ptr(label), 1.0, lp, L.ptr(self.g_f), B, n, st)
+        if dgl:
+            L.call("gdl_softmax_ce", L.ptr(self.out_a), L.ptr(label), self.alpha, lp + 4, L.ptr(self.g_a), B, n, st)
+            L.call("gdl_softmax_ce", L.ptr(self.out_v), L.ptr(label), self.alpha, lp + 8, L.ptr(self.g_v), B, n, st)
+            L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), L.ptr(self.g_a), L.ptr(self.g_v),
+                   L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]),
+                   L.ptr(self.gviews[1]), B, n, st)
+        else:  # BASELINE config 1: ConcatFusion + one CE loss (main.py:161-175)
+            L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), None, None, L.ptr(self.g_f), 1, 0,
+                   L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]), L.ptr(self.gviews[1]), B, n, st)
+        works = []
+        if self.pg is not None:
+            works.append(self._allreduce("fusion"))
+        ev2 = main.record_event()
+        self.s_a.wait_event(ev2)
+        self.s_v.wait_event(ev2)
+        with torch.cuda.stream(self.s_a):
+            self.eng_a.backward(self.gviews[2:62], dfeat=self.dfa)
+            if self.pg is not None:
+                works.append(self._allreduce("audio"))
+        with torch.cuda.stream(self.s_v):
+            self.eng_v.backward(self.gviews[62:122], dfeat=self.dfv)
+            if self.pg is not None:
+                works.append(self._allreduce("visual"))
+        main.wait_stream(self.s_a)
+        main.wait_stream(self.s_v)
+        for w in works:
+            w.wait()
+        gs = 1.0 / self.world
+        L.call("gdl_optim_grad_stats", self.opt, L.ptr(self.grads), self.max_norm, gs, L.ptr(self.stats),
+               L.ptr(self.opt_ws), self.opt_ws_bytes, st)
+        L.call("gdl_optim_sgd_step", self.opt, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.momentum),
+               L.ptr(self.stats), gs, self.lr, self.mu, self.wd, st)
+        self.steps += 1
+
+    def _allreduce(self, name):
+        lo, hi = self.bucket[name]
+        return self.dist.all_reduce(self.grads[lo:hi], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    # ------------------------------------------------------------------ results (host sync)
+    def read(self):
+        """Synchronises and returns the quantities the reference prints / logs per step."""
+        torch.cuda.synchronize(self.device)
+        s = self.stats.cpu().numpy()
+        ls = self.losses.cpu().numpy()
+        nseg = len(self.names)
+        r = {"loss_f": float(ls[0]), "loss_a": float(ls[1]), "loss_v": float(ls[2]), "total_norm": float(s[0]),
+             "clip_coef": float(s[1]), "audio_grad_sum": float(s[2]), "visual_grad_sum": float(s[3]),
+             "grad_norm": dict(zip(self.names, s[4:4 + nseg].tolist())),
+             "grad_absmean": dict(zip(self.names, s[4 + nseg:4 + 2 * nseg].tolist())),
+             "out": self.out.cpu().numpy()}
+        if self.mode == "dgl":
+            r["out_a"] = self.out_a.cpu().numpy()
+            r["out_v"] = self.out_v.cpu().numpy()
+        return r
+
+    def grad(self, name):
+        return self.gviews[self.names.index(name)]

@@ -1,0 +1,213 @@
+"""Drop-in mirror of /root/reference/models/backbone.py for the MI355X build.
+
+Same public names (`conv3x3`, `conv1x1`, `BasicBlock`, `ResNet`, `resnet18`), constructor
+arguments, attribute / parameter / buffer names, registration order and initialisation
+(backbone.py:75-132), so `state_dict`s, `model.apply(weight_init)` and seeded initial
+weights are interchangeable with the reference.  The torch.nn layers are only parameter
+containers: `ResNet.forward` runs the whole encoder as one planned sequence of hand-written
+gfx950 kernels (csrc/encoder.cpp) behind a single autograd node.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from gdl import _lib as L
+from gdl.encoder import EncoderEngine
+
+
+def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
+    """3x3 convolution with padding (backbone.py:20-23) -- parameter container."""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, groups=groups, bias=False,
+                     dilation=dilation)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    """1x1 convolution (backbone.py:26-28) -- parameter container."""
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """backbone.py:31-68.  Executed by the encoder engine as part of ResNet.forward."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
+                 norm_layer=None):
+        super(BasicBlock, self).__init__()
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        if groups != 1 or base_width != 64:
+            raise ValueError('BasicBlock only supports groups=1 and base_width=64')
+        if dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise NotImplementedError("gdl: BasicBlock runs inside the ResNet encoder engine; call the ResNet module")
+
+
+class _ResNetFn(torch.autograd.Function):
+    """One autograd node for the whole encoder.  `want` selects the output: 'fmap' is what the
+    reference's ResNet.forward returns ([N,512,h,w] float32 NCHW), 'feat' additionally folds the
+    pooling glue of basic_model.py:73-82 and returns [B,512]."""
+
+    @staticmethod
+    def forward(ctx, net, x, want, *params):
+        eng = net._engine(x)
+        net._bind(eng)
+        training = net.training
+        feat, fmap = eng.forward(x, training, want_feat=(want == "feat"), want_fmap=(want == "fmap"))
+        ctx.eng, ctx.want, ctx.training = eng, want, training
+        ctx.serial = eng.serial
+        ctx.pshapes = [p.shape for p in params]
+        ctx.pdev = params[0].device
+        return feat if want == "feat" else fmap
+
+    @staticmethod
+    def backward(ctx, g):
+        eng = ctx.eng
+        if not ctx.training:
+            raise RuntimeError("gdl: backward through an eval-mode encoder forward is not supported")
+        if ctx.serial != eng.serial:
+            raise RuntimeError("gdl: the encoder ran another training forward since this graph was built; "
+                               "its saved activations are gone")
+        flat = torch.empty(sum(eng.param_numel), device=ctx.pdev)
+        grads, o = [], 0
+        for s, n in zip(ctx.pshapes, eng.param_numel):
+            grads.append(flat[o:o + n].view(s))
+            o += n
+        if ctx.want == "feat":
+            eng.backward(grads, dfeat=g)
+        else:
+            eng.backward(grads, dfmap=g)
+        return (None, None, None) + tuple(grads)
+
+
+class ResNet(nn.Module):
+
+    def __init__(self, args, block, layers, modality, num_classes=1000, pool='avgpool', zero_init_residual=False,
+                 groups=1, width_per_group=64, replace_stride_with_dilation=None, norm_layer=None):
+        super(ResNet, self).__init__()
+        self.modality = modality
+        self.pool = pool
+        if norm_layer is None:
+            norm_layer = nn.BatchNorm2d
+        if norm_layer is not nn.BatchNorm2d or block is not BasicBlock or list(layers) != [2, 2, 2, 2]:
+            raise NotImplementedError("gdl: the MI355X engine implements resnet18 (BasicBlock [2,2,2,2], BatchNorm2d)")
+        self._norm_layer = norm_layer
+        self.inplanes = 64
+        self.dilation = 1
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None "
+                             "or a 3-element tuple, got {}".format(replace_stride_with_dilation))
+        if any(replace_stride_with_dilation) or groups != 1 or width_per_group != 64:
+            raise NotImplementedError("gdl: dilation / groups are not used by the reference and not implemented")
+        self.groups = groups
+        self.base_width = width_per_group
+        if modality == 'audio':
+            self.conv1 = nn.Conv2d(1, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        elif modality == 'visual':
+            self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        else:
+            raise NotImplementedError('Incorrect modality, should be audio or visual but got {}'.format(modality))
+        self.bn1 = norm_layer(self.inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.args = args
+        for m in self.modules():  # backbone.py:117-122
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.normal_(m.weight, mean=1, std=0.02)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
+        # engine state (not part of state_dict)
+        self.gdl_dtype = os.environ.get("GDL_DTYPE", "bf16")
+        self._engines = {}
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilate=False):
+        norm_layer = self._norm_layer
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                conv1x1(self.inplanes, planes * block.expansion, stride),
+                norm_layer(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, 1, norm_layer)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width,
+                                dilation=self.dilation, norm_layer=norm_layer))
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _bn_layers(self):
+        out = [self.bn1]
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                out += [blk.bn1, blk.bn2]
+                if blk.downsample is not None:
+                    out.append(blk.downsample[1])
+        return out
+
+    def _engine(self, x):
+        if self.modality == 'visual':
+            if x.dim() != 5:
+                raise RuntimeError("gdl: visual input must be [B,3,T,H,W] (backbone.py:162)")
+            B, C, T, H, W = x.shape
+            if C != 3:
+                raise RuntimeError(f"gdl: visual input has {C} channels, expected 3")
+        else:
+            if x.dim() != 4 or x.shape[1] != 1:
+                raise RuntimeError("gdl: audio input must be [B,1,F,T'] (main_dgl.py:100)")
+            B, _, H, W = x.shape
+            T = 1
+        if not x.is_cuda:
+            raise RuntimeError("gdl: the encoder runs on an MI355X only; move the model and inputs to cuda "
+                               "(there is no CPU path)")
+        key = (B, T, H, W, self.gdl_dtype, x.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = EncoderEngine(self.modality, self.gdl_dtype, B, T, H, W, x.device)
+            self._engines[key] = eng
+        return eng
+
+    def _bind(self, eng):
+        bns = self._bn_layers()
+        eng.set_params([p.data for p in self.parameters()], [b.running_mean for b in bns],
+                       [b.running_var for b in bns], [b.num_batches_tracked for b in bns])
+
+    def _run(self, x, want):
+        x = x.float().contiguous()
+        return _ResNetFn.apply(self, x, want, *self.parameters())
+
+    def forward(self, x):
+        """backbone.py:158-201: returns the un-pooled layer4 map [N,512,h,w] (N = B*T for visual)."""
+        return self._run(x, "fmap")
+
+    def forward_pooled(self, x):
+        """ResNet.forward followed by the pooling glue of basic_model.py:73-82 -> [B,512]."""
+        return self._run(x, "feat")
+
+
+def _resnet(arch, args, block, layers, modality, progress, **kwargs):
+    return ResNet(args, block, layers, modality, **kwargs)
+
+
+def resnet18(modality, args, progress=True, **kwargs):
+    return _resnet('resnet18', args, BasicBlock, [2, 2, 2, 2], modality, progress, **kwargs)

@@ -1,0 +1,87 @@
+"""Drop-in mirror of the concat fusion heads of /root/reference/models/fusion_modules.py.
+
+`ConcatFusion_DGL` (:45-59) and `ConcatFusion` (:33-42): same constructor arguments, parameter
+names (`fc_out`, and the never-used `fc_auxi` of the DGL head) and return order.
+The three Linear calls, two zero fills and three cats of the reference collapse into one
+gfx950 kernel per direction (csrc/head.hip).
+"""
+import torch
+import torch.nn as nn
+
+from gdl import _lib as L
+
+
+def _f32c(t):
+    return t.float().contiguous()
+
+
+class _ConcatDGLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, W, b):
+        x, y, W, b = _f32c(x), _f32c(y), _f32c(W), _f32c(b)
+        B, n = x.shape[0], W.shape[0]
+        if x.shape[1] != 512 or y.shape[1] != 512 or W.shape[1] != 1024:
+            raise RuntimeError("gdl: ConcatFusion_DGL expects 512-d audio and visual features and a 1024-wide fc_out")
+        out, x_out, y_out = (torch.empty((B, n), device=x.device) for _ in range(3))
+        L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B,
+               n, L.cur_stream())
+        ctx.save_for_backward(x, y, W)
+        return x_out, y_out, out
+
+    @staticmethod
+    def backward(ctx, g_x_out, g_y_out, g_out):
+        x, y, W = ctx.saved_tensors
+        B, n = x.shape[0], W.shape[0]
+        gx = _f32c(g_x_out) if g_x_out is not None else None
+        gy = _f32c(g_y_out) if g_y_out is not None else None
+        go = _f32c(g_out) if g_out is not None else None
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        dW, db = torch.empty_like(W), torch.empty(n, device=x.device)
+        # `output` was computed from cat(x, y).detach() (fusion_modules.py:53-56): it never reaches x / y
+        L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 1, L.ptr(dx),
+               L.ptr(dy), L.ptr(dW), L.ptr(db), B, n, L.cur_stream())
+        return dx, dy, dW, db
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, W, b):
+        x, y, W, b = _f32c(x), _f32c(y), _f32c(W), _f32c(b)
+        B, n = x.shape[0], W.shape[0]
+        out = torch.empty((B, n), device=x.device)
+        L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), None, None, B, n,
+               L.cur_stream())
+        ctx.save_for_backward(x, y, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, y, W = ctx.saved_tensors
+        B, n = x.shape[0], W.shape[0]
+        go = _f32c(g_out)
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        dW, db = torch.empty_like(W), torch.empty(n, device=x.device)
+        L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), None, None, L.ptr(go), 1, 0, L.ptr(dx), L.ptr(dy),
+               L.ptr(dW), L.ptr(db), B, n, L.cur_stream())
+        return dx, dy, dW, db
+
+
+class ConcatFusion(nn.Module):
+    def __init__(self, input_dim=1024, output_dim=100):
+        super(ConcatFusion, self).__init__()
+        self.fc_out = nn.Linear(input_dim, output_dim)
+
+    def forward(self, x, y):
+        output = _ConcatFn.apply(x, y, self.fc_out.weight, self.fc_out.bias)
+        return x, y, output
+
+
+class ConcatFusion_DGL(nn.Module):
+    def __init__(self, input_dim=512 * 2, output_dim=100):
+        super(ConcatFusion_DGL, self).__init__()
+        self.fc_out = nn.Linear(input_dim, output_dim)
+        self.fc_auxi = nn.Linear(input_dim, output_dim)  # registered but unused, as in the reference
+
+    def forward(self, x, y):
+        x_out, y_out, output = _ConcatDGLFn.apply(x, y, self.fc_out.weight, self.fc_out.bias)
+        return x_out, y_out, output

@@ -1,0 +1,229 @@
+/*
+ * gdl_hip.h -- C ABI of libgdl_hip.so: the MI355X (gfx950) implementation of the
+ * DGL audio-visual training step of shicaiwei123/ICCV2025-GDL (main_dgl.py:90-162).
+ *
+ * Conventions (every entry point):
+ *   - plain C, raw DEVICE pointers, explicit sizes; no torch / C++ types;
+ *   - returns 0 on success, a GDL_ERR_* code otherwise; gdl_last_error() gives a
+ *     thread-local message; nothing throws across the boundary;
+ *   - never allocates or frees device memory: workspaces are caller-provided and
+ *     sized by the *_workspace_bytes query;
+ *   - never synchronises the device: work is enqueued on the hipStream_t passed
+ *     (as void*); the library keeps no pointer after return except inside an
+ *     explicitly created gdl_encoder_t / gdl_optim_t object.
+ *
+ * Activations inside the library are NHWC in `dtype` (GDL_BF16 for the benchmark
+ * configuration, GDL_F32 for the exact-f32 parity mode).  Parameters, gradients,
+ * BatchNorm statistics, pooled features, logits and losses are float32 in the
+ * reference's own layouts (conv weight [K][C][R][S], linear weight [out][in]).
+ *
+ * Reference interface each group replaces is cited as file:line into
+ * /root/reference (the PyTorch operators the reference calls there).
+ */
+#ifndef GDL_HIP_H
+#define GDL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDL_API __attribute__((visibility("default")))
+
+enum { GDL_OK = 0, GDL_ERR_ARG = 1, GDL_ERR_HIP = 2, GDL_ERR_STATE = 3, GDL_ERR_WORKSPACE = 4 };
+enum { GDL_F32 = 0, GDL_BF16 = 1 };
+enum { GDL_AUDIO = 0, GDL_VISUAL = 1 };
+
+GDL_API const char* gdl_last_error(void);
+GDL_API int gdl_version(void);
+/* number of compute units / device name of the current device (host query) */
+GDL_API int gdl_device_info(int* cu_count, char* name, int name_len);
+
+/* ------------------------------------------------------------------ convolution
+ * nn.Conv2d(bias=False): backbone.py:20-23 (3x3 s1/s2 p1), :26-28 (1x1 s2),
+ * :96-101 (7x7 s2 p3 stem).  Implicit GEMM on MFMA.
+ *
+ * gdl_conv_fwd:  x NHWC [N][H][W][C] (dtype), w_krsc [K][R][S][C] (dtype, from
+ *   gdl_pack_weight) -> y NHWC [N][P][Q][K] (dtype).  C % (128/sizeof(dtype)) == 0,
+ *   K % 64 == 0.  If bn_partial != NULL the epilogue also writes per-channel
+ *   (sum, sum of squares) of the STORED values of each M-tile:
+ *   bn_partial[tile][K][2] float, tile < gdl_conv_bn_tiles(...).
+ * gdl_conv_dgrad: dy [N][P][Q][K], w_crsk [C][R][S][K] -> dx [N][H][W][C]
+ *   (+ addend, same shape as dx, may alias dx; NULL for none).
+ * gdl_conv_wgrad: dy, x -> dw [K][C][R][S] float32 (overwritten).  `ws` holds
+ *   split-K partials; size from gdl_conv_wgrad_workspace_bytes.
+ */
+GDL_API int gdl_conv_bn_tiles(int dtype, int N, int P, int Q, int K);
+GDL_API int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, int N, int H, int W,
+                         int C, int K, int R, int S, int stride, int pad, void* stream);
+GDL_API int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
+                           int W, int C, int K, int R, int S, int stride, int pad, void* stream);
+GDL_API size_t gdl_conv_wgrad_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                              int pad);
+GDL_API int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw_kcrs, int N, int H, int W, int C, int K,
+                           int R, int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+/* float32 [K][C][R][S] -> dtype [K][R][S][C] (w_krsc) and dtype [C][R][S][K] (w_crsk); either may be NULL */
+GDL_API int gdl_pack_weight(int dtype, const float* w_kcrs, void* w_krsc, void* w_crsk, int K, int C, int R, int S,
+                            void* stream);
+
+/* Stem 7x7/2 pad 3 (backbone.py:96-101) runs as im2col + the same GEMM kernels.
+ * x is the reference's own input tensor: float32 [B][Cin][T][H][W] (T = 1 and
+ * Cin = 1 for audio `spec.unsqueeze(1)`; the visual permute/view of
+ * backbone.py:162-164 is folded into the indexing).  col: [B*T*P*Q][Kp] dtype,
+ * Kp = gdl_stem_kp(Cin, dtype) >= Cin*49, zero padded.
+ * gdl_pack_stem_weight: float32 [64][Cin][7][7] -> dtype [64][Kp].
+ * gdl_unpack_stem_wgrad: float32 [64][Kp] -> float32 [64][Cin][7][7]. */
+GDL_API int gdl_stem_kp(int cin, int dtype);
+GDL_API int gdl_stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, void* stream);
+GDL_API int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* stream);
+/* dw [64][Cin][7][7] float32 from dy [M][64] and the im2col matrix; ws sized by
+ * gdl_conv_wgrad_workspace_bytes(dtype, M, 1, 1, Kp, 64, 1, 1, 1, 0) */
+GDL_API int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, int M, int Cin, void* ws,
+                           size_t ws_bytes, void* stream);
+
+/* layout conversion at the module boundary: NHWC dtype <-> NCHW float32 */
+GDL_API int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream);
+GDL_API int gdl_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm2d (+ReLU, +residual)
+ * nn.BatchNorm2d(eps 1e-5, momentum 0.1): backbone.py:45,48,104,144; nn.ReLU and
+ * `out += identity`: backbone.py:46,57,65-66,105.
+ *
+ * gdl_bn_finalize_train: reduces conv-epilogue partials [tiles][C][2] over `count`
+ *   elements per channel -> save_mean, save_rstd (biased variance), scale =
+ *   gamma*rstd, shift = beta - mean*scale; updates running_mean / running_var
+ *   (unbiased) with `momentum` and increments *num_batches_tracked (int64) when
+ *   the pointers are non-NULL.
+ * gdl_bn_finalize_eval: scale/shift from the running statistics.
+ * gdl_bn_act: out = [relu]( y*scale+shift + residual ), residual = none |
+ *   res (raw tensor) | res*res_scale+res_shift (downsample branch).
+ * gdl_bn_stats: per-channel partials of an existing tensor (when the producer
+ *   was not gdl_conv_fwd); same partial format, tiles = gdl_bn_stats_tiles(M).
+ */
+GDL_API int gdl_bn_stats_tiles(int M);
+GDL_API int gdl_bn_stats(int dtype, const void* y, float* partial, int M, int C, void* stream);
+GDL_API int gdl_bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* scale,
+                                  float* shift, void* stream);
+GDL_API int gdl_bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                                 const float* running_var, float* scale, float* shift, void* stream);
+GDL_API int gdl_bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                       const float* res_scale, const float* res_shift, int relu, void* out, size_t M, int C,
+                       void* stream);
+/* backward.  g = upstream gradient w.r.t. the BN output (after an optional fused
+ * ReLU mask: relu_mask != 0 applies (y*scale+shift > 0) to g).
+ * gdl_bn_bwd_reduce -> partial[blocks][C][2]; gdl_bn_bwd_finalize -> dgamma, dbeta
+ * (float32, overwritten) and coef[2][C] = {dbeta/M, dgamma/M};
+ * gdl_bn_bwd_apply: dy = gamma*rstd*(g - coef0 - xhat*coef1), may alias g. */
+GDL_API int gdl_bn_bwd_blocks(size_t M);
+GDL_API int gdl_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift,
+                              const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M,
+                              int C, void* stream);
+GDL_API int gdl_bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta,
+                                float* coef, void* stream);
+GDL_API int gdl_bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift,
+                             const float* save_mean, const float* save_rstd, const float* gamma, const float* coef,
+                             int relu_mask, void* dy, size_t M, int C, void* stream);
+/* dx = dy * (out > 0)   (may alias dy) */
+GDL_API int gdl_relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, void* stream);
+
+/* ------------------------------------------------------------------ pooling
+ * nn.MaxPool2d(3,2,1): backbone.py:106, fused with the stem's BN+ReLU:
+ *   out[n,p,q,c] = max over the window of relu(y*scale+shift); idx (uint8, 0..8)
+ *   records the first maximum in row-major window order.
+ * gdl_maxpool_bwd gathers: dx[n,h,w,c] = sum of dout over windows whose idx
+ *   points at (h,w).
+ * Global average pools of basic_model.py:73-82: x [B*T][HW][C] dtype -> feat
+ *   [B][C] float32 (mean over T*HW); backward broadcasts dfeat/(T*HW). */
+GDL_API int gdl_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out,
+                                    uint8_t* idx, int N, int H, int W, int C, void* stream);
+GDL_API int gdl_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C,
+                            void* stream);
+GDL_API int gdl_avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int C, void* stream);
+GDL_API int gdl_avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ fusion head + loss
+ * ConcatFusion_DGL.forward (fusion_modules.py:51-59) and ConcatFusion.forward
+ * (:38-42); nn.CrossEntropyLoss (main_dgl.py:71,102-104).  All float32.
+ *   x, y: [B][512] pooled audio / visual features; W [n][1024]; b [n].
+ * gdl_head_concat_fwd: out = [x,y]W^T+b, x_out = [x,0]W^T+b, y_out = [0,y]W^T+b
+ *   (x_out / y_out may be NULL for the non-DGL head).
+ * gdl_head_concat_bwd: autograd of the above for upstream gradients g_x_out,
+ *   g_y_out, g_out (each may be NULL):
+ *     dx = g_x_out W[:, :512] (+ g_out W[:, :512] if out_reaches_xy),
+ *     dy = g_y_out W[:, 512:] (+ ...),
+ *     dW = g_out^T [x,y] + (uni_in_dw ? g_x_out^T [x,0] + g_y_out^T [0,y] : 0), db likewise.
+ *   DGL (detach + dropped head grads, main_dgl.py:110-122): out_reaches_xy = 0,
+ *   uni_in_dw = 0.  Plain autograd of one backward call: uni_in_dw = 1.
+ * gdl_softmax_ce: loss[0] = mean CE; dlogits = scale*(softmax-onehot)/B (may be NULL). */
+GDL_API int gdl_head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out,
+                                float* x_out, float* y_out, int B, int n_classes, void* stream);
+GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out,
+                                const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
+                                float* dy, float* dW, float* db, int B, int n_classes, void* stream);
+GDL_API int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
+                           int n_classes, void* stream);
+
+/* ------------------------------------------------------------------ clip + grad stats + SGD
+ * clip_grad_norm_(params, 40, 2) (main_dgl.py:129), the logged
+ * sum_p mean|grad_p| per encoder (:132-143) and optim.SGD(momentum, weight_decay)
+ * (:249,154) over FLAT float32 arenas.  seg_offsets[nseg+1] (int64, element
+ * offsets, host memory) delimit the parameters; seg_group[nseg] (int32, host) is
+ * 0 = fusion head, 1 = audio_net, 2 = visual_net.
+ * gdl_optim_grad_stats writes stats[0..3] = {total_norm (pre-clip), clip_coef,
+ *   audio_grad_sum, visual_grad_sum (both post-clip)} on the device.
+ * gdl_optim_sgd_step: g *= clip_coef*grad_scale (written back); d = g + wd*p;
+ *   m = mu*m + d; p -= lr*m  (momentum arena starts at zero, which reproduces
+ *   torch's first-step `buf = d`). */
+typedef struct gdl_optim gdl_optim_t;
+GDL_API int gdl_optim_create(gdl_optim_t** out, const int64_t* seg_offsets, const int32_t* seg_group, int nseg);
+GDL_API void gdl_optim_destroy(gdl_optim_t* o);
+GDL_API size_t gdl_optim_workspace_bytes(const gdl_optim_t* o);
+GDL_API int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, float grad_scale, float* stats,
+                                 void* ws, size_t ws_bytes, void* stream);
+GDL_API int gdl_optim_stats_len(const gdl_optim_t* o); /* 4 + 2*nseg floats */
+GDL_API int gdl_optim_sgd_step(gdl_optim_t* o, float* params, float* grads, float* momentum, const float* stats,
+                               float grad_scale, float lr, float mu, float wd, void* stream);
+
+/* ------------------------------------------------------------------ ResNet18 encoder engine
+ * `resnet18(modality, args)` / ResNet.forward (backbone.py:75-201, 255-257) plus the
+ * pooling glue of AVClassifier_DGL.forward (basic_model.py:73-82), as one planned
+ * sequence of the kernels above on one stream.
+ *
+ * Parameter order everywhere below = named_parameters() order of the reference
+ * module (60 tensors): conv1.weight, bn1.weight, bn1.bias, then per BasicBlock
+ * conv1.weight, bn1.{weight,bias}, conv2.weight, bn2.{weight,bias}
+ * [, downsample.0.weight, downsample.1.{weight,bias}].  BatchNorm buffer order =
+ * the 20 BatchNorm layers in the same traversal.
+ */
+typedef struct gdl_encoder gdl_encoder_t;
+#define GDL_ENC_NPARAMS 60
+#define GDL_ENC_NBN 20
+GDL_API int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int T, int H, int W);
+GDL_API void gdl_encoder_destroy(gdl_encoder_t* e);
+GDL_API size_t gdl_encoder_workspace_bytes(const gdl_encoder_t* e);
+GDL_API int gdl_encoder_param_numel(const gdl_encoder_t* e, int64_t* numel /*[60]*/);
+GDL_API int gdl_encoder_out_shape(const gdl_encoder_t* e, int* n_img, int* h, int* w);
+/* bind the caller-owned workspace (device) and the parameter / gradient / buffer tables (host arrays of device ptrs) */
+GDL_API int gdl_encoder_bind(gdl_encoder_t* e, void* workspace, size_t bytes);
+GDL_API int gdl_encoder_set_params(gdl_encoder_t* e, const float* const* params, float* const* running_mean,
+                                   float* const* running_var, int64_t* const* num_batches_tracked);
+/* forward.  x: the reference's input tensor, float32 [B][Cin][T][H][W] contiguous.
+ * training != 0: batch statistics, running-stat update, activations kept for backward.
+ * feat_out: [B][512] float32 pooled features (may be NULL); fmap_nchw: [B*T][512][h][w]
+ * float32, the tensor ResNet.forward returns (may be NULL). */
+GDL_API int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* feat_out, float* fmap_nchw,
+                                void* stream);
+/* backward of the last training forward.  Exactly one of dfeat ([B][512]) / dfmap_nchw
+ * is non-NULL.  grads: 60 device pointers (float32, reference layouts), overwritten. */
+GDL_API int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfmap_nchw, float* const* grads,
+                                 void* stream);
+/* serial number of the last training forward (to detect stale activations) */
+GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDL_HIP_H */

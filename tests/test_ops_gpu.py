@@ -1,0 +1,296 @@
+"""GPU parity tests, op level: every HIP kernel behind the C ABI against the CPU oracle
+(oracle/) on the same seeded inputs.  For bf16 the inputs are pre-rounded to bf16 so that
+the comparison isolates the kernel (fp32 accumulation + one output rounding)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from gdl import _lib as L  # noqa: E402
+from gpu_util import (DEV, bf16_round, dev, empty, from_nhwc, pack_weight, quant, relerr, to_nhwc, tol)  # noqa: E402
+
+DTS = [L.GDL_F32, L.GDL_BF16]
+rng = np.random.default_rng(2024)
+
+
+def _conv_case(N, C, H, W, K, R, stride, pad, dt):
+    x = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    w = quant((rng.standard_normal((K, C, R, R), dtype=np.float32) * np.sqrt(2.0 / (C * R * R))).astype(np.float32), dt)
+    return x, w
+
+
+CONV_SHAPES = [
+    # N, C, H, W, K, R, stride, pad      -> tile config exercised
+    (2, 64, 17, 13, 64, 3, 1, 1),     # 256x64, ragged M tail, odd spatial dims
+    (3, 64, 20, 18, 128, 3, 2, 1),    # 64x64, stride 2
+    (2, 64, 9, 6, 128, 1, 2, 0),      # 1x1 stride 2 (downsample)
+    (1, 128, 7, 5, 256, 3, 1, 1),     # 64x64, deeper K
+    (4, 64, 112, 112, 128, 3, 1, 1),  # 128x128
+    (2, 256, 14, 14, 512, 3, 2, 1),   # 64x64, C=256
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_fwd(shape, dt):
+    N, C, H, W, K, R, stride, pad = shape
+    x, w = _conv_case(N, C, H, W, K, R, stride, pad, dt)
+    ref = orc.conv2d_fwd(x, w, stride, pad)
+    P, Q = ref.shape[2], ref.shape[3]
+    xd = to_nhwc(x, dt)
+    krsc, _ = pack_weight(w, dt)
+    y = empty((N, P, Q, K), dt)
+    tiles = L.load().gdl_conv_bn_tiles(dt, N, P, Q, K)
+    part = torch.full((tiles, K, 2), float("nan"), device=DEV)
+    L.call("gdl_conv_fwd", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), N, H, W, C, K, R, R, stride, pad,
+           L.cur_stream())
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert relerr(got, ref) < tol(dt, 2e-6, 3e-3), relerr(got, ref)
+    np.testing.assert_allclose(got, ref, rtol=tol(dt, 1e-4, 2e-2), atol=tol(dt, 1e-5, 2e-2))
+    # BatchNorm partials: sums of the STORED values
+    s = part.double().sum(0).cpu().numpy()
+    g64 = got.astype(np.float64)
+    np.testing.assert_allclose(s[:, 0], g64.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1], (g64 ** 2).sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_conv_dgrad(shape, dt, with_addend):
+    N, C, H, W, K, R, stride, pad = shape
+    _, w = _conv_case(N, C, H, W, K, R, stride, pad, dt)
+    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = quant(rng.standard_normal((N, K, P, Q), dtype=np.float32), dt)
+    ref = orc.conv2d_bwd_data(dy, w, (N, C, H, W), stride, pad)
+    add = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    if with_addend:
+        ref = ref + add
+    _, crsk = pack_weight(w, dt)
+    dyd = to_nhwc(dy, dt)
+    dx = to_nhwc(add, dt) if with_addend else empty((N, H, W, C), dt)
+    L.call("gdl_conv_dgrad", dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), L.ptr(dx) if with_addend else None, N, H, W, C, K,
+           R, R, stride, pad, L.cur_stream())
+    torch.cuda.synchronize()
+    got = from_nhwc(dx)
+    assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
+
+
+WGRAD_SHAPES = [
+    (2, 64, 17, 13, 64, 3, 1, 1),    # 64x64 tiles
+    (3, 64, 20, 18, 128, 3, 2, 1),   # TK=128, TC=64
+    (2, 128, 9, 6, 64, 3, 1, 1),     # TK=64, TC=128
+    (2, 128, 12, 10, 256, 3, 1, 1),  # 128x128
+    (2, 64, 9, 6, 128, 1, 2, 0),     # 1x1 stride 2
+    (3, 64, 56, 56, 64, 3, 1, 1),    # many splits
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_conv_wgrad(shape, dt):
+    N, C, H, W, K, R, stride, pad = shape
+    x, w = _conv_case(N, C, H, W, K, R, stride, pad, dt)
+    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = quant(rng.standard_normal((N, K, P, Q), dtype=np.float32), dt)
+    ref = orc.conv2d_bwd_weight(dy, x, w.shape, stride, pad)
+    xd, dyd = to_nhwc(x, dt), to_nhwc(dy, dt)
+    nbytes = L.load().gdl_conv_wgrad_workspace_bytes(dt, N, H, W, C, K, R, R, stride, pad)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((K, C, R, R), float("nan"), device=DEV)
+    L.call("gdl_conv_wgrad", dt, L.ptr(dyd), L.ptr(xd), L.ptr(dw), N, H, W, C, K, R, R, stride, pad, L.ptr(ws), nbytes,
+           L.cur_stream())
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy()
+    assert relerr(got, ref) < 2e-5, relerr(got, ref)  # fp32 accumulation of (for bf16: exact) products
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [("audio", 2, 1, 1, 65, 47), ("visual", 2, 3, 2, 40, 36)])
+def test_stem(case, dt):
+    """7x7/2 stem as im2col + GEMM (forward and weight gradient) against the oracle's direct conv."""
+    _, B, Cin, T, H, W = case
+    x = rng.standard_normal((B, Cin, T, H, W), dtype=np.float32)
+    w = (rng.standard_normal((64, Cin, 7, 7), dtype=np.float32) * 0.1).astype(np.float32)
+    xq = quant(x, dt)  # im2col rounds the input to the storage type
+    wq = quant(w, dt)
+    x4 = np.ascontiguousarray(xq.transpose(0, 2, 1, 3, 4)).reshape(B * T, Cin, H, W)
+    ref = orc.conv2d_fwd(x4, wq, 2, 3)
+    P, Q = ref.shape[2], ref.shape[3]
+    M = B * T * P * Q
+    kp = L.load().gdl_stem_kp(Cin, dt)
+    col = empty((M, kp), dt)
+    wp = empty((64, kp), dt)
+    y = empty((B * T, P, Q, 64), dt)
+    xd, wd = dev(x), dev(w)
+    st = L.cur_stream()
+    L.call("gdl_stem_im2col", dt, L.ptr(xd), L.ptr(col), B, Cin, T, H, W, st)
+    L.call("gdl_pack_stem_weight", dt, L.ptr(wd), L.ptr(wp), Cin, st)
+    L.call("gdl_conv_fwd", dt, L.ptr(col), L.ptr(wp), L.ptr(y), None, M, 1, 1, kp, 64, 1, 1, 1, 0, st)
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert relerr(got, ref) < tol(dt, 2e-6, 3e-3), relerr(got, ref)
+    dy = quant(rng.standard_normal((B * T, 64, P, Q), dtype=np.float32), dt)
+    refw = orc.conv2d_bwd_weight(dy, x4, (64, Cin, 7, 7), 2, 3)
+    dyd = to_nhwc(dy, dt)
+    nbytes = L.load().gdl_conv_wgrad_workspace_bytes(dt, M, 1, 1, kp, 64, 1, 1, 1, 0)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
+    L.call("gdl_stem_wgrad", dt, L.ptr(dyd), L.ptr(col), L.ptr(dw), M, Cin, L.ptr(ws), nbytes, st)
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu().numpy(), refw) < 2e-5, relerr(dw.cpu().numpy(), refw)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C,N,H,W", [(64, 3, 9, 7), (128, 2, 17, 12), (512, 4, 3, 2)])
+def test_bn_forward_backward(C, N, H, W, dt):
+    x = quant(rng.standard_normal((N, C, H, W), dtype=np.float32) * 1.7 + 0.3, dt)
+    gamma = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    rm = (0.05 * rng.standard_normal(C)).astype(np.float32)
+    rv = (1 + 0.1 * np.abs(rng.standard_normal(C))).astype(np.float32)
+    rm_ref, rv_ref = rm.copy(), rv.copy()
+    yref, mean, invstd = orc.bn_fwd_train(x, gamma, beta, rm_ref, rv_ref)
+    aref = np.maximum(yref, 0)
+    M = N * H * W
+    xd = to_nhwc(x, dt)
+    lib = L.load()
+    tiles = lib.gdl_bn_stats_tiles(M)
+    part = torch.empty((tiles, C, 2), device=DEV)
+    st = L.cur_stream()
+    L.call("gdl_bn_stats", dt, L.ptr(xd), L.ptr(part), M, C, st)
+    g_d, b_d, rm_d, rv_d = dev(gamma), dev(beta), dev(rm), dev(rv)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    sm, sr, sc, sh = (torch.empty(C, device=DEV) for _ in range(4))
+    L.call("gdl_bn_finalize_train", L.ptr(part), tiles, C, float(M), L.ptr(g_d), L.ptr(b_d), 1e-5, 0.1, L.ptr(rm_d),
+           L.ptr(rv_d), L.ptr(nbt), L.ptr(sm), L.ptr(sr), L.ptr(sc), L.ptr(sh), st)
+    a = empty((N, H, W, C), dt)
+    L.call("gdl_bn_act", dt, L.ptr(xd), L.ptr(sc), L.ptr(sh), None, None, None, 1, L.ptr(a), M, C, st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(sm.cpu().numpy(), mean, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(sr.cpu().numpy(), invstd, rtol=1e-4)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref, rtol=1e-4)
+    assert int(nbt.item()) == 1
+    assert relerr(from_nhwc(a), aref) < tol(dt, 2e-6, 3e-3)
+    # backward through relu + bn
+    da = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    dxref, dgref, dbref = orc.bn_bwd(orc.relu_bwd(da, aref), x, gamma, mean, invstd)
+    dad = to_nhwc(da, dt)
+    blocks = lib.gdl_bn_bwd_blocks(M)
+    bpart = torch.empty((blocks, C, 2), device=DEV)
+    dg, db, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)
+    L.call("gdl_bn_bwd_reduce", dt, L.ptr(dad), L.ptr(xd), L.ptr(sc), L.ptr(sh), L.ptr(sm), L.ptr(sr), 1, L.ptr(bpart),
+           M, C, st)
+    L.call("gdl_bn_bwd_finalize", L.ptr(bpart), blocks, C, float(M), L.ptr(dg), L.ptr(db), L.ptr(coef), st)
+    dx = empty((N, H, W, C), dt)
+    L.call("gdl_bn_bwd_apply", dt, L.ptr(dad), L.ptr(xd), L.ptr(sc), L.ptr(sh), L.ptr(sm), L.ptr(sr), L.ptr(g_d),
+           L.ptr(coef), 1, L.ptr(dx), M, C, st)
+    torch.cuda.synchronize()
+    # relu masks can differ where |bn output| ~ 0: allow a small norm-wise slack
+    assert relerr(dg.cpu().numpy(), dgref) < 2e-3
+    assert relerr(db.cpu().numpy(), dbref) < 2e-3
+    assert relerr(from_nhwc(dx), dxref) < tol(dt, 2e-3, 6e-3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_bn_act_residual_and_relu_bwd(dt):
+    N, C, H, W = 2, 128, 5, 7
+    M = N * H * W
+    y = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    r = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    sc, sh, rsc, rsh = (rng.standard_normal(C).astype(np.float32) for _ in range(4))
+    yd, rd = to_nhwc(y, dt), to_nhwc(r, dt)
+    scd, shd, rscd, rshd = dev(sc), dev(sh), dev(rsc), dev(rsh)
+    st = L.cur_stream()
+    bc = lambda v: v[None, :, None, None]
+    for mode in (1, 2):
+        ref = y * bc(sc) + bc(sh) + (r if mode == 1 else r * bc(rsc) + bc(rsh))
+        ref = np.maximum(ref, 0)
+        out = empty((N, H, W, C), dt)
+        L.call("gdl_bn_act", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(rd), L.ptr(rscd) if mode == 2 else None,
+               L.ptr(rshd) if mode == 2 else None, 1, L.ptr(out), M, C, st)
+        torch.cuda.synchronize()
+        assert relerr(from_nhwc(out), ref) < tol(dt, 2e-6, 3e-3)
+    dz = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    dzd = to_nhwc(dz, dt)
+    L.call("gdl_relu_bwd", dt, L.ptr(dzd), L.ptr(out), L.ptr(dzd), M * C, st)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(from_nhwc(dzd), np.where(from_nhwc(out) > 0, dz, 0).astype(np.float32))
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,H,W", [(2, 33, 24), (3, 16, 16), (1, 7, 9)])
+def test_maxpool(N, H, W, dt):
+    C = 64
+    y = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    sc = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    sc[::7] *= -1  # negative scales: max and BN do not commute
+    sh = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    a = np.maximum(y * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32)
+    a = quant(a, dt)
+    pref, idx = orc.maxpool_fwd(a)
+    P, Q = pref.shape[2], pref.shape[3]
+    yd = to_nhwc(y, dt)
+    out = empty((N, P, Q, C), dt)
+    ix = torch.empty((N, P, Q, C), dtype=torch.uint8, device=DEV)
+    st = L.cur_stream()
+    scd, shd = dev(sc), dev(sh)  # keep alive: the caching allocator reuses freed temporaries at once
+    L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(out), L.ptr(ix), N, H, W, C, st)
+    torch.cuda.synchronize()
+    got = from_nhwc(out)
+    np.testing.assert_allclose(got, pref, rtol=tol(dt, 1e-5, 1e-2), atol=tol(dt, 1e-6, 1e-2))
+    dout = quant(rng.standard_normal((N, C, P, Q), dtype=np.float32), dt)
+    # reference backward with the argmax recomputed from the DEVICE output's own choice is not
+    # available; where `a` has no exact ties inside a window both agree, so compare sums per
+    # window owner: use the oracle on `a` (ties only at relu zeros, which carry zero gradient
+    # after the relu mask applied below)
+    dref = orc.maxpool_bwd(dout, idx, a.shape)
+    dxd = empty((N, H, W, C), dt)
+    doutd = to_nhwc(dout, dt)
+    L.call("gdl_maxpool_bwd", dt, L.ptr(doutd), L.ptr(ix), L.ptr(dxd), N, H, W, C, st)
+    torch.cuda.synchronize()
+    mask = a > 0
+    gotb = from_nhwc(dxd)
+    if dt == L.GDL_F32:
+        np.testing.assert_allclose(gotb * mask, dref * mask, rtol=1e-5, atol=1e-6)
+    else:  # bf16 ties between positive neighbours may route differently; totals must still agree
+        np.testing.assert_allclose(gotb.sum((2, 3)), quant(dref, dt).sum((2, 3)), rtol=5e-2, atol=0.3)
+        assert relerr(gotb * mask, dref * mask) < 0.15
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_avgpool(dt):
+    B, T, C, H, W = 3, 2, 512, 3, 2
+    x = quant(rng.standard_normal((B * T, C, H, W), dtype=np.float32), dt)
+    ref = orc.avgpool_fwd(x, B, T)
+    feat = torch.empty((B, C), device=DEV)
+    st = L.cur_stream()
+    xd = to_nhwc(x, dt)
+    L.call("gdl_avgpool_fwd", dt, L.ptr(xd), L.ptr(feat), B, T, H * W, C, st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(feat.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+    df = rng.standard_normal((B, C), dtype=np.float32)
+    dx = empty((B * T, H, W, C), dt)
+    dfd = dev(df)
+    L.call("gdl_avgpool_bwd", dt, L.ptr(dfd), L.ptr(dx), B, T, H * W, C, st)
+    torch.cuda.synchronize()
+    assert relerr(from_nhwc(dx), orc.avgpool_bwd(df, x.shape, B, T)) < tol(dt, 1e-6, 3e-3)
+
+
+def test_layout_roundtrip():
+    for dt in DTS:
+        x = quant(rng.standard_normal((3, 70, 5, 9), dtype=np.float32), dt)
+        xd = dev(x)
+        t = empty((3, 5, 9, 70), dt)
+        back = torch.empty((3, 70, 5, 9), device=DEV)
+        st = L.cur_stream()
+        L.call("gdl_nchw_f32_to_nhwc", dt, L.ptr(xd), L.ptr(t), 3, 5, 9, 70, st)
+        L.call("gdl_nhwc_to_nchw_f32", dt, L.ptr(t), L.ptr(back), 3, 5, 9, 70, st)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(back.cpu().numpy(), x)
+        np.testing.assert_array_equal(from_nhwc(t), x)

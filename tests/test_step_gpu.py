@@ -1,0 +1,352 @@
+"""GPU parity tests, model level: fusion head, loss, fused optimizer, the encoder engine and the
+whole DGL step against the CPU oracle and the golden vectors captured from the reference."""
+import argparse
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+from gdl import _lib as L  # noqa: E402
+from gpu_util import DEV, dev, relerr  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+rng = np.random.default_rng(7)
+
+
+def _gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+# ------------------------------------------------------------------ fusion head / loss
+@pytest.mark.parametrize("name,n", [("head_dgl_c6", 6), ("head_dgl_c34", 34)])
+def test_head_dgl_golden(name, n):
+    g = _gold(name)
+    st_ = fx.make_state({"fusion_module.fc_out.weight": (n, 1024), "fusion_module.fc_out.bias": (n,)})
+    W, b = dev(st_["fusion_module.fc_out.weight"]), dev(st_["fusion_module.fc_out.bias"])
+    x, y = dev(g["x"]), dev(g["y"])
+    B = x.shape[0]
+    out, xo, yo = (torch.empty((B, n), device=DEV) for _ in range(3))
+    st = L.cur_stream()
+    L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), L.ptr(xo), L.ptr(yo), B, n, st)
+    torch.cuda.synchronize()
+    for t, k in ((out, "out"), (xo, "x_out"), (yo, "y_out")):
+        np.testing.assert_allclose(t.cpu().numpy(), g[k], rtol=1e-4, atol=1e-5)
+    gx, gy, go = dev(g["g_x_out"]), dev(g["g_y_out"]), dev(g["g_out"])
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    # phase 1 of main_dgl.py:110 (only the unimodal losses): plain autograd of x_out / y_out
+    L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), None, 0, 1, L.ptr(dx), L.ptr(dy),
+           L.ptr(dW), L.ptr(db), B, n, st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dx.cpu().numpy(), g["dx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dy.cpu().numpy(), g["dy"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dW.cpu().numpy(), g["dW_uni"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), g["db_uni"], rtol=1e-4, atol=1e-4)
+    # fused DGL form: encoders see only the unimodal grads, fc_out only the multimodal one
+    L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 0, L.ptr(dx),
+           L.ptr(dy), L.ptr(dW), L.ptr(db), B, n, st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dx.cpu().numpy(), g["dx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dy.cpu().numpy(), g["dy"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dW.cpu().numpy(), g["dW_f"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), g["db_f"], rtol=1e-4, atol=1e-4)
+
+
+def test_head_concat_golden():
+    g = _gold("head_concat_c6")
+    st_ = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
+    W, b = dev(st_["fusion_module.fc_out.weight"]), dev(st_["fusion_module.fc_out.bias"])
+    x, y, go = dev(g["x"]), dev(g["y"]), dev(g["g_out"])
+    B, n = x.shape[0], 6
+    out = torch.empty((B, n), device=DEV)
+    st = L.cur_stream()
+    L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), None, None, B, n, st)
+    dx, dy, dW, db = torch.empty_like(x), torch.empty_like(y), torch.empty_like(W), torch.empty_like(b)
+    L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), None, None, L.ptr(go), 1, 0, L.ptr(dx), L.ptr(dy),
+           L.ptr(dW), L.ptr(db), B, n, st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    for t, k in ((dx, "dx"), (dy, "dy"), (dW, "dW"), (db, "db")):
+        np.testing.assert_allclose(t.cpu().numpy(), g[k], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,n", [(64, 6), (5, 34), (300, 309)])
+def test_softmax_ce(B, n):
+    lg = (3 * rng.standard_normal((B, n))).astype(np.float32)
+    lab = rng.integers(0, n, B).astype(np.int64)
+    loss_ref, d_ref = orc.softmax_ce(lg, lab, 4.0)
+    lgd, labd = dev(lg), torch.from_numpy(lab).to(DEV)
+    loss, d = torch.zeros(1, device=DEV), torch.empty((B, n), device=DEV)
+    L.call("gdl_softmax_ce", L.ptr(lgd), L.ptr(labd), 4.0, L.ptr(loss), L.ptr(d), B, n, L.cur_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss.item(), loss_ref, rtol=1e-5)
+    np.testing.assert_allclose(d.cpu().numpy(), d_ref, rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------ fused clip + stats + SGD
+@pytest.mark.parametrize("scale", [0.01, 10.0])  # below / above the clipping threshold
+def test_optim(scale):
+    sizes = [6144, 6, 3136, 64, 64, 36864, 9, 147456, 8193]
+    group = [0, 0, 1, 1, 1, 1, 2, 2, 2]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offs[-1])
+    p0 = rng.standard_normal(n).astype(np.float32)
+    h = ctypes.c_void_p()
+    so = (ctypes.c_int64 * len(offs))(*offs.tolist())
+    sg = (ctypes.c_int32 * len(group))(*group)
+    L.call("gdl_optim_create", ctypes.byref(h), so, sg, len(group))
+    lib = L.load()
+    wsb = lib.gdl_optim_workspace_bytes(h)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    stats = torch.zeros(lib.gdl_optim_stats_len(h), device=DEV)
+    P, M = dev(p0), torch.zeros(n, device=DEV)
+    p_ref, m_ref = p0.copy(), np.zeros(n, np.float32)
+    for step in range(3):
+        g = (scale * rng.standard_normal(n)).astype(np.float32)
+        G = dev(g)
+        st = L.cur_stream()
+        L.call("gdl_optim_grad_stats", h, L.ptr(G), 40.0, 1.0, L.ptr(stats), L.ptr(ws), wsb, st)
+        L.call("gdl_optim_sgd_step", h, L.ptr(P), L.ptr(G), L.ptr(M), L.ptr(stats), 1.0, 2e-3, 0.9, 1e-4, st)
+        torch.cuda.synchronize()
+        total = np.sqrt(orc.sumsq(g))
+        coef = min(1.0, 40.0 / (total + 1e-6))
+        gc = (g * np.float32(coef)).astype(np.float32)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[0], total, rtol=1e-5)
+        np.testing.assert_allclose(s[1], coef, rtol=1e-5)
+        a_sum = sum(orc.abs_mean(gc[offs[i]:offs[i + 1]]) for i in range(len(sizes)) if group[i] == 1)
+        v_sum = sum(orc.abs_mean(gc[offs[i]:offs[i + 1]]) for i in range(len(sizes)) if group[i] == 2)
+        np.testing.assert_allclose(s[2], a_sum, rtol=1e-5)
+        np.testing.assert_allclose(s[3], v_sum, rtol=1e-5)
+        for i in range(len(sizes)):
+            np.testing.assert_allclose(s[4 + i], np.sqrt(orc.sumsq(gc[offs[i]:offs[i + 1]])), rtol=1e-5)
+        np.testing.assert_allclose(G.cpu().numpy(), gc, rtol=1e-6, atol=1e-9)  # grads are clipped in place
+        orc.sgd_(p_ref, gc, m_ref, 2e-3, 0.9, 1e-4, step == 0)
+        np.testing.assert_allclose(P.cpu().numpy(), p_ref, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(M.cpu().numpy(), m_ref, rtol=1e-5, atol=1e-7)
+    lib.gdl_optim_destroy(h)
+
+
+# ------------------------------------------------------------------ encoder engine vs reference goldens
+def _load_state(module, state):
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in state.items()}
+    module.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name,modality", [("enc_audio_tiny", "audio"), ("enc_visual_tiny", "visual")])
+def test_encoder_golden(name, modality, dtype):
+    from models.backbone import resnet18
+
+    g = _gold(name)
+    net = resnet18(modality=modality, args=None)
+    P = fx.make_state(fx.resnet18_param_shapes("", 1 if modality == "audio" else 3))
+    Bf = fx.make_state(fx.resnet18_buffer_shapes(""))
+    _load_state(net, {**P, **Bf})
+    net = net.to(DEV)
+    net.gdl_dtype = dtype
+    net.train()
+    x = dev(g["x"])
+    y = net(x)
+    assert tuple(y.shape) == g["y"].shape
+    f32 = dtype == "f32"
+    ry = relerr(y.detach().cpu().numpy(), g["y"])
+    assert ry < (2e-4 if f32 else 4e-2), ry
+    y.backward(dev(g["dy"]))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        got = p.grad.cpu().numpy()
+        if "grad." + k in g.files:
+            r = relerr(got, g["grad." + k])
+        else:
+            r = relerr(got.reshape(-1)[::997], g["gradsample." + k])
+        worst = max(worst, r)
+        # f32: same 1 % bound as the oracle-vs-golden test (one ReLU flip in the fp32 golden);
+        # bf16: storage rounding through 17 BatchNorm layers over 16-64 samples
+        assert r < (1e-2 if f32 else 0.25), (k, r)
+    for k, b in net.named_buffers():
+        np.testing.assert_allclose(b.cpu().numpy().astype(np.float64), g["buf." + k], rtol=1e-3 if f32 else 3e-2,
+                                   atol=1e-4 if f32 else 2e-2, err_msg=k)
+    net.eval()
+    with torch.no_grad():
+        ye = net(x)
+    assert relerr(ye.cpu().numpy(), g["y_eval"]) < (2e-4 if f32 else 4e-2)
+
+
+# ------------------------------------------------------------------ whole DGL step vs reference goldens
+def _make_model(cfg, dtype):
+    from models.basic_model import AVClassifier, AVClassifier_DGL
+
+    args = argparse.Namespace(fusion_method="concat", dataset=cfg["dataset"], modality="full", batch_size=cfg["batch"])
+    dgl = cfg["mode"] == "dgl"
+    model = AVClassifier_DGL(args) if dgl else AVClassifier(args)
+    P, Bf = fx.model_state(cfg["n_classes"], "concat_dgl" if dgl else "concat")
+    _load_state(model, {**P, **Bf})
+    model = model.to(DEV)
+    model.audio_net.gdl_dtype = dtype
+    model.visual_net.gdl_dtype = dtype
+    return model
+
+
+def _batch(cfg, st):
+    spec, image, label = fx.make_batch(cfg["seed"] + st, cfg["batch"], cfg["spec_hw"], cfg["frames"], cfg["image_hw"],
+                                       cfg["n_classes"])
+    return dev(spec), dev(image), torch.from_numpy(label).to(DEV)
+
+
+STEP_CASES = ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2"]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_native_step_golden(name, dtype):
+    """DGLTrainer (single-pass fused step) against the reference's two-phase step."""
+    from gdl.trainer import DGLTrainer
+
+    g = _gold(name)
+    cfg = json.loads(str(g["config"]))
+    model = _make_model(cfg, dtype)
+    model.train()
+    tr = DGLTrainer(model, lr=cfg["lr"], alpha=cfg["alpha"], mode=cfg["mode"])
+    f32 = dtype == "f32"
+    tiny = "tiny" in name
+    # tolerances: fp32 per SURVEY 8(c) (logits 1e-4 class, norms 1e-3 class; the tiny fixtures carry the
+    # ReLU-flip noise measured in tests/test_oracle_golden.py); bf16 per SURVEY 8(c): logits atol 3e-2 ...
+    for st in range(cfg["steps"]):
+        spec, image, label = _batch(cfg, st)
+        tr.step(spec, image, label)
+        r = tr.read()
+        pre = f"s{st}."
+        later = st > 0
+        lt = (1e-2 if later else 5e-4) if f32 else (0.15 if tiny else 4e-2)
+        np.testing.assert_allclose(r["out"], g[pre + "out"], rtol=lt, atol=lt)
+        np.testing.assert_allclose(r["loss_f"], g[pre + "loss_f"], rtol=lt, atol=lt)
+        if cfg["mode"] == "dgl":
+            np.testing.assert_allclose(r["out_a"], g[pre + "out_a"], rtol=lt, atol=lt)
+            np.testing.assert_allclose(r["out_v"], g[pre + "out_v"], rtol=lt, atol=lt)
+            np.testing.assert_allclose(r["loss_a"], g[pre + "loss_a"], rtol=lt, atol=lt)
+            np.testing.assert_allclose(r["loss_v"], g[pre + "loss_v"], rtol=lt, atol=lt)
+        nt = (2e-2 if later else 3e-3) if f32 else (0.2 if tiny else 3e-2)
+        np.testing.assert_allclose(r["total_norm"], g[pre + "total_norm"], rtol=nt)
+        np.testing.assert_allclose(r["audio_grad_sum"], g[pre + "audio_grad_sum"], rtol=2 * nt)
+        np.testing.assert_allclose(r["visual_grad_sum"], g[pre + "visual_grad_sum"], rtol=2 * nt)
+        names = [str(n) for n in g[pre + "grad_names"]]
+        gn, isnone = g[pre + "grad_norm"], g[pre + "grad_is_none"]
+        gt = (6e-2 if later else 1e-2) if f32 else (0.5 if tiny else 0.12)
+        tn = float(g[pre + "total_norm"])
+        clip = min(1.0, 40.0 / (tn + 1e-6))
+        for i, n in enumerate(names):
+            if isnone[i]:
+                assert n not in r["grad_norm"]  # fc_auxi is outside the optimised arena
+                continue
+            assert abs(r["grad_norm"][n] - gn[i]) <= gt * gn[i] + 1e-5 * clip * tn, (n, r["grad_norm"][n], gn[i])
+    last = f"s{cfg['steps'] - 1}."
+    names = [str(n) for n in g[last + "grad_names"]]
+    ps = g[last + "param_sums"]
+    sd = model.state_dict()
+    for i, n in enumerate(names):
+        got = sd[n].double().abs().sum().item()
+        np.testing.assert_allclose(got, ps[i][1], rtol=2e-5 if (f32 and cfg["steps"] == 1) else 1e-3, err_msg=n)
+    # fc_auxi untouched (grad None -> SGD skips it)
+    P0, _ = fx.model_state(cfg["n_classes"], "concat_dgl" if cfg["mode"] == "dgl" else "concat")
+    if cfg["mode"] == "dgl":
+        np.testing.assert_array_equal(sd["fusion_module.fc_auxi.weight"].cpu().numpy(), P0["fusion_module.fc_auxi.weight"])
+    for k in _bufnames(g, last):
+        tolr, tola = (2e-3, 1e-4) if f32 else (5e-2, 3e-2)
+        if cfg["steps"] > 1:
+            tola = max(tola, 1e-3)
+        np.testing.assert_allclose(sd[k].cpu().numpy().astype(np.float64), g[last + "buf." + k], rtol=tolr, atol=tola,
+                                   err_msg=k)
+    model.eval()
+    spec, image, label = _batch(cfg, 1000)
+    with torch.no_grad():
+        o = model(spec.unsqueeze(1), image)
+    ev = o[0] if cfg["mode"] == "dgl" else o[2]
+    et = (1e-2 if cfg["steps"] > 1 else 2e-3) if f32 else (0.2 if tiny else 5e-2)
+    np.testing.assert_allclose(ev.cpu().numpy(), g["eval.out"], rtol=et, atol=et)
+
+
+def _bufnames(g, pre):
+    return [k[len(pre + "buf."):] for k in g.files if k.startswith(pre + "buf.")]
+
+
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2"])
+def test_dropin_autograd_step_golden(name):
+    """The reference's own step body (main_dgl.py:97-154) run UNCHANGED on the drop-in modules:
+    torch autograd with retain_graph, grad=None on the head, second backward, torch clip + SGD."""
+    import torch.nn as nn
+
+    g = _gold(name)
+    cfg = json.loads(str(g["config"]))
+    model = _make_model(cfg, "f32")
+    model = nn.DataParallel(model, device_ids=[0])  # main_dgl.py:244 (supplies the 'module.' prefix)
+    optimizer = torch.optim.SGD(model.parameters(), lr=cfg["lr"], momentum=0.9, weight_decay=1e-4)
+    criterion = nn.CrossEntropyLoss()
+    model.train()
+    spec, image, label = _batch(cfg, 0)
+    optimizer.zero_grad()
+    out, out_a, out_v = model(spec.unsqueeze(1).float(), image.float())
+    loss_v = criterion(out_v, label)
+    loss_a = criterion(out_a, label)
+    loss_f = criterion(out, label)
+    loss_unimodal = (loss_a + loss_v) * cfg["alpha"]
+    loss_unimodal.backward(retain_graph=True)
+    for nme, parms in model.named_parameters():
+        layer = str(nme).split('.')[1]
+        if 'fusion' in layer:
+            parms.grad = None
+    loss_f.backward()
+    total = nn.utils.clip_grad_norm_(model.parameters(), max_norm=40, norm_type=2)
+    audio_grad_sum = sum(torch.abs(p.grad).mean().item() for p in model.module.audio_net.parameters())
+    visual_grad_sum = sum(torch.abs(p.grad).mean().item() for p in model.module.visual_net.parameters())
+    optimizer.step()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["s0.out"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(loss_f.item(), g["s0.loss_f"], rtol=5e-4)
+    np.testing.assert_allclose(loss_a.item(), g["s0.loss_a"], rtol=5e-4)
+    np.testing.assert_allclose(total.item(), g["s0.total_norm"], rtol=3e-3)
+    np.testing.assert_allclose(audio_grad_sum, g["s0.audio_grad_sum"], rtol=6e-3)
+    np.testing.assert_allclose(visual_grad_sum, g["s0.visual_grad_sum"], rtol=6e-3)
+    assert model.module.fusion_module.fc_auxi.weight.grad is None
+    names = [str(n) for n in g["s0.grad_names"]]
+    ps = g["s0.param_sums"]
+    sd = model.module.state_dict()
+    for i, n in enumerate(names):
+        np.testing.assert_allclose(sd[n].double().abs().sum().item(), ps[i][1], rtol=2e-5, err_msg=n)
+
+
+def test_full_size_properties():
+    """BASELINE config 2 (CREMA-D, B=64, T=3, bf16): size-independent properties at full size."""
+    from gdl.trainer import DGLTrainer
+
+    cfg = dict(dataset="CREMAD", n_classes=6, mode="dgl", batch=64, seed=0, spec_hw=[257, 188], frames=3,
+               image_hw=[224, 224])
+    outs = []
+    for rep in range(2):
+        model = _make_model(cfg, "bf16")
+        model.train()
+        tr = DGLTrainer(model, lr=2e-3, alpha=4.0)
+        spec, image, label = _batch(cfg, 0)
+        tr.step(spec, image, label)
+        r = tr.read()
+        outs.append((r, model.state_dict()["audio_net.layer4.1.conv2.weight"].clone()))
+    r0, r1 = outs[0][0], outs[1][0]
+    # run-to-run determinism (no atomics anywhere on the path): bit-identical
+    np.testing.assert_array_equal(r0["out"], r1["out"])
+    assert r0["total_norm"] == r1["total_norm"]
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert np.isfinite(r0["out"]).all() and np.isfinite(r0["total_norm"])
+    # out = a_out + v_out - b exactly in real arithmetic (fusion_modules.py:53-58)
+    b = fx.named_tensor("fusion_module.fc_out.bias", (6,))
+    np.testing.assert_allclose(r0["out"], r0["out_a"] + r0["out_v"] - b[None], rtol=1e-5, atol=1e-5)
+    # clipping: post-clip global norm == min(total, 40)
+    post = np.sqrt(sum(v * v for v in r0["grad_norm"].values()))
+    np.testing.assert_allclose(post, min(r0["total_norm"], 40.0), rtol=1e-4)
