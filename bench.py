@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- CREMA-D DGL train step on N MI355X (one process per GPU, RCCL over xGMI).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path of /root/reference/main_dgl.py:97-154 over one
+synthetic CREMA-D-shaped batch that is already resident in HBM: both ResNet18 encoders forward,
+the gradient-truncated fusion head + three cross-entropies, both encoder backwards, the
+per-bucket gradient all-reduce (N > 1), global-norm clipping, the logged per-encoder gradient
+statistics and the SGD(momentum, weight decay) update -- nothing skipped, nothing cached.
+Rank 0 prints ONE JSON line (see the driver contract); `roofline` is measured live with HIP
+events around every launch of the dominant kernel inside the timed region, `cpu_baseline` times
+the CPU oracle (oracle/, a C port of the reference's arithmetic) on this machine's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "iccv2025-gdl_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+TRAIN_GFLOP_PER_SAMPLE = 42.567  # BASELINE.md section 2 (CREMA-D, T=3; 2*MAC, convs only)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    ap.add_argument("--no-prof", action="store_true", help="do not tap per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, threads):
+    """The CPU oracle's DGL step (kind 'port') on a bounded sample: one warm-up + one timed step."""
+    from oracle import fixtures as fx
+    from oracle import oracle as orc
+
+    cores = os.cpu_count() or 1
+    thr = threads if threads > 0 else min(cores, 64)
+    orc.set_num_threads(thr)
+    P, Bf = fx.model_state(6, "concat_dgl")
+    model = orc.AVModel(P, Bf, "dgl")
+    spec, image, label = fx.make_batch(0, batch, (257, 188), 3, (224, 224), 6)
+    t0 = time.time()
+    model.train_step(spec, image, label, 4.0, 2e-3)
+    t1 = time.time()
+    model.train_step(spec, image, label, 4.0, 2e-3)
+    t2 = time.time()
+    dt = t2 - t1
+    return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": thr, "kind": "port",
+            "sample": f"oracle/ C port, CREMA-D T=3 DGL step, B={batch}, fp32, 1 warm-up ({t1 - t0:.1f} s) + 1 timed "
+                      f"step ({dt:.1f} s) on {thr} of {cores} host threads"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("bench.py: for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        pg = dist.group.WORLD
+
+    from gdl import _lib as L
+    from gdl.trainer import DGLTrainer
+    from models.basic_model import AVClassifier_DGL
+    from utils.utils import setup_seed, weight_init
+
+    lib = L.load()
+    # model exactly as main_dgl.py:230-246 builds it (random init; identical on every rank via the seed)
+    setup_seed(0)
+    args = argparse.Namespace(fusion_method="concat", dataset="CREMAD", modality="full", batch_size=a.batch)
+    model = AVClassifier_DGL(args)
+    model.apply(weight_init)
+    model.to(dev)
+    model.train()
+    tr = DGLTrainer(model, lr=2e-3, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype,
+                    process_group=pg)
+    # synthetic CREMA-D batch, seed 1234 + rank, resident on the device
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    B = a.batch
+    spec = torch.randn(B, 257, 188, generator=g).to(dev)
+    image = torch.randn(B, 3, 3, 224, 224, generator=g).to(dev)
+    label = torch.randint(0, 6, (B,), generator=g).to(dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier(device_ids=[local])
+
+    for _ in range(a.warmup):
+        tr.step(spec, image, label)
+    torch.cuda.synchronize()
+    barrier()
+    prof = (not a.no_prof) and rank == 0
+    if prof:
+        lib.gdl_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(spec, image, label)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res = tr.read()
+    roof, kernels = None, None
+    if prof:
+        import ctypes
+
+        lib.gdl_prof_enable(0)
+        ns = lib.gdl_prof_nslots()
+        n_l = (ctypes.c_int64 * ns)()
+        n_ms = (ctypes.c_double * ns)()
+        n_w = (ctypes.c_double * ns)()
+        L.call("gdl_prof_collect", n_l, n_ms, n_w)
+        kernels = []
+        for s in range(ns):
+            if n_l[s] == 0:
+                continue
+            bound = "mfma" if lib.gdl_prof_slot_bound(s) == 1 else "hbm"
+            avg_us = n_ms[s] / n_l[s] * 1e3
+            rate = n_w[s] / (n_ms[s] * 1e-3)  # flop/s or byte/s
+            peak = MFMA_PEAK_TFLOPS[a.dtype] if bound == "mfma" else HBM_PEAK_GBS
+            ach = rate / 1e12 if bound == "mfma" else rate / 1e9
+            kernels.append({"kernel": lib.gdl_prof_slot_name(s).decode(), "bound": bound,
+                            "launches_per_step": n_l[s] / a.steps, "avg_us": round(avg_us, 2),
+                            "ms_per_step": round(n_ms[s] / a.steps, 4), "achieved": round(ach, 2),
+                            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(ach / peak, 4)})
+        kernels.sort(key=lambda k: -k["ms_per_step"])
+        d = kernels[0]
+        roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
+                else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": None, "kernel": d["kernel"],
+                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
+    if rank != 0:
+        return
+    value = world * B * a.steps / elapsed
+    out = {
+        "metric": "audio-visual samples/sec, CREMA-D DGL train step (whole job)",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "CREMA-D DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x257x188 + frames "
+                               "3x3x224x224, alpha=4, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "buckets": "audio_net / visual_net / fusion fc_out, RCCL all-reduce" if world > 1 else "none"},
+        "samples_per_sec_per_gpu": round(value / world, 2),
+        "step_tflops": round(value * TRAIN_GFLOP_PER_SAMPLE / 1e3, 2),
+        "mfma_frac_end_to_end": round(value / world * TRAIN_GFLOP_PER_SAMPLE / 1e3 / MFMA_PEAK_TFLOPS[a.dtype], 4),
+        "loss_f": round(res["loss_f"], 5), "loss_a": round(res["loss_a"], 5), "loss_v": round(res["loss_v"], 5),
+        "total_norm": round(res["total_norm"], 4),
+        "roofline": roof, "kernels": kernels,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_threads)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

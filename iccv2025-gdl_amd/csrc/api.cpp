@@ -96,7 +96,7 @@ int gdl_bn_act(int dtype, const void* y, const float* scale, const float* shift,
     GDL_REQUIRE(dt_ok(dtype) && y && scale && shift && out, "bn_act: bad arguments");
     return bn_act(dtype, y, scale, shift, res, res_scale, res_shift, relu, out, M, C, (hipStream_t)stream);
 }
-int gdl_bn_bwd_blocks(size_t M) { return bn_bwd_blocks(M); }
+int gdl_bn_bwd_blocks(size_t M, int C) { return bn_bwd_blocks(M, C); }
 int gdl_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift,
                       const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M, int C,
                       void* stream) {

@@ -9,6 +9,7 @@
 // strides by a multiple of C keeps the same channels for its whole loop, so its scale /
 // shift / partial sums live in registers.
 #include "common.h"
+#include "prof.h"
 
 namespace gdl {
 
@@ -186,8 +187,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
 // grid sizing for channel-invariant grid-stride loops: total threads is a multiple of C/EPC
 static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec) {
     // threads = blocks*256 must be a multiple of cpr (cpr divides 256 or is a multiple of it handled by lcm)
-    size_t want = (nvec + BN_THREADS - 1) / BN_THREADS;
-    if (want > 4096) want = 4096;
+    // ~8 vectors per thread amortise the per-channel constant loads; at most 2048 blocks
+    size_t want = (nvec + BN_THREADS * 8 - 1) / (BN_THREADS * 8);
+    if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     // make blocks*256 % cpr == 0
     size_t unit = 1;
@@ -207,6 +209,7 @@ static int bn_act_t(const void* y, const float* scale, const float* shift, const
     size_t stride;
     ew_grid(nvec, C / EPC, blocks, stride);
     const int resmode = res ? (rscale ? 2 : 1) : 0;
+    ProfScope prof(PROF_BN_ACT, st, (double)nvec * 16.0 * (resmode ? 3 : 2));
 #define BN_ACT_LAUNCH(RM, RL)                                                                                        \
     hipLaunchKernelGGL((bn_act_kernel<T, RM, RL>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale, shift, \
                        (const T*)res, rscale, rshift, (T*)out, nvec, C, stride)
@@ -279,9 +282,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     }
 }
 
-int bn_bwd_blocks(size_t M) {
-    size_t b = (M + 511) / 512;
-    if (b > 1024) b = 1024;
+// one block per 16384 elements (8 bf16 / 16 f32 vectors per thread), at most 2048 blocks
+int bn_bwd_blocks(size_t M, int C) {
+    size_t b = (M * (size_t)C + 16383) / 16384;
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -293,9 +297,10 @@ static int bn_bwd_reduce_t(const void* g, const void* y, const float* scale, con
     const int cpr = C / EPC;
     GDL_REQUIRE(C % EPC == 0 && cpr <= BN_THREADS && BN_THREADS % cpr == 0, "bn_bwd: C=%d unsupported", C);
     const size_t nvec = M * (size_t)C / EPC;
-    const int blocks = bn_bwd_blocks(M);
+    const int blocks = bn_bwd_blocks(M, C);
     const size_t stride = (size_t)blocks * BN_THREADS;  // multiple of cpr since 256 % cpr == 0
     const size_t sh = (size_t)(BN_THREADS / cpr) * C * 2 * sizeof(float);
+    ProfScope prof(PROF_BN_BWD_REDUCE, st, (double)nvec * 16.0 * 2);
     if (relu_mask)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)g,
                            (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride);
@@ -386,6 +391,7 @@ static int bn_bwd_apply_t(const void* g, const void* y, const float* scale, cons
     int blocks;
     size_t stride;
     ew_grid(nvec, C / EPC, blocks, stride);
+    ProfScope prof(PROF_BN_BWD_APPLY, st, (double)nvec * 16.0 * 3);
     if (relu_mask)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)g, (const T*)y,
                            scale, shift, mean, rstd, gamma, coef, (T*)dy, nvec, C, stride);
@@ -423,6 +429,7 @@ int relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, hip
     const size_t nvec = n / epc;
     size_t blocks = (nvec + BN_THREADS - 1) / BN_THREADS;
     if (blocks > 4096) blocks = 4096;
+    ProfScope prof(PROF_RELU_BWD, st, (double)nvec * 16.0 * 3);
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(relu_bwd_kernel<bf16>, dim3((int)blocks), dim3(BN_THREADS), 0, st, (const bf16*)dy,
                            (const bf16*)out, (bf16*)dx, nvec);

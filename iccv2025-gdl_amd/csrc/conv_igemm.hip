@@ -18,7 +18,10 @@
 // epilogue stages the tile through LDS, then streams full rows: optional addend
 // (dgrad accumulation), optional per-channel sum / sum-of-squares of the STORED
 // values (BatchNorm statistics), 16-byte coalesced stores.
+#include <stdlib.h>
+
 #include "common.h"
+#include "prof.h"
 
 namespace gdl {
 
@@ -292,12 +295,30 @@ struct TileCfg {
     int bm, bn;
 };
 
+static int forced_cfg() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_CONV_CFG");  // tuning aid: 1 = 256x64, 3 = 64x64, 4 = 128x64
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 static TileCfg pick_cfg(int M, int OC, int dtype) {
     (void)dtype;
-    if (OC == 64) return {256, 64};
-    // 128x128 while it still yields >= 2 blocks per CU's worth of tiles, else 64x64
-    const long blocks = (long)((M + 127) / 128) * (OC / 128);
-    if (OC % 128 == 0 && blocks >= 384) return {128, 128};
+    switch (forced_cfg()) {
+        case 1: return {256, 64};
+        case 3: return {64, 64};
+        case 4: return {128, 64};
+        default: break;
+    }
+    // Measured on MI355X (tools/bench_conv.py, CREMA-D B=64 shapes): 256x64 wins whenever it still
+    // yields >= ~160 blocks, also for wide layers (the A panel re-read per N-tile is served by L2);
+    // below that the smaller M-tiles fill the chip better.
+    const long b256 = (long)((M + 255) / 256) * (OC / 64);
+    if (b256 >= 160) return {256, 64};
+    const long b128 = (long)((M + 127) / 128) * (OC / 64);
+    if (b128 >= 160) return {128, 64};
     return {64, 64};
 }
 
@@ -314,6 +335,8 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     }
     const int ntn = a.OC / BN;
     const int grid = ((a.mtiles + 7) / 8) * 8 * ntn;
+    const int slot = (MODE == MODE_FWD ? PROF_CONV_FWD_256x64 : PROF_CONV_DGRAD_256x64) + (BM == 256 ? 0 : (BM == 128 ? 1 : 2));
+    ProfScope prof(slot, st, 2.0 * (double)a.M * a.OC * a.R * a.S * a.IC);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_igemm_kernel");
     return GDL_OK;
@@ -323,7 +346,7 @@ template <typename T, int MODE>
 static int launch_mode(ConvArgs& a, int dtype, hipStream_t st) {
     const TileCfg c = pick_cfg(a.M, a.OC, dtype);
     if (c.bm == 256) return launch_one<T, 256, 64, 4, 1, MODE>(a, st);
-    if (c.bm == 128) return launch_one<T, 128, 128, 2, 2, MODE>(a, st);
+    if (c.bm == 128 && c.bn == 64) return launch_one<T, 128, 64, 2, 2, MODE>(a, st);
     return launch_one<T, 64, 64, 2, 2, MODE>(a, st);
 }
 

@@ -16,6 +16,7 @@
 // gradient layout.  Tap is the fastest-varying index among blocks that share an XCD,
 // so the 9 taps of one pixel slice reuse dy / x from that XCD's L2.
 #include "common.h"
+#include "prof.h"
 
 namespace gdl {
 
@@ -237,18 +238,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // out[k][c][r][s] = sum_split partial[split][k][rs][c], c < Cout (Cout <= C drops im2col padding)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int nsplit, int K, int RS,
-                                    int C, int Cout) {
+// Block = 256 threads = (256/LANES) consecutive outputs x LANES split-lanes; lane l sums splits
+// l, l+LANES, ... and the lanes are folded through LDS in a fixed order (deterministic).
+template <int LANES>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                           int nsplit, int K, int RS, int C, int Cout) {
+    constexpr int OUTS = 256 / LANES;
+    __shared__ float red[LANES][OUTS];
     const size_t total = (size_t)K * RS * C;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int o = threadIdx.x % OUTS, l = threadIdx.x / OUTS;
+    const size_t i = blockIdx.x * (size_t)OUTS + o;
+    float s = 0.f;
+    if (i < total)
+        for (int sp = l; sp < nsplit; sp += LANES) s += partial[(size_t)sp * total + i];
+    if (LANES > 1) {
+        red[l][o] = s;
+        __syncthreads();
+        if (l == 0) {
+            s = red[0][o];
+#pragma unroll
+            for (int j = 1; j < LANES; ++j) s += red[j][o];
+        }
+    }
+    if (l == 0 && i < total) {
         const int c = (int)(i % C);
         const size_t t = i / C;
         const int rs = (int)(t % RS);
         const int k = (int)(t / RS);
-        if (c >= Cout) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * total + i];
-        out[((size_t)k * Cout + c) * RS + rs] = s;
+        if (c < Cout) out[((size_t)k * Cout + c) * RS + rs] = s;
     }
 }
 
@@ -292,6 +309,7 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
     }
     const int per_slice = a.R * a.S * a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
+    ProfScope prof(PROF_CONV_WGRAD, st, 2.0 * (double)a.M * a.K * a.C * a.R * a.S);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_wgrad_kernel");
     return GDL_OK;
@@ -355,8 +373,16 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H
     }
     if (rc) return rc;
     const size_t total = (size_t)K * R * S * C;
-    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, a.partial, dw, p.nsplit, K, R * S, C, Cout);
+    ProfScope prof(PROF_WGRAD_REDUCE, st, (double)total * 4.0 * (p.nsplit + 1));
+    if (p.nsplit >= 64)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, a.partial, dw,
+                           p.nsplit, K, R * S, C, Cout);
+    else if (p.nsplit > 8)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, a.partial, dw,
+                           p.nsplit, K, R * S, C, Cout);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.partial, dw,
+                           p.nsplit, K, R * S, C, Cout);
     GDL_CHECK_LAUNCH("wgrad_reduce_kernel");
     return GDL_OK;
 }

@@ -80,6 +80,12 @@ struct gdl_encoder {
     int64_t serial = 0;
     bool have_train_fwd = false;
     int64_t numel[GDL_ENC_NPARAMS];
+    // batched weight packing
+    std::vector<PackDescHost> pack_host;
+    void* pack_dev = nullptr;
+    bool pack_dirty = true;
+    int pack_blocks = 0;
+    double pack_bytes = 0.0;
 
     size_t plan(unsigned char* base);
 };
@@ -95,6 +101,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     x1 = b.take((size_t)n_img * h1 * w1 * 64 * e);
     idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
     dw0p = (float*)b.take((size_t)64 * kp * sizeof(float));
+    pack_dev = b.take(32 * sizeof(PackDescHost));
     auto bn_alloc = [&](BN& n) {
         n.scale = (float*)b.take(sizeof(float) * n.c);
         n.shift = (float*)b.take(sizeof(float) * n.c);
@@ -110,7 +117,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     bn_alloc(bn0);
     size_t max_act = (size_t)n_img * h1 * w1 * 64;  // elements
     size_t max_tiles_c = (size_t)conv_tiles_m(dtype, (int)m0, 64) * 64;
-    size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0) * 64;
+    size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0, 64) * 64;
     size_t wg = conv_wgrad_ws_bytes((int)m0, kp, 64, 1);
     const void* prev = x1;
     for (Block& k : blocks) {
@@ -135,7 +142,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
         const int M = k.n * k.p * k.q;
         const size_t tc = (size_t)conv_tiles_m(dtype, M, k.cout) * k.cout;
         if (tc > max_tiles_c) max_tiles_c = tc;
-        const size_t bb = (size_t)bn_bwd_blocks((size_t)M) * k.cout;
+        const size_t bb = (size_t)bn_bwd_blocks((size_t)M, k.cout) * k.cout;
         if (bb > max_bnb) max_bnb = bb;
         size_t w1 = conv_wgrad_ws_bytes(M, k.cin, k.cout, 9);
         size_t w2 = conv_wgrad_ws_bytes(M, k.cout, k.cout, 9);
@@ -280,6 +287,7 @@ int gdl_encoder_bind(gdl_encoder_t* e, void* workspace, size_t bytes) {
     GDL_REQUIRE(((uintptr_t)workspace & 255) == 0, "encoder_bind: workspace must be 256-byte aligned");
     e->ws = workspace;
     e->plan((unsigned char*)workspace);
+    e->pack_dirty = true;
     e->have_train_fwd = false;
     return GDL_OK;
 }
@@ -298,6 +306,7 @@ int gdl_encoder_set_params(gdl_encoder_t* e, const float* const* params, float* 
         e->nbt[i] = num_batches_tracked ? num_batches_tracked[i] : nullptr;
     }
     e->params_set = true;
+    e->pack_dirty = true;
     return GDL_OK;
 }
 
@@ -335,15 +344,39 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     if (!training) e->have_train_fwd = false;  // an eval pass overwrites the saved activations
     // weights -> kernel layouts (float32 master copies stay with the caller)
     RC(pack_stem_weight(dt, e->params[0], e->w0p, e->cin, st));
-    for (Block& k : e->blocks) {
-        RC(pack_weight(dt, e->params[k.c1.pidx], k.c1.w_krsc, training ? k.c1.w_crsk : nullptr, k.c1.cout, k.c1.cin, 3, 3,
-                       st));
-        RC(pack_weight(dt, e->params[k.c2.pidx], k.c2.w_krsc, training ? k.c2.w_crsk : nullptr, k.c2.cout, k.c2.cin, 3, 3,
-                       st));
-        if (k.has_ds)
-            RC(pack_weight(dt, e->params[k.cd.pidx], k.cd.w_krsc, training ? k.cd.w_crsk : nullptr, k.cd.cout, k.cd.cin, 1,
-                           1, st));
+    if (e->pack_dirty) {  // (re)build the descriptor table of the batched packing launch
+        e->pack_host.clear();
+        int blk = 0;
+        double bytes = 0.0;
+        auto add = [&](const Conv& c) {
+            PackDescHost d;
+            d.w = e->params[c.pidx];
+            d.krsc = c.w_krsc;
+            d.crsk = c.w_crsk;
+            d.K = c.cout;
+            d.C = c.cin;
+            d.RS = c.r * c.s;
+            d.blk0 = blk;
+            const size_t total = (size_t)c.cout * c.cin * c.r * c.s;
+            int nb = (int)((total + 1023) / 1024);
+            if (nb > 256) nb = 256;
+            blk += nb;
+            bytes += (double)total * (4.0 + 2.0 * e->esz);
+            e->pack_host.push_back(d);
+        };
+        for (Block& k : e->blocks) {
+            add(k.c1);
+            add(k.c2);
+            if (k.has_ds) add(k.cd);
+        }
+        e->pack_blocks = blk;
+        e->pack_bytes = bytes;
+        hipError_t he = hipMemcpyAsync(e->pack_dev, e->pack_host.data(), e->pack_host.size() * sizeof(PackDescHost),
+                                       hipMemcpyHostToDevice, st);
+        if (he != hipSuccess) return check_hip(he, "encoder_forward: descriptor upload");
+        e->pack_dirty = false;
     }
+    RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
     // stem: conv1 (7x7/2) as im2col + GEMM, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     RC(stem_im2col(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
     RC(conv_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0,
@@ -375,7 +408,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
 
 static int bn_backward(gdl_encoder* e, BN& n, const void* g, const void* y, int relu_mask, void* dy, size_t M,
                        float* const* grads, hipStream_t st) {
-    const int blocks = bn_bwd_blocks(M);
+    const int blocks = bn_bwd_blocks(M, n.c);
     RC(bn_bwd_reduce(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, st));
     RC(bn_bwd_finalize(e->bnb_partial, blocks, n.c, (double)M, grads[n.pidx], grads[n.pidx + 1], n.coef, st));
     return bn_bwd_apply(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, relu_mask, dy, M, n.c,

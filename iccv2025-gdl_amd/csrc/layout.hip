@@ -4,6 +4,7 @@
 // 96-101) and activations NCHW.  Inside the library activations are NHWC `dtype`, weights
 // are [K][R][S][C] for forward / wgrad and [C][R][S][K] for the data gradient.
 #include "common.h"
+#include "prof.h"
 
 namespace gdl {
 
@@ -28,6 +29,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C, int R, int S, hipStream_t st) {
     const size_t total = (size_t)K * C * R * S;
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    const double esz = dtype == GDL_BF16 ? 2.0 : 4.0;
+    ProfScope prof(PROF_PACK_WEIGHT, st, (double)total * (4.0 + esz * ((krsc ? 1 : 0) + (crsk ? 1 : 0))));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid), dim3(256), 0, st, w, (bf16*)krsc, (bf16*)crsk, K, C, R * S);
     else
@@ -66,52 +69,99 @@ int pack_stem_weight(int dtype, const float* w, void* wp, int cin, hipStream_t s
 
 // im2col of the 7x7 / stride 2 / pad 3 stem.  x float32 [B][Cin][T][H][W] (the reference's own
 // input tensor; image n = b*T + t, backbone.py:162-164).  col [M][Kp], M = B*T*P*Q,
-// column j = (c*7 + r)*7 + s.  One thread produces one 16-byte chunk of one row; the 7x7 windows
-// of neighbouring pixels overlap, so the gathers are served by L1/L2 and HBM sees the input once.
+// column j = (c*7 + r)*7 + s.  One block = one output row (n, p): the 7 input rows it needs are
+// staged once in LDS (zero padded, coalesced float loads), then every thread assembles 16-byte
+// chunks from LDS through a j -> patch-offset table.  HBM sees the input ~once (7/2 re-reads of a
+// row by neighbouring blocks are L2 hits) and the im2col matrix once.
 template <typename T>
-__global__ void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int Cin, int Tn, int H, int W,
-                                   int P, int Q, int kp) {
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int Cin, int Tn,
+                                                          int H, int W, int P, int Q, int kp) {
     constexpr int EPC = TT<T>::EPC;
+    extern __shared__ float patch[];  // [Cin*7][Wp] then int offtab[kp]
+    const int Wp = W + 6;
+    const int npatch = Cin * 7 * Wp;
+    int* offtab = (int*)(patch + npatch);
+    const int n = blockIdx.x / P, p = blockIdx.x - n * P;
+    const int b = n / Tn, t = n - b * Tn;
+    for (int idx = threadIdx.x; idx < npatch; idx += 256) {
+        const int cr = idx / Wp, xw = idx - cr * Wp;
+        const int c = cr / 7, r = cr - c * 7;
+        const int ih = 2 * p - 3 + r, iw = xw - 3;
+        float v = 0.f;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+            v = x[((((size_t)b * Cin + c) * Tn + t) * H + ih) * W + iw];
+        patch[idx] = v;
+    }
+    for (int j = threadIdx.x; j < kp; j += 256) offtab[j] = j < Cin * 49 ? (j / 7) * Wp + (j % 7) : -1;
+    __syncthreads();
     const int cpr = kp / EPC;
-    const size_t total = (size_t)B * Tn * P * Q * cpr;
-    const int kin = Cin * 49;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % cpr);
-        size_t m = i / cpr;
-        const int q = (int)(m % Q);
-        m /= Q;
-        const int p = (int)(m % P);
-        m /= P;
-        const int t = (int)(m % Tn);
-        const int b = (int)(m / Tn);
+    T* dst = col + (size_t)blockIdx.x * Q * kp;
+    for (int i = threadIdx.x; i < Q * cpr; i += 256) {
+        const int q = i / cpr, ch = i - q * cpr;
         float f[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const int j = ch * EPC + e;
-            float v = 0.f;
-            if (j < kin) {
-                const int c = j / 49, rs = j - c * 49;
-                const int r = rs / 7, s = rs - r * 7;
-                const int ih = p * 2 - 3 + r, iw = q * 2 - 3 + s;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-                    v = x[((((size_t)b * Cin + c) * Tn + t) * H + ih) * W + iw];
-            }
-            f[e] = v;
+            const int o = offtab[ch * EPC + e];
+            f[e] = o >= 0 ? patch[o + 2 * q] : 0.f;
         }
-        *(uint4*)((unsigned char*)col + i * 16) = pack16<T>(f);
+        *(uint4*)(dst + (size_t)i * EPC) = pack16<T>(f);
     }
 }
 int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, hipStream_t st) {
     const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1;
     const int kp = stem_kp(Cin, dtype);
     const size_t total = (size_t)B * T * P * Q * (kp / (dtype == GDL_BF16 ? 8 : 4));
-    const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    const size_t sh = (size_t)Cin * 7 * (W + 6) * sizeof(float) + (size_t)kp * sizeof(int);
+    GDL_REQUIRE(sh <= 64 * 1024, "stem_im2col: input rows of %d floats do not fit the LDS patch", W);
+    // algorithmic bytes: read the float32 input once, write the im2col matrix once
+    ProfScope prof(PROF_STEM_IM2COL, st, (double)B * Cin * T * H * W * 4.0 + (double)total * 16.0);
     if (dtype == GDL_BF16)
-        hipLaunchKernelGGL(stem_im2col_kernel<bf16>, dim3(grid), dim3(256), 0, st, x, (bf16*)col, B, Cin, T, H, W, P, Q, kp);
-    else
-        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)col, B, Cin, T, H, W, P, Q,
+        hipLaunchKernelGGL(stem_im2col_kernel<bf16>, dim3(B * T * P), dim3(256), sh, st, x, (bf16*)col, Cin, T, H, W, P, Q,
                            kp);
+    else
+        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(B * T * P), dim3(256), sh, st, x, (float*)col, Cin, T, H, W, P,
+                           Q, kp);
     GDL_CHECK_LAUNCH("stem_im2col_kernel");
+    return GDL_OK;
+}
+
+// ---------------------------------------------------------------- batched weight packing
+// One launch packs every conv weight of an encoder: desc[i] names a float32 [K][C][RS] source and
+// its two destinations; block ranges [blk0, blk0+nblk) are assigned per tensor.
+struct PackDesc {
+    const float* w;
+    void* krsc;
+    void* crsk;
+    int K, C, RS, blk0;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ desc, int ndesc) {
+    int d = 0;
+    while (d + 1 < ndesc && (int)blockIdx.x >= desc[d + 1].blk0) ++d;
+    const PackDesc pd = desc[d];
+    const size_t total = (size_t)pd.K * pd.C * pd.RS;
+    const int nblk = (d + 1 < ndesc ? desc[d + 1].blk0 : (int)gridDim.x) - pd.blk0;
+    T* krsc = (T*)pd.krsc;
+    T* crsk = (T*)pd.crsk;
+    for (size_t i = ((size_t)blockIdx.x - pd.blk0) * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
+        const int c = (int)(i % pd.C);
+        const size_t t = i / pd.C;
+        const int rs = (int)(t % pd.RS);
+        const int k = (int)(t / pd.RS);
+        const float v = pd.w[((size_t)k * pd.C + c) * pd.RS + rs];
+        storeT<T>(krsc + i, v);
+        if (crsk) storeT<T>(crsk + ((size_t)c * pd.RS + rs) * pd.K + k, v);
+    }
+}
+int pack_weights_batched(int dtype, const void* desc_dev, int ndesc, int total_blocks, double bytes, hipStream_t st) {
+    ProfScope prof(PROF_PACK_WEIGHT, st, bytes);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3(total_blocks), dim3(256), 0, st,
+                           (const PackDesc*)desc_dev, ndesc);
+    else
+        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, st,
+                           (const PackDesc*)desc_dev, ndesc);
+    GDL_CHECK_LAUNCH("pack_weights_batched_kernel");
     return GDL_OK;
 }
 

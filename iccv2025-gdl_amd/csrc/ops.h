@@ -19,6 +19,13 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H
                int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 // layout.hip
 int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C, int R, int S, hipStream_t st);
+struct PackDescHost {  // mirrors layout.hip::PackDesc
+    const float* w;
+    void* krsc;
+    void* crsk;
+    int K, C, RS, blk0;
+};
+int pack_weights_batched(int dtype, const void* desc_dev, int ndesc, int total_blocks, double bytes, hipStream_t st);
 int stem_kp(int cin, int dtype);
 int pack_stem_weight(int dtype, const float* w, void* wp, int cin, hipStream_t st);
 int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, hipStream_t st);
@@ -34,7 +41,7 @@ int bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, co
                      float* scale, float* shift, hipStream_t st);
 int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
            const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st);
-int bn_bwd_blocks(size_t M);
+int bn_bwd_blocks(size_t M, int C);
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,

@@ -9,6 +9,7 @@
 // double), one tiny finalise kernel that leaves {total_norm, clip_coef, audio_sum,
 // visual_sum, per-parameter norms} on the device, and one streaming update kernel.
 #include "common.h"
+#include "prof.h"
 
 #include <vector>
 
@@ -201,9 +202,9 @@ int gdl_optim_create(gdl_optim_t** out, const int64_t* seg_offsets, const int32_
         gdl_optim_destroy(o);
         return check_hip(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "optim_create: hipMalloc");
     }
-    hipMemcpy(o->d_chunks, chunks.data(), chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
-    hipMemcpy(o->d_segrange, segrange.data(), segrange.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    hipMemcpy(o->d_segnumel, numel.data(), numel.size() * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemcpy(o->d_chunks, chunks.data(), chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
+    (void)hipMemcpy(o->d_segrange, segrange.data(), segrange.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    (void)hipMemcpy(o->d_segnumel, numel.data(), numel.size() * sizeof(double), hipMemcpyHostToDevice);
     *out = o;
     return GDL_OK;
 }
@@ -233,7 +234,10 @@ int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, flo
     hipStream_t st = (hipStream_t)stream;
     double* partial = (double*)ws;
     double* segsum = partial + (size_t)o->nchunks * 2;
-    hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)o->d_chunks, partial);
+    {
+        ProfScope prof(PROF_GRAD_STATS, st, (double)o->total * 4.0);
+        hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)o->d_chunks, partial);
+    }
     GDL_CHECK_LAUNCH("grad_stats_kernel");
     hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial,
                        (const int32_t*)o->d_segrange, (const double*)o->d_segnumel, o->nseg, max_norm, grad_scale, stats,
@@ -251,6 +255,7 @@ int gdl_optim_sgd_step(gdl_optim_t* o, float* params, float* grads, float* momen
     int64_t blocks = (nv + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
+    ProfScope prof(PROF_SGD, (hipStream_t)stream, (double)o->total * 4.0 * 6);
     hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum, stats,
                        grad_scale, lr, mu, wd, o->total);
     GDL_CHECK_LAUNCH("sgd_kernel");

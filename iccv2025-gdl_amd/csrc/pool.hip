@@ -4,6 +4,7 @@
 // applied to relu(bn1(conv1(x))) (:166-173).  F.adaptive_avg_pool2d(a,1) /
 // F.adaptive_avg_pool3d(v,1): /root/reference/models/basic_model.py:73-82.
 #include "common.h"
+#include "prof.h"
 
 namespace gdl {
 
@@ -73,6 +74,8 @@ int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const floa
     GDL_REQUIRE(C % epc == 0, "maxpool: C=%d", C);
     const size_t total = (size_t)N * P * Q * (C / epc);
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    // read the stem output once, write pooled values + 1-byte indices
+    ProfScope prof(PROF_MAXPOOL_FWD, st, (double)N * H * W * C * (16.0 / epc) + (double)total * (16.0 + epc));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, scale, shift,
                            (bf16*)out, idx, N, H, W, C, P, Q);
@@ -144,6 +147,7 @@ int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     const size_t total = (size_t)N * H * W * (C / epc);
     const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    ProfScope prof(PROF_MAXPOOL_BWD, st, (double)total * 16.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H,
                            W, C, P, Q);

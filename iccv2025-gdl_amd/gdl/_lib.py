@@ -38,7 +38,7 @@ SIGNATURES = {
     "gdl_bn_finalize_train": ("i", "pii" + "d" + "pp" + "ff" + "ppp" + "pppp" + "p"),
     "gdl_bn_finalize_eval": ("i", "ippf" + "pppp" + "p"),
     "gdl_bn_act": ("i", "ippp" + "ppp" + "i" + "p" + "zi" + "p"),
-    "gdl_bn_bwd_blocks": ("i", "z"),
+    "gdl_bn_bwd_blocks": ("i", "zi"),
     "gdl_bn_bwd_reduce": ("i", "ipppppp" + "i" + "p" + "zi" + "p"),
     "gdl_bn_bwd_finalize": ("i", "pii" + "d" + "ppp" + "p"),
     "gdl_bn_bwd_apply": ("i", "ipppppppp" + "i" + "p" + "zi" + "p"),
@@ -66,6 +66,11 @@ SIGNATURES = {
     "gdl_encoder_forward": ("i", "ppippp"),
     "gdl_encoder_backward": ("i", "ppppp"),
     "gdl_encoder_forward_serial": ("l", "p"),
+    "gdl_prof_enable": ("i", "i"),
+    "gdl_prof_nslots": ("i", ""),
+    "gdl_prof_slot_name": ("s", "i"),
+    "gdl_prof_slot_bound": ("i", "i"),
+    "gdl_prof_collect": ("i", "ppp"),
 }
 
 _lib = None

@@ -33,12 +33,6 @@ class DGLTrainer:
         self.lr, self.alpha, self.mu, self.wd, self.max_norm = float(lr), float(alpha), float(momentum), \
             float(weight_decay), float(max_norm)
         self.pg = process_group
-        self.world = 1
-        if process_group is not None:
-            import torch.distributed as dist
-
-            self.dist = dist
-            self.world = dist.get_world_size(process_group)
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
         head = model.fusion_module
         self.device = head.fc_out.weight.device
@@ -68,6 +62,13 @@ class DGLTrainer:
             self.pviews.append(v)
             self.gviews.append(self.grads[offs[i]:offs[i + 1]].view(p.shape))
         self.bucket = {"fusion": (0, offs[2]), "audio": (offs[2], offs[62]), "visual": (offs[62], offs[122])}
+        self.reducer = None
+        self.world = 1
+        if process_group is not None:
+            from .ddp import BucketReducer
+
+            self.reducer = BucketReducer(self.grads, self.bucket, process_group)
+            self.world = self.reducer.world
         h = ctypes.c_void_p()
         so = (ctypes.c_int64 * len(offs))(*offs)
         sg = (ctypes.c_int32 * len(group))(*group)
@@ -150,34 +151,30 @@ class DGLTrainer:
         else:  # BASELINE config 1: ConcatFusion + one CE loss (main.py:161-175)
             L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), None, None, L.ptr(self.g_f), 1, 0,
                    L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]), L.ptr(self.gviews[1]), B, n, st)
-        works = []
-        if self.pg is not None:
-            works.append(self._allreduce("fusion"))
+        red = self.reducer
+        if red is not None:
+            red.launch("fusion")
         ev2 = main.record_event()
         self.s_a.wait_event(ev2)
         self.s_v.wait_event(ev2)
         with torch.cuda.stream(self.s_a):
             self.eng_a.backward(self.gviews[2:62], dfeat=self.dfa)
-            if self.pg is not None:
-                works.append(self._allreduce("audio"))
+            if red is not None:
+                red.launch("audio")
         with torch.cuda.stream(self.s_v):
             self.eng_v.backward(self.gviews[62:122], dfeat=self.dfv)
-            if self.pg is not None:
-                works.append(self._allreduce("visual"))
+            if red is not None:
+                red.launch("visual")
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_v)
-        for w in works:
-            w.wait()
+        if red is not None:
+            red.wait_all()
         gs = 1.0 / self.world
         L.call("gdl_optim_grad_stats", self.opt, L.ptr(self.grads), self.max_norm, gs, L.ptr(self.stats),
                L.ptr(self.opt_ws), self.opt_ws_bytes, st)
         L.call("gdl_optim_sgd_step", self.opt, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.momentum),
                L.ptr(self.stats), gs, self.lr, self.mu, self.wd, st)
         self.steps += 1
-
-    def _allreduce(self, name):
-        lo, hi = self.bucket[name]
-        return self.dist.all_reduce(self.grads[lo:hi], op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     # ------------------------------------------------------------------ results (host sync)
     def read(self):

@@ -117,7 +117,7 @@ GDL_API int gdl_bn_act(int dtype, const void* y, const float* scale, const float
  * gdl_bn_bwd_reduce -> partial[blocks][C][2]; gdl_bn_bwd_finalize -> dgamma, dbeta
  * (float32, overwritten) and coef[2][C] = {dbeta/M, dgamma/M};
  * gdl_bn_bwd_apply: dy = gamma*rstd*(g - coef0 - xhat*coef1), may alias g. */
-GDL_API int gdl_bn_bwd_blocks(size_t M);
+GDL_API int gdl_bn_bwd_blocks(size_t M, int C);
 GDL_API int gdl_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift,
                               const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M,
                               int C, void* stream);
@@ -222,6 +222,18 @@ GDL_API int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const flo
                                  void* stream);
 /* serial number of the last training forward (to detect stale activations) */
 GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
+
+/* ------------------------------------------------------------------ measurement tap
+ * Optional HIP-event timing of every kernel launch (off by default).  While enabled, each
+ * launcher records an event pair on the launching stream and its algorithmic work (flops for
+ * the MFMA-bound conv kernels, bytes for the HBM-bound ones).  gdl_prof_collect synchronises
+ * the device and returns per-slot totals: launches[s], ms[s], work[s], s < gdl_prof_nslots().
+ * gdl_prof_slot_bound: 1 = MFMA-bound (work in flops), 0 = HBM-bound (work in bytes). */
+GDL_API int gdl_prof_enable(int on);
+GDL_API int gdl_prof_nslots(void);
+GDL_API const char* gdl_prof_slot_name(int slot);
+GDL_API int gdl_prof_slot_bound(int slot);
+GDL_API int gdl_prof_collect(int64_t* launches, double* ms, double* work);
 
 #ifdef __cplusplus
 }

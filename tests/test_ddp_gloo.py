@@ -1,0 +1,82 @@
+"""World-size-2 CPU (gloo) test of the per-bucket gradient all-reduce used by the N > 1 step.
+Checks what stock DDP gets wrong for DGL: every bucket -- including the fusion head --
+is summed across ranks exactly once, and the folded 1/world scale yields the mean."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "iccv2025-gdl_amd"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gdl.ddp import BucketReducer
+
+    n_f, n_a, n_v = 6150, 20000, 30000  # fusion / audio / visual bucket sizes (scaled down)
+    offs = [0, n_f, n_f + n_a, n_f + n_a + n_v]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(offs[-1], generator=g)
+    mine = flat.clone()
+    red = BucketReducer(flat, {"fusion": (offs[0], offs[1]), "audio": (offs[1], offs[2]), "visual": (offs[2], offs[3])})
+    ok = True
+    # order of the real step: fusion first, then the two encoders
+    red.launch("fusion")
+    red.launch("audio")
+    try:
+        red.launch("audio")
+        ok = False  # a bucket must not be reduced twice
+    except RuntimeError:
+        pass
+    try:
+        red.wait_all()
+        ok = False  # a step that forgot a bucket must fail loudly
+    except RuntimeError:
+        pass
+    red.launch("visual")
+    red.wait_all()
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    expect = sum(gathered)
+    ok = ok and torch.allclose(flat, expect, rtol=1e-6, atol=1e-6)
+    ok = ok and abs(red.grad_scale - 1.0 / world) < 1e-12
+    mean = flat * red.grad_scale
+    ok = ok and torch.allclose(mean, expect / world, rtol=1e-6, atol=1e-6)
+    # buffers follow rank 0
+    buf = torch.full((5,), float(rank))
+    red.broadcast_buffers([buf])
+    ok = ok and bool((buf == 0).all())
+    q.put((rank, ok, float(flat.double().sum())))
+    dist.destroy_process_group()
+
+
+def test_bucket_allreduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    sums = [s for _, _, s in res]
+    np.testing.assert_allclose(sums[0], sums[1], rtol=1e-9)  # both ranks hold identical reduced grads

@@ -23,13 +23,15 @@ def _conv_case(N, C, H, W, K, R, stride, pad, dt):
 
 
 CONV_SHAPES = [
-    # N, C, H, W, K, R, stride, pad      -> tile config exercised
-    (2, 64, 17, 13, 64, 3, 1, 1),     # 256x64, ragged M tail, odd spatial dims
+    # N, C, H, W, K, R, stride, pad      -> tile config exercised (fwd)
+    (2, 64, 17, 13, 64, 3, 1, 1),     # 64x64, ragged M tail, odd spatial dims
     (3, 64, 20, 18, 128, 3, 2, 1),    # 64x64, stride 2
     (2, 64, 9, 6, 128, 1, 2, 0),      # 1x1 stride 2 (downsample)
-    (1, 128, 7, 5, 256, 3, 1, 1),     # 64x64, deeper K
-    (4, 64, 112, 112, 128, 3, 1, 1),  # 128x128
-    (2, 256, 14, 14, 512, 3, 2, 1),   # 64x64, C=256
+    (1, 128, 7, 5, 256, 3, 1, 1),     # 64x64, two K-steps per tap
+    (10, 64, 33, 31, 128, 3, 1, 1),   # 128x64, ragged tail
+    (3, 64, 120, 115, 64, 3, 1, 1),   # 256x64, ragged tail
+    (4, 64, 112, 112, 128, 3, 1, 1),  # 256x64, two N-tiles
+    (2, 256, 14, 14, 512, 3, 2, 1),   # stride 2, C=256
 ]
 
 
@@ -181,7 +183,7 @@ def test_bn_forward_backward(C, N, H, W, dt):
     da = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
     dxref, dgref, dbref = orc.bn_bwd(orc.relu_bwd(da, aref), x, gamma, mean, invstd)
     dad = to_nhwc(da, dt)
-    blocks = lib.gdl_bn_bwd_blocks(M)
+    blocks = lib.gdl_bn_bwd_blocks(M, C)
     bpart = torch.empty((blocks, C, 2), device=DEV)
     dg, db, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)
     L.call("gdl_bn_bwd_reduce", dt, L.ptr(dad), L.ptr(xd), L.ptr(sc), L.ptr(sh), L.ptr(sm), L.ptr(sr), 1, L.ptr(bpart),
