@@ -26,25 +26,34 @@ static bool dt_ok(int dtype) { return dtype == GDL_F32 || dtype == GDL_BF16; }
 
 int gdl_conv_bn_tiles(int dtype, int N, int P, int Q, int K) { return conv_tiles_m(dtype, N * P * Q, K); }
 
-int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, int N, int H, int W, int C, int K,
-                 int R, int S, int stride, int pad, void* stream) {
-    GDL_REQUIRE(x && w_krsc && y, "conv_fwd: null pointer");
-    return conv_fwd(dtype, x, w_krsc, y, bn_partial, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+size_t gdl_conv_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad) {
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    return (size_t)(mode == GATHER_FWD ? N * P * Q : N * H * W) * sizeof(GatherEntry);
 }
-int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H, int W, int C,
-                   int K, int R, int S, int stride, int pad, void* stream) {
+int gdl_conv_build_table(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                         void* table, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && table && (mode == GATHER_FWD || mode == GATHER_DGRAD), "conv_build_table: bad arguments");
+    return build_gather_table(mode, dtype, N, H, W, C, K, R, S, stride, pad, (GatherEntry*)table, (hipStream_t)stream);
+}
+int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
+                 int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
+    GDL_REQUIRE(x && w_krsc && y, "conv_fwd: null pointer");
+    return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+}
+int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N,
+                   int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
     GDL_REQUIRE(dy && w_crsk && dx, "conv_dgrad: null pointer");
-    return conv_dgrad(dtype, dy, w_crsk, dx, addend, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+    return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
 }
 size_t gdl_conv_wgrad_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     (void)dtype;
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
     return conv_wgrad_ws_bytes(N * P * Q, C, K, R * S);
 }
-int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int R, int S,
-                   int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C,
+                   int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
     GDL_REQUIRE(dy && x && dw, "conv_wgrad: null pointer");
-    return conv_wgrad(dtype, dy, x, dw, N, H, W, C, K, R, S, stride, pad, C, ws, ws_bytes, (hipStream_t)stream);
+    return conv_wgrad(dtype, dy, x, dw, table, N, H, W, C, K, R, S, stride, pad, C, ws, ws_bytes, (hipStream_t)stream);
 }
 int gdl_pack_weight(int dtype, const float* w, void* w_krsc, void* w_crsk, int K, int C, int R, int S, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && w, "pack_weight: bad arguments");
@@ -59,10 +68,10 @@ int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* str
     GDL_REQUIRE(dt_ok(dtype) && w && wp, "pack_stem_weight: bad arguments");
     return pack_stem_weight(dtype, w, wp, Cin, (hipStream_t)stream);
 }
-int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, int M, int Cin, void* ws, size_t ws_bytes,
-                   void* stream) {
+int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, const void* table, int M, int Cin, void* ws,
+                   size_t ws_bytes, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && dy && col && dw, "stem_wgrad: bad arguments");
-    return conv_wgrad(dtype, dy, col, dw, M, 1, 1, stem_kp(Cin, dtype), 64, 1, 1, 1, 0, Cin * 49, ws, ws_bytes,
+    return conv_wgrad(dtype, dy, col, dw, table, M, 1, 1, stem_kp(Cin, dtype), 64, 1, 1, 1, 0, Cin * 49, ws, ws_bytes,
                       (hipStream_t)stream);
 }
 int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream) {

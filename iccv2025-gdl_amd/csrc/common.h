@@ -19,16 +19,19 @@ struct bf16 {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    bf16x2_t h;
+    h.x = (__bf16)lo;
+    h.y = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, h);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T>
 struct TT;

@@ -21,21 +21,22 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gather.h"
 #include "prof.h"
 
 namespace gdl {
 
 struct ConvArgs {
-    const void* in;      // gather source, NHWC [N][IH][IW][IC]
-    const void* wt;      // [OC][R][S][IC]
-    void* out;           // NHWC [N][OH][OW][OC]
-    const void* addend;  // optional, like out
-    float* stats;        // optional [mtiles][OC][2]
-    int N, IH, IW, IC, OH, OW, OC, R, S, stride, pad;
-    int M;       // N*OH*OW
+    const void* in;            // gather source (NHWC)
+    const void* wt;            // [OC][ntaps][IC]
+    void* out;                 // NHWC rows of OC channels, row m = GEMM row m
+    const void* addend;        // optional, like out
+    float* stats;              // optional [mtiles][OC][2]
+    const GatherEntry* table;  // [M]
+    int M, OC, IC, ntaps;
     int mtiles;  // ceil(M/BM)
-    int ohow;
-    float rcp_ohow, rcp_ow;
+    unsigned in_bytes, wt_bytes;
+    int delta[9];
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -94,68 +95,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     if (mtile >= a.mtiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
-    // ---- per-thread gather bookkeeping for the A (pixel) rows
+    // ---- per-thread gather bookkeeping: rows row0 + 32*i of the tile, one 16-byte chunk each.
+    // Source addresses are 32-bit byte offsets into buffer descriptors: an invalid tap (padding,
+    // stride-2 parity, M tail) gets an offset beyond the descriptor and the hardware returns zeros.
     const int chunk = tid & 7, row0 = tid >> 3;
-    int a_base[AROWS], a_hs[AROWS], a_ws[AROWS];
+    int a_off[AROWS];
+    unsigned a_mask[AROWS];
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
         const int m = m0 + row0 + 32 * i;
-        if (m < a.M) {
-            const int n = fdiv_small(m, a.ohow, a.rcp_ohow);
-            const int rem = m - n * a.ohow;
-            const int oh = fdiv_small(rem, a.OW, a.rcp_ow);
-            const int ow = rem - oh * a.OW;
-            a_base[i] = n * a.IH * a.IW;
-            if (MODE == MODE_FWD) {
-                a_hs[i] = oh * a.stride - a.pad;
-                a_ws[i] = ow * a.stride - a.pad;
-            } else {
-                a_hs[i] = oh + a.pad;
-                a_ws[i] = ow + a.pad;
-            }
-        } else {
-            a_base[i] = -1;
-            a_hs[i] = 0;
-            a_ws[i] = 0;
-        }
+        GatherEntry e;
+        e.off0 = 0;
+        e.mask = 0;
+        if (m < a.M) e = a.table[m];
+        a_off[i] = e.off0 + chunk * 16;
+        a_mask[i] = e.mask;
     }
+    const int esz = (int)sizeof(T);
+    int b_off[BROWS];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + chunk * 16;
     const int kpt = a.IC / BKE;  // K-steps per tap
-    const int nk = a.R * a.S * kpt;
-    const T* __restrict__ gin = (const T*)a.in;
-    const T* __restrict__ gw = (const T*)a.wt;
-    const int sshift = (a.stride == 2) ? 1 : 0;
+    const int nk = a.ntaps * kpt;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
 
-    uint4 va[AROWS], vb[BROWS];
-    auto load_tile = [&](int kt) {
-        const int tap = kt / kpt;
-        const int c0 = (kt - tap * kpt) * BKE + chunk * EPC;
-        const int r = tap / a.S, s = tap - r * a.S;
+    u32x4_t va[AROWS], vb[BROWS];
+    int ld_tap = 0, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
+    auto load_tile = [&]() {
+        const int ua = a.delta[ld_tap] + ld_kc * 128;                   // uniform
+        const int ub = (ld_tap * a.IC) * esz + ld_kc * 128;             // uniform
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            int ih, iw;
-            bool ok = a_base[i] >= 0;
-            if (MODE == MODE_FWD) {
-                ih = a_hs[i] + r;
-                iw = a_ws[i] + s;
-            } else {
-                const int th = a_hs[i] - r, tw = a_ws[i] - s;
-                ok = ok && th >= 0 && tw >= 0 && (((th | tw) & sshift) == 0);
-                ih = th >> sshift;
-                iw = tw >> sshift;
-            }
-            ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-            if (ok) {
-                const size_t off = (size_t)(a_base[i] + ih * a.IW + iw) * a.IC + c0;
-                va[i] = *(const uint4*)(gin + off);
-            } else {
-                va[i] = make_uint4(0, 0, 0, 0);
-            }
+            const int v = ((a_mask[i] >> ld_tap) & 1u) ? a_off[i] + ua : (int)0x80000000;
+            va[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, v, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            const int oc = n0 + row0 + 32 * i;
-            const size_t off = ((size_t)oc * (a.R * a.S) + tap) * a.IC + c0;
-            vb[i] = *(const uint4*)(gw + off);
+        for (int i = 0; i < BROWS; ++i) vb[i] = __builtin_amdgcn_raw_buffer_load_b128(rwt, b_off[i] + ub, 0, 0);
+        if (++ld_kc == kpt) {
+            ld_kc = 0;
+            ++ld_tap;
         }
     };
     auto store_tile = [&](int buf) {
@@ -164,12 +143,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const int row = row0 + 32 * i;
-            *(uint4*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = va[i];
+            *(u32x4_t*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = va[i];
         }
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) {
             const int row = row0 + 32 * i;
-            *(uint4*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = vb[i];
+            *(u32x4_t*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = vb[i];
         }
     };
 
@@ -184,12 +163,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int off_kk0 = frow * 128 + (((0 + fg) ^ fswz) << 4);
     const int off_kk1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
 
-    load_tile(0);
+    load_tile();
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) load_tile();
         const unsigned char* As = smem + buf * SM::STAGE + (wm * WTM) * 128;
         const unsigned char* Bs = smem + buf * SM::STAGE + BM * 128 + (wn * WTN) * 128;
 #pragma unroll
@@ -336,7 +315,7 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     const int ntn = a.OC / BN;
     const int grid = ((a.mtiles + 7) / 8) * 8 * ntn;
     const int slot = (MODE == MODE_FWD ? PROF_CONV_FWD_256x64 : PROF_CONV_DGRAD_256x64) + (BM == 256 ? 0 : (BM == 128 ? 1 : 2));
-    ProfScope prof(slot, st, 2.0 * (double)a.M * a.OC * a.R * a.S * a.IC);
+    ProfScope prof(slot, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_igemm_kernel");
     return GDL_OK;
@@ -355,69 +334,53 @@ int conv_tiles_m(int dtype, int M, int OC) {
     return ceil_div(M, c.bm);
 }
 
-static int fill_common(ConvArgs& a, int dtype) {
-    const int bke = (dtype == GDL_BF16) ? 64 : 32;
+static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
+                    const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                    hipStream_t st) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
+    GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
+    const int bke = (dtype == GDL_BF16) ? 64 : 32;
+    const int esz = (dtype == GDL_BF16) ? 2 : 4;
+    GatherGeom g;
+    int rc = gather_geom(mode, dtype, N, H, W, C, K, R, S, stride, pad, &g);
+    if (rc) return rc;
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    ConvArgs a{};
+    a.in = in;
+    a.wt = wt;
+    a.out = out;
+    a.addend = addend;
+    a.stats = stats;
+    a.table = (const GatherEntry*)table;
+    a.M = g.rows;
+    a.ntaps = g.ntaps;
+    for (int t = 0; t < 9; ++t) a.delta[t] = g.delta[t];
+    if (mode == GATHER_FWD) {
+        a.IC = C;
+        a.OC = K;
+        a.in_bytes = (unsigned)((size_t)N * H * W * C * esz);
+    } else {
+        a.IC = K;
+        a.OC = C;
+        a.in_bytes = (unsigned)((size_t)N * P * Q * K * esz);
+    }
+    a.wt_bytes = (unsigned)((size_t)K * C * R * S * esz);
     GDL_REQUIRE(a.IC % bke == 0, "conv: gather channels %d not a multiple of %d", a.IC, bke);
     GDL_REQUIRE(a.OC % 64 == 0, "conv: output channels %d not a multiple of 64", a.OC);
-    GDL_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride %d unsupported", a.stride);
-    GDL_REQUIRE((long)a.N * a.OH * a.OW < (1L << 24), "conv: M = %ld exceeds 2^24", (long)a.N * a.OH * a.OW);
-    GDL_REQUIRE((size_t)a.N * a.IH * a.IW * (size_t)a.IC < (1UL << 31), "conv: input too large for 32-bit pixel index");
-    a.M = a.N * a.OH * a.OW;
-    a.ohow = a.OH * a.OW;
-    a.rcp_ohow = 1.0f / (float)a.ohow;
-    a.rcp_ow = 1.0f / (float)a.OW;
-    return GDL_OK;
+    GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
+    if (dtype == GDL_BF16)
+        return mode == GATHER_FWD ? launch_mode<bf16, MODE_FWD>(a, dtype, st) : launch_mode<bf16, MODE_DGRAD>(a, dtype, st);
+    return mode == GATHER_FWD ? launch_mode<float, MODE_FWD>(a, dtype, st) : launch_mode<float, MODE_DGRAD>(a, dtype, st);
 }
 
-int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, int N, int H, int W, int C, int K, int R,
-             int S, int stride, int pad, hipStream_t st) {
-    ConvArgs a{};
-    a.in = x;
-    a.wt = w;
-    a.out = y;
-    a.addend = nullptr;
-    a.stats = bn_partial;
-    a.N = N;
-    a.IH = H;
-    a.IW = W;
-    a.IC = C;
-    a.OH = (H + 2 * pad - R) / stride + 1;
-    a.OW = (W + 2 * pad - S) / stride + 1;
-    a.OC = K;
-    a.R = R;
-    a.S = S;
-    a.stride = stride;
-    a.pad = pad;
-    int rc = fill_common(a, dtype);
-    if (rc) return rc;
-    if (dtype == GDL_BF16) return launch_mode<bf16, MODE_FWD>(a, dtype, st);
-    return launch_mode<float, MODE_FWD>(a, dtype, st);
+int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,
+             int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
+    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st);
 }
 
-int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H, int W, int C,
-               int K, int R, int S, int stride, int pad, hipStream_t st) {
-    ConvArgs a{};
-    a.in = dy;
-    a.wt = w_crsk;
-    a.out = dx;
-    a.addend = addend;
-    a.stats = nullptr;
-    a.N = N;
-    a.IH = (H + 2 * pad - R) / stride + 1;  // P
-    a.IW = (W + 2 * pad - S) / stride + 1;  // Q
-    a.IC = K;
-    a.OH = H;
-    a.OW = W;
-    a.OC = C;
-    a.R = R;
-    a.S = S;
-    a.stride = stride;
-    a.pad = pad;
-    int rc = fill_common(a, dtype);
-    if (rc) return rc;
-    if (dtype == GDL_BF16) return launch_mode<bf16, MODE_DGRAD>(a, dtype, st);
-    return launch_mode<float, MODE_DGRAD>(a, dtype, st);
+int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
+               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st);
 }
 
 }  // namespace gdl

@@ -16,19 +16,21 @@
 // gradient layout.  Tap is the fastest-varying index among blocks that share an XCD,
 // so the 9 taps of one pixel slice reuse dy / x from that XCD's L2.
 #include "common.h"
+#include "gather.h"
 #include "prof.h"
 
 namespace gdl {
 
 struct WgradArgs {
-    const void* dy;  // [N][P][Q][K]
-    const void* x;   // [N][H][W][C]
-    float* partial;  // [nsplit][K][RS][C]
-    int N, H, W, C, P, Q, K, R, S, stride, pad;
-    int M, pq;
-    float rcp_pq, rcp_q;
+    const void* dy;            // [M][K]
+    const void* x;             // gather source [N][H][W][C]
+    float* partial;            // [nsplit][K][RS][C]
+    const GatherEntry* table;  // forward gather table of this convolution, [M]
+    int C, K, RS, M;
     int nsplit, chunk;  // pixels per split (multiple of 64)
     int tiles_k, tiles_c;
+    unsigned dy_bytes, x_bytes;
+    int delta[9];
 };
 
 constexpr int WG_BP = 64;  // pixels per LDS stage
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
     // block -> (slice, tap, ktile, ctile); blocks b, b+8, b+16.. share an XCD: keep the taps and
     // channel tiles of one pixel slice on it
-    const int RS = a.R * a.S;
+    const int RS = a.RS;
     const int per_slice = RS * a.tiles_k * a.tiles_c;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int slices_per_xcd = (a.nsplit + 7) >> 3;
@@ -73,45 +75,60 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     rem /= RS;
     const int kt = rem % a.tiles_k, ct = rem / a.tiles_k;
     const int k0 = kt * TK, c0 = ct * TC;
-    const int r = tap / a.S, s = tap - r * a.S;
 
     const int m_begin = slice * a.chunk;
     const int m_end = min(a.M, m_begin + a.chunk);
     const int nst = (m_end - m_begin + WG_BP - 1) / WG_BP;
 
-    const T* __restrict__ gdy = (const T*)a.dy;
-    const T* __restrict__ gx = (const T*)a.x;
+    // 32-bit byte offsets into buffer descriptors; invalid rows / taps read zeros (offset out of range)
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    const int esz = (int)sizeof(T);
+    const int tap_delta = a.delta[tap] + c0 * esz;
+    int dy_off[LK];  // offset of this thread's chunk in the CURRENT stage
+#pragma unroll
+    for (int i = 0; i < LK; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / CPR_K, ch = idx % CPR_K;
+        dy_off[i] = (m_begin + row) * (a.K * esz) + k0 * esz + ch * 16;
+    }
+    GatherEntry ent[LC];  // table entries of the NEXT stage to load
+#pragma unroll
+    for (int i = 0; i < LC; ++i) {
+        const int idx = tid + 256 * i;
+        const int m = m_begin + idx / CPR_C;
+        ent[i].off0 = 0;
+        ent[i].mask = 0;
+        if (m < m_end) ent[i] = a.table[m];
+    }
+    int ld_m = m_begin;  // first pixel of the next stage to load
 
-    uint4 vk[LK], vc[LC];
-    auto load_stage = [&](int st) {
-        const int mb = m_begin + st * WG_BP;
+    u32x4_t vk[LK], vc[LC];
+    auto load_stage = [&]() {
 #pragma unroll
         for (int i = 0; i < LK; ++i) {
             const int idx = tid + 256 * i;
-            const int row = idx / CPR_K, ch = idx % CPR_K;
-            const int m = mb + row;
-            if (m < m_end)
-                vk[i] = *(const uint4*)(gdy + (size_t)m * a.K + k0 + ch * EPC);
-            else
-                vk[i] = make_uint4(0, 0, 0, 0);
+            const int m = ld_m + idx / CPR_K;
+            vk[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, m < m_end ? dy_off[i] : (int)0x80000000, 0, 0);
+            dy_off[i] += WG_BP * a.K * esz;
         }
 #pragma unroll
         for (int i = 0; i < LC; ++i) {
             const int idx = tid + 256 * i;
-            const int row = idx / CPR_C, ch = idx % CPR_C;
-            const int m = mb + row;
-            bool ok = m < m_end;
-            size_t off = 0;
-            if (ok) {
-                const int n = fdiv_small(m, a.pq, a.rcp_pq);
-                const int rm = m - n * a.pq;
-                const int p = fdiv_small(rm, a.Q, a.rcp_q);
-                const int q = rm - p * a.Q;
-                const int ih = p * a.stride - a.pad + r, iw = q * a.stride - a.pad + s;
-                ok = (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-                off = ((size_t)(n * a.H + ih) * a.W + iw) * a.C + c0 + ch * EPC;
-            }
-            vc[i] = ok ? *(const uint4*)(gx + off) : make_uint4(0, 0, 0, 0);
+            const int ch = idx % CPR_C;
+            const int v = ((ent[i].mask >> tap) & 1u) ? ent[i].off0 + tap_delta + ch * 16 : (int)0x80000000;
+            vc[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, v, 0, 0);
+        }
+        ld_m += WG_BP;
+#pragma unroll
+        for (int i = 0; i < LC; ++i) {  // prefetch the table entries of the following stage
+            const int idx = tid + 256 * i;
+            const int m = ld_m + idx / CPR_C;
+            GatherEntry e;
+            e.off0 = 0;
+            e.mask = 0;
+            if (m < m_end) e = a.table[m];
+            ent[i] = e;
         }
     };
     auto store_stage = [&](int buf) {
@@ -122,14 +139,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const int idx = tid + 256 * i;
             const int row = idx / CPR_K, ch = idx % CPR_K;
             const int pch = (((ch >> 1) ^ wg_swz<PK>(row)) << 1) | (ch & 1);
-            *(uint4*)(Ks + row * PK + pch * 16) = vk[i];
+            *(u32x4_t*)(Ks + row * PK + pch * 16) = vk[i];
         }
 #pragma unroll
         for (int i = 0; i < LC; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx / CPR_C, ch = idx % CPR_C;
             const int pch = (((ch >> 1) ^ wg_swz<PC>(row)) << 1) | (ch & 1);
-            *(uint4*)(Cs + row * PC + pch * 16) = vc[i];
+            *(u32x4_t*)(Cs + row * PC + pch * 16) = vc[i];
         }
     };
 
@@ -142,13 +159,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int g = lane >> 4, li = lane & 15;
 
     if (nst > 0) {
-        load_stage(0);
+        load_stage();
         store_stage(0);
     }
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nst) load_stage(st + 1);
+        if (st + 1 < nst) load_stage();
         const unsigned char* Ks = smem + buf * STAGE;
         const unsigned char* Cs = Ks + WG_BP * PK;
         if (sizeof(T) == 2) {
@@ -307,39 +324,37 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad)");
         attr_set = true;
     }
-    const int per_slice = a.R * a.S * a.tiles_k * a.tiles_c;
+    const int per_slice = a.RS * a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
-    ProfScope prof(PROF_CONV_WGRAD, st, 2.0 * (double)a.M * a.K * a.C * a.R * a.S);
+    ProfScope prof(PROF_CONV_WGRAD, st, 2.0 * (double)a.M * a.K * a.C * a.RS);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_wgrad_kernel");
     return GDL_OK;
 }
 
 // Cout: number of leading input channels kept in dw (== C except for the padded stem im2col)
-int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int R, int S,
-               int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K,
+               int R, int S, int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+    GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "wgrad: bad dtype %d", dtype);
+    GDL_REQUIRE(table, "wgrad: gather table is null (build it with gdl_conv_build_table)");
+    GDL_REQUIRE(C % 64 == 0 && K % 64 == 0, "wgrad: C=%d K=%d must be multiples of 64", C, K);
+    GatherGeom g;
+    int rc = gather_geom(GATHER_FWD, dtype, N, H, W, C, K, R, S, stride, pad, &g);
+    if (rc) return rc;
+    const int esz = dtype == GDL_BF16 ? 2 : 4;
     WgradArgs a{};
     a.dy = dy;
     a.x = x;
-    a.N = N;
-    a.H = H;
-    a.W = W;
+    a.table = (const GatherEntry*)table;
     a.C = C;
     a.K = K;
-    a.R = R;
-    a.S = S;
-    a.stride = stride;
-    a.pad = pad;
-    a.P = (H + 2 * pad - R) / stride + 1;
-    a.Q = (W + 2 * pad - S) / stride + 1;
-    GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "wgrad: bad dtype %d", dtype);
-    GDL_REQUIRE(C % 64 == 0 && K % 64 == 0, "wgrad: C=%d K=%d must be multiples of 64", C, K);
-    GDL_REQUIRE((long)N * a.P * a.Q < (1L << 24), "wgrad: M exceeds 2^24");
-    GDL_REQUIRE((size_t)N * H * W < (1UL << 31), "wgrad: too many input pixels");
-    a.M = N * a.P * a.Q;
-    a.pq = a.P * a.Q;
-    a.rcp_pq = 1.0f / (float)a.pq;
-    a.rcp_q = 1.0f / (float)a.Q;
+    a.RS = R * S;
+    a.M = g.rows;
+    for (int t = 0; t < 9; ++t) a.delta[t] = g.delta[t];
+    GDL_REQUIRE(a.M < (1 << 24), "wgrad: M exceeds 2^24");
+    GDL_REQUIRE((size_t)a.M * K * esz < (1UL << 31), "wgrad: dy exceeds 2 GiB");
+    a.dy_bytes = (unsigned)((size_t)a.M * K * esz);
+    a.x_bytes = (unsigned)((size_t)N * H * W * C * esz);
     const WgradPlan p = plan_wgrad(a.M, C, K, R * S);
     a.nsplit = p.nsplit;
     a.chunk = p.chunk;
@@ -351,7 +366,6 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H
         return GDL_ERR_WORKSPACE;
     }
     a.partial = (float*)ws;
-    int rc;
     if (dtype == GDL_BF16) {
         if (p.tk == 128 && p.tc == 128)
             rc = launch_wg<bf16, 128, 128>(a, st);

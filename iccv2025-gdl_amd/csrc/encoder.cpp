@@ -10,6 +10,8 @@
 //                           y2 = conv2(a1); [yd = convd(x)]; z = relu(bn2(y2) + (bnd(yd) | x)).
 // Backward:  do2 = dz*(z>0); bn2/bnd backward (two passes each); wgrad; dgrad with the identity /
 //            downsample gradient accumulated in the dgrad epilogue.
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "ops.h"
@@ -24,6 +26,8 @@ struct Conv {
     int pidx;        // index of the weight in the 60-parameter table
     void* w_krsc = nullptr;
     void* w_crsk = nullptr;
+    void* tab_fwd = nullptr;    // gather tables (shared between convolutions of equal geometry)
+    void* tab_dgrad = nullptr;
 };
 struct BN {
     int c;
@@ -80,6 +84,14 @@ struct gdl_encoder {
     int64_t serial = 0;
     bool have_train_fwd = false;
     int64_t numel[GDL_ENC_NPARAMS];
+    // gather tables: geometry -> workspace slot; built lazily on the first forward's stream
+    struct TabJob {
+        int mode, N, H, W, C, K, R, S, stride, pad;
+        void* dst;
+    };
+    std::vector<TabJob> tab_jobs;
+    bool tabs_dirty = true;
+    void* tab_stem = nullptr;
     // batched weight packing
     std::vector<PackDescHost> pack_host;
     void* pack_dev = nullptr;
@@ -115,6 +127,22 @@ size_t gdl_encoder::plan(unsigned char* base) {
         c.w_crsk = b.take(n);
     };
     bn_alloc(bn0);
+    // gather tables, one per distinct (mode, geometry)
+    tab_jobs.clear();
+    std::map<std::tuple<int, int, int, int, int, int, int, int, int>, void*> seen;
+    auto table_for = [&](int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) -> void* {
+        const int src_ch = mode == GATHER_FWD ? C : K;  // the table depends on the gathered tensor's row size
+        auto key = std::make_tuple(mode, N, H, W, src_ch, R, S, stride, pad);
+        auto it = seen.find(key);
+        if (it != seen.end()) return it->second;
+        const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+        const size_t rows = mode == GATHER_FWD ? (size_t)N * P * Q : (size_t)N * H * W;
+        void* dst = b.take(rows * sizeof(GatherEntry));
+        seen[key] = dst;
+        tab_jobs.push_back(TabJob{mode, N, H, W, C, K, R, S, stride, pad, dst});
+        return dst;
+    };
+    tab_stem = table_for(GATHER_FWD, (int)m0, 1, 1, kp, 64, 1, 1, 1, 0);
     size_t max_act = (size_t)n_img * h1 * w1 * 64;  // elements
     size_t max_tiles_c = (size_t)conv_tiles_m(dtype, (int)m0, 64) * 64;
     size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0, 64) * 64;
@@ -129,11 +157,17 @@ size_t gdl_encoder::plan(unsigned char* base) {
         k.z = b.take(out_el * e);
         conv_alloc(k.c1);
         conv_alloc(k.c2);
+        for (Conv* c : {&k.c1, &k.c2}) {
+            c->tab_fwd = table_for(GATHER_FWD, k.n, c->h, c->w, c->cin, c->cout, c->r, c->s, c->stride, c->pad);
+            c->tab_dgrad = table_for(GATHER_DGRAD, k.n, c->h, c->w, c->cin, c->cout, c->r, c->s, c->stride, c->pad);
+        }
         bn_alloc(k.b1);
         bn_alloc(k.b2);
         if (k.has_ds) {
             k.yd = b.take(out_el * e);
             conv_alloc(k.cd);
+            k.cd.tab_fwd = table_for(GATHER_FWD, k.n, k.cd.h, k.cd.w, k.cd.cin, k.cd.cout, 1, 1, k.cd.stride, 0);
+            k.cd.tab_dgrad = table_for(GATHER_DGRAD, k.n, k.cd.h, k.cd.w, k.cd.cin, k.cd.cout, 1, 1, k.cd.stride, 0);
             bn_alloc(k.bd);
         }
         const size_t in_el = (size_t)k.n * k.h * k.w * k.cin;
@@ -288,6 +322,7 @@ int gdl_encoder_bind(gdl_encoder_t* e, void* workspace, size_t bytes) {
     e->ws = workspace;
     e->plan((unsigned char*)workspace);
     e->pack_dirty = true;
+    e->tabs_dirty = true;
     e->have_train_fwd = false;
     return GDL_OK;
 }
@@ -328,8 +363,8 @@ static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double co
 }
 
 static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st) {
-    RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? e->bn_partial : nullptr, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s,
-                c.stride, c.pad, st));
+    RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? e->bn_partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout,
+                c.r, c.s, c.stride, c.pad, st));
     const int M = nimg * c.p * c.q;
     return bn_finalize(e, n, training, conv_tiles_m(e->dtype, M, c.cout), (double)M, st);
 }
@@ -344,6 +379,11 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     if (!training) e->have_train_fwd = false;  // an eval pass overwrites the saved activations
     // weights -> kernel layouts (float32 master copies stay with the caller)
     RC(pack_stem_weight(dt, e->params[0], e->w0p, e->cin, st));
+    if (e->tabs_dirty) {  // gather tables: once per bound workspace
+        for (const gdl_encoder::TabJob& j : e->tab_jobs)
+            RC(build_gather_table(j.mode, dt, j.N, j.H, j.W, j.C, j.K, j.R, j.S, j.stride, j.pad, (GatherEntry*)j.dst, st));
+        e->tabs_dirty = false;
+    }
     if (e->pack_dirty) {  // (re)build the descriptor table of the batched packing launch
         e->pack_host.clear();
         int blk = 0;
@@ -379,8 +419,8 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
     // stem: conv1 (7x7/2) as im2col + GEMM, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     RC(stem_im2col(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
-    RC(conv_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0,
-                st));
+    RC(conv_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, (int)e->m0, 1, 1, e->kp, 64,
+                1, 1, 1, 0, st));
     RC(bn_finalize(e, e->bn0, training, conv_tiles_m(dt, (int)e->m0, 64), (double)e->m0, st));
     RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, e->n_img, e->h0, e->w0, 64, st));
     // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
@@ -442,25 +482,28 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
         void* do2 = dz;
         // bn2 / conv2
         RC(bn_backward(e, k.b2, do2, k.y2, 0, e->gB, Mo, grads, st));  // gB = dy2
-        RC(conv_wgrad(dt, e->gB, k.a1, grads[k.c2.pidx], k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout, e->wg_ws,
-                      e->wg_ws_bytes, st));
-        RC(conv_dgrad(dt, e->gB, k.c2.w_crsk, e->gC, nullptr, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, st));  // gC = da1
+        RC(conv_wgrad(dt, e->gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
+                      e->wg_ws, e->wg_ws_bytes, st));
+        RC(conv_dgrad(dt, e->gB, k.c2.w_crsk, e->gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
+                      st));  // gC = da1
         // relu + bn1 / conv1
         RC(bn_backward(e, k.b1, e->gC, k.y1, 1, e->gC, Mo, grads, st));  // gC = dy1 (in place)
-        RC(conv_wgrad(dt, e->gC, k.xin, grads[k.c1.pidx], k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1, k.cin,
-                      e->wg_ws, e->wg_ws_bytes, st));
+        RC(conv_wgrad(dt, e->gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
+                      k.cin, e->wg_ws, e->wg_ws_bytes, st));
         void* dxin;
         if (k.has_ds) {
             RC(bn_backward(e, k.bd, do2, k.yd, 0, e->gD, Mo, grads, st));  // gD = dyd
-            RC(conv_wgrad(dt, e->gD, k.xin, grads[k.cd.pidx], k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0, k.cin,
-                          e->wg_ws, e->wg_ws_bytes, st));
-            RC(conv_dgrad(dt, e->gD, k.cd.w_crsk, spare, nullptr, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0, st));
-            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, spare, spare, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1, st));
+            RC(conv_wgrad(dt, e->gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride,
+                          0, k.cin, e->wg_ws, e->wg_ws_bytes, st));
+            RC(conv_dgrad(dt, e->gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
+                          k.cd.stride, 0, st));
+            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, spare, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3,
+                          k.c1.stride, 1, st));
             dxin = spare;
             spare = dz;  // the old dz buffer is free now
         } else {
             // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
-            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, do2, do2, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
+            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
             dxin = do2;
         }
         dz = dxin;
@@ -468,8 +511,8 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
     // stem: maxpool -> relu -> bn1 -> conv1 weight gradient (the input needs no gradient)
     RC(maxpool_bwd(dt, dz, e->idx, e->g0, e->n_img, e->h0, e->w0, 64, st));
     RC(bn_backward(e, e->bn0, e->g0, e->y0, 1, e->g0, (size_t)e->m0, grads, st));
-    RC(conv_wgrad(dt, e->g0, e->col, grads[0], (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0, e->cin * 49, e->wg_ws,
-                  e->wg_ws_bytes, st));
+    RC(conv_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0, e->cin * 49,
+                  e->wg_ws, e->wg_ws_bytes, st));
     return GDL_OK;
 }
 

@@ -2,6 +2,7 @@
 // engine in encoder.cpp are thin layers over these.
 #pragma once
 #include "common.h"
+#include "gather.h"
 
 namespace gdl {
 
@@ -9,14 +10,14 @@ const char* last_error();
 
 // conv_igemm.hip
 int conv_tiles_m(int dtype, int M, int OC);
-int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, int N, int H, int W, int C, int K,
-             int R, int S, int stride, int pad, hipStream_t st);
-int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H, int W, int C,
-               int K, int R, int S, int stride, int pad, hipStream_t st);
+int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
+             int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
+int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
+               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // conv_wgrad.hip
 size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS);
-int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int R, int S,
-               int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K,
+               int R, int S, int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 // layout.hip
 int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C, int R, int S, hipStream_t st);
 struct PackDescHost {  // mirrors layout.hip::PackDesc

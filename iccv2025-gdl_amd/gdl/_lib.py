@@ -11,6 +11,7 @@ SO_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "build", "libgdl_hip.so")
 
 GDL_F32, GDL_BF16 = 0, 1
 GDL_AUDIO, GDL_VISUAL = 0, 1
+GATHER_FWD, GATHER_DGRAD = 0, 1
 ENC_NPARAMS, ENC_NBN = 60, 20
 
 _C = {"i": ctypes.c_int, "p": ctypes.c_void_p, "z": ctypes.c_size_t, "f": ctypes.c_float, "d": ctypes.c_double,
@@ -22,15 +23,17 @@ SIGNATURES = {
     "gdl_version": ("i", ""),
     "gdl_device_info": ("i", "ppi"),
     "gdl_conv_bn_tiles": ("i", "iiiii"),
-    "gdl_conv_fwd": ("i", "ipppp" + "iiiiiiiii" + "p"),
-    "gdl_conv_dgrad": ("i", "ipppp" + "iiiiiiiii" + "p"),
+    "gdl_conv_table_bytes": ("z", "iiiiiiii"),
+    "gdl_conv_build_table": ("i", "ii" + "iiiiiiiii" + "pp"),
+    "gdl_conv_fwd": ("i", "ippppp" + "iiiiiiiii" + "p"),
+    "gdl_conv_dgrad": ("i", "ippppp" + "iiiiiiiii" + "p"),
     "gdl_conv_wgrad_workspace_bytes": ("z", "iiiiiiiiii"),
-    "gdl_conv_wgrad": ("i", "ippp" + "iiiiiiiii" + "pzp"),
+    "gdl_conv_wgrad": ("i", "ipppp" + "iiiiiiiii" + "pzp"),
     "gdl_pack_weight": ("i", "ippp" + "iiii" + "p"),
     "gdl_stem_kp": ("i", "ii"),
     "gdl_stem_im2col": ("i", "ipp" + "iiiii" + "p"),
     "gdl_pack_stem_weight": ("i", "ippip"),
-    "gdl_stem_wgrad": ("i", "ippp" + "ii" + "pzp"),
+    "gdl_stem_wgrad": ("i", "ipppp" + "ii" + "pzp"),
     "gdl_nhwc_to_nchw_f32": ("i", "ipp" + "iiii" + "p"),
     "gdl_nchw_f32_to_nhwc": ("i", "ipp" + "iiii" + "p"),
     "gdl_bn_stats_tiles": ("i", "i"),

@@ -54,15 +54,26 @@ GDL_API int gdl_device_info(int* cu_count, char* name, int name_len);
  * gdl_conv_wgrad: dy, x -> dw [K][C][R][S] float32 (overwritten).  `ws` holds
  *   split-K partials; size from gdl_conv_wgrad_workspace_bytes.
  */
+/* Gather tables: every conv kernel addresses its gathered operand as table[m].off0 + delta[tap]
+ * (8 bytes per GEMM row: byte offset of tap 0 + a validity bit per tap), so the K-loops carry no
+ * division / multiplication / bounds arithmetic.  Built once per geometry:
+ *   mode GDL_GATHER_FWD   rows = output pixels; used by gdl_conv_fwd and gdl_conv_wgrad
+ *   mode GDL_GATHER_DGRAD rows = input pixels;  used by gdl_conv_dgrad */
+enum { GDL_GATHER_FWD = 0, GDL_GATHER_DGRAD = 1 };
+GDL_API size_t gdl_conv_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad);
+GDL_API int gdl_conv_build_table(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                 int pad, void* table, void* stream);
 GDL_API int gdl_conv_bn_tiles(int dtype, int N, int P, int Q, int K);
-GDL_API int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, int N, int H, int W,
-                         int C, int K, int R, int S, int stride, int pad, void* stream);
-GDL_API int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, int N, int H,
-                           int W, int C, int K, int R, int S, int stride, int pad, void* stream);
+GDL_API int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table,
+                         int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream);
+GDL_API int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
+                           const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                           void* stream);
 GDL_API size_t gdl_conv_wgrad_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
                                               int pad);
-GDL_API int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw_kcrs, int N, int H, int W, int C, int K,
-                           int R, int S, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+GDL_API int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw_kcrs, const void* table, int N, int H,
+                           int W, int C, int K, int R, int S, int stride, int pad, void* ws, size_t ws_bytes,
+                           void* stream);
 /* float32 [K][C][R][S] -> dtype [K][R][S][C] (w_krsc) and dtype [C][R][S][K] (w_crsk); either may be NULL */
 GDL_API int gdl_pack_weight(int dtype, const float* w_kcrs, void* w_krsc, void* w_crsk, int K, int C, int R, int S,
                             void* stream);
@@ -77,10 +88,12 @@ GDL_API int gdl_pack_weight(int dtype, const float* w_kcrs, void* w_krsc, void* 
 GDL_API int gdl_stem_kp(int cin, int dtype);
 GDL_API int gdl_stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, void* stream);
 GDL_API int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* stream);
-/* dw [64][Cin][7][7] float32 from dy [M][64] and the im2col matrix; ws sized by
+/* The GEMM on the im2col matrix is gdl_conv_fwd with N = M, H = W = 1, C = Kp, K = 64, R = S = 1 and a
+ * GDL_GATHER_FWD table of that geometry; the same table serves gdl_stem_wgrad:
+ * dw [64][Cin][7][7] float32 from dy [M][64] and the im2col matrix; ws sized by
  * gdl_conv_wgrad_workspace_bytes(dtype, M, 1, 1, Kp, 64, 1, 1, 1, 0) */
-GDL_API int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, int M, int Cin, void* ws,
-                           size_t ws_bytes, void* stream);
+GDL_API int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, const void* table, int M, int Cin,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* layout conversion at the module boundary: NHWC dtype <-> NCHW float32 */
 GDL_API int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream);

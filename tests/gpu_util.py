@@ -52,3 +52,11 @@ def pack_weight(w, dt):
     crsk = empty((C, R, S, K), dt)
     L.call("gdl_pack_weight", dt, L.ptr(wd), L.ptr(krsc), L.ptr(crsk), K, C, R, S, L.cur_stream())
     return krsc, crsk
+
+
+def gather_table(mode, dt, N, H, W, C, K, R, S, stride, pad):
+    """Build the gather table of one convolution geometry (returns the owning uint8 tensor)."""
+    nbytes = L.load().gdl_conv_table_bytes(mode, N, H, W, R, S, stride, pad)
+    t = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    L.call("gdl_conv_build_table", mode, dt, N, H, W, C, K, R, S, stride, pad, L.ptr(t), L.cur_stream())
+    return t

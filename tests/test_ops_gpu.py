@@ -10,7 +10,8 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 from gdl import _lib as L  # noqa: E402
-from gpu_util import (DEV, bf16_round, dev, empty, from_nhwc, pack_weight, quant, relerr, to_nhwc, tol)  # noqa: E402
+from gpu_util import (DEV, bf16_round, dev, empty, from_nhwc, gather_table, pack_weight, quant, relerr, to_nhwc,  # noqa: E402
+                      tol)
 
 DTS = [L.GDL_F32, L.GDL_BF16]
 rng = np.random.default_rng(2024)
@@ -47,7 +48,8 @@ def test_conv_fwd(shape, dt):
     y = empty((N, P, Q, K), dt)
     tiles = L.load().gdl_conv_bn_tiles(dt, N, P, Q, K)
     part = torch.full((tiles, K, 2), float("nan"), device=DEV)
-    L.call("gdl_conv_fwd", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), N, H, W, C, K, R, R, stride, pad,
+    tab = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
+    L.call("gdl_conv_fwd", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), L.ptr(tab), N, H, W, C, K, R, R, stride, pad,
            L.cur_stream())
     torch.cuda.synchronize()
     got = from_nhwc(y)
@@ -75,8 +77,9 @@ def test_conv_dgrad(shape, dt, with_addend):
     _, crsk = pack_weight(w, dt)
     dyd = to_nhwc(dy, dt)
     dx = to_nhwc(add, dt) if with_addend else empty((N, H, W, C), dt)
-    L.call("gdl_conv_dgrad", dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), L.ptr(dx) if with_addend else None, N, H, W, C, K,
-           R, R, stride, pad, L.cur_stream())
+    tab = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, R, R, stride, pad)
+    L.call("gdl_conv_dgrad", dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), L.ptr(dx) if with_addend else None, L.ptr(tab), N, H,
+           W, C, K, R, R, stride, pad, L.cur_stream())
     torch.cuda.synchronize()
     got = from_nhwc(dx)
     assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
@@ -104,8 +107,9 @@ def test_conv_wgrad(shape, dt):
     nbytes = L.load().gdl_conv_wgrad_workspace_bytes(dt, N, H, W, C, K, R, R, stride, pad)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((K, C, R, R), float("nan"), device=DEV)
-    L.call("gdl_conv_wgrad", dt, L.ptr(dyd), L.ptr(xd), L.ptr(dw), N, H, W, C, K, R, R, stride, pad, L.ptr(ws), nbytes,
-           L.cur_stream())
+    tab = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
+    L.call("gdl_conv_wgrad", dt, L.ptr(dyd), L.ptr(xd), L.ptr(dw), L.ptr(tab), N, H, W, C, K, R, R, stride, pad, L.ptr(ws),
+           nbytes, L.cur_stream())
     torch.cuda.synchronize()
     got = dw.cpu().numpy()
     assert relerr(got, ref) < 2e-5, relerr(got, ref)  # fp32 accumulation of (for bf16: exact) products
@@ -132,7 +136,8 @@ def test_stem(case, dt):
     st = L.cur_stream()
     L.call("gdl_stem_im2col", dt, L.ptr(xd), L.ptr(col), B, Cin, T, H, W, st)
     L.call("gdl_pack_stem_weight", dt, L.ptr(wd), L.ptr(wp), Cin, st)
-    L.call("gdl_conv_fwd", dt, L.ptr(col), L.ptr(wp), L.ptr(y), None, M, 1, 1, kp, 64, 1, 1, 1, 0, st)
+    tab = gather_table(L.GATHER_FWD, dt, M, 1, 1, kp, 64, 1, 1, 1, 0)
+    L.call("gdl_conv_fwd", dt, L.ptr(col), L.ptr(wp), L.ptr(y), None, L.ptr(tab), M, 1, 1, kp, 64, 1, 1, 1, 0, st)
     torch.cuda.synchronize()
     got = from_nhwc(y)
     assert relerr(got, ref) < tol(dt, 2e-6, 3e-3), relerr(got, ref)
@@ -142,7 +147,7 @@ def test_stem(case, dt):
     nbytes = L.load().gdl_conv_wgrad_workspace_bytes(dt, M, 1, 1, kp, 64, 1, 1, 1, 0)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     dw = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
-    L.call("gdl_stem_wgrad", dt, L.ptr(dyd), L.ptr(col), L.ptr(dw), M, Cin, L.ptr(ws), nbytes, st)
+    L.call("gdl_stem_wgrad", dt, L.ptr(dyd), L.ptr(col), L.ptr(dw), L.ptr(tab), M, Cin, L.ptr(ws), nbytes, st)
     torch.cuda.synchronize()
     assert relerr(dw.cpu().numpy(), refw) < 2e-5, relerr(dw.cpu().numpy(), refw)
 

@@ -62,12 +62,18 @@ def main():
         part = torch.empty(tiles, K, 2, device=dev)
         nb = L.load().gdl_conv_wgrad_workspace_bytes(dt, N, H, W, C, K, R, R, stride, pad)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        tabs = []
+        for mode in (0, 1):
+            t = torch.empty(L.load().gdl_conv_table_bytes(mode, N, H, W, R, R, stride, pad), dtype=torch.uint8, device=dev)
+            L.call("gdl_conv_build_table", mode, dt, N, H, W, C, K, R, R, stride, pad, t.data_ptr(), st)
+            tabs.append(t)
+        tf, td_ = tabs[0].data_ptr(), tabs[1].data_ptr()
         gf = 2.0 * N * P * Q * K * C * R * R / 1e9
-        t_f = timeit(lambda: L.call("gdl_conv_fwd", dt, x.data_ptr(), wk.data_ptr(), y.data_ptr(), part.data_ptr(), N, H,
+        t_f = timeit(lambda: L.call("gdl_conv_fwd", dt, x.data_ptr(), wk.data_ptr(), y.data_ptr(), part.data_ptr(), tf, N, H,
                                     W, C, K, R, R, stride, pad, st), a.iters)
-        t_d = timeit(lambda: L.call("gdl_conv_dgrad", dt, dy.data_ptr(), wc.data_ptr(), dx.data_ptr(), None, N, H, W, C,
+        t_d = timeit(lambda: L.call("gdl_conv_dgrad", dt, dy.data_ptr(), wc.data_ptr(), dx.data_ptr(), None, td_, N, H, W, C,
                                     K, R, R, stride, pad, st), a.iters)
-        t_w = timeit(lambda: L.call("gdl_conv_wgrad", dt, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, H, W, C, K, R, R,
+        t_w = timeit(lambda: L.call("gdl_conv_wgrad", dt, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), tf, N, H, W, C, K, R, R,
                                     stride, pad, ws.data_ptr(), nb, st), a.iters)
         tot["fwd"] += t_f * cnt
         tot["dgrad"] += t_d * cnt
