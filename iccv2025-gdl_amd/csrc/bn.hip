@@ -187,8 +187,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
 // grid sizing for channel-invariant grid-stride loops: total threads is a multiple of C/EPC
 static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec) {
     // threads = blocks*256 must be a multiple of cpr (cpr divides 256 or is a multiple of it handled by lcm)
-    // ~8 vectors per thread amortise the per-channel constant loads; at most 2048 blocks
-    size_t want = (nvec + BN_THREADS * 8 - 1) / (BN_THREADS * 8);
+    // one vector per thread until the chip is full (small tensors are latency bound: a serial
+    // per-thread loop costs ~1 us per iteration), then grid-stride with at most 2048 blocks
+    size_t want = (nvec + BN_THREADS - 1) / BN_THREADS;
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     // make blocks*256 % cpr == 0
@@ -282,9 +283,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     }
 }
 
-// one block per 16384 elements (8 bf16 / 16 f32 vectors per thread), at most 2048 blocks
+// one block per 2048 elements (1 bf16 / 2 f32 vectors per thread) until 2048 blocks, then grid-stride
 int bn_bwd_blocks(size_t M, int C) {
-    size_t b = (M * (size_t)C + 16383) / 16384;
+    size_t b = (M * (size_t)C + 2047) / 2048;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;

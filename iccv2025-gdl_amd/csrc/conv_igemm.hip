@@ -10,8 +10,10 @@
 // fragment order.
 //
 // Block = 256 threads (4 waves), tile BM pixels x BN channels, BK = 128 bytes.
-// Two LDS stages, register-staged (the gather needs per-row predication / zero
-// fill for padding), one barrier per K-step.  LDS rows are 128 B with a 16-byte
+// Two LDS stages filled by LDS-DMA (buffer_load ... lds): the gather's zero fill
+// (padding, stride-2 parity, M tail) comes from the buffer descriptor's bounds
+// check, the per-pixel offsets from a precomputed gather table (gather.h); one
+// barrier per K-step.  LDS rows are 128 B with a 16-byte
 // chunk XOR swizzle chunk ^= (row>>1)&7, conflict-free for the ds_read_b128
 // fragment reads.  Operands are swapped (weights = MFMA "A", pixels = MFMA "B")
 // so a lane ends up with 4 consecutive output channels of one pixel.  The
@@ -41,6 +43,20 @@ struct ConvArgs {
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
+// 16 bytes per lane, global -> LDS without passing through VGPRs (buffer_load_dwordx4 ... lds).
+// LDS destination = wave-uniform `lds_row_base` + lane*16; `voffset` is the per-lane byte offset
+// into the buffer (out of range -> zeros).  The builtin only exists in the device pass.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_row_base, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_row_base, 16, voffset, 0, 0,
+                                             0);
+#else
+    (void)rsrc;
+    (void)lds_row_base;
+    (void)voffset;
+#endif
+}
+
 template <typename T>
 struct Mma;
 template <>
@@ -62,10 +78,28 @@ struct Mma<float> {
     }
 };
 
+// LDS fragment read hidden from the compiler: hipcc waits vmcnt(0) before any ds_read it can see
+// while an LDS-DMA is in flight (it cannot prove the ring slots disjoint), which would serialise
+// the whole pipeline.  The data is valid only after lds_wait() (form (iii) of the guide's inline-asm
+// rules: "=v" loads, one wait-only statement, sched_barrier).
+__device__ __forceinline__ uint4 lds_read16_asm(unsigned addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 template <int BM, int BN, typename T>
 struct ConvSmem {
     static constexpr int STAGE = (BM + BN) * 128;
-    static constexpr int MAIN = 2 * STAGE;
+    static constexpr int NSTAGE = 2;  // LDS ring: one stage being consumed, NSTAGE-1 in flight
+    static constexpr int MAIN = NSTAGE * STAGE;
     static constexpr int PITCH = BN * (int)sizeof(T) + 16;
     static constexpr int CS = BM * PITCH;
     static constexpr int RED = 4 * BN * 2 * 4;
@@ -98,7 +132,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // ---- per-thread gather bookkeeping: rows row0 + 32*i of the tile, one 16-byte chunk each.
     // Source addresses are 32-bit byte offsets into buffer descriptors: an invalid tap (padding,
     // stride-2 parity, M tail) gets an offset beyond the descriptor and the hardware returns zeros.
-    const int chunk = tid & 7, row0 = tid >> 3;
+    // Tiles go global -> LDS directly (buffer_load ... lds, no VGPR staging, no ds_write): one wave
+    // instruction fills 8 consecutive 128-byte rows, lane L -> row L>>3, physical chunk L&7, so the
+    // XOR swizzle is applied to the SOURCE chunk each lane fetches.
+    const int pchunk = tid & 7, row0 = tid >> 3;
+    const int schunk = pchunk ^ ((row0 >> 1) & 7);  // (row0 + 32*i)>>1 & 7 is the same for every i
     int a_off[AROWS];
     unsigned a_mask[AROWS];
 #pragma unroll
@@ -108,47 +146,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         e.off0 = 0;
         e.mask = 0;
         if (m < a.M) e = a.table[m];
-        a_off[i] = e.off0 + chunk * 16;
+        a_off[i] = e.off0 + schunk * 16;
         a_mask[i] = e.mask;
     }
     const int esz = (int)sizeof(T);
     int b_off[BROWS];
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + chunk * 16;
+    for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + schunk * 16;
     const int kpt = a.IC / BKE;  // K-steps per tap
     const int nk = a.ntaps * kpt;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    const int wrow = (tid >> 6) * 8;  // first tile row this wave's DMA instruction covers (plus 32*i)
 
-    u32x4_t va[AROWS], vb[BROWS];
     int ld_tap = 0, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
-    auto load_tile = [&]() {
-        const int ua = a.delta[ld_tap] + ld_kc * 128;                   // uniform
-        const int ub = (ld_tap * a.IC) * esz + ld_kc * 128;             // uniform
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
-            const int v = ((a_mask[i] >> ld_tap) & 1u) ? a_off[i] + ua : (int)0x80000000;
-            va[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, v, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i) vb[i] = __builtin_amdgcn_raw_buffer_load_b128(rwt, b_off[i] + ub, 0, 0);
-        if (++ld_kc == kpt) {
-            ld_kc = 0;
-            ++ld_tap;
-        }
-    };
-    auto store_tile = [&](int buf) {
+    // Every call issues exactly AROWS+BROWS DMA instructions per wave (the counted s_waitcnt below
+    // relies on it); past the last K-step they are all out of range: no memory traffic, zeros into
+    // a ring slot nobody reads.
+    auto load_tile = [&](int buf) {
+        const bool live = ld_tap < a.ntaps;
+        const int tap = live ? ld_tap : 0;
+        const int ua = a.delta[tap] + ld_kc * 128;        // uniform
+        const int ub = (tap * a.IC) * esz + ld_kc * 128;  // uniform
         unsigned char* As = smem + buf * SM::STAGE;
         unsigned char* Bs = As + BM * 128;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            const int row = row0 + 32 * i;
-            *(u32x4_t*)(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = va[i];
+            const int v = (live && ((a_mask[i] >> tap) & 1u)) ? a_off[i] + ua : (int)0x80000000;
+            dma16(rin, As + (wrow + 32 * i) * 128, v);
         }
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) {
-            const int row = row0 + 32 * i;
-            *(u32x4_t*)(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = vb[i];
+        for (int i = 0; i < BROWS; ++i) dma16(rwt, Bs + (wrow + 32 * i) * 128, live ? b_off[i] + ub : (int)0x80000000);
+        if (++ld_kc == kpt) {
+            ld_kc = 0;
+            ++ld_tap;
         }
     };
 
@@ -163,30 +194,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int off_kk0 = frow * 128 + (((0 + fg) ^ fswz) << 4);
     const int off_kk1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
 
-    load_tile();
-    store_tile(0);
-    __syncthreads();
+    // ---- main loop: NSTAGE-deep LDS ring, loads NSTAGE-1 K-steps ahead of the MFMAs.
+    //   wait (counted vmcnt: only the OLDEST stage must have landed) -> barrier (every wave's part of
+    //   that stage landed, every wave is done reading the slot about to be refilled) -> issue the
+    //   stage NSTAGE-1 ahead -> MFMAs on the landed stage.  One barrier per K-step, no vmcnt(0).
+    const unsigned smem_base = lds_addr(smem);
+    constexpr int NST = SM::NSTAGE;
+    constexpr int LPS = AROWS + BROWS;  // DMA instructions per stage per wave
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) load_tile(s);
+    int buf = 0, ldbuf = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile();
-        const unsigned char* As = smem + buf * SM::STAGE + (wm * WTM) * 128;
-        const unsigned char* Bs = smem + buf * SM::STAGE + BM * 128 + (wn * WTN) * 128;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        load_tile(ldbuf);
+        const unsigned As = smem_base + buf * SM::STAGE + (wm * WTM) * 128;
+        const unsigned Bs = smem_base + buf * SM::STAGE + BM * 128 + (wn * WTN) * 128;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int off = kk ? off_kk1 : off_kk0;
             uint4 px[MI], wf[NI];
 #pragma unroll
-            for (int m = 0; m < MI; ++m) px[m] = *(const uint4*)(As + m * 16 * 128 + off);
+            for (int m = 0; m < MI; ++m) px[m] = lds_read16_asm(As + m * 16 * 128 + off);
 #pragma unroll
-            for (int n = 0; n < NI; ++n) wf[n] = *(const uint4*)(Bs + n * 16 * 128 + off);
+            for (int n = 0; n < NI; ++n) wf[n] = lds_read16_asm(Bs + n * 16 * 128 + off);
+            lds_wait();
 #pragma unroll
             for (int n = 0; n < NI; ++n)
 #pragma unroll
                 for (int m = 0; m < MI; ++m) Mma<T>::run(wf[n], px[m], acc[n][m]);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        ldbuf = ldbuf + 1 == NST ? 0 : ldbuf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (empty) tail stages before LDS is reused
+    __syncthreads();
 
     // ---- epilogue: accumulators -> LDS tile [BM][BN] of T.
     // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.

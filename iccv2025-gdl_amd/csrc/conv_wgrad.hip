@@ -15,6 +15,8 @@
 // kernel folds the splits in a fixed order and writes the reference's [K][C][R][S]
 // gradient layout.  Tap is the fastest-varying index among blocks that share an XCD,
 // so the 9 taps of one pixel slice reuse dy / x from that XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gather.h"
 #include "prof.h"
@@ -52,7 +54,6 @@ __device__ __forceinline__ int wg_swz(int row) {
 template <typename T, int TK, int TC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int EPC = TT<T>::EPC;
     constexpr int PK = TK * (int)sizeof(T), PC = TC * (int)sizeof(T);  // row pitches (bytes)
     constexpr int STAGE = WG_BP * (PK + PC);
     constexpr int CPR_K = PK / 16, CPR_C = PC / 16;                    // 16-byte chunks per row
@@ -296,8 +297,15 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS) {
     p.tk = (K % 128 == 0) ? 128 : 64;
     p.tc = (C % 128 == 0) ? 128 : 64;
     const int tiles = (K / p.tk) * (C / p.tc) * RS;
-    // aim at ~2048 blocks, at least 2 stages of work per block, split count a multiple of 8
-    int ns = (2048 + tiles - 1) / tiles;
+    // Every block leaves a TKxTC fp32 partial tile, so partial traffic = blocks x 16..64 KB: aim at
+    // one resident wave of blocks (~3 per CU), at least 2 stages of work per block, split count a
+    // multiple of 8 (XCD mapping).  GDL_WGRAD_BLOCKS overrides the target (tuning aid).
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("GDL_WGRAD_BLOCKS");
+        target = e ? atoi(e) : 384;
+    }
+    int ns = (target + tiles - 1) / tiles;
     const int max_ns = (M + 2 * WG_BP - 1) / (2 * WG_BP);
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;

@@ -398,9 +398,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
             d.RS = c.r * c.s;
             d.blk0 = blk;
             const size_t total = (size_t)c.cout * c.cin * c.r * c.s;
-            int nb = (int)((total + 1023) / 1024);
-            if (nb > 256) nb = 256;
-            blk += nb;
+            blk += (c.cout / 32) * (c.cin / 32);  // one block per 32x32 (k, c) patch
             bytes += (double)total * (4.0 + 2.0 * e->esz);
             e->pack_host.push_back(d);
         };

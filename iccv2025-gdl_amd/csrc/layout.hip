@@ -134,24 +134,38 @@ struct PackDesc {
     void* crsk;
     int K, C, RS, blk0;
 };
+// Block = one 32(k) x 32(c) patch of one tensor, all R*S taps: the float32 source rows
+// w[k][c0..c0+31][:] are contiguous runs, the patch is transposed through LDS and both
+// destinations are written in 64-byte runs (krsc: 32 consecutive c; crsk: 32 consecutive k).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ desc, int ndesc) {
+    __shared__ float tile[32][32 * 9 + 1];
     int d = 0;
     while (d + 1 < ndesc && (int)blockIdx.x >= desc[d + 1].blk0) ++d;
     const PackDesc pd = desc[d];
-    const size_t total = (size_t)pd.K * pd.C * pd.RS;
-    const int nblk = (d + 1 < ndesc ? desc[d + 1].blk0 : (int)gridDim.x) - pd.blk0;
+    const int RS = pd.RS;
+    const int ctiles = pd.C / 32;
+    const int local = (int)blockIdx.x - pd.blk0;
+    const int k0 = (local / ctiles) * 32, c0 = (local % ctiles) * 32;
+    const int run = 32 * RS;  // contiguous floats per k row of the patch
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int kk = i / run, j = i - kk * run;  // j = cc*RS + rs
+        tile[kk][j] = pd.w[((size_t)(k0 + kk) * pd.C + c0) * RS + j];
+    }
+    __syncthreads();
     T* krsc = (T*)pd.krsc;
     T* crsk = (T*)pd.crsk;
-    for (size_t i = ((size_t)blockIdx.x - pd.blk0) * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
-        const int c = (int)(i % pd.C);
-        const size_t t = i / pd.C;
-        const int rs = (int)(t % pd.RS);
-        const int k = (int)(t / pd.RS);
-        const float v = pd.w[((size_t)k * pd.C + c) * pd.RS + rs];
-        storeT<T>(krsc + i, v);
-        if (crsk) storeT<T>(crsk + ((size_t)c * pd.RS + rs) * pd.K + k, v);
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {  // krsc[k][rs][c]: c fastest
+        const int cc = i & 31, t = i >> 5;
+        const int rs = t % RS, kk = t / RS;
+        storeT<T>(krsc + ((size_t)(k0 + kk) * RS + rs) * pd.C + c0 + cc, tile[kk][cc * RS + rs]);
     }
+    if (crsk)
+        for (int i = threadIdx.x; i < 32 * run; i += 256) {  // crsk[c][rs][k]: k fastest
+            const int kk = i & 31, t = i >> 5;
+            const int rs = t % RS, cc = t / RS;
+            storeT<T>(crsk + ((size_t)(c0 + cc) * RS + rs) * pd.K + k0 + kk, tile[kk][cc * RS + rs]);
+        }
 }
 int pack_weights_batched(int dtype, const void* desc_dev, int ndesc, int total_blocks, double bytes, hipStream_t st) {
     ProfScope prof(PROF_PACK_WEIGHT, st, bytes);
