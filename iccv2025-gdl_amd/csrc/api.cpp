@@ -24,7 +24,9 @@ int gdl_device_info(int* cu_count, char* name, int name_len) {
 
 static bool dt_ok(int dtype) { return dtype == GDL_F32 || dtype == GDL_BF16; }
 
-int gdl_conv_bn_tiles(int dtype, int N, int P, int Q, int K) { return conv_tiles_m(dtype, N * P * Q, K); }
+int gdl_conv_bn_tiles(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    return conv_tiles_m(dtype, N, H, W, C, K, R, S, stride, pad);
+}
 
 size_t gdl_conv_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad) {
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;

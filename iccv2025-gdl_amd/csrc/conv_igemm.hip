@@ -39,6 +39,9 @@ struct ConvArgs {
     int mtiles;  // ceil(M/BM)
     unsigned in_bytes, wt_bytes;
     int delta[9];
+    // slab kernel only (3x3, stride 1): image width, per-tap pixel shift, source pixel count, slab rows
+    int W, in_pixels, slab_rows;
+    int pshift[9];
 };
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
@@ -105,6 +108,98 @@ struct ConvSmem {
     static constexpr int RED = 4 * BN * 2 * 4;
     static constexpr int BYTES = (MAIN > CS + RED) ? MAIN : (CS + RED);
 };
+
+// ---- epilogue shared by the kernels below: accumulators -> LDS tile [BM][BN] of T -> full rows.
+// Must be entered after every wave is done with the main-loop LDS contents (barrier) and with no
+// LDS-DMA in flight.
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], unsigned char* smem,
+                                              const ConvArgs& a, int m0, int n0, int mtile) {
+    using SM = ConvSmem<BM, BN, T>;
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    // accumulators -> LDS tile [BM][BN] of T.
+    // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
+    unsigned char* Cs = smem;
+    {
+        const int px_row = wm * WTM + (lane & 15);
+        const int ch = wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+            for (int m = 0; m < MI; ++m) {
+                unsigned char* p = Cs + (px_row + m * 16) * SM::PITCH + (ch + n * 16) * (int)sizeof(T);
+                if (sizeof(T) == 2) {
+                    *(uint2*)p = make_uint2(pack2bf(acc[n][m][0], acc[n][m][1]), pack2bf(acc[n][m][2], acc[n][m][3]));
+                } else {
+                    *(float4*)p = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+                }
+            }
+    }
+    __syncthreads();
+    constexpr int CH = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
+    constexpr int RPI = 256 / CH;                  // rows per pass
+    const int ec = tid % CH, er0 = tid / CH;
+    float ssum[EPC], ssq[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) ssum[e] = ssq[e] = 0.f;
+    T* __restrict__ gout = (T*)a.out;
+    const T* __restrict__ gadd = (const T*)a.addend;
+    for (int row = er0; row < BM; row += RPI) {
+        const int m = m0 + row;
+        if (m >= a.M) break;
+        uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
+        const size_t goff = (size_t)m * a.OC + n0 + ec * EPC;
+        if (gadd) {
+            float f[EPC], g[EPC];
+            unpack16<T>(v, f);
+            const uint4 w = *(const uint4*)(gadd + goff);
+            unpack16<T>(w, g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            v = pack16<T>(f);
+        }
+        if (a.stats) {
+            float f[EPC];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                ssum[e] += f[e];
+                ssq[e] += f[e] * f[e];
+            }
+        }
+        *(uint4*)(gout + goff) = v;
+    }
+    if (a.stats) {
+        // lanes with equal (lane % CH) hold the same channels: fold them, then fold the 4 waves in fixed order
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            for (int msk = CH; msk < 64; msk <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], msk);
+                ssq[e] += __shfl_xor(ssq[e], msk);
+            }
+        }
+        float* red = (float*)(smem + SM::CS);  // [4 waves][BN][2]
+        if (CH >= 64 || lane < CH) {
+            // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
+            const int c = (lane % CH) * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                red[(wave * BN + c + e) * 2 + 0] = ssum[e];
+                red[(wave * BN + c + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int c = tid >> 1, w = tid & 1;
+            const float s = ((red[(0 * BN + c) * 2 + w] + red[(1 * BN + c) * 2 + w]) + red[(2 * BN + c) * 2 + w]) +
+                            red[(3 * BN + c) * 2 + w];
+            a.stats[((size_t)mtile * a.OC + n0 + c) * 2 + w] = s;
+        }
+    }
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -208,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        load_tile(ldbuf);
+        if (NST > 2 || kt + 1 < nk) load_tile(ldbuf);  // deeper rings need the constant DMA count per K-step
         const unsigned As = smem_base + buf * SM::STAGE + (wm * WTM) * 128;
         const unsigned Bs = smem_base + buf * SM::STAGE + BM * 128 + (wn * WTN) * 128;
 #pragma unroll
@@ -231,85 +326,153 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (empty) tail stages before LDS is reused
     __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS tile [BM][BN] of T.
-    // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
-    unsigned char* Cs = smem;
-    {
-        const int px_row = wm * WTM + (lane & 15);
-        const int ch = wn * WTN + (lane >> 4) * 4;
-#pragma unroll
-        for (int n = 0; n < NI; ++n)
-#pragma unroll
-            for (int m = 0; m < MI; ++m) {
-                unsigned char* p = Cs + (px_row + m * 16) * SM::PITCH + (ch + n * 16) * (int)sizeof(T);
-                if (sizeof(T) == 2) {
-                    *(uint2*)p = make_uint2(pack2bf(acc[n][m][0], acc[n][m][1]), pack2bf(acc[n][m][2], acc[n][m][3]));
-                } else {
-                    *(float4*)p = make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
-                }
-            }
-    }
+    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile);
+}
+
+// =====================================================================================================
+// 3x3 stride-1 "slab" kernel (forward and data gradient).
+//
+// With NHWC storage the pixels [m0-(W+1), m0+BM+(W+1)) around a flat output tile [m0, m0+BM) are ONE
+// contiguous slab of the input tensor, and tap (r,s) of output pixel m reads pixel m + pshift[tap],
+// pshift in [-(W+1), W+1] -- also across image-row and image boundaries, where the gather table's
+// mask bit says "padding" and the lane reads a zero row instead.  So the A operand of all 9 taps is
+// loaded ONCE per 64-channel chunk (contiguous LDS-DMA, no gather) and the K-loop only streams the
+// 8 KB weight tiles: ~3x less L2->LDS traffic than the flat kernel, which is what bounds it
+// (memory latency x limited bytes in flight per CU).
+// Measured alternatives that LOST on MI355X (tools/bench_conv.py, B=64): a 3-deep weight ring with
+// counted vmcnt and dummy DMA padding (-26 %), weight fragments straight from L2 to registers with a
+// barrier-free K-loop (-80 %).
+// LDS: [weight ring: 2 x BN x 128][slab 0][slab 1 (only when IC > one chunk)][zero row].
+// =====================================================================================================
+template <typename T, int BM, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BN = 64, WM = 4, WN = 1;
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int BKE = 8 * EPC;
+    constexpr int BROWS = BN / 32;
+    constexpr int WTM = BM / WM, MI = WTM / 16, NI = BN / 16;
+    constexpr int WSTAGE = BN * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave;
+    const int ntn = a.OC / BN;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int mt_per_xcd = (a.mtiles + 7) >> 3;
+    const int mtile = xcd * mt_per_xcd + j / ntn;
+    const int ntile = j % ntn;
+    if (mtile >= a.mtiles) return;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int esz = (int)sizeof(T);
+    const int kpt = a.IC / BKE;  // channel chunks
+    const int nins = (a.slab_rows + 7) >> 3;
+    const int slab_bytes = nins * 1024;
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned slab_base = smem_base + 2 * WSTAGE;
+    const unsigned zrow = slab_base + (kpt > 1 ? 2 : 1) * slab_bytes;
+
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+
+    // zero row (ordinary LDS store, before any DMA is in flight)
+    if (tid < 8) *(uint4*)(smem + (zrow - smem_base) + tid * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    constexpr int CH = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
-    constexpr int RPI = 256 / CH;                  // rows per pass
-    const int ec = tid % CH, er0 = tid / CH;
-    float ssum[EPC], ssq[EPC];
+
+    // per-lane validity masks of the MI pixel fragments this wave multiplies
+    const int frow = lane & 15, fg = lane >> 4;
+    unsigned fmask[MI];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) ssum[e] = ssq[e] = 0.f;
-    T* __restrict__ gout = (T*)a.out;
-    const T* __restrict__ gadd = (const T*)a.addend;
-    for (int row = er0; row < BM; row += RPI) {
-        const int m = m0 + row;
-        if (m >= a.M) break;
-        uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
-        const size_t goff = (size_t)m * a.OC + n0 + ec * EPC;
-        if (gadd) {
-            float f[EPC], g[EPC];
-            unpack16<T>(v, f);
-            const uint4 w = *(const uint4*)(gadd + goff);
-            unpack16<T>(w, g);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] += g[e];
-            v = pack16<T>(f);
-        }
-        if (a.stats) {
-            float f[EPC];
-            unpack16<T>(v, f);
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                ssum[e] += f[e];
-                ssq[e] += f[e] * f[e];
-            }
-        }
-        *(uint4*)(gout + goff) = v;
+    for (int m = 0; m < MI; ++m) {
+        const int mm = m0 + wm * WTM + m * 16 + frow;
+        fmask[m] = mm < a.M ? a.table[mm].mask : 0u;
     }
-    if (a.stats) {
-        // lanes with equal (lane % CH) hold the same channels: fold them, then fold the 4 waves in fixed order
+    // weight tile DMA: lane -> row (tid>>3) + 32*i, physical chunk tid&7 (source chunk swizzled)
+    const int row0 = tid >> 3, schunk = (tid & 7) ^ ((row0 >> 1) & 7);
+    int b_off[BROWS];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            for (int msk = CH; msk < 64; msk <<= 1) {
-                ssum[e] += __shfl_xor(ssum[e], msk);
-                ssq[e] += __shfl_xor(ssq[e], msk);
-            }
-        }
-        float* red = (float*)(smem + SM::CS);  // [4 waves][BN][2]
-        if (CH >= 64 || lane < CH) {
-            // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
-            const int c = (lane % CH) * EPC;
+    for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + schunk * 16;
+    const int wrow = wave * 8;
+    auto load_w = [&](int buf, int kc, int tap) {
+        const int ub = (tap * a.IC) * esz + kc * 128;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                red[(wave * BN + c + e) * 2 + 0] = ssum[e];
-                red[(wave * BN + c + e) * 2 + 1] = ssq[e];
-            }
+        for (int i = 0; i < BROWS; ++i) dma16(rwt, smem + buf * WSTAGE + (wrow + 32 * i) * 128, b_off[i] + ub);
+    };
+    // slab DMA: instruction jj covers slab rows 8*jj .. 8*jj+7; waves take jj = wave, wave+4, ...
+    auto load_slab = [&](int sbuf, int kc) {
+        unsigned char* dst = smem + 2 * WSTAGE + sbuf * slab_bytes;
+        for (int jj = wave; jj < nins; jj += 4) {
+            const int sr = jj * 8 + (lane >> 3);
+            const int pix = m0 - (a.W + 1) + sr;
+            const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.in_pixels;
+            const int v = ok ? pix * a.IC * esz + kc * 128 + (((lane & 7) ^ ((sr >> 1) & 7)) << 4) : (int)0x80000000;
+            dma16(rin, dst + jj * 1024, v);
         }
-        __syncthreads();
-        if (tid < BN * 2) {
-            const int c = tid >> 1, w = tid & 1;
-            const float s = ((red[(0 * BN + c) * 2 + w] + red[(1 * BN + c) * 2 + w]) + red[(2 * BN + c) * 2 + w]) +
-                            red[(3 * BN + c) * 2 + w];
-            a.stats[((size_t)mtile * a.OC + n0 + c) * 2 + w] = s;
+    };
+
+    f32x4_t acc[NI][MI];
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int m = 0; m < MI; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fswz = (frow >> 1) & 7;
+    const int woff0 = frow * 128 + (((0 + fg) ^ fswz) << 4), woff1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
+    int prow[MI];
+#pragma unroll
+    for (int m = 0; m < MI; ++m) prow[m] = wm * WTM + m * 16 + frow + (a.W + 1);
+
+    load_slab(0, 0);
+    load_w(0, 0, 0);
+    int wbuf = 0;
+    for (int kc = 0; kc < kpt; ++kc) {
+        const unsigned slab = slab_base + (kc & 1) * slab_bytes;
+        for (int tap = 0; tap < a.ntaps; ++tap) {
+            // everything issued during the previous K-step (next weight tile, next slab) has landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {  // prefetch: the weight tile of the next K-step; at tap 0 also the next chunk's slab
+                int ntap = tap + 1, nkc = kc;
+                if (ntap == a.ntaps) {
+                    ntap = 0;
+                    ++nkc;
+                }
+                if (nkc < kpt) load_w(wbuf ^ 1, nkc, ntap);
+                if (tap == 0 && kc + 1 < kpt) load_slab((kc + 1) & 1, kc + 1);
+            }
+            const unsigned Bs = smem_base + wbuf * WSTAGE;
+            const int sh = a.pshift[tap];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 px[MI], wf[NI];
+#pragma unroll
+                for (int m = 0; m < MI; ++m) {
+                    const int sr = prow[m] + sh;
+                    const unsigned ad = slab + sr * 128 + ((((kk * 4 + fg) ^ ((sr >> 1) & 7))) << 4);
+                    px[m] = lds_read16_asm(((fmask[m] >> tap) & 1u) ? ad : zrow + ((kk * 4 + fg) << 4));
+                }
+#pragma unroll
+                for (int n = 0; n < NI; ++n) wf[n] = lds_read16_asm(Bs + n * 16 * 128 + (kk ? woff1 : woff0));
+                lds_wait();
+#pragma unroll
+                for (int n = 0; n < NI; ++n)
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) Mma<T>::run(wf[n], px[m], acc[n][m]);
+            }
+            wbuf ^= 1;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile);
+}
+
+static size_t slab_lds_bytes(int BM, int W, int IC, int dtype) {
+    const int bke = dtype == GDL_BF16 ? 64 : 32, esz = dtype == GDL_BF16 ? 2 : 4;
+    const int rows = BM + 2 * W + 2;
+    const size_t slab = (size_t)((rows + 7) / 8) * 1024;
+    const size_t main = 2 * 64 * 128 + (IC / bke > 1 ? 2 : 1) * slab + 128;
+    const size_t epi = (size_t)BM * (64 * esz + 16) + 4 * 64 * 2 * 4;
+    return main > epi ? main : epi;
 }
 
 // ---------------------------------------------------------------- host side
@@ -364,17 +527,73 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     return GDL_OK;
 }
 
+template <typename T, int BM, int MODE>
+static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
+    a.mtiles = ceil_div(a.M, BM);
+    auto kfn = conv3x3_slab_kernel<T, BM, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_slab)");
+        attr_set = true;
+    }
+    const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / 64);
+    const int slot = (MODE == MODE_FWD ? PROF_CONV_FWD_256x64 : PROF_CONV_DGRAD_256x64) + (BM == 256 ? 0 : 1);
+    ProfScope prof(slot, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+    GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
+    return GDL_OK;
+}
+
+// which kernel / tile a convolution runs with (shared by the launcher and by the BatchNorm partial count)
+struct ConvPlan {
+    int slab;  // 1: conv3x3_slab_kernel
+    int bm, bn;
+    size_t lds;
+};
+static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad) {
+    ConvPlan p{};
+    static int noslab = -1;
+    if (noslab < 0) {
+        const char* e = getenv("GDL_CONV_NOSLAB");  // tuning aid
+        noslab = e ? atoi(e) : 0;
+    }
+    if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
+        for (int bm : {256, 128}) {
+            const size_t lds = slab_lds_bytes(bm, W, IC, dtype);
+            const long blocks = (long)((M + bm - 1) / bm) * (OC / 64);
+            if (lds <= 80 * 1024 && (blocks >= 160 || bm == 128)) {
+                p.slab = 1;
+                p.bm = bm;
+                p.bn = 64;
+                p.lds = lds;
+                return p;
+            }
+        }
+    }
+    const TileCfg c = pick_cfg(M, OC, dtype);
+    p.slab = 0;
+    p.bm = c.bm;
+    p.bn = c.bn;
+    return p;
+}
+
 template <typename T, int MODE>
-static int launch_mode(ConvArgs& a, int dtype, hipStream_t st) {
-    const TileCfg c = pick_cfg(a.M, a.OC, dtype);
-    if (c.bm == 256) return launch_one<T, 256, 64, 4, 1, MODE>(a, st);
-    if (c.bm == 128 && c.bn == 64) return launch_one<T, 128, 64, 2, 2, MODE>(a, st);
+static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
+    if (pl.slab) {
+        if (pl.bm == 256) return launch_slab<T, 256, MODE>(a, pl.lds, st);
+        return launch_slab<T, 128, MODE>(a, pl.lds, st);
+    }
+    if (pl.bm == 256) return launch_one<T, 256, 64, 4, 1, MODE>(a, st);
+    if (pl.bm == 128) return launch_one<T, 128, 64, 2, 2, MODE>(a, st);
     return launch_one<T, 64, 64, 2, 2, MODE>(a, st);
 }
 
-int conv_tiles_m(int dtype, int M, int OC) {
-    const TileCfg c = pick_cfg(M, OC, dtype);
-    return ceil_div(M, c.bm);
+// number of M-tiles (= BatchNorm partial rows) the forward kernel of this convolution produces
+int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    const ConvPlan pl = plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad);
+    return ceil_div(N * P * Q, pl.bm);
 }
 
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
@@ -411,9 +630,19 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     GDL_REQUIRE(a.IC % bke == 0, "conv: gather channels %d not a multiple of %d", a.IC, bke);
     GDL_REQUIRE(a.OC % 64 == 0, "conv: output channels %d not a multiple of 64", a.OC);
     GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
+    // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
+    const ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
+    if (pl.slab) {
+        a.W = W;
+        a.in_pixels = N * H * W;
+        a.slab_rows = pl.bm + 2 * W + 2;
+        for (int r = 0; r < 3; ++r)
+            for (int s2 = 0; s2 < 3; ++s2)
+                a.pshift[r * 3 + s2] = mode == GATHER_FWD ? (r - 1) * W + (s2 - 1) : (1 - r) * W + (1 - s2);
+    }
     if (dtype == GDL_BF16)
-        return mode == GATHER_FWD ? launch_mode<bf16, MODE_FWD>(a, dtype, st) : launch_mode<bf16, MODE_DGRAD>(a, dtype, st);
-    return mode == GATHER_FWD ? launch_mode<float, MODE_FWD>(a, dtype, st) : launch_mode<float, MODE_DGRAD>(a, dtype, st);
+        return mode == GATHER_FWD ? launch_mode<bf16, MODE_FWD>(a, pl, st) : launch_mode<bf16, MODE_DGRAD>(a, pl, st);
+    return mode == GATHER_FWD ? launch_mode<float, MODE_FWD>(a, pl, st) : launch_mode<float, MODE_DGRAD>(a, pl, st);
 }
 
 int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,

@@ -144,7 +144,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     };
     tab_stem = table_for(GATHER_FWD, (int)m0, 1, 1, kp, 64, 1, 1, 1, 0);
     size_t max_act = (size_t)n_img * h1 * w1 * 64;  // elements
-    size_t max_tiles_c = (size_t)conv_tiles_m(dtype, (int)m0, 64) * 64;
+    size_t max_tiles_c = (size_t)conv_tiles_m(dtype, (int)m0, 1, 1, kp, 64, 1, 1, 1, 0) * 64;
     size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0, 64) * 64;
     size_t wg = conv_wgrad_ws_bytes((int)m0, kp, 64, 1);
     const void* prev = x1;
@@ -174,8 +174,12 @@ size_t gdl_encoder::plan(unsigned char* base) {
         if (out_el > max_act) max_act = out_el;
         if (in_el > max_act) max_act = in_el;
         const int M = k.n * k.p * k.q;
-        const size_t tc = (size_t)conv_tiles_m(dtype, M, k.cout) * k.cout;
-        if (tc > max_tiles_c) max_tiles_c = tc;
+        for (const Conv* c : {&k.c1, &k.c2, &k.cd}) {
+            if (c == &k.cd && !k.has_ds) continue;
+            const size_t tc = (size_t)conv_tiles_m(dtype, k.n, c->h, c->w, c->cin, c->cout, c->r, c->s, c->stride, c->pad) *
+                              c->cout;
+            if (tc > max_tiles_c) max_tiles_c = tc;
+        }
         const size_t bb = (size_t)bn_bwd_blocks((size_t)M, k.cout) * k.cout;
         if (bb > max_bnb) max_bnb = bb;
         size_t w1 = conv_wgrad_ws_bytes(M, k.cin, k.cout, 9);
@@ -366,7 +370,8 @@ static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int n
     RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? e->bn_partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout,
                 c.r, c.s, c.stride, c.pad, st));
     const int M = nimg * c.p * c.q;
-    return bn_finalize(e, n, training, conv_tiles_m(e->dtype, M, c.cout), (double)M, st);
+    return bn_finalize(e, n, training, conv_tiles_m(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad),
+                       (double)M, st);
 }
 
 int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* feat_out, float* fmap_nchw,
@@ -419,7 +424,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     RC(stem_im2col(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
     RC(conv_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, (int)e->m0, 1, 1, e->kp, 64,
                 1, 1, 1, 0, st));
-    RC(bn_finalize(e, e->bn0, training, conv_tiles_m(dt, (int)e->m0, 64), (double)e->m0, st));
+    RC(bn_finalize(e, e->bn0, training, conv_tiles_m(dt, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0), (double)e->m0, st));
     RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, e->n_img, e->h0, e->w0, 64, st));
     // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
     for (Block& k : e->blocks) {

@@ -9,7 +9,7 @@ namespace gdl {
 const char* last_error();
 
 // conv_igemm.hip
-int conv_tiles_m(int dtype, int M, int OC);
+int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
              int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,

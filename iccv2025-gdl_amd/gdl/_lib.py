@@ -22,7 +22,7 @@ SIGNATURES = {
     "gdl_last_error": ("s", ""),
     "gdl_version": ("i", ""),
     "gdl_device_info": ("i", "ppi"),
-    "gdl_conv_bn_tiles": ("i", "iiiii"),
+    "gdl_conv_bn_tiles": ("i", "iiiiiiiiii"),
     "gdl_conv_table_bytes": ("z", "iiiiiiii"),
     "gdl_conv_build_table": ("i", "ii" + "iiiiiiiii" + "pp"),
     "gdl_conv_fwd": ("i", "ippppp" + "iiiiiiiii" + "p"),

@@ -63,7 +63,7 @@ enum { GDL_GATHER_FWD = 0, GDL_GATHER_DGRAD = 1 };
 GDL_API size_t gdl_conv_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad);
 GDL_API int gdl_conv_build_table(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
                                  int pad, void* table, void* stream);
-GDL_API int gdl_conv_bn_tiles(int dtype, int N, int P, int Q, int K);
+GDL_API int gdl_conv_bn_tiles(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 GDL_API int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table,
                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream);
 GDL_API int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,

@@ -46,7 +46,7 @@ def test_conv_fwd(shape, dt):
     xd = to_nhwc(x, dt)
     krsc, _ = pack_weight(w, dt)
     y = empty((N, P, Q, K), dt)
-    tiles = L.load().gdl_conv_bn_tiles(dt, N, P, Q, K)
+    tiles = L.load().gdl_conv_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
     part = torch.full((tiles, K, 2), float("nan"), device=DEV)
     tab = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
     L.call("gdl_conv_fwd", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), L.ptr(tab), N, H, W, C, K, R, R, stride, pad,
@@ -301,3 +301,48 @@ def test_layout_roundtrip():
         torch.cuda.synchronize()
         np.testing.assert_array_equal(back.cpu().numpy(), x)
         np.testing.assert_array_equal(from_nhwc(t), x)
+
+
+def test_conv_run_to_run_determinism():
+    """Race screen (found a real one once: packed-f32 BatchNorm sums): every conv op of a few
+    geometries, four runs each with fresh NaN-poisoned outputs and other kernels in between, must be
+    bit-identical -- outputs, BatchNorm partials, data and weight gradients."""
+    dt = L.GDL_BF16
+    st = L.cur_stream()
+    for (N, C, H, W, K, R, stride, pad) in [(16, 64, 65, 47, 128, 3, 2, 1), (16, 64, 65, 47, 128, 1, 2, 0),
+                                             (24, 64, 56, 56, 64, 3, 1, 1), (48, 512, 7, 7, 512, 3, 1, 1)]:
+        P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        x = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)
+        dy = torch.randn(N, P, Q, K, device=DEV).to(torch.bfloat16)
+        wk = torch.randn(K, R, R, C, device=DEV).to(torch.bfloat16)
+        wc = torch.randn(C, R, R, K, device=DEV).to(torch.bfloat16)
+        tiles = L.load().gdl_conv_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
+        nb = L.load().gdl_conv_wgrad_workspace_bytes(dt, N, H, W, C, K, R, R, stride, pad)
+        tf = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
+        tdg = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, R, R, stride, pad)
+        first = None
+        for rep in range(4):
+            y = torch.full((N, P, Q, K), float("nan"), device=DEV, dtype=torch.bfloat16)
+            dx = torch.full((N, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+            dw = torch.full((K, C, R, R), float("nan"), device=DEV)
+            part = torch.full((tiles, K, 2), float("nan"), device=DEV)
+            ws = torch.empty(nb, dtype=torch.uint8, device=DEV).random_()
+            L.call("gdl_conv_fwd", dt, L.ptr(x), L.ptr(wk), L.ptr(y), L.ptr(part), L.ptr(tf), N, H, W, C, K, R, R, stride,
+                   pad, st)
+            L.call("gdl_conv_dgrad", dt, L.ptr(dy), L.ptr(wc), L.ptr(dx), None, L.ptr(tdg), N, H, W, C, K, R, R, stride,
+                   pad, st)
+            L.call("gdl_conv_wgrad", dt, L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(tf), N, H, W, C, K, R, R, stride, pad,
+                   L.ptr(ws), nb, st)
+            torch.cuda.synchronize()
+            cur = (y.view(torch.int16).clone(), part.view(torch.int32).clone(), dx.view(torch.int16).clone(),
+                   dw.view(torch.int32).clone())
+            assert not torch.isnan(part).any() and not torch.isnan(dw).any()
+            if first is None:
+                first = cur
+                # the partials must also be the exact sums of the stored outputs
+                yf = y.double().view(-1, K)
+                np.testing.assert_allclose(part.double().sum(0)[:, 0].cpu().numpy(), yf.sum(0).cpu().numpy(), rtol=1e-5,
+                                           atol=1e-2)
+            else:
+                for a_, b_, nm in zip(first, cur, ("y", "bn partials", "dx", "dw")):
+                    assert torch.equal(a_, b_), (nm, (N, C, H, W, K, R, stride))

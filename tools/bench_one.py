@@ -31,7 +31,7 @@ def main():
     y = torch.empty(N, P, Q, K, device=dev, dtype=td)
     dx = torch.empty(N, H, W, C, device=dev, dtype=td)
     dw = torch.empty(K, C, R, R, device=dev)
-    tiles = L.load().gdl_conv_bn_tiles(dt, N, P, Q, K)
+    tiles = L.load().gdl_conv_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
     part = torch.empty(tiles, K, 2, device=dev)
     nb = L.load().gdl_conv_wgrad_workspace_bytes(dt, N, H, W, C, K, R, R, stride, pad)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
