@@ -187,9 +187,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
 // grid sizing for channel-invariant grid-stride loops: total threads is a multiple of C/EPC
 static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec) {
     // threads = blocks*256 must be a multiple of cpr (cpr divides 256 or is a multiple of it handled by lcm)
-    // one vector per thread until the chip is full (small tensors are latency bound: a serial
-    // per-thread loop costs ~1 us per iteration), then grid-stride with at most 2048 blocks
-    size_t want = (nvec + BN_THREADS - 1) / BN_THREADS;
+    // Measured (bench.py kernel table): 8 vectors per thread amortise the per-channel constant loads
+    // on the big tensors (34 us vs 50 us per launch with 1 vector per thread); at most 2048 blocks
+    size_t want = (nvec + BN_THREADS * 8 - 1) / (BN_THREADS * 8);
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     // make blocks*256 % cpr == 0
@@ -210,7 +210,10 @@ static int bn_act_t(const void* y, const float* scale, const float* shift, const
     size_t stride;
     ew_grid(nvec, C / EPC, blocks, stride);
     const int resmode = res ? (rscale ? 2 : 1) : 0;
-    ProfScope prof(PROF_BN_ACT, st, (double)nvec * 16.0 * (resmode ? 3 : 2));
+    static char pname[6][96];
+    char* pn = pname[resmode * 2 + (relu ? 1 : 0)];
+    if (!pn[0]) snprintf(pn, 96, "gdl::bn_act_kernel<%s, %d, %s>", prof_tname<T>(), resmode, relu ? "true" : "false");
+    ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * (resmode ? 3 : 2));
 #define BN_ACT_LAUNCH(RM, RL)                                                                                        \
     hipLaunchKernelGGL((bn_act_kernel<T, RM, RL>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale, shift, \
                        (const T*)res, rscale, rshift, (T*)out, nvec, C, stride)
@@ -283,9 +286,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     }
 }
 
-// one block per 2048 elements (1 bf16 / 2 f32 vectors per thread) until 2048 blocks, then grid-stride
+// one block per 16384 elements (8 bf16 / 16 f32 vectors per thread), at most 2048 blocks
 int bn_bwd_blocks(size_t M, int C) {
-    size_t b = (M * (size_t)C + 2047) / 2048;
+    size_t b = (M * (size_t)C + 16383) / 16384;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
@@ -301,7 +304,10 @@ static int bn_bwd_reduce_t(const void* g, const void* y, const float* scale, con
     const int blocks = bn_bwd_blocks(M, C);
     const size_t stride = (size_t)blocks * BN_THREADS;  // multiple of cpr since 256 % cpr == 0
     const size_t sh = (size_t)(BN_THREADS / cpr) * C * 2 * sizeof(float);
-    ProfScope prof(PROF_BN_BWD_REDUCE, st, (double)nvec * 16.0 * 2);
+    static char pname[2][96];
+    char* pn = pname[relu_mask ? 1 : 0];
+    if (!pn[0]) snprintf(pn, 96, "gdl::bn_bwd_reduce_kernel<%s, %s>", prof_tname<T>(), relu_mask ? "true" : "false");
+    ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * 2);
     if (relu_mask)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)g,
                            (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride);
@@ -392,7 +398,10 @@ static int bn_bwd_apply_t(const void* g, const void* y, const float* scale, cons
     int blocks;
     size_t stride;
     ew_grid(nvec, C / EPC, blocks, stride);
-    ProfScope prof(PROF_BN_BWD_APPLY, st, (double)nvec * 16.0 * 3);
+    static char pname[2][96];
+    char* pn = pname[relu_mask ? 1 : 0];
+    if (!pn[0]) snprintf(pn, 96, "gdl::bn_bwd_apply_kernel<%s, %s>", prof_tname<T>(), relu_mask ? "true" : "false");
+    ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * 3);
     if (relu_mask)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)g, (const T*)y,
                            scale, shift, mean, rstd, gamma, coef, (T*)dy, nvec, C, stride);
@@ -430,7 +439,8 @@ int relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, hip
     const size_t nvec = n / epc;
     size_t blocks = (nvec + BN_THREADS - 1) / BN_THREADS;
     if (blocks > 4096) blocks = 4096;
-    ProfScope prof(PROF_RELU_BWD, st, (double)nvec * 16.0 * 3);
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::relu_bwd_kernel<gdl::bf16>" : "gdl::relu_bwd_kernel<float>", PROF_HBM, st,
+                   (double)nvec * 16.0 * 3);
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(relu_bwd_kernel<bf16>, dim3((int)blocks), dim3(BN_THREADS), 0, st, (const bf16*)dy,
                            (const bf16*)out, (bf16*)dx, nvec);

@@ -520,8 +520,10 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     }
     const int ntn = a.OC / BN;
     const int grid = ((a.mtiles + 7) / 8) * 8 * ntn;
-    const int slot = (MODE == MODE_FWD ? PROF_CONV_FWD_256x64 : PROF_CONV_DGRAD_256x64) + (BM == 256 ? 0 : (BM == 128 ? 1 : 2));
-    ProfScope prof(slot, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
+    static char pname[96] = "";
+    if (!pname[0])
+        snprintf(pname, sizeof(pname), "gdl::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, WM, WN, MODE);
+    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_igemm_kernel");
     return GDL_OK;
@@ -538,8 +540,9 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
         attr_set = true;
     }
     const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / 64);
-    const int slot = (MODE == MODE_FWD ? PROF_CONV_FWD_256x64 : PROF_CONV_DGRAD_256x64) + (BM == 256 ? 0 : 1);
-    ProfScope prof(slot, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
+    static char pname[96] = "";
+    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d>", prof_tname<T>(), BM, MODE);
+    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
     GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
     return GDL_OK;

@@ -44,6 +44,33 @@ __device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
+// 16 bytes per lane, global -> LDS without VGPR staging (see conv_igemm.hip::dma16)
+__device__ __forceinline__ void wg_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, 0);
+#else
+    (void)rsrc;
+    (void)lds_base;
+    (void)voffset;
+#endif
+}
+// transpose read hidden from the compiler (it would wait vmcnt(0) before any LDS read it can see while
+// an LDS-DMA is in flight); valid after wg_lds_wait()
+__device__ __forceinline__ uint2 lds_tr16_asm(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ float lds_read_f32_asm(unsigned addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void wg_lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // 32-byte granule swizzle of a [pixel][channel] LDS tile (see DESIGN.md "wgrad LDS image")
 template <int PITCH>
 __device__ __forceinline__ int wg_swz(int row) {
@@ -86,12 +113,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
     const int esz = (int)sizeof(T);
     const int tap_delta = a.delta[tap] + c0 * esz;
+    // Tiles go global -> LDS by LDS-DMA: chunk idx = tid + 256*i lands at LDS byte idx*16 (lane-linear),
+    // i.e. row idx/CPR, PHYSICAL chunk idx%CPR, so each lane fetches the source chunk whose swizzled
+    // position that is (the 32-byte-granule XOR is an involution).
     int dy_off[LK];  // offset of this thread's chunk in the CURRENT stage
 #pragma unroll
     for (int i = 0; i < LK; ++i) {
         const int idx = tid + 256 * i;
-        const int row = idx / CPR_K, ch = idx % CPR_K;
+        const int row = idx / CPR_K, pc = idx % CPR_K;
+        const int ch = (((pc >> 1) ^ wg_swz<PK>(row)) << 1) | (pc & 1);
         dy_off[i] = (m_begin + row) * (a.K * esz) + k0 * esz + ch * 16;
+    }
+    int x_ch[LC];
+#pragma unroll
+    for (int i = 0; i < LC; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / CPR_C, pc = idx % CPR_C;
+        x_ch[i] = ((((pc >> 1) ^ wg_swz<PC>(row)) << 1) | (pc & 1)) * 16;
     }
     GatherEntry ent[LC];  // table entries of the NEXT stage to load
 #pragma unroll
@@ -103,22 +141,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         if (m < m_end) ent[i] = a.table[m];
     }
     int ld_m = m_begin;  // first pixel of the next stage to load
+    const int wbase = (tid >> 6) * 64 * 16;  // LDS byte offset of this wave's first lane within a 256-chunk group
 
-    u32x4_t vk[LK], vc[LC];
-    auto load_stage = [&]() {
+    auto load_stage = [&](int buf) {
+        unsigned char* Ks = smem + buf * STAGE;
+        unsigned char* Cs = Ks + WG_BP * PK;
 #pragma unroll
         for (int i = 0; i < LK; ++i) {
             const int idx = tid + 256 * i;
             const int m = ld_m + idx / CPR_K;
-            vk[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, m < m_end ? dy_off[i] : (int)0x80000000, 0, 0);
+            wg_dma16(rdy, Ks + 256 * 16 * i + wbase, m < m_end ? dy_off[i] : (int)0x80000000);
             dy_off[i] += WG_BP * a.K * esz;
         }
 #pragma unroll
         for (int i = 0; i < LC; ++i) {
-            const int idx = tid + 256 * i;
-            const int ch = idx % CPR_C;
-            const int v = ((ent[i].mask >> tap) & 1u) ? ent[i].off0 + tap_delta + ch * 16 : (int)0x80000000;
-            vc[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, v, 0, 0);
+            const int v = ((ent[i].mask >> tap) & 1u) ? ent[i].off0 + tap_delta + x_ch[i] : (int)0x80000000;
+            wg_dma16(rx, Cs + 256 * 16 * i + wbase, v);
         }
         ld_m += WG_BP;
 #pragma unroll
@@ -132,24 +170,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             ent[i] = e;
         }
     };
-    auto store_stage = [&](int buf) {
-        unsigned char* Ks = smem + buf * STAGE;
-        unsigned char* Cs = Ks + WG_BP * PK;
-#pragma unroll
-        for (int i = 0; i < LK; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / CPR_K, ch = idx % CPR_K;
-            const int pch = (((ch >> 1) ^ wg_swz<PK>(row)) << 1) | (ch & 1);
-            *(u32x4_t*)(Ks + row * PK + pch * 16) = vk[i];
-        }
-#pragma unroll
-        for (int i = 0; i < LC; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx / CPR_C, ch = idx % CPR_C;
-            const int pch = (((ch >> 1) ^ wg_swz<PC>(row)) << 1) | (ch & 1);
-            *(u32x4_t*)(Cs + row * PC + pch * 16) = vc[i];
-        }
-    };
 
     f32x4_t acc[FK][FC];
 #pragma unroll
@@ -159,23 +179,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
     const int g = lane >> 4, li = lane & 15;
 
-    if (nst > 0) {
-        load_stage();
-        store_stage(0);
-    }
-    __syncthreads();
+    const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+    if (nst > 0) load_stage(0);
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nst) load_stage();
-        const unsigned char* Ks = smem + buf * STAGE;
-        const unsigned char* Cs = Ks + WG_BP * PK;
+        // the stage issued one iteration ago has landed in every wave's part; all waves are done
+        // reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < nst) load_stage(buf ^ 1);
+        const unsigned Ks = smem_base + buf * STAGE;
+        const unsigned Cs = Ks + WG_BP * PK;
         if (sizeof(T) == 2) {
             // bf16: K-step = 32 pixels; lane group g owns pixels ks*32 + g*8 + {0..7}, fetched as two
             // transposed 4x16 blocks: lane li supplies row (li>>2), columns (li&3)*4.. and receives
             // column li of the block (verified on gfx950 by csrc/probe).
 #pragma unroll
             for (int ks = 0; ks < WG_BP / 32; ++ks) {
-                uint4 fa[FK], fb[FC];
+                uint2 alo[FK], ahi[FK], blo[FC], bhi[FC];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int row = ks * 32 + g * 8 + h * 4 + (li >> 2);
@@ -183,36 +205,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                     for (int i = 0; i < FK; ++i) {
                         const int chb = (wk * WTK + i * 16 + (li & 3) * 4) * 2;  // byte offset in row
                         const int addr = row * PK + ((((chb >> 5) ^ wg_swz<PK>(row)) << 5) | (chb & 31));
-                        const uint2 u = lds_tr16(Ks + addr);
-                        if (h == 0) {
-                            fa[i].x = u.x;
-                            fa[i].y = u.y;
-                        } else {
-                            fa[i].z = u.x;
-                            fa[i].w = u.y;
-                        }
+                        if (h == 0)
+                            alo[i] = lds_tr16_asm(Ks + addr);
+                        else
+                            ahi[i] = lds_tr16_asm(Ks + addr);
                     }
 #pragma unroll
                     for (int jj = 0; jj < FC; ++jj) {
                         const int chb = (wc * WTC + jj * 16 + (li & 3) * 4) * 2;
                         const int addr = row * PC + ((((chb >> 5) ^ wg_swz<PC>(row)) << 5) | (chb & 31));
-                        const uint2 u = lds_tr16(Cs + addr);
-                        if (h == 0) {
-                            fb[jj].x = u.x;
-                            fb[jj].y = u.y;
-                        } else {
-                            fb[jj].z = u.x;
-                            fb[jj].w = u.y;
-                        }
+                        if (h == 0)
+                            blo[jj] = lds_tr16_asm(Cs + addr);
+                        else
+                            bhi[jj] = lds_tr16_asm(Cs + addr);
                     }
                 }
+                wg_lds_wait();
 #pragma unroll
-                for (int i = 0; i < FK; ++i)
+                for (int i = 0; i < FK; ++i) {
+                    const uint4 fa = make_uint4(alo[i].x, alo[i].y, ahi[i].x, ahi[i].y);
 #pragma unroll
-                    for (int jj = 0; jj < FC; ++jj)
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[i]),
-                                                                           __builtin_bit_cast(bf16x8_t, fb[jj]),
-                                                                           acc[i][jj], 0, 0, 0);
+                    for (int jj = 0; jj < FC; ++jj) {
+                        const uint4 fb = make_uint4(blo[jj].x, blo[jj].y, bhi[jj].x, bhi[jj].y);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                           __builtin_bit_cast(bf16x8_t, fb), acc[i][jj], 0,
+                                                                           0, 0);
+                    }
+                }
             }
         } else {
             // f32: 16x16x4 MFMA, A[i = li][k = g], B[k = g][j = li]: one float per lane, pixel = ks*4 + g
@@ -223,13 +242,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
                 for (int i = 0; i < FK; ++i) {
                     const int chb = (wk * WTK + i * 16 + li) * 4;
-                    fa[i] = *(const float*)(Ks + row * PK + ((((chb >> 5) ^ wg_swz<PK>(row)) << 5) | (chb & 31)));
+                    fa[i] = lds_read_f32_asm(Ks + row * PK + ((((chb >> 5) ^ wg_swz<PK>(row)) << 5) | (chb & 31)));
                 }
 #pragma unroll
                 for (int jj = 0; jj < FC; ++jj) {
                     const int chb = (wc * WTC + jj * 16 + li) * 4;
-                    fb[jj] = *(const float*)(Cs + row * PC + ((((chb >> 5) ^ wg_swz<PC>(row)) << 5) | (chb & 31)));
+                    fb[jj] = lds_read_f32_asm(Cs + row * PC + ((((chb >> 5) ^ wg_swz<PC>(row)) << 5) | (chb & 31)));
                 }
+                wg_lds_wait();
 #pragma unroll
                 for (int i = 0; i < FK; ++i)
 #pragma unroll
@@ -237,8 +257,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
             }
         }
-        if (st + 1 < nst) store_stage(buf ^ 1);
-        __syncthreads();
     }
     // D[i][j]: i = k channel = g*4 + reg, j = c channel = li
     float* part = a.partial + (size_t)slice * a.K * RS * a.C;
@@ -334,7 +352,9 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
     }
     const int per_slice = a.RS * a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
-    ProfScope prof(PROF_CONV_WGRAD, st, 2.0 * (double)a.M * a.K * a.C * a.RS);
+    static char pname[96] = "";
+    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv_wgrad_kernel<%s, %d, %d>", prof_tname<T>(), TK, TC);
+    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.K * a.C * a.RS);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_wgrad_kernel");
     return GDL_OK;
@@ -395,7 +415,8 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
     }
     if (rc) return rc;
     const size_t total = (size_t)K * R * S * C;
-    ProfScope prof(PROF_WGRAD_REDUCE, st, (double)total * 4.0 * (p.nsplit + 1));
+    ProfScope prof(p.nsplit >= 64 ? "gdl::wgrad_reduce_kernel<16>" : (p.nsplit > 8 ? "gdl::wgrad_reduce_kernel<4>" : "gdl::wgrad_reduce_kernel<1>"),
+                   PROF_HBM, st, (double)total * 4.0 * (p.nsplit + 1));
     if (p.nsplit >= 64)
         hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, a.partial, dw,
                            p.nsplit, K, R * S, C, Cout);

@@ -30,7 +30,8 @@ int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C,
     const size_t total = (size_t)K * C * R * S;
     const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     const double esz = dtype == GDL_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_PACK_WEIGHT, st, (double)total * (4.0 + esz * ((krsc ? 1 : 0) + (crsk ? 1 : 0))));
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::pack_weight_kernel<gdl::bf16>" : "gdl::pack_weight_kernel<float>", PROF_HBM, st,
+                   (double)total * (4.0 + esz * ((krsc ? 1 : 0) + (crsk ? 1 : 0))));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(grid), dim3(256), 0, st, w, (bf16*)krsc, (bf16*)crsk, K, C, R * S);
     else
@@ -114,7 +115,8 @@ int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int
     const size_t sh = (size_t)Cin * 7 * (W + 6) * sizeof(float) + (size_t)kp * sizeof(int);
     GDL_REQUIRE(sh <= 64 * 1024, "stem_im2col: input rows of %d floats do not fit the LDS patch", W);
     // algorithmic bytes: read the float32 input once, write the im2col matrix once
-    ProfScope prof(PROF_STEM_IM2COL, st, (double)B * Cin * T * H * W * 4.0 + (double)total * 16.0);
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::stem_im2col_kernel<gdl::bf16>" : "gdl::stem_im2col_kernel<float>", PROF_HBM, st,
+                   (double)B * Cin * T * H * W * 4.0 + (double)total * 16.0);
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(stem_im2col_kernel<bf16>, dim3(B * T * P), dim3(256), sh, st, x, (bf16*)col, Cin, T, H, W, P, Q,
                            kp);
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
         }
 }
 int pack_weights_batched(int dtype, const void* desc_dev, int ndesc, int total_blocks, double bytes, hipStream_t st) {
-    ProfScope prof(PROF_PACK_WEIGHT, st, bytes);
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::pack_weights_batched_kernel<gdl::bf16>" : "gdl::pack_weights_batched_kernel<float>",
+                   PROF_HBM, st, bytes);
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(pack_weights_batched_kernel<bf16>, dim3(total_blocks), dim3(256), 0, st,
                            (const PackDesc*)desc_dev, ndesc);

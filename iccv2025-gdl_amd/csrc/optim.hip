@@ -235,7 +235,7 @@ int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, flo
     double* partial = (double*)ws;
     double* segsum = partial + (size_t)o->nchunks * 2;
     {
-        ProfScope prof(PROF_GRAD_STATS, st, (double)o->total * 4.0);
+        ProfScope prof("gdl::grad_stats_kernel", PROF_HBM, st, (double)o->total * 4.0);
         hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)o->d_chunks, partial);
     }
     GDL_CHECK_LAUNCH("grad_stats_kernel");
@@ -255,7 +255,7 @@ int gdl_optim_sgd_step(gdl_optim_t* o, float* params, float* grads, float* momen
     int64_t blocks = (nv + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    ProfScope prof(PROF_SGD, (hipStream_t)stream, (double)o->total * 4.0 * 6);
+    ProfScope prof("gdl::sgd_kernel", PROF_HBM, (hipStream_t)stream, (double)o->total * 4.0 * 6);
     hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum, stats,
                        grad_scale, lr, mu, wd, o->total);
     GDL_CHECK_LAUNCH("sgd_kernel");

@@ -75,7 +75,7 @@ int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const floa
     const size_t total = (size_t)N * P * Q * (C / epc);
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     // read the stem output once, write pooled values + 1-byte indices
-    ProfScope prof(PROF_MAXPOOL_FWD, st, (double)N * H * W * C * (16.0 / epc) + (double)total * (16.0 + epc));
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::bn_relu_maxpool_kernel<gdl::bf16>" : "gdl::bn_relu_maxpool_kernel<float>", PROF_HBM, st, (double)N * H * W * C * (16.0 / epc) + (double)total * (16.0 + epc));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, scale, shift,
                            (bf16*)out, idx, N, H, W, C, P, Q);
@@ -147,7 +147,7 @@ int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     const size_t total = (size_t)N * H * W * (C / epc);
     const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    ProfScope prof(PROF_MAXPOOL_BWD, st, (double)total * 16.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::maxpool_bwd_kernel<gdl::bf16>" : "gdl::maxpool_bwd_kernel<float>", PROF_HBM, st, (double)total * 16.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H,
                            W, C, P, Q);

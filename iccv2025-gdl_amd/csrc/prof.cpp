@@ -2,18 +2,15 @@
 #include "prof.h"
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace gdl {
 
-static const char* kSlotNames[PROF_NSLOTS] = {
-    "conv_igemm_kernel<bf16|f32,256,64,4,1,FWD>", "conv_igemm_kernel<128,128,2,2,FWD>", "conv_igemm_kernel<64,64,2,2,FWD>",
-    "conv_igemm_kernel<256,64,4,1,DGRAD>", "conv_igemm_kernel<128,128,2,2,DGRAD>", "conv_igemm_kernel<64,64,2,2,DGRAD>",
-    "conv_wgrad_kernel", "wgrad_reduce_kernel", "bn_act_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel",
-    "relu_bwd_kernel", "bn_relu_maxpool_kernel", "maxpool_bwd_kernel", "stem_im2col_kernel", "pack_weight_kernel",
-    "sgd_kernel", "grad_stats_kernel"};
-static const int kSlotBound[PROF_NSLOTS] = {1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // 1 = mfma, 0 = hbm
-
+struct Slot {
+    std::string name;
+    int bound;
+};
 struct Rec {
     int slot;
     hipEvent_t e0, e1;
@@ -21,14 +18,25 @@ struct Rec {
 };
 static std::mutex g_mu;
 static bool g_on = false;
+static std::vector<Slot> g_slots;
 static std::vector<Rec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 
 bool prof_enabled() { return g_on; }
 
-int prof_begin(int slot, hipStream_t st) {
+int prof_begin(const char* name, int bound, hipStream_t st) {
     if (!g_on) return -1;
     std::lock_guard<std::mutex> lk(g_mu);
+    int slot = -1;
+    for (size_t i = 0; i < g_slots.size(); ++i)
+        if (g_slots[i].name == name) {
+            slot = (int)i;
+            break;
+        }
+    if (slot < 0) {
+        g_slots.push_back(Slot{name, bound});
+        slot = (int)g_slots.size() - 1;
+    }
     Rec r;
     r.slot = slot;
     r.work = 0;
@@ -63,19 +71,29 @@ int gdl_prof_enable(int on) {
     return GDL_OK;
 }
 
-int gdl_prof_nslots(void) { return PROF_NSLOTS; }
+int gdl_prof_nslots(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (int)g_slots.size();
+}
 
-const char* gdl_prof_slot_name(int slot) { return (slot >= 0 && slot < PROF_NSLOTS) ? kSlotNames[slot] : ""; }
+const char* gdl_prof_slot_name(int slot) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (slot >= 0 && slot < (int)g_slots.size()) ? g_slots[slot].name.c_str() : "";
+}
 
-int gdl_prof_slot_bound(int slot) { return (slot >= 0 && slot < PROF_NSLOTS) ? kSlotBound[slot] : -1; }
+int gdl_prof_slot_bound(int slot) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (slot >= 0 && slot < (int)g_slots.size()) ? g_slots[slot].bound : -1;
+}
 
 // Synchronises the device, folds all recorded launches into per-slot totals and clears the log.
-// launches[s], ms[s], work[s] for s < gdl_prof_nslots().
+// launches[s], ms[s], work[s] for s < gdl_prof_nslots() (call gdl_prof_nslots() AFTER the timed region).
 int gdl_prof_collect(int64_t* launches, double* ms, double* work) {
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return check_hip(e, "prof_collect: hipDeviceSynchronize");
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int s = 0; s < PROF_NSLOTS; ++s) {
+    const int ns = (int)g_slots.size();
+    for (int s = 0; s < ns; ++s) {
         launches[s] = 0;
         ms[s] = 0.0;
         work[s] = 0.0;
