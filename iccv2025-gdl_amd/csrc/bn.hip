@@ -323,6 +323,110 @@ int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, c
     return bn_bwd_reduce_t<float>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, st);
 }
 
+// Fused head of a BasicBlock's backward: do2 = dz * (z > 0) (written out: the identity / downsample
+// path and both BN applies read it) together with the reductions of bn2 and, when the block has a
+// downsample branch, of its BatchNorm -- one pass over dz, z, y2 (, yd) instead of relu_bwd +
+// two reduce kernels.  partial2 / partiald: [blocks][C][2].
+template <typename T, bool DS>
+__global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                                      const T* __restrict__ y2, const T* __restrict__ yd,
+                                                                      const float* __restrict__ mean2,
+                                                                      const float* __restrict__ rstd2,
+                                                                      const float* __restrict__ meand,
+                                                                      const float* __restrict__ rstdd, T* __restrict__ do2,
+                                                                      float* __restrict__ partial2,
+                                                                      float* __restrict__ partiald, size_t nvec, int C,
+                                                                      size_t stride_vec) {
+    constexpr int EPC = TT<T>::EPC;
+    extern __shared__ float red[];  // [rpp][C][2] (+ the same again for the downsample branch)
+    const int cpr = C / EPC;
+    size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
+    const int c0 = (int)((i * EPC) % C);
+    float mu2[EPC], rs2[EPC], mud[EPC], rsd[EPC], a1[EPC], a2[EPC], b1[EPC], b2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        mu2[e] = mean2[c0 + e];
+        rs2[e] = rstd2[c0 + e];
+        if (DS) {
+            mud[e] = meand[c0 + e];
+            rsd[e] = rstdd[c0 + e];
+        }
+        a1[e] = a2[e] = b1[e] = b2[e] = 0.f;
+    }
+    for (; i < nvec; i += stride_vec) {
+        float gv[EPC], zv[EPC], yv[EPC], dv[EPC];
+        unpack16<T>(*(const uint4*)(dz + i * EPC), gv);
+        unpack16<T>(*(const uint4*)(z + i * EPC), zv);
+        unpack16<T>(*(const uint4*)(y2 + i * EPC), yv);
+        if (DS) unpack16<T>(*(const uint4*)(yd + i * EPC), dv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float gg = zv[e] > 0.f ? gv[e] : 0.f;
+            gv[e] = gg;
+            a1[e] += gg;
+            a2[e] += gg * ((yv[e] - mu2[e]) * rs2[e]);
+            if (DS) b2[e] += gg * ((dv[e] - mud[e]) * rsd[e]);
+        }
+        *(uint4*)(do2 + i * EPC) = pack16<T>(gv);
+    }
+    const int rpp = BN_THREADS / cpr, vr = threadIdx.x / cpr;
+    float* redd = red + (size_t)rpp * C * 2;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[((size_t)vr * C + c0 + e) * 2 + 0] = a1[e];
+        red[((size_t)vr * C + c0 + e) * 2 + 1] = a2[e];
+        if (DS) {
+            redd[((size_t)vr * C + c0 + e) * 2 + 0] = a1[e];  // sum of do2 is shared by both BatchNorms
+            redd[((size_t)vr * C + c0 + e) * 2 + 1] = b2[e];
+        }
+    }
+    (void)b1;
+    __syncthreads();
+    for (int k = threadIdx.x; k < C * 2; k += BN_THREADS) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rpp; ++r) {
+            a += red[(size_t)r * C * 2 + k];
+            if (DS) b += redd[(size_t)r * C * 2 + k];
+        }
+        partial2[(size_t)blockIdx.x * C * 2 + k] = a;
+        if (DS) partiald[(size_t)blockIdx.x * C * 2 + k] = b;
+    }
+}
+
+template <typename T>
+static int block_bwd_reduce_t(const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
+                              const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
+                              float* partiald, size_t M, int C, hipStream_t st) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    GDL_REQUIRE(C % EPC == 0 && cpr <= BN_THREADS && BN_THREADS % cpr == 0, "block_bwd_reduce: C=%d unsupported", C);
+    const size_t nvec = M * (size_t)C / EPC;
+    const int blocks = bn_bwd_blocks(M, C);
+    const size_t stride = (size_t)blocks * BN_THREADS;
+    const size_t sh = (size_t)(BN_THREADS / cpr) * C * 2 * sizeof(float) * (yd ? 2 : 1);
+    static char pname[2][96];
+    char* pn = pname[yd ? 1 : 0];
+    if (!pn[0]) snprintf(pn, 96, "gdl::block_bwd_reduce_kernel<%s, %s>", prof_tname<T>(), yd ? "true" : "false");
+    ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * (yd ? 5 : 4));
+    if (yd)
+        hipLaunchKernelGGL((block_bwd_reduce_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)dz,
+                           (const T*)z, (const T*)y2, (const T*)yd, mean2, rstd2, meand, rstdd, (T*)do2, partial2, partiald,
+                           nvec, C, stride);
+    else
+        hipLaunchKernelGGL((block_bwd_reduce_kernel<T, false>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)dz,
+                           (const T*)z, (const T*)y2, (const T*)nullptr, mean2, rstd2, meand, rstdd, (T*)do2, partial2,
+                           partiald, nvec, C, stride);
+    GDL_CHECK_LAUNCH("block_bwd_reduce_kernel");
+    return GDL_OK;
+}
+int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
+                     const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
+                     float* partiald, size_t M, int C, hipStream_t st) {
+    if (dtype == GDL_BF16)
+        return block_bwd_reduce_t<bf16>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, st);
+    return block_bwd_reduce_t<float>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, st);
+}
+
 // dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M
 __global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
                                                               double count, float* dgamma, float* dbeta, float* coef) {

@@ -70,7 +70,7 @@ struct gdl_encoder {
     int hf, wf;  // final map
     // scratch
     void *gA = nullptr, *gB = nullptr, *gC = nullptr, *gD = nullptr, *gE = nullptr, *g0 = nullptr;
-    float *bn_partial = nullptr, *bnb_partial = nullptr, *dw0p = nullptr;
+    float *bn_partial = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr, *dw0p = nullptr;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
     size_t ws_bytes = 0;
@@ -200,6 +200,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     bnb_partial_floats = max_bnb * 2;
     bn_partial = (float*)b.take(bn_partial_floats * sizeof(float));
     bnb_partial = (float*)b.take(bnb_partial_floats * sizeof(float));
+    bnb_partial2 = (float*)b.take(bnb_partial_floats * sizeof(float));
     wg_ws_bytes = wg;
     wg_ws = b.take(wg);
     return align_up(b.off, 256);
@@ -479,12 +480,24 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
     for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
         Block& k = e->blocks[bi];
         const size_t Mo = (size_t)k.n * k.p * k.q;
-        const size_t out_el = Mo * k.cout;
-        // do2 = dz * (z > 0), in place                                  (relu of backbone.py:66)
-        RC(relu_bwd(dt, dz, k.z, dz, out_el, st));
+        // fused: do2 = dz * (z > 0) in place (relu of backbone.py:66) + reductions of bn2 (and of the
+        // downsample BatchNorm); then finalize + apply per BatchNorm
         void* do2 = dz;
-        // bn2 / conv2
-        RC(bn_backward(e, k.b2, do2, k.y2, 0, e->gB, Mo, grads, st));  // gB = dy2
+        RC(block_bwd_reduce(dt, dz, k.z, k.y2, k.has_ds ? k.yd : nullptr, k.b2.mean, k.b2.rstd, k.has_ds ? k.bd.mean : nullptr,
+                            k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st));
+        {
+            const int blocks = bn_bwd_blocks(Mo, k.cout);
+            RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef,
+                               st));
+            RC(bn_bwd_apply(dt, do2, k.y2, k.b2.scale, k.b2.shift, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, 0,
+                            e->gB, Mo, k.cout, st));  // gB = dy2
+            if (k.has_ds) {
+                RC(bn_bwd_finalize(e->bnb_partial2, blocks, k.cout, (double)Mo, grads[k.bd.pidx], grads[k.bd.pidx + 1],
+                                   k.bd.coef, st));
+                RC(bn_bwd_apply(dt, do2, k.yd, k.bd.scale, k.bd.shift, k.bd.mean, k.bd.rstd, e->params[k.bd.pidx],
+                                k.bd.coef, 0, e->gD, Mo, k.cout, st));  // gD = dyd
+            }
+        }
         RC(conv_wgrad(dt, e->gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
                       e->wg_ws, e->wg_ws_bytes, st));
         RC(conv_dgrad(dt, e->gB, k.c2.w_crsk, e->gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
@@ -495,7 +508,6 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
                       k.cin, e->wg_ws, e->wg_ws_bytes, st));
         void* dxin;
         if (k.has_ds) {
-            RC(bn_backward(e, k.bd, do2, k.yd, 0, e->gD, Mo, grads, st));  // gD = dyd
             RC(conv_wgrad(dt, e->gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride,
                           0, k.cin, e->wg_ws, e->wg_ws_bytes, st));
             RC(conv_dgrad(dt, e->gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,

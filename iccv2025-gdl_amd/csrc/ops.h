@@ -45,6 +45,9 @@ int bn_act(int dtype, const void* y, const float* scale, const float* shift, con
 int bn_bwd_blocks(size_t M, int C);
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
+int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
+                     const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
+                     float* partiald, size_t M, int C, hipStream_t st);
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                     hipStream_t st);
 int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,

@@ -1,0 +1,100 @@
+"""N > 1 path on the single-GPU box: two ranks share cuda:0 and exchange gradients over gloo (RCCL
+refuses two ranks on one device).  Checks the native step's per-bucket all-reduce end to end:
+both ranks end with identical parameters, equal to the oracle's emulation of the same 2-rank step
+(per-rank batches, per-rank BatchNorm statistics, averaged gradients, one clip, one SGD update)."""
+import argparse
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "iccv2025-gdl_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gdl.trainer import DGLTrainer
+    from models.basic_model import AVClassifier_DGL
+    from oracle import fixtures as fx
+
+    dev = "cuda:0"
+    B, spec_hw, T, img_hw, ncls = 2, (65, 47), 2, (64, 64), 6
+    P, Bf = fx.model_state(ncls, "concat_dgl")
+    args = argparse.Namespace(fusion_method="concat", dataset="CREMAD", modality="full", batch_size=B)
+    model = AVClassifier_DGL(args)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in {**P, **Bf}.items()})
+    model = model.to(dev).train()
+    tr = DGLTrainer(model, lr=2e-3, alpha=4.0, dtype="f32", process_group=dist.group.WORLD)
+    spec, image, label = fx.make_batch(100 + rank, B, spec_hw, T, img_hw, ncls)
+    tr.step(torch.from_numpy(spec).to(dev), torch.from_numpy(image).to(dev), torch.from_numpy(label).to(dev))
+    r = tr.read()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if "num_batches" not in k}
+    q.put((rank, r["total_norm"], r["loss_f"], {k: sd[k] for k in ("fusion_module.fc_out.weight", "audio_net.conv1.weight",
+                                                                     "visual_net.layer4.1.conv2.weight",
+                                                                     "audio_net.layer2.0.downsample.1.weight")}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_oracle():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # both ranks hold the same parameters and the same (global) gradient norm
+    assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)
+    for k in res[0][3]:
+        np.testing.assert_array_equal(res[0][3][k], res[1][3][k])
+    # oracle emulation of the 2-rank step
+    sys.path.insert(0, ROOT)
+    from oracle import fixtures as fx
+    from oracle import oracle as orc
+
+    B, spec_hw, T, img_hw, ncls = 2, (65, 47), 2, (64, 64), 6
+    grads, losses = [], []
+    for rank in range(world):
+        P, Bf = fx.model_state(ncls, "concat_dgl")
+        m = orc.AVModel(P, Bf, "dgl")
+        spec, image, label = fx.make_batch(100 + rank, B, spec_hw, T, img_hw, ncls)
+        r = m.train_step(spec, image, label, 4.0, 0.0, max_norm=1e30)  # lr 0, no clip: just the raw gradients
+        grads.append(r["grads"])
+        losses.append(r["loss_f"])
+    P, _ = fx.model_state(ncls, "concat_dgl")
+    avg = {k: (grads[0][k] + grads[1][k]) * np.float32(0.5) for k in grads[0]}
+    total = float(np.sqrt(sum(orc.sumsq(g) for g in avg.values())))
+    coef = min(1.0, 40.0 / (total + 1e-6))
+    assert res[0][1] == pytest.approx(total, rel=5e-3)
+    assert res[0][2] == pytest.approx(losses[0], rel=1e-3, abs=1e-3)
+    for k, got in res[0][3].items():
+        g = (avg[k] * np.float32(coef)).astype(np.float32)
+        p = P[k].copy()
+        buf = np.zeros_like(p)
+        orc.sgd_(p, g, buf, 2e-3, 0.9, 1e-4, True)
+        np.testing.assert_allclose(got, p, rtol=1e-4, atol=2e-5, err_msg=k)
