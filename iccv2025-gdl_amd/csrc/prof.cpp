@@ -18,6 +18,7 @@ struct Rec {
 };
 static std::mutex g_mu;
 static bool g_on = false;
+static std::string g_filter;  // when non-empty only launches of this kernel name are recorded
 static std::vector<Slot> g_slots;
 static std::vector<Rec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
@@ -27,6 +28,7 @@ bool prof_enabled() { return g_on; }
 int prof_begin(const char* name, int bound, hipStream_t st) {
     if (!g_on) return -1;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_filter.empty() && g_filter != name) return -1;
     int slot = -1;
     for (size_t i = 0; i < g_slots.size(); ++i)
         if (g_slots[i].name == name) {
@@ -68,6 +70,12 @@ extern "C" {
 int gdl_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
+    return GDL_OK;
+}
+
+int gdl_prof_set_filter(const char* name) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_filter = name ? name : "";
     return GDL_OK;
 }
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "gdl_encoder_backward": ("i", "ppppp"),
     "gdl_encoder_forward_serial": ("l", "p"),
     "gdl_prof_enable": ("i", "i"),
+    "gdl_prof_set_filter": ("i", "s"),
     "gdl_prof_nslots": ("i", ""),
     "gdl_prof_slot_name": ("s", "i"),
     "gdl_prof_slot_bound": ("i", "i"),

@@ -82,6 +82,7 @@ class DGLTrainer:
         self.s_v = torch.cuda.Stream(device=self.device)
         self.eng_a = self.eng_v = None
         self.steps = 0
+        self.phase_events = None  # set to [] to record (name, event) marks on the main stream per step
 
     def __del__(self):
         try:
@@ -127,15 +128,19 @@ class DGLTrainer:
         label = label.contiguous()
         B, n = self.B, self.n_classes
         W, b = self.pviews[0], self.pviews[1]
+        self._mark(main, "start")
         ev = main.record_event()
         self.s_a.wait_event(ev)
         self.s_v.wait_event(ev)
-        with torch.cuda.stream(self.s_a):
-            self.eng_a.forward(audio, True, feat_out=self.fa)
+        # the visual encoder is the critical path (3x the audio work): enqueue it first so the single
+        # host thread's ~100 launches per encoder pass do not delay it
         with torch.cuda.stream(self.s_v):
             self.eng_v.forward(image, True, feat_out=self.fv)
+        with torch.cuda.stream(self.s_a):
+            self.eng_a.forward(audio, True, feat_out=self.fa)
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_v)
+        self._mark(main, "fwd_done")
         st = main.cuda_stream
         dgl = self.mode == "dgl"
         L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), L.ptr(b), L.ptr(self.out),
@@ -151,30 +156,39 @@ class DGLTrainer:
         else:  # BASELINE config 1: ConcatFusion + one CE loss (main.py:161-175)
             L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), None, None, L.ptr(self.g_f), 1, 0,
                    L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]), L.ptr(self.gviews[1]), B, n, st)
+        self._mark(main, "head_done")
         red = self.reducer
         if red is not None:
             red.launch("fusion")
         ev2 = main.record_event()
         self.s_a.wait_event(ev2)
         self.s_v.wait_event(ev2)
-        with torch.cuda.stream(self.s_a):
-            self.eng_a.backward(self.gviews[2:62], dfeat=self.dfa)
-            if red is not None:
-                red.launch("audio")
         with torch.cuda.stream(self.s_v):
             self.eng_v.backward(self.gviews[62:122], dfeat=self.dfv)
             if red is not None:
                 red.launch("visual")
+        with torch.cuda.stream(self.s_a):
+            self.eng_a.backward(self.gviews[2:62], dfeat=self.dfa)
+            if red is not None:
+                red.launch("audio")
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_v)
         if red is not None:
             red.wait_all()
+        self._mark(main, "bwd_done")
         gs = 1.0 / self.world
         L.call("gdl_optim_grad_stats", self.opt, L.ptr(self.grads), self.max_norm, gs, L.ptr(self.stats),
                L.ptr(self.opt_ws), self.opt_ws_bytes, st)
         L.call("gdl_optim_sgd_step", self.opt, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.momentum),
                L.ptr(self.stats), gs, self.lr, self.mu, self.wd, st)
+        self._mark(main, "end")
         self.steps += 1
+
+    def _mark(self, stream, name):
+        if self.phase_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            self.phase_events.append((name, e))
 
     # ------------------------------------------------------------------ results (host sync)
     def read(self):

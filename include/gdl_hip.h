@@ -243,6 +243,8 @@ GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
  * the device and returns per-slot totals: launches[s], ms[s], work[s], s < gdl_prof_nslots().
  * gdl_prof_slot_bound: 1 = MFMA-bound (work in flops), 0 = HBM-bound (work in bytes). */
 GDL_API int gdl_prof_enable(int on);
+/* record only launches of the kernel with this name (NULL or "" = all kernels) */
+GDL_API int gdl_prof_set_filter(const char* name);
 GDL_API int gdl_prof_nslots(void);
 GDL_API const char* gdl_prof_slot_name(int slot);
 GDL_API int gdl_prof_slot_bound(int slot);
