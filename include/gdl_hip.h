@@ -83,8 +83,7 @@ GDL_API int gdl_pack_weight(int dtype, const float* w_kcrs, void* w_krsc, void* 
  * Cin = 1 for audio `spec.unsqueeze(1)`; the visual permute/view of
  * backbone.py:162-164 is folded into the indexing).  col: [B*T*P*Q][Kp] dtype,
  * Kp = gdl_stem_kp(Cin, dtype) >= Cin*49, zero padded.
- * gdl_pack_stem_weight: float32 [64][Cin][7][7] -> dtype [64][Kp].
- * gdl_unpack_stem_wgrad: float32 [64][Kp] -> float32 [64][Cin][7][7]. */
+ * gdl_pack_stem_weight: float32 [64][Cin][7][7] -> dtype [64][Kp]. */
 GDL_API int gdl_stem_kp(int cin, int dtype);
 GDL_API int gdl_stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, void* stream);
 GDL_API int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* stream);
