@@ -3,7 +3,21 @@
 
 using namespace gdl;
 
+#ifdef GDL_TIMING
+namespace gdl { extern unsigned long long* g_timing_buf; }
+#endif
 extern "C" {
+// tuning aid (only active in a -DGDL_TIMING build): per-block s_memtime stamps go to buf[block][8]
+GDL_API int gdl_debug_timing_buffer(void* buf) {
+#ifdef GDL_TIMING
+    gdl::g_timing_buf = (unsigned long long*)buf;
+    return GDL_OK;
+#else
+    (void)buf;
+    return GDL_ERR_ARG;
+#endif
+}
+
 
 const char* gdl_last_error(void) { return last_error(); }
 int gdl_version(void) { return 100; }

@@ -42,7 +42,22 @@ struct ConvArgs {
     // slab kernel only (3x3, stride 1): image width, per-tap pixel shift, source pixel count, slab rows
     int W, in_pixels, slab_rows;
     int pshift[9];
+#ifdef GDL_TIMING
+    unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
+#endif
 };
+
+#ifdef GDL_TIMING
+unsigned long long* g_timing_buf = nullptr;
+#define GDL_STAMP(i)                                                                            \
+    do {                                                                                        \
+        if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GDL_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
@@ -90,8 +105,26 @@ __device__ __forceinline__ uint4 lds_read16_asm(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// same with a compile-time byte offset folded into the instruction (no VALU for base + constant)
+template <int OFF>
+__device__ __forceinline__ uint4 lds_read16_asm_off(unsigned addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// The sched_barrier in front pins the MFMAs that precede the wait in program order (register-only
+// instructions may otherwise sink below an asm statement), the one behind pins the consumers.
 __device__ __forceinline__ void lds_wait() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// counted form: returns once at most N of the LDS reads issued so far are still outstanding (LDS
+// returns in order; a stray scalar load in the count only makes the wait longer, never shorter)
+template <int N>
+__device__ __forceinline__ void lds_wait_n() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
@@ -344,6 +377,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // barrier-free K-loop (-80 %).
 // LDS: [weight ring: 2 x BN x 128][slab 0][slab 1 (only when IC > one chunk)][zero row].
 // =====================================================================================================
+// fragment reads of one 32-channel half: MI pixel fragments (base pb[m] + 2048*m) and NI weight
+// fragments (wb + 2048*n), all through instruction offsets
+template <int MI, int NI>
+__device__ __forceinline__ void slab_reads(uint4 (&px)[MI], uint4 (&wf)[NI], const unsigned (&pb)[MI], unsigned wb) {
+    static_assert(MI == 2 || MI == 4, "MI");
+    static_assert(NI == 4, "NI");
+    px[0] = lds_read16_asm_off<0>(pb[0]);
+    px[1] = lds_read16_asm_off<2048>(pb[1]);
+    if constexpr (MI == 4) {
+        px[2] = lds_read16_asm_off<4096>(pb[2]);
+        px[3] = lds_read16_asm_off<6144>(pb[3]);
+    }
+    wf[0] = lds_read16_asm_off<0>(wb);
+    wf[1] = lds_read16_asm_off<2048>(wb);
+    wf[2] = lds_read16_asm_off<4096>(wb);
+    wf[3] = lds_read16_asm_off<6144>(wb);
+}
+
 template <typename T, int BM, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -363,6 +414,10 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     const int ntile = j % ntn;
     if (mtile >= a.mtiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
+    GDL_STAMP(0);
+#ifdef GDL_TIMING
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+#endif
     const int esz = (int)sizeof(T);
     const int kpt = a.IC / BKE;  // channel chunks
     const int nins = (a.slab_rows + 7) >> 3;
@@ -374,9 +429,8 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
 
-    // zero row (ordinary LDS store, before any DMA is in flight)
-    if (tid < 8) *(uint4*)(smem + (zrow - smem_base) + tid * 16) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    // zero row: an out-of-range LDS-DMA deposits zeros (1 KiB, one wave instruction) -- no LDS store, no barrier
+    if (wave == 0) dma16(rin, smem + (zrow - smem_base), (int)0x80000000);
 
     // per-lane validity masks of the MI pixel fragments this wave multiplies
     const int frow = lane & 15, fg = lane >> 4;
@@ -417,19 +471,42 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     const int fswz = (frow >> 1) & 7;
     const int woff0 = frow * 128 + (((0 + fg) ^ fswz) << 4), woff1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
     int prow[MI];
+    unsigned zb[MI];  // zero-row address of fragment m, pre-biased by the instruction offset 2048*m
 #pragma unroll
-    for (int m = 0; m < MI; ++m) prow[m] = wm * WTM + m * 16 + frow + (a.W + 1);
+    for (int m = 0; m < MI; ++m) {
+        prow[m] = wm * WTM + m * 16 + frow + (a.W + 1);
+        zb[m] = zrow + (fg << 4) - 2048u * m;
+    }
 
     load_slab(0, 0);
     load_w(0, 0, 0);
+    GDL_STAMP(1);
+    // pixel shift of tap t without a scalar load per tap: +d1 inside a filter row, +d3 at a row change
+    const int sh0 = a.pshift[0], d1 = a.pshift[1] - a.pshift[0], d3 = a.pshift[3] - a.pshift[2];
     int wbuf = 0;
+#ifdef GDL_TIMING
+    unsigned long long ta, tb, acc_wait = 0, acc_issue = 0, acc_rd = 0, acc_m0 = 0, acc_m1 = 0;
+#define TSEG(accv)                          \
+    tb = __builtin_amdgcn_s_memtime();      \
+    accv += tb - ta;                        \
+    ta = tb;
+#else
+#define TSEG(accv)
+#endif
     for (int kc = 0; kc < kpt; ++kc) {
         const unsigned slab = slab_base + (kc & 1) * slab_bytes;
+        int sh = sh0, scol = 0;
         for (int tap = 0; tap < a.ntaps; ++tap) {
+#ifdef GDL_TIMING
+            ta = __builtin_amdgcn_s_memtime();
+#endif
             // everything issued during the previous K-step (next weight tile, next slab) has landed
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            TSEG(acc_wait)
+            if (kc == 0 && tap == 0) GDL_STAMP(2);
+            if (kc == 0 && tap == 1) GDL_STAMP(3);
             {  // prefetch: the weight tile of the next K-step; at tap 0 also the next chunk's slab
                 int ntap = tap + 1, nkc = kc;
                 if (ntap == a.ntaps) {
@@ -439,38 +516,70 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
                 if (nkc < kpt) load_w(wbuf ^ 1, nkc, ntap);
                 if (tap == 0 && kc + 1 < kpt) load_slab((kc + 1) & 1, kc + 1);
             }
+            TSEG(acc_issue)
             const unsigned Bs = smem_base + wbuf * WSTAGE;
-            const int sh = a.pshift[tap];
+            // both 32-channel halves' fragments are requested up front; the second half's LDS latency
+            // hides behind the first half's MFMAs
+            uint4 px[2][MI], wf[2][NI];
+            // Pixel fragment m sits 16 rows (2048 bytes) below fragment 0 and 16 rows do not change the
+            // swizzle term, so ONE address is computed per tap; the per-fragment part is an instruction
+            // offset.  A masked (padding) tap reads the zero row: its base is pre-biased by -2048*m.
+            // The second 32-channel half is chunk^4, i.e. address^64.
+            const int sr0 = prow[0] + sh;
+            const unsigned ad0 = slab + sr0 * 128 + (((fg ^ ((sr0 >> 1) & 7))) << 4);
+            unsigned pb[MI];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                uint4 px[MI], wf[NI];
+            for (int m = 0; m < MI; ++m) pb[m] = ((fmask[m] >> tap) & 1u) ? ad0 : zb[m];
+            const unsigned wb0 = Bs + woff0, wb1 = Bs + woff1;
+            slab_reads<MI, NI>(px[0], wf[0], pb, wb0);
 #pragma unroll
-                for (int m = 0; m < MI; ++m) {
-                    const int sr = prow[m] + sh;
-                    const unsigned ad = slab + sr * 128 + ((((kk * 4 + fg) ^ ((sr >> 1) & 7))) << 4);
-                    px[m] = lds_read16_asm(((fmask[m] >> tap) & 1u) ? ad : zrow + ((kk * 4 + fg) << 4));
-                }
+            for (int m = 0; m < MI; ++m) pb[m] ^= 64u;
+            slab_reads<MI, NI>(px[1], wf[1], pb, wb1);
+            lds_wait_n<MI + NI>();
+            TSEG(acc_rd)
 #pragma unroll
-                for (int n = 0; n < NI; ++n) wf[n] = lds_read16_asm(Bs + n * 16 * 128 + (kk ? woff1 : woff0));
-                lds_wait();
+            for (int n = 0; n < NI; ++n)
 #pragma unroll
-                for (int n = 0; n < NI; ++n)
+                for (int m = 0; m < MI; ++m) Mma<T>::run(wf[0][n], px[0][m], acc[n][m]);
+            lds_wait();
+            TSEG(acc_m0)
 #pragma unroll
-                    for (int m = 0; m < MI; ++m) Mma<T>::run(wf[n], px[m], acc[n][m]);
-            }
+            for (int n = 0; n < NI; ++n)
+#pragma unroll
+                for (int m = 0; m < MI; ++m) Mma<T>::run(wf[1][n], px[1][m], acc[n][m]);
+            TSEG(acc_m1)
             wbuf ^= 1;
+            if (++scol == 3) {
+                scol = 0;
+                sh += d3;
+            } else {
+                sh += d1;
+            }
         }
     }
+    GDL_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile);
+    GDL_STAMP(5);
+#ifdef GDL_TIMING
+    if (a.dbg && threadIdx.x == 0) {
+        unsigned long long* d = a.dbg + ((size_t)(1 << 15) + blockIdx.x) * 8;
+        d[0] = acc_wait;
+        d[1] = acc_issue;
+        d[2] = acc_rd;
+        d[3] = acc_m0;
+        d[4] = acc_m1;
+        d[5] = (unsigned long long)kpt * a.ntaps;
+    }
+#endif
 }
 
 static size_t slab_lds_bytes(int BM, int W, int IC, int dtype) {
     const int bke = dtype == GDL_BF16 ? 64 : 32, esz = dtype == GDL_BF16 ? 2 : 4;
     const int rows = BM + 2 * W + 2;
     const size_t slab = (size_t)((rows + 7) / 8) * 1024;
-    const size_t main = 2 * 64 * 128 + (IC / bke > 1 ? 2 : 1) * slab + 128;
+    const size_t main = 2 * 64 * 128 + (IC / bke > 1 ? 2 : 1) * slab + 1024;
     const size_t epi = (size_t)BM * (64 * esz + 16) + 4 * 64 * 2 * 4;
     return main > epi ? main : epi;
 }
@@ -611,6 +720,9 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     if (rc) return rc;
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
     ConvArgs a{};
+#ifdef GDL_TIMING
+    a.dbg = g_timing_buf;
+#endif
     a.in = in;
     a.wt = wt;
     a.out = out;

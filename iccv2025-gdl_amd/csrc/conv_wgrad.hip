@@ -33,7 +33,13 @@ struct WgradArgs {
     int tiles_k, tiles_c;
     unsigned dy_bytes, x_bytes;
     int delta[9];
+#ifdef GDL_TIMING
+    unsigned long long* dbg;
+#endif
 };
+#ifdef GDL_TIMING
+extern unsigned long long* g_timing_buf;
+#endif
 
 constexpr int WG_BP = 64;  // pixels per LDS stage
 
@@ -180,15 +186,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int g = lane >> 4, li = lane & 15;
 
     const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+#ifdef GDL_TIMING
+    unsigned long long t_entry = __builtin_amdgcn_s_memtime(), t_wait = 0, t_comp = 0, t_issue = 0, t_a, t_b;
+#endif
     if (nst > 0) load_stage(0);
+#ifdef GDL_TIMING
+    unsigned long long t_first = __builtin_amdgcn_s_memtime();
+#endif
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
+#ifdef GDL_TIMING
+        t_a = __builtin_amdgcn_s_memtime();
+#endif
         // the stage issued one iteration ago has landed in every wave's part; all waves are done
         // reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef GDL_TIMING
+        t_b = __builtin_amdgcn_s_memtime();
+        t_wait += t_b - t_a;
+#endif
         if (st + 1 < nst) load_stage(buf ^ 1);
+#ifdef GDL_TIMING
+        t_a = __builtin_amdgcn_s_memtime();
+        t_issue += t_a - t_b;
+#endif
         const unsigned Ks = smem_base + buf * STAGE;
         const unsigned Cs = Ks + WG_BP * PK;
         if (sizeof(T) == 2) {
@@ -258,6 +281,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
     }
+#ifdef GDL_TIMING
+    // the loop body's compute time = everything not wait / issue
+    unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+    t_comp = (t_loop_end - t_first) - t_wait - t_issue;
+#endif
     // D[i][j]: i = k channel = g*4 + reg, j = c channel = li
     float* part = a.partial + (size_t)slice * a.K * RS * a.C;
 #pragma unroll
@@ -271,6 +299,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 part[((size_t)k * RS + tap) * a.C + c] = acc[i][jj][e];
             }
         }
+#ifdef GDL_TIMING
+    if (a.dbg && tid == 0) {
+        unsigned long long* d = a.dbg + (size_t)blockIdx.x * 8;
+        d[0] = t_entry;
+        d[1] = t_first - t_entry;
+        d[2] = t_wait;
+        d[3] = t_issue;
+        d[4] = t_comp;
+        d[5] = __builtin_amdgcn_s_memtime() - t_loop_end;
+        d[6] = nst;
+    }
+#endif
 }
 
 // out[k][c][r][s] = sum_split partial[split][k][rs][c], c < Cout (Cout <= C drops im2col padding)
@@ -371,6 +411,9 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
     if (rc) return rc;
     const int esz = dtype == GDL_BF16 ? 2 : 4;
     WgradArgs a{};
+#ifdef GDL_TIMING
+    a.dbg = g_timing_buf;
+#endif
     a.dy = dy;
     a.x = x;
     a.table = (const GatherEntry*)table;

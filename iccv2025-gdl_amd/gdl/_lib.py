@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "build", "libgdl_hip.so")
+SO_PATH = os.environ.get("GDL_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "build", "libgdl_hip.so")  # GDL_LIB: tuning builds
 
 GDL_F32, GDL_BF16 = 0, 1
 GDL_AUDIO, GDL_VISUAL = 0, 1
@@ -71,6 +71,7 @@ SIGNATURES = {
     "gdl_encoder_forward_serial": ("l", "p"),
     "gdl_prof_enable": ("i", "i"),
     "gdl_prof_set_filter": ("i", "s"),
+    "gdl_debug_timing_buffer": ("i", "p"),
     "gdl_prof_nslots": ("i", ""),
     "gdl_prof_slot_name": ("s", "i"),
     "gdl_prof_slot_bound": ("i", "i"),

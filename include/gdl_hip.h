@@ -242,6 +242,9 @@ GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
  * the device and returns per-slot totals: launches[s], ms[s], work[s], s < gdl_prof_nslots().
  * gdl_prof_slot_bound: 1 = MFMA-bound (work in flops), 0 = HBM-bound (work in bytes). */
 GDL_API int gdl_prof_enable(int on);
+/* tuning aid: in a -DGDL_TIMING build the conv kernels write per-block s_memtime stamps to buf[block][8]
+ * (uint64); in the normal build this returns GDL_ERR_ARG */
+GDL_API int gdl_debug_timing_buffer(void* buf);
 /* record only launches of the kernel with this name (NULL or "" = all kernels) */
 GDL_API int gdl_prof_set_filter(const char* name);
 GDL_API int gdl_prof_nslots(void);
