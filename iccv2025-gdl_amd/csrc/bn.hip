@@ -8,6 +8,8 @@
 // Channel of a vector: with NHWC storage the flat element index modulo C; a thread that
 // strides by a multiple of C keeps the same channels for its whole loop, so its scale /
 // shift / partial sums live in registers.
+#include <stdlib.h>
+
 #include "common.h"
 #include "prof.h"
 
@@ -146,6 +148,20 @@ int bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, co
     return GDL_OK;
 }
 
+// per-channel constants of the EPC consecutive channels a thread owns: 16-byte loads (c0 % EPC == 0),
+// not EPC scalar ones -- the scalar form cost more than the data traffic on the small layers
+template <int EPC>
+__device__ __forceinline__ void ld_chan(const float* __restrict__ p, int c0, float (&v)[EPC]) {
+#pragma unroll
+    for (int q = 0; q < EPC / 4; ++q) {
+        const float4 t = *(const float4*)(p + c0 + 4 * q);
+        v[4 * q + 0] = t.x;
+        v[4 * q + 1] = t.y;
+        v[4 * q + 2] = t.z;
+        v[4 * q + 3] = t.w;
+    }
+}
+
 // ---------------------------------------------------------------- forward apply
 // out = [relu]( y*scale+shift + residual ),  RES: 0 none, 1 raw tensor, 2 tensor*res_scale+res_shift
 template <typename T, int RES, bool RELU>
@@ -159,19 +175,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
     if (i >= nvec) return;
     const int c0 = (int)((i * EPC) % C);  // stride_vec*EPC is a multiple of C: channels are loop invariant
     float sc[EPC], sf[EPC], rsc[EPC], rsf[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        sc[e] = scale[c0 + e];
-        sf[e] = shift[c0 + e];
-        if (RES == 2) {
-            rsc[e] = rscale[c0 + e];
-            rsf[e] = rshift[c0 + e];
-        }
+    ld_chan<EPC>(scale, c0, sc);
+    ld_chan<EPC>(shift, c0, sf);
+    if (RES == 2) {
+        ld_chan<EPC>(rscale, c0, rsc);
+        ld_chan<EPC>(rshift, c0, rsf);
     }
-    for (; i < nvec; i += stride_vec) {
+    auto one = [&](size_t j, const uint4& yv, const uint4& rv) {
         float f[EPC], g[EPC];
-        unpack16<T>(*(const uint4*)(y + i * EPC), f);
-        if (RES) unpack16<T>(*(const uint4*)(res + i * EPC), g);
+        unpack16<T>(yv, f);
+        if (RES) unpack16<T>(rv, g);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float v = f[e] * sc[e] + sf[e];
@@ -180,8 +193,35 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
             if (RELU) v = v > 0.f ? v : 0.f;
             f[e] = v;
         }
-        *(uint4*)(out + i * EPC) = pack16<T>(f);
+        *(uint4*)(out + j * EPC) = pack16<T>(f);
+    };
+    // two vectors per trip: both loads are in flight before either is consumed
+    for (; i + stride_vec < nvec; i += 2 * stride_vec) {
+        const size_t j = i + stride_vec;
+        const uint4 y0 = *(const uint4*)(y + i * EPC), y1 = *(const uint4*)(y + j * EPC);
+        uint4 r0 = y0, r1 = y1;
+        if (RES) {
+            r0 = *(const uint4*)(res + i * EPC);
+            r1 = *(const uint4*)(res + j * EPC);
+        }
+        one(i, y0, r0);
+        one(j, y1, r1);
     }
+    if (i < nvec) {
+        const uint4 y0 = *(const uint4*)(y + i * EPC);
+        uint4 r0 = y0;
+        if (RES) r0 = *(const uint4*)(res + i * EPC);
+        one(i, y0, r0);
+    }
+}
+
+static bool ew_v4() {  // tuning aid: GDL_EW_V4=1 -> 4 instead of 8 vectors per thread on small tensors
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_EW_V4");
+        v = e ? atoi(e) : 0;
+    }
+    return v != 0;
 }
 
 // grid sizing for channel-invariant grid-stride loops: total threads is a multiple of C/EPC
@@ -189,7 +229,10 @@ static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec
     // threads = blocks*256 must be a multiple of cpr (cpr divides 256 or is a multiple of it handled by lcm)
     // Measured (bench.py kernel table): 8 vectors per thread amortise the per-channel constant loads
     // on the big tensors (34 us vs 50 us per launch with 1 vector per thread); at most 2048 blocks
+    // (the kernels keep two vectors in flight per trip); tensors too small to fill 2048 blocks that
+    // way get 4 vectors per thread so that the launch still spreads over every CU
     size_t want = (nvec + BN_THREADS * 8 - 1) / (BN_THREADS * 8);
+    if (want < 2048 && ew_v4()) want = (nvec + BN_THREADS * 4 - 1) / (BN_THREADS * 4);
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     // make blocks*256 % cpr == 0
@@ -249,20 +292,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
     const int c0 = (int)((i * EPC) % C);
     float sc[EPC], sf[EPC], mu[EPC], rs[EPC], s1[EPC], s2[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        mu[e] = mean[c0 + e];
-        rs[e] = rstd[c0 + e];
-        if (MASK) {
-            sc[e] = scale[c0 + e];
-            sf[e] = shift[c0 + e];
-        }
-        s1[e] = s2[e] = 0.f;
+    ld_chan<EPC>(mean, c0, mu);
+    ld_chan<EPC>(rstd, c0, rs);
+    if (MASK) {
+        ld_chan<EPC>(scale, c0, sc);
+        ld_chan<EPC>(shift, c0, sf);
     }
-    for (; i < nvec; i += stride_vec) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+    auto one = [&](const uint4& gq, const uint4& yq) {
         float gv[EPC], yv[EPC];
-        unpack16<T>(*(const uint4*)(g + i * EPC), gv);
-        unpack16<T>(*(const uint4*)(y + i * EPC), yv);
+        unpack16<T>(gq, gv);
+        unpack16<T>(yq, yv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float gg = gv[e];
@@ -270,7 +311,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
             s1[e] += gg;
             s2[e] += gg * ((yv[e] - mu[e]) * rs[e]);
         }
+    };
+    for (; i + stride_vec < nvec; i += 2 * stride_vec) {
+        const size_t j = i + stride_vec;
+        const uint4 g0 = *(const uint4*)(g + i * EPC), g1 = *(const uint4*)(g + j * EPC);
+        const uint4 y0 = *(const uint4*)(y + i * EPC), y1 = *(const uint4*)(y + j * EPC);
+        one(g0, y0);
+        one(g1, y1);
     }
+    if (i < nvec) one(*(const uint4*)(g + i * EPC), *(const uint4*)(y + i * EPC));
     // 256 % cpr == 0: thread t holds channel vector t % cpr of row-lane t / cpr
     const int rpp = BN_THREADS / cpr, vr = threadIdx.x / cpr;
 #pragma unroll
@@ -286,9 +335,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
     }
 }
 
-// one block per 16384 elements (8 bf16 / 16 f32 vectors per thread), at most 2048 blocks
+// one block per 16384 elements (8 bf16 / 16 f32 vectors per thread), at most 2048 blocks; tensors
+// that would not fill 2048 blocks that way get one block per 8192 elements
 int bn_bwd_blocks(size_t M, int C) {
     size_t b = (M * (size_t)C + 16383) / 16384;
+    if (b < 2048 && ew_v4()) b = (M * (size_t)C + 8191) / 8192;
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
@@ -343,22 +394,20 @@ __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* _
     size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
     const int c0 = (int)((i * EPC) % C);
     float mu2[EPC], rs2[EPC], mud[EPC], rsd[EPC], a1[EPC], a2[EPC], b1[EPC], b2[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        mu2[e] = mean2[c0 + e];
-        rs2[e] = rstd2[c0 + e];
-        if (DS) {
-            mud[e] = meand[c0 + e];
-            rsd[e] = rstdd[c0 + e];
-        }
-        a1[e] = a2[e] = b1[e] = b2[e] = 0.f;
+    ld_chan<EPC>(mean2, c0, mu2);
+    ld_chan<EPC>(rstd2, c0, rs2);
+    if (DS) {
+        ld_chan<EPC>(meand, c0, mud);
+        ld_chan<EPC>(rstdd, c0, rsd);
     }
-    for (; i < nvec; i += stride_vec) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) a1[e] = a2[e] = b1[e] = b2[e] = 0.f;
+    auto one = [&](size_t j, const uint4& gq, const uint4& zq, const uint4& yq, const uint4& dq) {
         float gv[EPC], zv[EPC], yv[EPC], dv[EPC];
-        unpack16<T>(*(const uint4*)(dz + i * EPC), gv);
-        unpack16<T>(*(const uint4*)(z + i * EPC), zv);
-        unpack16<T>(*(const uint4*)(y2 + i * EPC), yv);
-        if (DS) unpack16<T>(*(const uint4*)(yd + i * EPC), dv);
+        unpack16<T>(gq, gv);
+        unpack16<T>(zq, zv);
+        unpack16<T>(yq, yv);
+        if (DS) unpack16<T>(dq, dv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const float gg = zv[e] > 0.f ? gv[e] : 0.f;
@@ -367,7 +416,26 @@ __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* _
             a2[e] += gg * ((yv[e] - mu2[e]) * rs2[e]);
             if (DS) b2[e] += gg * ((dv[e] - mud[e]) * rsd[e]);
         }
-        *(uint4*)(do2 + i * EPC) = pack16<T>(gv);
+        *(uint4*)(do2 + j * EPC) = pack16<T>(gv);
+    };
+    for (; i + stride_vec < nvec; i += 2 * stride_vec) {
+        const size_t j = i + stride_vec;
+        const uint4 g0 = *(const uint4*)(dz + i * EPC), g1 = *(const uint4*)(dz + j * EPC);
+        const uint4 z0 = *(const uint4*)(z + i * EPC), z1 = *(const uint4*)(z + j * EPC);
+        const uint4 y0 = *(const uint4*)(y2 + i * EPC), y1 = *(const uint4*)(y2 + j * EPC);
+        uint4 d0 = y0, d1 = y1;
+        if (DS) {
+            d0 = *(const uint4*)(yd + i * EPC);
+            d1 = *(const uint4*)(yd + j * EPC);
+        }
+        one(i, g0, z0, y0, d0);
+        one(j, g1, z1, y1, d1);
+    }
+    if (i < nvec) {
+        const uint4 y0 = *(const uint4*)(y2 + i * EPC);
+        uint4 d0 = y0;
+        if (DS) d0 = *(const uint4*)(yd + i * EPC);
+        one(i, *(const uint4*)(dz + i * EPC), *(const uint4*)(z + i * EPC), y0, d0);
     }
     const int rpp = BN_THREADS / cpr, vr = threadIdx.x / cpr;
     float* redd = red + (size_t)rpp * C * 2;
@@ -468,30 +536,37 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T* __res
     if (i >= nvec) return;
     const int c0 = (int)((i * EPC) % C);
     float sc[EPC], sf[EPC], mu[EPC], rs[EPC], gr[EPC], k1[EPC], k2[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        mu[e] = mean[c0 + e];
-        rs[e] = rstd[c0 + e];
-        gr[e] = gamma[c0 + e] * rs[e];
-        k1[e] = coef[c0 + e];
-        k2[e] = coef[C + c0 + e];
-        if (MASK) {
-            sc[e] = scale[c0 + e];
-            sf[e] = shift[c0 + e];
-        }
+    ld_chan<EPC>(mean, c0, mu);
+    ld_chan<EPC>(rstd, c0, rs);
+    ld_chan<EPC>(gamma, c0, gr);
+    ld_chan<EPC>(coef, c0, k1);
+    ld_chan<EPC>(coef + C, c0, k2);
+    if (MASK) {
+        ld_chan<EPC>(scale, c0, sc);
+        ld_chan<EPC>(shift, c0, sf);
     }
-    for (; i < nvec; i += stride_vec) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) gr[e] *= rs[e];
+    auto one = [&](size_t j, const uint4& gq, const uint4& yq) {
         float gv[EPC], yv[EPC];
-        unpack16<T>(*(const uint4*)(g + i * EPC), gv);
-        unpack16<T>(*(const uint4*)(y + i * EPC), yv);
+        unpack16<T>(gq, gv);
+        unpack16<T>(yq, yv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             float gg = gv[e];
             if (MASK) gg = (yv[e] * sc[e] + sf[e] > 0.f) ? gg : 0.f;
             gv[e] = gr[e] * (gg - k1[e] - (yv[e] - mu[e]) * rs[e] * k2[e]);
         }
-        *(uint4*)(dy + i * EPC) = pack16<T>(gv);
+        *(uint4*)(dy + j * EPC) = pack16<T>(gv);
+    };
+    for (; i + stride_vec < nvec; i += 2 * stride_vec) {
+        const size_t j = i + stride_vec;
+        const uint4 g0 = *(const uint4*)(g + i * EPC), g1 = *(const uint4*)(g + j * EPC);
+        const uint4 y0 = *(const uint4*)(y + i * EPC), y1 = *(const uint4*)(y + j * EPC);
+        one(i, g0, y0);
+        one(j, g1, y1);
     }
+    if (i < nvec) one(i, *(const uint4*)(g + i * EPC), *(const uint4*)(y + i * EPC));
 }
 template <typename T>
 static int bn_bwd_apply_t(const void* g, const void* y, const float* scale, const float* shift, const float* mean,

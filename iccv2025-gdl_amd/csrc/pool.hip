@@ -29,9 +29,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
         float sc[EPC], sf[EPC], best[EPC];
         int bi[EPC];
 #pragma unroll
+        for (int q4 = 0; q4 < EPC / 4; ++q4) {  // 16-byte loads of the per-channel constants
+            const float4 a = *(const float4*)(scale + vc * EPC + 4 * q4), b = *(const float4*)(shift + vc * EPC + 4 * q4);
+            sc[4 * q4 + 0] = a.x, sc[4 * q4 + 1] = a.y, sc[4 * q4 + 2] = a.z, sc[4 * q4 + 3] = a.w;
+            sf[4 * q4 + 0] = b.x, sf[4 * q4 + 1] = b.y, sf[4 * q4 + 2] = b.z, sf[4 * q4 + 3] = b.w;
+        }
+#pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            sc[e] = scale[vc * EPC + e];
-            sf[e] = shift[vc * EPC + e];
             best[e] = -INFINITY;
             bi[e] = -1;
         }

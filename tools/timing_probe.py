@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="192,64,56,56,64,3,1,1")
     ap.add_argument("--op", default="fwd")
-    ap.add_argument("--names", default="entry,issued,landed,tap1,kloop_end,end")
+    ap.add_argument("--names", default="entry,issued,landed,kloop_end,kloop_end2,end")
     a = ap.parse_args()
     N, C, H, W, K, R, stride, pad = [int(v) for v in a.shape.split(",")]
     lib = L.load()
