@@ -43,8 +43,7 @@ int gdl_conv_bn_tiles(int dtype, int N, int H, int W, int C, int K, int R, int S
 }
 
 size_t gdl_conv_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad) {
-    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-    return (size_t)(mode == GATHER_FWD ? N * P * Q : N * H * W) * sizeof(GatherEntry);
+    return gather_table_bytes(mode, N, H, W, R, S, stride, pad);
 }
 int gdl_conv_build_table(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                          void* table, void* stream) {

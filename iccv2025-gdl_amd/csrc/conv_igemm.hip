@@ -42,6 +42,10 @@ struct ConvArgs {
     // slab kernel only (3x3, stride 1): image width, per-tap pixel shift, source pixel count, slab rows
     int W, in_pixels, slab_rows;
     int pshift[9];
+    // permuted stride-2 data gradient (gather.h): output pixel of each GEMM row (-1: padding row)
+    const int* orow;
+    const unsigned* tile_taps;  // per M-tile: OR of its rows' tap masks
+    double flops;  // algorithmic work of the launch (measurement tap)
 #ifdef GDL_TIMING
     unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
 #endif
@@ -153,6 +157,18 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
+    // output row of every pass of the store loop below, fetched now so that the (permuted data
+    // gradient's) row-index loads overlap the staging through LDS; -1 = nothing to store
+    constexpr int CH = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
+    constexpr int RPI = 256 / CH;                  // rows per pass
+    constexpr int NPASS = BM / RPI;
+    const int ec = tid % CH, er0 = tid / CH;
+    int om[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int m = m0 + er0 + p * RPI;
+        om[p] = m < a.M ? (a.orow ? a.orow[m] : m) : -1;
+    }
     // accumulators -> LDS tile [BM][BN] of T.
     // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
     unsigned char* Cs = smem;
@@ -172,19 +188,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             }
     }
     __syncthreads();
-    constexpr int CH = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
-    constexpr int RPI = 256 / CH;                  // rows per pass
-    const int ec = tid % CH, er0 = tid / CH;
     float ssum[EPC], ssq[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) ssum[e] = ssq[e] = 0.f;
     T* __restrict__ gout = (T*)a.out;
     const T* __restrict__ gadd = (const T*)a.addend;
-    for (int row = er0; row < BM; row += RPI) {
-        const int m = m0 + row;
-        if (m >= a.M) break;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (om[p] < 0) continue;
+        const int row = er0 + p * RPI;
         uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
-        const size_t goff = (size_t)m * a.OC + n0 + ec * EPC;
+        const size_t goff = (size_t)om[p] * a.OC + n0 + ec * EPC;
         if (gadd) {
             float f[EPC], g[EPC];
             unpack16<T>(v, f);
@@ -282,12 +296,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + schunk * 16;
     const int kpt = a.IC / BKE;  // K-steps per tap
-    const int nk = a.ntaps * kpt;
+    // taps this tile multiplies: all of them, or (class-pure tiles of a permuted stride-2 data gradient)
+    // only those that are valid for at least one of its rows
+    const unsigned tapset = a.tile_taps ? a.tile_taps[mtile] : (1u << a.ntaps) - 1u;
+    const int nk = __popc(tapset) * kpt;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
     const int wrow = (tid >> 6) * 8;  // first tile row this wave's DMA instruction covers (plus 32*i)
 
-    int ld_tap = 0, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
+    int ld_tap = tapset ? __builtin_ctz(tapset) : a.ntaps, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
     // Every call issues exactly AROWS+BROWS DMA instructions per wave (the counted s_waitcnt below
     // relies on it); past the last K-step they are all out of range: no memory traffic, zeros into
     // a ring slot nobody reads.
@@ -307,7 +324,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < BROWS; ++i) dma16(rwt, Bs + (wrow + 32 * i) * 128, live ? b_off[i] + ub : (int)0x80000000);
         if (++ld_kc == kpt) {
             ld_kc = 0;
-            ++ld_tap;
+            const unsigned rest = ld_tap + 1 < 32 ? tapset >> (ld_tap + 1) : 0u;
+            ld_tap = rest ? ld_tap + 1 + __builtin_ctz(rest) : a.ntaps;  // next tap of the set
         }
     };
 
@@ -632,7 +650,7 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, WM, WN, MODE);
-    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, a);
     GDL_CHECK_LAUNCH("conv_igemm_kernel");
     return GDL_OK;
@@ -651,7 +669,7 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
     const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / 64);
     static char pname[96] = "";
     if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d>", prof_tname<T>(), BM, MODE);
-    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.OC * a.ntaps * a.IC);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops);
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
     GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
     return GDL_OK;
@@ -708,6 +726,11 @@ int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int
     return ceil_div(N * P * Q, pl.bm);
 }
 
+// M-tile of a data gradient (the permuted stride-2 table is laid out for it)
+int conv_dgrad_bm(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    return plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad).bm;
+}
+
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st) {
@@ -747,6 +770,12 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
     // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
     const ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
+    a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction
+    if (mode == GATHER_DGRAD && stride == 2) {
+        a.orow = (const int*)((const GatherEntry*)table + dgrad_perm_cap(N, H, W));
+        a.tile_taps = (const unsigned*)(a.orow + dgrad_perm_cap(N, H, W));
+        a.M = dgrad_perm_rows(N, H, W, pl.bm);
+    }
     if (pl.slab) {
         a.W = W;
         a.in_pixels = N * H * W;

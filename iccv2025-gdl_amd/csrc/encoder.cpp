@@ -132,12 +132,13 @@ size_t gdl_encoder::plan(unsigned char* base) {
     std::map<std::tuple<int, int, int, int, int, int, int, int, int>, void*> seen;
     auto table_for = [&](int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) -> void* {
         const int src_ch = mode == GATHER_FWD ? C : K;  // the table depends on the gathered tensor's row size
-        auto key = std::make_tuple(mode, N, H, W, src_ch, R, S, stride, pad);
+        // (a stride-2 data-gradient table is permuted for the M-tile its convolution runs with, which
+        // depends on the other channel count too: fold it into the key)
+        auto key = std::make_tuple(mode, N, H, W, (mode == GATHER_DGRAD && stride == 2) ? src_ch * 4096 + C : src_ch, R, S,
+                                   stride, pad);
         auto it = seen.find(key);
         if (it != seen.end()) return it->second;
-        const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-        const size_t rows = mode == GATHER_FWD ? (size_t)N * P * Q : (size_t)N * H * W;
-        void* dst = b.take(rows * sizeof(GatherEntry));
+        void* dst = b.take(gather_table_bytes(mode, N, H, W, R, S, stride, pad));
         seen[key] = dst;
         tab_jobs.push_back(TabJob{mode, N, H, W, C, K, R, S, stride, pad, dst});
         return dst;

@@ -31,6 +31,21 @@ struct GatherGeom {
 
 enum { GATHER_FWD = 0, GATHER_DGRAD = 1 };
 
+// Stride-2 data gradients use a PERMUTED table: the input pixels (GEMM rows) are grouped by the parity
+// class (h&1, w&1) -- only taps of matching parity reach a pixel, 1 / 2 / 2 / 4 of the 9 taps of a 3x3
+// kernel and none at all for three of the four classes of a 1x1 -- each class padded to a multiple of
+// the M-tile `bm`, so that every tile is class-pure and its K-loop runs over the taps that can be valid
+// only (4x fewer MFMAs than masking all 9).  Layout: GatherEntry[cap], int32 orow[cap] (output pixel of
+// the GEMM row, -1 for padding rows), uint32 tile_taps[cap/64] (OR of the row masks of every M-tile),
+// cap = N*H*W + 4*256.
+inline size_t dgrad_perm_cap(int N, int H, int W) { return (size_t)N * H * W + 4 * 256; }
+// number of GEMM rows of the permuted table for M-tile bm
+int dgrad_perm_rows(int N, int H, int W, int bm);
+int build_dgrad_perm_table(int dtype, int N, int H, int W, int C, int K, int R, int S, int pad, int bm, GatherEntry* table,
+                           hipStream_t st);
+// bytes of a table (any mode / stride)
+size_t gather_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad);
+
 // fills `g`; returns GDL_OK or an error
 int gather_geom(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, GatherGeom* g);
 int build_gather_table(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,

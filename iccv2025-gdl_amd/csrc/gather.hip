@@ -58,8 +58,13 @@ __global__ void gather_table_kernel(GatherEntry* __restrict__ tab, int mode, int
     tab[m] = e;
 }
 
+int conv_dgrad_bm(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);  // conv_igemm.hip
+
 int build_gather_table(int mode, int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                        GatherEntry* table, hipStream_t st) {
+    if (mode == GATHER_DGRAD && stride == 2)
+        return build_dgrad_perm_table(dtype, N, H, W, C, K, R, S, pad, conv_dgrad_bm(dtype, N, H, W, C, K, R, S, stride, pad),
+                                      table, st);
     GatherGeom g;
     int rc = gather_geom(mode, dtype, N, H, W, C, K, R, S, stride, pad, &g);
     if (rc) return rc;
@@ -72,6 +77,85 @@ int build_gather_table(int mode, int dtype, int N, int H, int W, int C, int K, i
         hipLaunchKernelGGL(gather_table_kernel, dim3(grid), dim3(256), 0, st, table, mode, g.rows, P, Q, H, W, R, S, stride,
                            pad, g.row_bytes);
     GDL_CHECK_LAUNCH("gather_table_kernel");
+    return GDL_OK;
+}
+
+// ---- permuted stride-2 data-gradient table (see gather.h)
+struct PermGeom {
+    int seg[5];     // first GEMM row of class c = (h&1)*2 + (w&1); seg[4] = total rows
+    int hc[2], wc[2];
+};
+static PermGeom perm_geom(int N, int H, int W, int bm) {
+    PermGeom g;
+    g.hc[0] = (H + 1) / 2, g.hc[1] = H / 2;
+    g.wc[0] = (W + 1) / 2, g.wc[1] = W / 2;
+    int at = 0;
+    for (int c = 0; c < 4; ++c) {
+        g.seg[c] = at;
+        const int cnt = N * g.hc[c >> 1] * g.wc[c & 1];
+        at += ceil_div(cnt, bm) * bm;
+    }
+    g.seg[4] = at;
+    return g;
+}
+int dgrad_perm_rows(int N, int H, int W, int bm) { return perm_geom(N, H, W, bm).seg[4]; }
+
+size_t gather_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad) {
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    if (mode == GATHER_FWD) return (size_t)N * P * Q * sizeof(GatherEntry);
+    if (stride == 2) return dgrad_perm_cap(N, H, W) * (sizeof(GatherEntry) + sizeof(int)) + (dgrad_perm_cap(N, H, W) / 64 + 1) * 4;
+    return (size_t)N * H * W * sizeof(GatherEntry);
+}
+
+__global__ void dgrad_perm_table_kernel(GatherEntry* __restrict__ tab, int* __restrict__ orow, unsigned* __restrict__ ttaps,
+                                        int bm, PermGeom pg, int N, int H, int W, int OH, int OW, int R, int S, int pad,
+                                        int row_bytes) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= pg.seg[4]) return;
+    int c = 0;
+    while (c < 3 && j >= pg.seg[c + 1]) ++c;
+    const int ch = c >> 1, cw = c & 1, hc = pg.hc[ch], wc = pg.wc[cw];
+    const int q = j - pg.seg[c];
+    GatherEntry e;
+    e.off0 = 0;
+    e.mask = 0;
+    int o = -1;
+    if (q < N * hc * wc) {
+        const int n = q / (hc * wc), rem = q - n * hc * wc;
+        const int h = 2 * (rem / wc) + ch, w = 2 * (rem % wc) + cw;
+        o = (n * H + h) * W + w;
+        // source dy is [N][OH][OW][K]; same arithmetic as gather_table_kernel's stride-2 branch
+        const int hs = h + pad, ws = w + pad;
+        e.off0 = ((n * OH + (hs >> 1)) * OW + (ws >> 1)) * row_bytes;
+        for (int r = 0; r < R; ++r)
+            for (int s = 0; s < S; ++s) {
+                const int th = hs - r, tw = ws - s;
+                if (th < 0 || tw < 0) continue;
+                if ((th | tw) & 1) continue;
+                if ((th >> 1) < OH && (tw >> 1) < OW) e.mask |= 1u << (r * S + s);
+            }
+    }
+    tab[j] = e;
+    orow[j] = o;
+    if (e.mask) atomicOr(&ttaps[j / bm], e.mask);  // integer OR: order-independent
+}
+
+int build_dgrad_perm_table(int dtype, int N, int H, int W, int C, int K, int R, int S, int pad, int bm, GatherEntry* table,
+                           hipStream_t st) {
+    GatherGeom g;
+    int rc = gather_geom(GATHER_DGRAD, dtype, N, H, W, C, K, R, S, 2, pad, &g);
+    if (rc) return rc;
+    const int P = (H + 2 * pad - R) / 2 + 1, Q = (W + 2 * pad - S) / 2 + 1;
+    const PermGeom pg = perm_geom(N, H, W, bm);
+    GDL_REQUIRE((size_t)pg.seg[4] <= dgrad_perm_cap(N, H, W), "gather: permuted table overflow");
+    const size_t cap = dgrad_perm_cap(N, H, W);
+    int* orow = (int*)(table + cap);
+    unsigned* ttaps = (unsigned*)(orow + cap);
+    hipError_t he = hipMemsetAsync(ttaps, 0, (cap / 64 + 1) * 4, st);
+    if (he != hipSuccess) return check_hip(he, "hipMemsetAsync(tile taps)");
+    hipLaunchKernelGGL(dgrad_perm_table_kernel, dim3(ceil_div(pg.seg[4], 256)), dim3(256), 0, st, table, orow, ttaps, bm, pg, N,
+                       H, W, P, Q, R, S, pad, g.row_bytes);
+    GDL_CHECK_LAUNCH("dgrad_perm_table_kernel");
     return GDL_OK;
 }
 
