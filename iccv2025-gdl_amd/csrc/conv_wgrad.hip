@@ -345,6 +345,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// conv_wgrad9.hip: all 9 taps per block for the 3x3 stride-1 convolutions (bf16)
+bool conv_wgrad9_enabled();
+bool conv_wgrad9_ok(int dtype, int W, int C, int K, int R, int S, int stride, int pad);
+size_t conv_wgrad9_ws_bytes(int M, int C, int K);
+int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K, void* ws,
+                size_t ws_bytes, hipStream_t st);
+
 // ---------------------------------------------------------------- host side
 struct WgradPlan {
     int tk, tc, nsplit, chunk;
@@ -377,7 +384,12 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS) {
 
 size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS) {
     const WgradPlan p = plan_wgrad(M, C, K, RS);
-    return (size_t)p.nsplit * K * RS * C * sizeof(float);
+    size_t b = (size_t)p.nsplit * K * RS * C * sizeof(float);
+    if (RS == 9 && conv_wgrad9_enabled()) {  // the 9-tap kernel's slices (geometry-independent upper bound)
+        const size_t b9 = conv_wgrad9_ws_bytes(M, C, K);
+        if (b9 > b) b = b9;
+    }
+    return b;
 }
 
 template <typename T, int TK, int TC>
@@ -406,6 +418,8 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "wgrad: bad dtype %d", dtype);
     GDL_REQUIRE(table, "wgrad: gather table is null (build it with gdl_conv_build_table)");
     GDL_REQUIRE(C % 64 == 0 && K % 64 == 0, "wgrad: C=%d K=%d must be multiples of 64", C, K);
+    if (Cout == C && conv_wgrad9_ok(dtype, W, C, K, R, S, stride, pad))
+        return conv_wgrad9(dy, x, dw, table, N, H, W, C, K, ws, ws_bytes, st);
     GatherGeom g;
     int rc = gather_geom(GATHER_FWD, dtype, N, H, W, C, K, R, S, stride, pad, &g);
     if (rc) return rc;

@@ -1,0 +1,388 @@
+// conv_wgrad9.hip -- weight gradient of the 3x3 stride-1 pad-1 convolutions, all 9 taps per block.
+//
+// Replaces the weight-gradient of nn.Conv2d(3x3, stride 1, padding 1)
+// (/root/reference/models/backbone.py:20-23; 32 of the 40 convolutions of the two encoders):
+//     dw[k][r][s][c] = sum_m dy[m][k] * x[m + (r-1)*W + (s-1)][c]      (flat NHWC pixel index m,
+//                                                                        zero where the tap is padding)
+// The per-tap kernel of conv_wgrad.hip re-reads dy and x once per tap: measured on MI355X it spends as
+// long issuing its LDS-DMA (the L2 -> LDS path saturates at ~52 B/clk/CU, tools/micro/dma_issue.hip)
+// as multiplying.  Here one block owns a 64(k) x 64(c) tile for ALL NINE taps and one slice of the
+// pixel range: per 64-pixel stage it fetches the dy tile (8 KB) and ONE contiguous slab of x,
+// pixels [m0-(W+1), m0+64+(W+1)), and every tap is a row shift of the LDS read address -- ~5x fewer
+// bytes through the DMA path per flop.  The reduction index (pixels) is the slow index of both LDS
+// tiles, so the MFMA fragments come from ds_read_b64_tr_b16 transpose reads, as in conv_wgrad.hip.
+//
+// Wave w of the 4 owns channels c0+16w..+15 for all 64 k: 36 accumulator fragments (9 taps x 4
+// k-fragments = 144 VGPRs); per 32-pixel K-step it reads the 4 dy fragments once and one x fragment
+// per tap, three taps ahead of the MFMAs (counted lgkmcnt).  All LDS addresses are precomputed per
+// lane (the swizzle of a shifted slab row does not change from stage to stage); a padding tap is a
+// per-lane select of the zero row, driven by the forward gather table's tap mask of the lane's pixel.
+// Partials go to the workspace in fragment order ([slice][tile][wave][tap][kfrag][lane][4], 16-byte
+// stores, 1 KiB per wave instruction); wgrad9_reduce_kernel folds the slices in a fixed order and
+// scatters to the reference's [K][C][3][3] layout (deterministic, no atomics).
+#include <stdlib.h>
+
+#include "common.h"
+#include "gather.h"
+#include "prof.h"
+
+namespace gdl {
+
+struct Wgrad9Args {
+    const void* dy;            // [M][K] bf16
+    const void* x;             // [M][C] bf16 (stride 1: same pixel grid as dy)
+    float* partial;            // [nsplit][K/64][C/64][4 waves][9][4][64][4]
+    const GatherEntry* table;  // forward gather table (tap masks), [M]
+    int C, K, M, W;
+    int nsplit, chunk;         // pixels per split (multiple of 64)
+    int tiles_k, tiles_c;
+    int slab_rows;             // 64 + 2W + 2
+    unsigned dy_bytes, x_bytes;
+};
+
+constexpr int W9_BP = 64;  // pixels per stage
+
+__device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 16, voffset, 0, 0, 0);
+#else
+    (void)rsrc;
+    (void)lds_base;
+    (void)voffset;
+#endif
+}
+// transpose read hidden from the compiler (see conv_wgrad.hip), with an instruction byte offset
+template <int OFF>
+__device__ __forceinline__ uint2 w9_tr(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void w9_wait() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// 32-byte granule swizzle of a 128-byte [pixel][64 channels] row (same as conv_wgrad.hip's wg_swz<128>)
+__device__ __forceinline__ int w9_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+
+    // block -> (slice, ktile, ctile); the tiles of one pixel slice are neighbours on one XCD
+    const int per_slice = a.tiles_k * a.tiles_c;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int slices_per_xcd = (a.nsplit + 7) >> 3;
+    const int slice = xcd * slices_per_xcd + j / per_slice;
+    if (slice >= a.nsplit) return;
+    const int rem = j % per_slice;
+    const int kt = rem % a.tiles_k, ct = rem / a.tiles_k;
+    const int k0 = kt * 64, c0 = ct * 64;
+    const int m_begin = slice * a.chunk;
+    const int m_end = min(a.M, m_begin + a.chunk);
+    const int nst = (m_end - m_begin + W9_BP - 1) / W9_BP;
+
+    const int nins = (a.slab_rows + 7) >> 3;        // 1 KiB DMA pieces of the slab
+    const int STAGE = W9_BP * 128 + nins * 1024;    // dy tile + slab
+    const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned zrow = smem_base + 2 * STAGE;    // 1 KiB of zeros
+
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+    if (wave == 0) w9_dma16(rx, smem + 2 * STAGE, (int)0x80000000);  // zero row (out-of-range DMA deposits zeros)
+
+    // ---- DMA bookkeeping.  A piece = 8 rows x 128 B; lane L -> row L>>3, physical 16-byte chunk L&7;
+    // the source chunk is the one whose swizzled position that is.
+    const int prow = lane >> 3, pch = lane & 7;
+    // dy tile: 8 pieces, wave w takes pieces w and w+4
+    int dy_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 4 * i) * 8 + prow;
+        const int ch = (((pch >> 1) ^ w9_swz(row)) << 1) | (pch & 1);
+        dy_off[i] = (m_begin + row) * (a.K * 2) + k0 * 2 + ch * 16;
+    }
+    int ld_m = m_begin;  // first pixel of the next stage to load
+    auto load_stage = [&](int buf) {
+        unsigned char* Ks = smem + buf * STAGE;
+        unsigned char* Xs = Ks + W9_BP * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = ld_m + (wave + 4 * i) * 8 + prow;
+            w9_dma16(rdy, Ks + (wave + 4 * i) * 1024, m < m_end ? dy_off[i] : (int)0x80000000);
+            dy_off[i] += W9_BP * a.K * 2;
+        }
+        for (int jj = wave; jj < nins; jj += 4) {
+            const int sr = jj * 8 + prow;
+            const int pix = ld_m - (a.W + 1) + sr;
+            const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.M;
+            const int ch = (((pch >> 1) ^ w9_swz(sr)) << 1) | (pch & 1);
+            w9_dma16(rx, Xs + jj * 1024, ok ? pix * (a.C * 2) + c0 * 2 + ch * 16 : (int)0x80000000);
+        }
+        ld_m += W9_BP;
+    };
+
+    // ---- per-lane LDS read addresses (stage buffer 0; the other buffer is +STAGE).
+    // transpose read: lane supplies row (li>>2) of its 16-lane group's 4x16 block, 8 bytes at element
+    // (li&3)*4 of the fragment's 16 channels; group g covers pixels g*8 + h*4 + 0..3 of the K-step.
+    const int lrow = g * 8 + (li >> 2);  // + h*4 + ks*32
+    unsigned aaddr[4][2];                // dy fragment i (k = 16i..), half h
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = lrow + h * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aaddr[i][h] = smem_base + row * 128 + ((i ^ w9_swz(row)) << 5) + (li & 3) * 8;
+    }
+    unsigned baddr[9][2];  // x fragment of tap t (this wave's 16 channels), half h
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int sh = (t / 3 - 1) * a.W + (t % 3 - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sr = lrow + h * 4 + (a.W + 1) + sh;
+            baddr[t][h] = smem_base + W9_BP * 128 + sr * 128 + ((wave ^ w9_swz(sr)) << 5) + (li & 3) * 8;
+        }
+    }
+    const unsigned zaddr = zrow + (li & 3) * 8;  // any 8 bytes of the zero KiB (K-step 1 reads at +4096: pre-biased there)
+    // tap masks of this lane's 4 pixels of a stage: [ks][h]
+    unsigned pmask[2][2], nmask[2][2];
+    auto load_masks = [&](int mbase, unsigned (&mk)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = mbase + ks * 32 + lrow + h * 4;
+                mk[ks][h] = m < m_end ? a.table[m].mask : 0u;
+            }
+    };
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) {
+        load_stage(0);
+        load_masks(m_begin, pmask);
+    }
+    for (int st = 0; st < nst; ++st) {
+        // the stage issued one iteration ago (and the masks) have landed; every wave is done with the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < nst) {
+            load_stage((st + 1) & 1);
+            load_masks(m_begin + (st + 1) * W9_BP, nmask);
+        }
+        // ---- two K-steps of 32 pixels (the second one 32 rows = 4096 bytes further: instruction offset)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint2 af[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) af[i][h] = ks ? w9_tr<4096>(aaddr[i][h]) : w9_tr<0>(aaddr[i][h]);
+            uint2 bf[3][2];  // ring of 3 taps
+            auto issue_b = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned ad = ((pmask[ks][h] >> t) & 1u) ? baddr[t][h] : (ks ? zaddr - 4096u : zaddr);
+                    bf[t % 3][h] = ks ? w9_tr<4096>(ad) : w9_tr<0>(ad);
+                }
+            };
+            issue_b(0);
+            issue_b(1);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 2 < 9) issue_b(t + 2);
+                // outstanding reads younger than tap t's: 2 per tap issued ahead
+                if (t + 2 < 9)
+                    w9_wait<4>();
+                else if (t + 1 < 9)
+                    w9_wait<2>();
+                else
+                    w9_wait<0>();
+                const uint4 fb = make_uint4(bf[t % 3][0].x, bf[t % 3][0].y, bf[t % 3][1].x, bf[t % 3][1].y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 fa = make_uint4(af[i][0].x, af[i][0].y, af[i][1].x, af[i][1].y);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                       __builtin_bit_cast(bf16x8_t, fb), acc[t][i], 0, 0, 0);
+                }
+            }
+        }
+        // next stage lives in the other buffer: move every read address over
+        const int dlt = (st & 1) ? -STAGE : STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) aaddr[i][h] += dlt;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) baddr[t][h] += dlt;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) pmask[ks][h] = nmask[ks][h];
+    }
+    // ---- partial tile in fragment order: [slice][kt][ct][wave][tap][i][lane][4]
+    float4* part = (float4*)a.partial + ((((size_t)slice * per_slice + rem) * 4 + wave) * 36) * 64;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            part[(t * 4 + i) * 64 + lane] = make_float4(acc[t][i][0], acc[t][i][1], acc[t][i][2], acc[t][i][3]);
+}
+
+// out[k][c][r][s] = sum_slice partial[slice][tile][wave][tap][i][lane][e], fixed order.
+// Block = 256 threads = 16 consecutive float4 outputs x 16 split-lanes (lane l sums slices l, l+16, ..);
+// D[i][j] fragment layout: k = 16i + (lane>>4)*4 + e, c = 16*wave + (lane&15).
+__global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float4* __restrict__ partial, float* __restrict__ out,
+                                                            int nsplit, int K, int C, int tiles_k, int tiles_c) {
+    __shared__ float4 red[16][16];
+    const size_t total4 = (size_t)K * C * 9 / 4;  // float4 elements per slice
+    const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const size_t idx = blockIdx.x * (size_t)16 + o;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < total4) {
+        int sp = l;
+        for (; sp + 16 < nsplit; sp += 32) {  // two slices in flight
+            const float4 v0 = partial[(size_t)sp * total4 + idx], v1 = partial[(size_t)(sp + 16) * total4 + idx];
+            s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
+            s.x += v1.x, s.y += v1.y, s.z += v1.z, s.w += v1.w;
+        }
+        if (sp < nsplit) {
+            const float4 v0 = partial[(size_t)sp * total4 + idx];
+            s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
+        }
+    }
+    red[l][o] = s;
+    __syncthreads();
+    if (l == 0 && idx < total4) {
+#pragma unroll
+        for (int jj = 1; jj < 16; ++jj) {
+            const float4 v = red[jj][o];
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
+        // decode fragment order: idx = (((tile*4 + wave)*9 + tap)*4 + i)*64 + lane
+        const int lane = (int)(idx & 63);
+        size_t r = idx >> 6;
+        const int i = (int)(r & 3);
+        r >>= 2;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int wave = (int)(r & 3);
+        const int tile = (int)(r >> 2);
+        const int kt = tile % tiles_k, ct = tile / tiles_k;
+        const int k = kt * 64 + i * 16 + (lane >> 4) * 4, c = ct * 64 + wave * 16 + (lane & 15);
+        float* dst = out + ((size_t)k * C + c) * 9 + tap;
+        const size_t kstride = (size_t)C * 9;
+        dst[0] = s.x;
+        dst[kstride] = s.y;
+        dst[2 * kstride] = s.z;
+        dst[3 * kstride] = s.w;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct W9Plan {
+    int nsplit, chunk;
+};
+static W9Plan plan_w9(int M, int C, int K) {
+    const int tiles = (K / 64) * (C / 64);
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("GDL_WGRAD9_BLOCKS");  // tuning aid
+        target = e ? atoi(e) : 512;
+    }
+    int ns = (target + tiles - 1) / tiles;
+    const int max_ns = (M + 2 * W9_BP - 1) / (2 * W9_BP);
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 1) ns = 1;
+    int chunk = (M + ns - 1) / ns;
+    chunk = (chunk + W9_BP - 1) / W9_BP * W9_BP;
+    W9Plan p;
+    p.nsplit = (M + chunk - 1) / chunk;
+    p.chunk = chunk;
+    return p;
+}
+
+bool conv_wgrad9_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_WGRAD9");  // tuning aid: 0 = per-tap kernel everywhere
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
+size_t conv_wgrad9_ws_bytes(int M, int C, int K) {
+    const W9Plan p = plan_w9(M, C, K);
+    return (size_t)p.nsplit * K * 9 * C * sizeof(float);
+}
+
+static size_t w9_lds_bytes(int W) {
+    const int rows = W9_BP + 2 * W + 2;
+    return 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024;
+}
+
+// true if this geometry runs on the 9-tap kernel
+bool conv_wgrad9_ok(int dtype, int W, int C, int K, int R, int S, int stride, int pad) {
+    return conv_wgrad9_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 64 == 0 &&
+           K % 64 == 0 && w9_lds_bytes(W) <= 80 * 1024;
+}
+
+int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K, void* ws,
+                size_t ws_bytes, hipStream_t st) {
+    Wgrad9Args a{};
+    a.dy = dy;
+    a.x = x;
+    a.table = (const GatherEntry*)table;
+    a.C = C;
+    a.K = K;
+    a.M = N * H * W;
+    a.W = W;
+    GDL_REQUIRE(a.M < (1 << 24), "wgrad: M exceeds 2^24");
+    GDL_REQUIRE((size_t)a.M * K * 2 < (1UL << 31) && (size_t)a.M * C * 2 < (1UL << 31), "wgrad: tensor exceeds 2 GiB");
+    a.dy_bytes = (unsigned)((size_t)a.M * K * 2);
+    a.x_bytes = (unsigned)((size_t)a.M * C * 2);
+    const W9Plan p = plan_w9(a.M, C, K);
+    a.nsplit = p.nsplit;
+    a.chunk = p.chunk;
+    a.tiles_k = K / 64;
+    a.tiles_c = C / 64;
+    a.slab_rows = W9_BP + 2 * W + 2;
+    const size_t need = (size_t)p.nsplit * K * 9 * C * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        set_error("wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDL_ERR_WORKSPACE;
+    }
+    a.partial = (float*)ws;
+    const size_t lds = w9_lds_bytes(W);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad9)");
+        attr_set = true;
+    }
+    const int per_slice = a.tiles_k * a.tiles_c;
+    const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
+    {
+        ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9);
+        hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(grid), dim3(256), lds, st, a);
+        GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
+    }
+    const size_t total4 = (size_t)K * C * 9 / 4;
+    ProfScope prof("gdl::wgrad9_reduce_kernel", PROF_HBM, st, (double)total4 * 16.0 * (p.nsplit + 1));
+    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, (const float4*)a.partial, dw,
+                       p.nsplit, K, C, a.tiles_k, a.tiles_c);
+    GDL_CHECK_LAUNCH("wgrad9_reduce_kernel");
+    return GDL_OK;
+}
+
+}  // namespace gdl
