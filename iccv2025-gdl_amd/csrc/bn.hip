@@ -89,22 +89,50 @@ __device__ __forceinline__ double block_sum_double(double v, double* sh) {
     return r;
 }
 
-__global__ __launch_bounds__(128) void bn_finalize_train_kernel(const float* __restrict__ partial, int tiles, int C,
-                                                                double count, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, float eps, float momentum,
-                                                                float* running_mean, float* running_var, int64_t* nbt,
-                                                                float* save_mean, float* save_rstd, float* scale,
-                                                                float* shift) {
-    __shared__ double sh[128];
-    const int c = blockIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
-        s += (double)partial[((size_t)t * C + c) * 2 + 0];
-        q += (double)partial[((size_t)t * C + c) * 2 + 1];
+// Column sums of a [rows][C][2] float array in double, FIN_CH channels per block: thread (rl, cl) adds
+// rows rl, rl+FIN_RL, .. of channel c0+cl (16 lanes read one 128-byte line; 8 rows in flight), the FIN_RL
+// row-lanes are then folded through LDS in a fixed order.  Returns the two sums to the threads rl == 0.
+constexpr int FIN_CH = 16, FIN_RL = 64;  // block = 1024 threads
+__device__ __forceinline__ void fin_colsum(const float* __restrict__ partial, int rows, int C, int c, double& s, double& q) {
+    __shared__ double sh[FIN_RL][FIN_CH][2];
+    const int rl = threadIdx.x / FIN_CH, cl = threadIdx.x % FIN_CH;
+    const float2* __restrict__ p2 = (const float2*)partial;
+    s = 0.0, q = 0.0;
+    int t = c < C ? rl : rows;  // channels past C (C not a multiple of FIN_CH) only take part in the barrier
+    for (; t + 7 * FIN_RL < rows; t += 8 * FIN_RL) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p2[(size_t)(t + u * FIN_RL) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s += (double)v[u].x;
+            q += (double)v[u].y;
+        }
     }
-    s = block_sum_double(s, sh);
-    q = block_sum_double(q, sh);
-    if (threadIdx.x == 0) {
+    for (; t < rows; t += FIN_RL) {
+        const float2 v = p2[(size_t)t * C + c];
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+    sh[rl][cl][0] = s;
+    sh[rl][cl][1] = q;
+    __syncthreads();
+    if (rl == 0) {
+        for (int r = 1; r < FIN_RL; ++r) {
+            s += sh[r][cl][0];
+            q += sh[r][cl][1];
+        }
+    }
+}
+
+__global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_finalize_train_kernel(
+    const float* __restrict__ partial, int tiles, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
+    float* save_mean, float* save_rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    double s, q;
+    fin_colsum(partial, tiles, C, c, s, q);
+    if (threadIdx.x < FIN_CH && c < C) {
         const double mean = s / count;
         double var = q / count - mean * mean;  // biased
         if (var < 0.0) var = 0.0;
@@ -125,8 +153,8 @@ __global__ __launch_bounds__(128) void bn_finalize_train_kernel(const float* __r
 int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
                       float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(C), dim3(128), 0, st, partial, tiles, C, count, gamma, beta, eps,
-                       momentum, rm, rv, nbt, save_mean, save_rstd, scale, shift);
+    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_RL), 0, st, partial, tiles, C, count,
+                       gamma, beta, eps, momentum, rm, rv, nbt, save_mean, save_rstd, scale, shift);
     GDL_CHECK_LAUNCH("bn_finalize_train_kernel");
     return GDL_OK;
 }
@@ -496,18 +524,13 @@ int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, c
 }
 
 // dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M
-__global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
-                                                              double count, float* dgamma, float* dbeta, float* coef) {
-    __shared__ double sh[128];
-    const int c = blockIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int t = threadIdx.x; t < blocks; t += blockDim.x) {
-        a += (double)partial[((size_t)t * C + c) * 2 + 0];
-        b += (double)partial[((size_t)t * C + c) * 2 + 1];
-    }
-    a = block_sum_double(a, sh);
-    b = block_sum_double(b, sh);
-    if (threadIdx.x == 0) {
+__global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                                         double count, float* dgamma, float* dbeta,
+                                                                         float* coef) {
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    double a, b;
+    fin_colsum(partial, blocks, C, c, a, b);
+    if (threadIdx.x < FIN_CH && c < C) {
         dbeta[c] = (float)a;
         dgamma[c] = (float)b;
         coef[c] = (float)(a / count);
@@ -516,7 +539,8 @@ __global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const float* __res
 }
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                     hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(128), 0, st, partial, blocks, C, count, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_RL), 0, st, partial, blocks, C, count, dgamma,
+                       dbeta, coef);
     GDL_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     return GDL_OK;
 }

@@ -688,8 +688,14 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
         const char* e = getenv("GDL_CONV_NOSLAB");  // tuning aid
         noslab = e ? atoi(e) : 0;
     }
+    static int slab_bm = -1;
+    if (slab_bm < 0) {
+        const char* e = getenv("GDL_SLAB_BM");  // tuning aid: force the slab kernel's M-tile (128 / 256)
+        slab_bm = e ? atoi(e) : 0;
+    }
     if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
         for (int bm : {256, 128}) {
+            if (slab_bm && bm != slab_bm) continue;
             const size_t lds = slab_lds_bytes(bm, W, IC, dtype);
             const long blocks = (long)((M + bm - 1) / bm) * (OC / 64);
             if (lds <= 80 * 1024 && (blocks >= 160 || bm == 128)) {

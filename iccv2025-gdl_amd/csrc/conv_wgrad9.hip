@@ -300,8 +300,14 @@ static W9Plan plan_w9(int M, int C, int K) {
         const char* e = getenv("GDL_WGRAD9_BLOCKS");  // tuning aid
         target = e ? atoi(e) : 512;
     }
+    // every block leaves 144 KB of partials: at least W9_MIN_STAGES stages of work per block
+    static int min_st = -1;
+    if (min_st < 0) {
+        const char* e = getenv("GDL_WGRAD9_MINST");  // tuning aid
+        min_st = e ? atoi(e) : 8;
+    }
     int ns = (target + tiles - 1) / tiles;
-    const int max_ns = (M + 2 * W9_BP - 1) / (2 * W9_BP);
+    const int max_ns = (M + min_st * W9_BP - 1) / (min_st * W9_BP);
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
     int chunk = (M + ns - 1) / ns;

@@ -69,7 +69,22 @@ struct gdl_encoder {
     std::vector<Block> blocks;
     int hf, wf;  // final map
     // scratch
-    void *gA = nullptr, *gB = nullptr, *gC = nullptr, *gD = nullptr, *gE = nullptr, *g0 = nullptr;
+    void *gA = nullptr, *gE = nullptr, *g0 = nullptr;
+    void *gB[2] = {nullptr, nullptr}, *gC[2] = {nullptr, nullptr}, *gD[2] = {nullptr, nullptr};  // by block parity
+    // Weight gradients run on an engine-owned low-priority side stream, forked from / joined into the
+    // caller's stream with events: they are off the dy -> dx dependency chain, so they fill the CUs
+    // the (often small) kernels of that chain leave idle.  The gradient buffers they read alternate
+    // with the block parity; ev_side[p] = "the side stream is done with parity p's buffers".
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side[2] = {nullptr, nullptr};
+    bool side_pending[2] = {false, false};
+    ~gdl_encoder() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (int p = 0; p < 2; ++p)
+            if (ev_side[p]) (void)hipEventDestroy(ev_side[p]);
+        if (side) (void)hipStreamDestroy(side);
+    }
     float *bn_partial = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr, *dw0p = nullptr;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
@@ -192,9 +207,11 @@ size_t gdl_encoder::plan(unsigned char* base) {
         prev = k.z;
     }
     gA = b.take(max_act * e);
-    gB = b.take(max_act * e);
-    gC = b.take(max_act * e);
-    gD = b.take(max_act * e);
+    for (int p = 0; p < 2; ++p) {
+        gB[p] = b.take(max_act * e);
+        gC[p] = b.take(max_act * e);
+        gD[p] = b.take(max_act * e);
+    }
     gE = b.take(max_act * e);
     g0 = b.take((size_t)m0 * 64 * e);
     bn_partial_floats = max_tiles_c * 2;
@@ -296,6 +313,26 @@ int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int 
         return GDL_ERR_STATE;
     }
     e->ws_bytes = e->plan(nullptr);
+    {
+        // Side stream policy.  Measured on MI355X: the step slows down 1.15-1.4x as soon as more than four
+        // streams carry work (hardware-queue oversubscription) or when a stream is created with a
+        // non-default priority, and only the visual encoder is on the critical path -- so by default only
+        // the visual engine forks its weight gradients (caller: main + audio + visual streams, + this one).
+        // GDL_SIDE_STREAM: 0 = never, 1 = every engine, unset = visual engines only.
+        const char* env = getenv("GDL_SIDE_STREAM");
+        const int mode = env ? atoi(env) : -1;
+        const bool want = mode == 1 || (mode == -1 && modality == GDL_VISUAL);
+        if (want) {
+            hipError_t he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+            for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipEventCreateWithFlags(&e->ev_side[p], hipEventDisableTiming);
+            if (he != hipSuccess) {
+                delete e;
+                return check_hip(he, "encoder_create: side stream");
+            }
+        }
+    }
     *out = e;
     return GDL_OK;
 }
@@ -478,9 +515,25 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
         RC(nchw_f32_to_nhwc(dt, dfmap_nchw, e->gA, e->n_img, e->hf, e->wf, 512, st));
     void* dz = e->gA;    // gradient w.r.t. the current block's output
     void* spare = e->gE;  // receives the gradient w.r.t. the block's input
+    // weight gradients: forked onto the side stream (sw) once their dy exists on st
+    hipStream_t sw = e->side ? e->side : st;
+    auto fork = [&]() -> int {  // sw waits for everything enqueued on st so far
+        if (!e->side) return GDL_OK;
+        hipError_t he = hipEventRecord(e->ev_fork, st);
+        if (he == hipSuccess) he = hipStreamWaitEvent(e->side, e->ev_fork, 0);
+        return he == hipSuccess ? GDL_OK : check_hip(he, "encoder_backward: fork");
+    };
+    e->side_pending[0] = e->side_pending[1] = false;
     for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
         Block& k = e->blocks[bi];
         const size_t Mo = (size_t)k.n * k.p * k.q;
+        const int par = bi & 1;
+        void *gB = e->gB[par], *gC = e->gC[par], *gD = e->gD[par];
+        if (e->side && e->side_pending[par]) {  // the side stream still reads this parity's buffers (two blocks ago)
+            hipError_t he = hipStreamWaitEvent(st, e->ev_side[par], 0);
+            if (he != hipSuccess) return check_hip(he, "encoder_backward: buffer wait");
+            e->side_pending[par] = false;
+        }
         // fused: do2 = dz * (z > 0) in place (relu of backbone.py:66) + reductions of bn2 (and of the
         // downsample BatchNorm); then finalize + apply per BatchNorm
         void* do2 = dz;
@@ -491,35 +544,43 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
             RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef,
                                st));
             RC(bn_bwd_apply(dt, do2, k.y2, k.b2.scale, k.b2.shift, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, 0,
-                            e->gB, Mo, k.cout, st));  // gB = dy2
+                            gB, Mo, k.cout, st));  // gB = dy2
             if (k.has_ds) {
                 RC(bn_bwd_finalize(e->bnb_partial2, blocks, k.cout, (double)Mo, grads[k.bd.pidx], grads[k.bd.pidx + 1],
                                    k.bd.coef, st));
                 RC(bn_bwd_apply(dt, do2, k.yd, k.bd.scale, k.bd.shift, k.bd.mean, k.bd.rstd, e->params[k.bd.pidx],
-                                k.bd.coef, 0, e->gD, Mo, k.cout, st));  // gD = dyd
+                                k.bd.coef, 0, gD, Mo, k.cout, st));  // gD = dyd
             }
         }
-        RC(conv_wgrad(dt, e->gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
-                      e->wg_ws, e->wg_ws_bytes, st));
-        RC(conv_dgrad(dt, e->gB, k.c2.w_crsk, e->gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
+        RC(fork());  // dy2 (and dyd) exist
+        RC(conv_wgrad(dt, gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
+                      e->wg_ws, e->wg_ws_bytes, sw));
+        if (k.has_ds)
+            RC(conv_wgrad(dt, gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0,
+                          k.cin, e->wg_ws, e->wg_ws_bytes, sw));
+        RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
                       st));  // gC = da1
         // relu + bn1 / conv1
-        RC(bn_backward(e, k.b1, e->gC, k.y1, 1, e->gC, Mo, grads, st));  // gC = dy1 (in place)
-        RC(conv_wgrad(dt, e->gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
-                      k.cin, e->wg_ws, e->wg_ws_bytes, st));
+        RC(bn_backward(e, k.b1, gC, k.y1, 1, gC, Mo, grads, st));  // gC = dy1 (in place)
+        RC(fork());  // dy1 exists
+        RC(conv_wgrad(dt, gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
+                      k.cin, e->wg_ws, e->wg_ws_bytes, sw));
+        if (e->side) {
+            hipError_t he = hipEventRecord(e->ev_side[par], e->side);
+            if (he != hipSuccess) return check_hip(he, "encoder_backward: side event");
+            e->side_pending[par] = true;
+        }
         void* dxin;
         if (k.has_ds) {
-            RC(conv_wgrad(dt, e->gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride,
-                          0, k.cin, e->wg_ws, e->wg_ws_bytes, st));
-            RC(conv_dgrad(dt, e->gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
+            RC(conv_dgrad(dt, gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
                           k.cd.stride, 0, st));
-            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, spare, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3,
+            RC(conv_dgrad(dt, gC, k.c1.w_crsk, spare, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3,
                           k.c1.stride, 1, st));
             dxin = spare;
             spare = dz;  // the old dz buffer is free now
         } else {
             // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
-            RC(conv_dgrad(dt, e->gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
+            RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
             dxin = do2;
         }
         dz = dxin;
@@ -527,8 +588,15 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
     // stem: maxpool -> relu -> bn1 -> conv1 weight gradient (the input needs no gradient)
     RC(maxpool_bwd(dt, dz, e->idx, e->g0, e->n_img, e->h0, e->w0, 64, st));
     RC(bn_backward(e, e->bn0, e->g0, e->y0, 1, e->g0, (size_t)e->m0, grads, st));
+    RC(fork());
     RC(conv_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0, e->cin * 49,
-                  e->wg_ws, e->wg_ws_bytes, st));
+                  e->wg_ws, e->wg_ws_bytes, sw));
+    if (e->side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
+        hipError_t he = hipEventRecord(e->ev_join, e->side);
+        if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);
+        if (he != hipSuccess) return check_hip(he, "encoder_backward: join");
+        e->side_pending[0] = e->side_pending[1] = false;
+    }
     return GDL_OK;
 }
 
