@@ -313,31 +313,28 @@ int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int 
         return GDL_ERR_STATE;
     }
     e->ws_bytes = e->plan(nullptr);
-    {
-        // Side stream policy.  Measured on MI355X: the step slows down 1.15-1.4x as soon as more than four
-        // streams carry work (hardware-queue oversubscription) or when a stream is created with a
-        // non-default priority, and only the visual encoder is on the critical path -- so by default only
-        // the visual engine forks its weight gradients (caller: main + audio + visual streams, + this one).
-        // GDL_SIDE_STREAM: 0 = never, 1 = every engine, unset = visual engines only.
-        const char* env = getenv("GDL_SIDE_STREAM");
-        const int mode = env ? atoi(env) : -1;
-        const bool want = mode == 1 || (mode == -1 && modality == GDL_VISUAL);
-        if (want) {
-            hipError_t he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-            if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
-            for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipEventCreateWithFlags(&e->ev_side[p], hipEventDisableTiming);
-            if (he != hipSuccess) {
-                delete e;
-                return check_hip(he, "encoder_create: side stream");
-            }
-        }
-    }
     *out = e;
     return GDL_OK;
 }
 
 void gdl_encoder_destroy(gdl_encoder_t* e) { delete e; }
+
+int gdl_encoder_side_stream(gdl_encoder_t* e, int enable) {
+    GDL_REQUIRE(e, "encoder_side_stream: null");
+    if (enable && !e->side) {
+        hipError_t he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+        for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipEventCreateWithFlags(&e->ev_side[p], hipEventDisableTiming);
+        if (he != hipSuccess) return check_hip(he, "encoder_side_stream");
+    } else if (!enable && e->side) {
+        hipError_t he = hipStreamSynchronize(e->side);
+        if (he != hipSuccess) return check_hip(he, "encoder_side_stream: sync");
+        (void)hipStreamDestroy(e->side);
+        e->side = nullptr;
+    }
+    return GDL_OK;
+}
 
 size_t gdl_encoder_workspace_bytes(const gdl_encoder_t* e) { return e ? e->ws_bytes : 0; }
 

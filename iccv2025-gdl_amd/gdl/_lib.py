@@ -61,6 +61,7 @@ SIGNATURES = {
     "gdl_optim_sgd_step": ("i", "ppppp" + "ffff" + "p"),
     "gdl_encoder_create": ("i", "piiiiii"),
     "gdl_encoder_destroy": (None, "p"),
+    "gdl_encoder_side_stream": ("i", "pi"),
     "gdl_encoder_workspace_bytes": ("z", "p"),
     "gdl_encoder_param_numel": ("i", "pp"),
     "gdl_encoder_out_shape": ("i", "pppp"),

@@ -35,6 +35,10 @@ class EncoderEngine:
         self.out_shape = (n.value, 512, hh.value, ww.value)
         self._bound = None
 
+    def side_stream(self, enable=True):
+        """Fork the weight gradients of backward() onto an engine-owned side stream (see include/gdl_hip.h)."""
+        L.call("gdl_encoder_side_stream", self.h, 1 if enable else 0)
+
     def __del__(self):
         try:
             if getattr(self, "h", None):

@@ -17,6 +17,7 @@ single-pass form is bit-identical in exact arithmetic, and tests/test_step_gpu.p
 against golden vectors of the reference.
 """
 import ctypes
+import os
 
 import torch
 
@@ -104,6 +105,13 @@ class DGLTrainer:
         self._key = key
         self.eng_a = EncoderEngine("audio", self.dtype, B, 1, F_, T_, self.device)
         self.eng_v = EncoderEngine("visual", self.dtype, B, T, H, W, self.device)
+        # A fourth stream for the visual (critical-path) encoder's weight gradients -- but never a fifth:
+        # with a process group the collective's stream is the fourth (see gdl_encoder_side_stream).
+        side = os.environ.get("GDL_SIDE_STREAM")  # tuning aid: 0 = off, 1 = both engines
+        if side == "1":
+            self.eng_a.side_stream(True)
+        if side == "1" or (side is None and self.reducer is None):
+            self.eng_v.side_stream(True)
         n, d = self.n_classes, self.device
         self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
         self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)

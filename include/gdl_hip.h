@@ -215,6 +215,13 @@ typedef struct gdl_encoder gdl_encoder_t;
 #define GDL_ENC_NBN 20
 GDL_API int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int T, int H, int W);
 GDL_API void gdl_encoder_destroy(gdl_encoder_t* e);
+/* enable != 0: gdl_encoder_backward forks the weight gradients (which are off the dy -> dx dependency chain)
+ * onto an engine-owned side stream and joins it back into the caller's stream before returning control of
+ * that stream, so the call keeps its single-stream semantics.  Off by default.  Measured on MI355X: a whole
+ * step slows down 1.15-1.4x once more than FOUR streams carry work, or when a stream has a non-default
+ * priority, so a caller running {main, audio, visual} streams enables this for the visual engine only (the
+ * critical path) and not at all when a collective's stream is active as well. */
+GDL_API int gdl_encoder_side_stream(gdl_encoder_t* e, int enable);
 GDL_API size_t gdl_encoder_workspace_bytes(const gdl_encoder_t* e);
 GDL_API int gdl_encoder_param_numel(const gdl_encoder_t* e, int64_t* numel /*[60]*/);
 GDL_API int gdl_encoder_out_shape(const gdl_encoder_t* e, int* n_img, int* h, int* w);

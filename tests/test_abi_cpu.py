@@ -1,0 +1,121 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/gdl_hip.h declares, the ctypes binding covers all of them, the pure host queries
+(table / workspace / tile counts, engine planning) behave, errors are reported the documented way,
+and the Python mirror of the reference interface keeps the reference's names and ordering."""
+import argparse
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "iccv2025-gdl_amd"))
+
+from gdl import _lib as L  # noqa: E402
+
+HEADER = os.path.join(ROOT, "include", "gdl_hip.h")
+
+
+def header_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"GDL_API\s+[\w\s\*]+?\b(gdl_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(L.SO_PATH)  # loads without a GPU: no HIP call happens at load time
+    names = header_symbols()
+    assert len(names) > 50
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/gdl_hip.h but not exported: {missing}"
+
+
+def test_binding_table_matches_header():
+    names = set(header_symbols())
+    bound = set(L.SIGNATURES)
+    assert names - bound == set(), f"no ctypes signature for {sorted(names - bound)}"
+    assert bound - names == set(), f"bound but not declared in the header: {sorted(bound - names)}"
+
+
+def test_host_queries_need_no_gpu():
+    lib = L.load()
+    bf16, f32 = L.dtype_code("bf16"), L.dtype_code("f32")
+    # stem K padding: 147 -> 192 (bf16, 64-element K-steps), 49 -> 64
+    assert lib.gdl_stem_kp(3, bf16) == 192 and lib.gdl_stem_kp(1, bf16) == 64
+    assert lib.gdl_stem_kp(3, f32) >= 147 and lib.gdl_stem_kp(3, f32) % 32 == 0 and lib.gdl_stem_kp(1, f32) == 64
+    # gather tables: 8 bytes per GEMM row; the permuted stride-2 data-gradient table carries row indices too
+    N, H, W = 4, 56, 56
+    assert lib.gdl_conv_table_bytes(L.GDL_GATHER_FWD if hasattr(L, "GDL_GATHER_FWD") else 0, N, H, W, 3, 3, 1, 1) == N * H * W * 8
+    assert lib.gdl_conv_table_bytes(0, N, H, W, 3, 3, 2, 1) == N * 28 * 28 * 8
+    assert lib.gdl_conv_table_bytes(1, N, H, W, 3, 3, 1, 1) == N * H * W * 8
+    assert lib.gdl_conv_table_bytes(1, N, H, W, 3, 3, 2, 1) > N * H * W * 12
+    # BatchNorm partial rows of a convolution = its M-tiles; workspace queries are monotone in the problem size
+    t_small = lib.gdl_conv_bn_tiles(bf16, 2, 56, 56, 64, 64, 3, 3, 1, 1)
+    t_big = lib.gdl_conv_bn_tiles(bf16, 192, 56, 56, 64, 64, 3, 3, 1, 1)
+    assert 0 < t_small < t_big
+    w_small = lib.gdl_conv_wgrad_workspace_bytes(bf16, 2, 56, 56, 64, 64, 3, 3, 1, 1)
+    w_big = lib.gdl_conv_wgrad_workspace_bytes(bf16, 192, 56, 56, 64, 64, 3, 3, 1, 1)
+    assert 0 < w_small <= w_big
+    assert lib.gdl_bn_bwd_blocks(1 << 20, 64) <= 2048 and lib.gdl_bn_bwd_blocks(1024, 64) >= 1
+
+
+def test_engine_plans_without_gpu_and_reports_errors():
+    lib = L.load()
+    h = ctypes.c_void_p()
+    L.call("gdl_encoder_create", ctypes.byref(h), L.GDL_VISUAL, L.dtype_code("bf16"), 2, 3, 224, 224)
+    try:
+        ws = lib.gdl_encoder_workspace_bytes(h)
+        assert ws > 0
+        numel = (ctypes.c_int64 * L.ENC_NPARAMS)()
+        L.call("gdl_encoder_param_numel", h, numel)
+        assert sum(numel) == 11176512  # visual ResNet18 without fc (SURVEY: 11.18 M)
+        n, hh, ww = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.call("gdl_encoder_out_shape", h, ctypes.byref(n), ctypes.byref(hh), ctypes.byref(ww))
+        assert (n.value, hh.value, ww.value) == (6, 7, 7)
+        # backward without a training forward: documented state error, message available
+        grads = (ctypes.c_void_p * L.ENC_NPARAMS)()
+        rc = lib.gdl_encoder_backward(h, None, None, grads, None)
+        assert rc != 0 and lib.gdl_last_error()
+    finally:
+        lib.gdl_encoder_destroy(h)
+    h2 = ctypes.c_void_p()
+    with pytest.raises(L.GdlError):
+        L.call("gdl_encoder_create", ctypes.byref(h2), L.GDL_AUDIO, L.dtype_code("bf16"), 2, 3, 257, 188)  # audio takes T=1
+    big = ctypes.c_void_p()
+    L.call("gdl_encoder_create", ctypes.byref(big), L.GDL_VISUAL, L.dtype_code("bf16"), 64, 3, 224, 224)
+    small_ws = ws
+    try:
+        assert lib.gdl_encoder_workspace_bytes(big) > 16 * small_ws  # sized for the real batch
+    finally:
+        lib.gdl_encoder_destroy(big)
+
+
+def test_mirror_keeps_reference_interface():
+    from models.basic_model import AVClassifier, AVClassifier_DGL
+    from models.fusion_modules import ConcatFusion, ConcatFusion_DGL
+    from utils.utils import setup_seed, weight_init
+
+    setup_seed(0)
+    args = argparse.Namespace(fusion_method="concat", dataset="CREMAD", modality="full")
+    m = AVClassifier_DGL(args)
+    m.apply(weight_init)
+    names = [n for n, _ in m.named_parameters()]
+    # main_dgl.py:117-121 drops the gradients of parameters whose name contains "fusion"; registration order
+    # fusion (4) -> audio_net (60) -> visual_net (60) as in basic_model.py:11-61
+    assert names[:4] == ["fusion_module.fc_out.weight", "fusion_module.fc_out.bias", "fusion_module.fc_auxi.weight",
+                         "fusion_module.fc_auxi.bias"]
+    assert names[4].startswith("audio_net.") and names[64].startswith("visual_net.") and len(names) == 124
+    assert m.audio_net.conv1.weight.shape == (64, 1, 7, 7) and m.visual_net.conv1.weight.shape == (64, 3, 7, 7)
+    assert m.fusion_module.fc_out.weight.shape == (6, 1024)
+    sd = m.state_dict()
+    assert "audio_net.bn1.num_batches_tracked" in sd and "visual_net.layer4.1.bn2.running_var" in sd
+    assert isinstance(m.fusion_module, ConcatFusion_DGL) and isinstance(AVClassifier(args).fusion_module, ConcatFusion)
+    for method in ("sum", "film", "gated"):
+        with pytest.raises(NotImplementedError):
+            AVClassifier_DGL(argparse.Namespace(fusion_method=method, dataset="CREMAD", modality="full"))
+    # no CPU fallback: CPU tensors are refused loudly
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 1, 257, 188), torch.zeros(1, 3, 3, 224, 224))

@@ -109,7 +109,7 @@ def check_step_against_golden(g, model_step, cfg, steps, rtol_logits=1e-3, rtol_
             assert abs(got - gn[i]) <= rtol_gn * gn[i] + 1e-6 * float(g[pre + "total_norm"]), (n, got, gn[i])
 
 
-@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "concat_cremad_b2"])
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2"])
 def test_step(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = json.loads(str(g["config"]))
