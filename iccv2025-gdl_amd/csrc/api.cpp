@@ -89,6 +89,38 @@ int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, const 
     return conv_wgrad(dtype, dy, col, dw, table, M, 1, 1, stem_kp(Cin, dtype), 64, 1, 1, 1, 0, Cin * 49, ws, ws_bytes,
                       (hipStream_t)stream);
 }
+// direct stem
+size_t gdl_stem_pad_bytes(int dtype, int n_img, int H, int W) { return dt_ok(dtype) ? stem_pad_bytes(dtype, n_img, H, W) : 0; }
+size_t gdl_stem_weight_bytes(int dtype) {
+    return dt_ok(dtype) ? (size_t)64 * stem_taps(dtype) * stem_ic(dtype) * (dtype == GDL_BF16 ? 2 : 4) : 0;
+}
+size_t gdl_stem_table_bytes(int n_img, int H, int W) {
+    return (size_t)n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * sizeof(GatherEntry);
+}
+int gdl_stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && xp, "stem_pad: bad arguments");
+    return stem_pad(dtype, x, xp, B, Cin, T, H, W, (hipStream_t)stream);
+}
+int gdl_pack_stem_rows(int dtype, const float* w, void* wp, int Cin, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && w && wp && Cin >= 1 && Cin <= 4, "pack_stem_rows: bad arguments");
+    return pack_stem_rows(dtype, w, wp, Cin, (hipStream_t)stream);
+}
+int gdl_stem_build_table(int dtype, int n_img, int H, int W, void* table, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && table, "stem_build_table: bad arguments");
+    return build_stem_table(dtype, n_img, H, W, stem_taps(dtype), (GatherEntry*)table, (hipStream_t)stream);
+}
+int gdl_stem_conv_bn_tiles(int dtype, int n_img, int H, int W) { return conv_stem_tiles_m(dtype, n_img, H, W); }
+int gdl_stem_conv_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img,
+                      int H, int W, int Cin, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype), "stem_conv_fwd: bad dtype");
+    return conv_stem_fwd(dtype, xp, wp, y, bn_partial, table, n_img, H, W, Cin, (hipStream_t)stream);
+}
+size_t gdl_stem_conv_wgrad_workspace_bytes(int n_img, int H, int W) { return conv_stem_wgrad_ws_bytes(n_img, H, W); }
+int gdl_stem_conv_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W,
+                        int Cin, void* ws, size_t ws_bytes, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && Cin >= 1 && Cin <= 4, "stem_conv_wgrad: bad arguments");
+    return conv_stem_wgrad(dtype, dy, xp, dw, table, n_img, H, W, Cin, ws, ws_bytes, (hipStream_t)stream);
+}
 int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && x && y, "nhwc_to_nchw: bad arguments");
     return nhwc_to_nchw_f32(dtype, x, y, N, H, W, C, (hipStream_t)stream);

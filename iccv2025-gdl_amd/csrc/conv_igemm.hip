@@ -45,6 +45,10 @@ struct ConvArgs {
     // permuted stride-2 data gradient (gather.h): output pixel of each GEMM row (-1: padding row)
     const int* orow;
     const unsigned* tile_taps;  // per M-tile: OR of its rows' tap masks
+    // direct bf16 stem (layout.hip): a 128-byte K-step is TWO 64-byte filter rows -- chunks 0..3 of a tile row
+    // come from off0 + delta[tap], chunks 4..7 from off0 + delta_hi[tap]
+    int split;
+    int delta_hi[9];
     double flops;  // algorithmic work of the launch (measurement tap)
 #ifdef GDL_TIMING
     unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
@@ -288,9 +292,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         e.off0 = 0;
         e.mask = 0;
         if (m < a.M) e = a.table[m];
-        a_off[i] = e.off0 + schunk * 16;
+        a_off[i] = e.off0 + (a.split ? (schunk & 3) : schunk) * 16;
         a_mask[i] = e.mask;
     }
+    const bool a_hi = a.split && (schunk >> 2);  // this lane's chunk belongs to the second filter row
     const int esz = (int)sizeof(T);
     int b_off[BROWS];
 #pragma unroll
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     auto load_tile = [&](int buf) {
         const bool live = ld_tap < a.ntaps;
         const int tap = live ? ld_tap : 0;
-        const int ua = a.delta[tap] + ld_kc * 128;        // uniform
+        const int ua = (a_hi ? a.delta_hi[tap] : a.delta[tap]) + ld_kc * 128;  // uniform unless split
         const int ub = (tap * a.IC) * esz + ld_kc * 128;  // uniform
         unsigned char* As = smem + buf * SM::STAGE;
         unsigned char* Bs = As + BM * 128;
@@ -798,6 +803,54 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
 int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,
              int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
     return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st);
+}
+
+// ---- direct stem forward (layout.hip / gather.h): implicit GEMM over the padded NHWC4 input
+int stem_taps(int dtype);
+int stem_ic(int dtype);
+int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
+    const int M = n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    return ceil_div(M, pick_cfg(M, 64, dtype).bm);
+}
+int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
+                  int W, int Cin, hipStream_t st) {
+    GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "stem: bad dtype %d", dtype);
+    GDL_REQUIRE(xp && wp && y && table, "stem: null pointer");
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
+    const int esz = dtype == GDL_BF16 ? 2 : 4, pix = 4 * esz;
+    ConvArgs a{};
+#ifdef GDL_TIMING
+    a.dbg = nullptr;
+#endif
+    a.in = xp;
+    a.wt = wp;
+    a.out = y;
+    a.stats = bn_partial;
+    a.table = (const GatherEntry*)table;
+    a.M = n_img * P * Q;
+    a.OC = 64;
+    a.IC = stem_ic(dtype);
+    a.ntaps = stem_taps(dtype);
+    a.in_bytes = (unsigned)((size_t)n_img * Hp * Wp * pix);
+    a.wt_bytes = (unsigned)((size_t)64 * a.ntaps * a.IC * esz);
+    if (dtype == GDL_BF16) {
+        a.split = 1;
+        for (int t = 0; t < 4; ++t) {
+            a.delta[t] = (2 * t) * Wp * pix;
+            a.delta_hi[t] = 2 * t + 1 < 7 ? (2 * t + 1) * Wp * pix : 0x40000000;  // no 8th filter row: out of range -> zeros
+        }
+    } else {
+        for (int t = 0; t < 7; ++t) a.delta[t] = t * Wp * pix;
+    }
+    GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
+    a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
+    const TileCfg c = pick_cfg(a.M, 64, dtype);
+    ConvPlan pl{};
+    pl.slab = 0;
+    pl.bm = c.bm;
+    pl.bn = c.bn;
+    if (dtype == GDL_BF16) return launch_mode<bf16, MODE_FWD>(a, pl, st);
+    return launch_mode<float, MODE_FWD>(a, pl, st);
 }
 
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,

@@ -33,6 +33,10 @@ struct WgradArgs {
     int tiles_k, tiles_c;
     unsigned dy_bytes, x_bytes;
     int delta[9];
+    // direct stem (layout.hip): the TC channels of a tap are TWO filter rows of the padded input -- the first
+    // half of a tile row comes from off0 + delta[tap], the second half from off0 + delta_hi[tap]
+    int split;
+    int delta_hi[9];
 #ifdef GDL_TIMING
     unsigned long long* dbg;
 #endif
@@ -131,12 +135,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         dy_off[i] = (m_begin + row) * (a.K * esz) + k0 * esz + ch * 16;
     }
     int x_ch[LC];
+    bool x_hi[LC];
 #pragma unroll
     for (int i = 0; i < LC; ++i) {
         const int idx = tid + 256 * i;
         const int row = idx / CPR_C, pc = idx % CPR_C;
-        x_ch[i] = ((((pc >> 1) ^ wg_swz<PC>(row)) << 1) | (pc & 1)) * 16;
+        const int lc = (((pc >> 1) ^ wg_swz<PC>(row)) << 1) | (pc & 1);  // logical chunk of this lane's LDS slot
+        x_hi[i] = a.split && lc >= CPR_C / 2;
+        x_ch[i] = (x_hi[i] ? lc - CPR_C / 2 : lc) * 16;
     }
+    const int tap_delta_hi = a.delta_hi[tap];
     GatherEntry ent[LC];  // table entries of the NEXT stage to load
 #pragma unroll
     for (int i = 0; i < LC; ++i) {
@@ -161,7 +169,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < LC; ++i) {
-            const int v = ((ent[i].mask >> tap) & 1u) ? ent[i].off0 + tap_delta + x_ch[i] : (int)0x80000000;
+            const int v = ((ent[i].mask >> tap) & 1u) ? ent[i].off0 + (x_hi[i] ? tap_delta_hi : tap_delta) + x_ch[i]
+                                                      : (int)0x80000000;
             wg_dma16(rx, Cs + 256 * 16 * i + wbase, v);
         }
         ld_m += WG_BP;
@@ -484,6 +493,73 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.partial, dw,
                            p.nsplit, K, R * S, C, Cout);
     GDL_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return GDL_OK;
+}
+
+// ---- direct stem weight gradient: dw[k][c][r][s] from dy [M][64] and the padded NHWC4 input.
+// GEMM per "tap" t = filter rows 2t, 2t+1: 64 k x 64 columns (2 rows x 8 pixels x 4 channels); the
+// reduce kernel picks the 7x7xCin real entries out of the [64][4][64] tile.
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                int nsplit, int Cin) {
+    const int total = 64 * Cin * 49;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int s = i % 7, r = (i / 7) % 7, c = (i / 49) % Cin, k = i / (49 * Cin);
+    const size_t idx = ((size_t)k * 4 + (r >> 1)) * 64 + (r & 1) * 32 + s * 4 + c;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int sp = 0; sp < nsplit; ++sp) acc += partial[(size_t)sp * (64 * 4 * 64) + idx];
+    out[i] = acc;
+}
+
+static WgradPlan plan_stem_wgrad(int M) { return plan_wgrad(M, 64, 64, 4); }
+size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W) {
+    const int M = n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    return (size_t)plan_stem_wgrad(M).nsplit * 64 * 4 * 64 * sizeof(float);
+}
+int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
+                    void* ws, size_t ws_bytes, hipStream_t st) {
+    GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "stem wgrad: bad dtype %d", dtype);
+    GDL_REQUIRE(dy && xp && dw && table, "stem wgrad: null pointer");
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
+    const int esz = dtype == GDL_BF16 ? 2 : 4, pix = 4 * esz;
+    WgradArgs a{};
+#ifdef GDL_TIMING
+    a.dbg = nullptr;
+#endif
+    a.dy = dy;
+    a.x = xp;
+    a.table = (const GatherEntry*)table;
+    a.C = 64;
+    a.K = 64;
+    a.RS = 4;
+    a.M = n_img * P * Q;
+    a.split = 1;
+    for (int t = 0; t < 4; ++t) {
+        a.delta[t] = (2 * t) * Wp * pix;
+        a.delta_hi[t] = 2 * t + 1 < 7 ? (2 * t + 1) * Wp * pix : 0x40000000;  // no 8th filter row: out of range -> zeros
+    }
+    GDL_REQUIRE(a.M < (1 << 24), "stem wgrad: M exceeds 2^24");
+    GDL_REQUIRE((size_t)a.M * 64 * esz < (1UL << 31), "stem wgrad: dy exceeds 2 GiB");
+    a.dy_bytes = (unsigned)((size_t)a.M * 64 * esz);
+    a.x_bytes = (unsigned)((size_t)n_img * Hp * Wp * pix);
+    const WgradPlan p = plan_stem_wgrad(a.M);
+    a.nsplit = p.nsplit;
+    a.chunk = p.chunk;
+    a.tiles_k = 1;
+    a.tiles_c = 1;
+    const size_t need = (size_t)p.nsplit * 64 * 4 * 64 * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        set_error("stem wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDL_ERR_WORKSPACE;
+    }
+    a.partial = (float*)ws;
+    int rc = dtype == GDL_BF16 ? launch_wg<bf16, 64, 64>(a, st) : launch_wg<float, 64, 64>(a, st);
+    if (rc) return rc;
+    ProfScope prof("gdl::stem_wgrad_reduce_kernel", PROF_HBM, st, (double)64 * Cin * 49 * 4.0 * (p.nsplit + 1));
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(64 * Cin * 49, 256)), dim3(256), 0, st, a.partial, dw, p.nsplit,
+                       Cin);
+    GDL_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
     return GDL_OK;
 }
 

@@ -122,8 +122,8 @@ size_t gdl_encoder::plan(unsigned char* base) {
     Bump b;
     b.base = base;
     const size_t e = (size_t)esz;
-    col = b.take((size_t)m0 * kp * e);
-    w0p = b.take((size_t)64 * kp * e);
+    col = b.take(stem_pad_bytes(dtype, n_img, H, W));  // zero-padded NHWC4 copy of the input (direct stem)
+    w0p = b.take((size_t)64 * stem_taps(dtype) * stem_ic(dtype) * e);
     y0 = b.take((size_t)m0 * 64 * e);
     x1 = b.take((size_t)n_img * h1 * w1 * 64 * e);
     idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
@@ -158,11 +158,11 @@ size_t gdl_encoder::plan(unsigned char* base) {
         tab_jobs.push_back(TabJob{mode, N, H, W, C, K, R, S, stride, pad, dst});
         return dst;
     };
-    tab_stem = table_for(GATHER_FWD, (int)m0, 1, 1, kp, 64, 1, 1, 1, 0);
+    tab_stem = b.take((size_t)m0 * sizeof(GatherEntry));
     size_t max_act = (size_t)n_img * h1 * w1 * 64;  // elements
-    size_t max_tiles_c = (size_t)conv_tiles_m(dtype, (int)m0, 1, 1, kp, 64, 1, 1, 1, 0) * 64;
+    size_t max_tiles_c = (size_t)conv_stem_tiles_m(dtype, n_img, H, W) * 64;
     size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0, 64) * 64;
-    size_t wg = conv_wgrad_ws_bytes((int)m0, kp, 64, 1);
+    size_t wg = conv_stem_wgrad_ws_bytes(n_img, H, W);
     const void* prev = x1;
     for (Block& k : blocks) {
         const size_t out_el = (size_t)k.n * k.p * k.q * k.cout;
@@ -403,6 +403,17 @@ static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double co
 }
 
 static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st) {
+    static int sep = -1;
+    if (sep < 0) {
+        const char* env = getenv("GDL_SEPARATE_STATS");  // tuning aid: statistics by a separate pass over y
+        sep = env ? atoi(env) : 0;
+    }
+    if (sep && training) {
+        RC(conv_fwd(e->dtype, x, c.w_krsc, y, nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st));
+        const int M = nimg * c.p * c.q;
+        RC(bn_stats(e->dtype, y, e->bn_partial, M, c.cout, st));
+        return bn_finalize(e, n, training, bn_stats_tiles(M), (double)M, st);
+    }
     RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? e->bn_partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout,
                 c.r, c.s, c.stride, c.pad, st));
     const int M = nimg * c.p * c.q;
@@ -419,8 +430,9 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     const int dt = e->dtype;
     if (!training) e->have_train_fwd = false;  // an eval pass overwrites the saved activations
     // weights -> kernel layouts (float32 master copies stay with the caller)
-    RC(pack_stem_weight(dt, e->params[0], e->w0p, e->cin, st));
+    RC(pack_stem_rows(dt, e->params[0], e->w0p, e->cin, st));
     if (e->tabs_dirty) {  // gather tables: once per bound workspace
+        RC(build_stem_table(dt, e->n_img, e->H, e->W, stem_taps(dt), (GatherEntry*)e->tab_stem, st));
         for (const gdl_encoder::TabJob& j : e->tab_jobs)
             RC(build_gather_table(j.mode, dt, j.N, j.H, j.W, j.C, j.K, j.R, j.S, j.stride, j.pad, (GatherEntry*)j.dst, st));
         e->tabs_dirty = false;
@@ -457,10 +469,10 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     }
     RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
     // stem: conv1 (7x7/2) as im2col + GEMM, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
-    RC(stem_im2col(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
-    RC(conv_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, (int)e->m0, 1, 1, e->kp, 64,
-                1, 1, 1, 0, st));
-    RC(bn_finalize(e, e->bn0, training, conv_tiles_m(dt, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0), (double)e->m0, st));
+    RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
+    RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin,
+                     st));
+    RC(bn_finalize(e, e->bn0, training, conv_stem_tiles_m(dt, e->n_img, e->H, e->W), (double)e->m0, st));
     RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, e->n_img, e->h0, e->w0, 64, st));
     // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
     for (Block& k : e->blocks) {
@@ -586,8 +598,7 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
     RC(maxpool_bwd(dt, dz, e->idx, e->g0, e->n_img, e->h0, e->w0, 64, st));
     RC(bn_backward(e, e->bn0, e->g0, e->y0, 1, e->g0, (size_t)e->m0, grads, st));
     RC(fork());
-    RC(conv_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, (int)e->m0, 1, 1, e->kp, 64, 1, 1, 1, 0, e->cin * 49,
-                  e->wg_ws, e->wg_ws_bytes, sw));
+    RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
     if (e->side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
         hipError_t he = hipEventRecord(e->ev_join, e->side);
         if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);

@@ -43,6 +43,8 @@ inline size_t dgrad_perm_cap(int N, int H, int W) { return (size_t)N * H * W + 4
 int dgrad_perm_rows(int N, int H, int W, int bm);
 int build_dgrad_perm_table(int dtype, int N, int H, int W, int C, int K, int R, int S, int pad, int bm, GatherEntry* table,
                            hipStream_t st);
+// direct stem (layout.hip): rows = output pixels (n,p,q), off0 = byte offset of padded pixel (n, 2p, 2q)
+int build_stem_table(int dtype, int n_img, int H, int W, int ntaps, GatherEntry* table, hipStream_t st);
 // bytes of a table (any mode / stride)
 size_t gather_table_bytes(int mode, int N, int H, int W, int R, int S, int stride, int pad);
 

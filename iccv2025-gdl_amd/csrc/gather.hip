@@ -80,6 +80,29 @@ int build_gather_table(int mode, int dtype, int N, int H, int W, int C, int K, i
     return GDL_OK;
 }
 
+// ---- direct-stem table: output pixel (n,p,q) -> padded input pixel (n, 2p, 2q); every K-step valid
+__global__ void stem_table_kernel(GatherEntry* __restrict__ tab, int rows, int P, int Q, int Hp, int Wp, int pixbytes,
+                                  unsigned mask) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= rows) return;
+    const int n = m / (P * Q), rem = m - n * P * Q;
+    const int p = rem / Q, q = rem - p * Q;
+    GatherEntry e;
+    e.off0 = ((n * Hp + 2 * p) * Wp + 2 * q) * pixbytes;
+    e.mask = mask;
+    tab[m] = e;
+}
+int build_stem_table(int dtype, int n_img, int H, int W, int ntaps, GatherEntry* table, hipStream_t st) {
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
+    const int pixbytes = 4 * (dtype == GDL_BF16 ? 2 : 4);
+    GDL_REQUIRE((size_t)n_img * Hp * Wp * pixbytes < (1UL << 30), "stem table: padded input exceeds 1 GiB");
+    const int rows = n_img * P * Q;
+    hipLaunchKernelGGL(stem_table_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, table, rows, P, Q, Hp, Wp, pixbytes,
+                       (1u << ntaps) - 1u);
+    GDL_CHECK_LAUNCH("stem_table_kernel");
+    return GDL_OK;
+}
+
 // ---- permuted stride-2 data-gradient table (see gather.h)
 struct PermGeom {
     int seg[5];     // first GEMM row of class c = (h&1)*2 + (w&1); seg[4] = total rows

@@ -127,6 +127,80 @@ int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int
     return GDL_OK;
 }
 
+// ---------------------------------------------------------------- direct (implicit-GEMM) stem
+// The 7x7/2 pad-3 stem as an implicit GEMM needs no im2col matrix if the network input is first copied
+// ONCE into a zero-padded channels-last image with 4 channels per pixel:
+//     xp [n_img][H+6][W+8][4] of T   (3 rows / columns of zeros before, >= 3 rows / 5 columns after)
+// A filter row of an output pixel (p,q) is then the 8 consecutive pixels (2p+r, 2q..2q+7) = 32 elements
+// = 64 bytes (bf16) / 128 bytes (f32), always in bounds, 8 / 16-byte aligned; the 8th pixel and the 4th
+// channel meet zero weights.  The GEMM's K-steps ("taps") are 128 bytes: one filter row in f32, two in
+// bf16.  For CREMA-D's visual batch this replaces a 925 MB matrix (written once, read by the forward
+// GEMM and by the weight gradient) by an 82 MB image that stays cache resident.
+int stem_pad_hp(int H) { return H + 6; }
+int stem_pad_wp(int W) { return W + 8; }
+size_t stem_pad_bytes(int dtype, int n_img, int H, int W) {
+    return (size_t)n_img * stem_pad_hp(H) * stem_pad_wp(W) * 4 * (dtype == GDL_BF16 ? 2 : 4);
+}
+int stem_taps(int dtype) { return dtype == GDL_BF16 ? 4 : 7; }  // K-steps of the forward GEMM
+int stem_ic(int dtype) { return dtype == GDL_BF16 ? 64 : 32; }   // elements per K-step
+
+// x float32 [B][Cin][T][H][W] (image n = b*T + t, backbone.py:162-164) -> xp.  One thread = one pixel.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pad_kernel(const float* __restrict__ x, T* __restrict__ xp, int Cin, int Tn, int H,
+                                                       int W, int Hp, int Wp, size_t total) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int wp = (int)(i % Wp);
+        size_t t = i / Wp;
+        const int hp = (int)(t % Hp);
+        const int n = (int)(t / Hp);
+        const int h = hp - 3, w = wp - 3;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            const int b = n / Tn, tt = n - b * Tn;
+            for (int c = 0; c < Cin; ++c) v[c] = x[((((size_t)b * Cin + c) * Tn + tt) * H + h) * W + w];
+        }
+        if (sizeof(T) == 2)
+            *(uint2*)(xp + i * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else
+            *(float4*)(xp + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st) {
+    GDL_REQUIRE(Cin >= 1 && Cin <= 4, "stem_pad: Cin=%d", Cin);
+    const int Hp = stem_pad_hp(H), Wp = stem_pad_wp(W);
+    const size_t total = (size_t)B * T * Hp * Wp;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::stem_pad_kernel<gdl::bf16>" : "gdl::stem_pad_kernel<float>", PROF_HBM, st,
+                   (double)B * Cin * T * H * W * 4.0 + (double)total * 4 * (dtype == GDL_BF16 ? 2 : 4));
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(stem_pad_kernel<bf16>, dim3(grid), dim3(256), 0, st, x, (bf16*)xp, Cin, T, H, W, Hp, Wp, total);
+    else
+        hipLaunchKernelGGL(stem_pad_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)xp, Cin, T, H, W, Hp, Wp, total);
+    GDL_CHECK_LAUNCH("stem_pad_kernel");
+    return GDL_OK;
+}
+
+// float32 [64][Cin][7][7] -> T [64][taps][IC]: element e of K-step t is filter row r = t*rows + e/32
+// (rows = filter rows per K-step), pixel s = (e%32)/4, channel e%4; everything else is zero.
+template <typename T>
+__global__ void pack_stem_rows_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int taps, int ic) {
+    const int total = 64 * taps * ic, rows = ic / 32;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int e = i % ic, t = (i / ic) % taps, k = i / (ic * taps);
+        const int r = t * rows + e / 32, s = (e % 32) / 4, c = e % 4;
+        storeT<T>(wp + i, (r < 7 && s < 7 && c < Cin) ? w[((k * Cin + c) * 7 + r) * 7 + s] : 0.f);
+    }
+}
+int pack_stem_rows(int dtype, const float* w, void* wp, int cin, hipStream_t st) {
+    const int taps = stem_taps(dtype), ic = stem_ic(dtype);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(pack_stem_rows_kernel<bf16>, dim3(64), dim3(256), 0, st, w, (bf16*)wp, cin, taps, ic);
+    else
+        hipLaunchKernelGGL(pack_stem_rows_kernel<float>, dim3(64), dim3(256), 0, st, w, (float*)wp, cin, taps, ic);
+    GDL_CHECK_LAUNCH("pack_stem_rows_kernel");
+    return GDL_OK;
+}
+
 // ---------------------------------------------------------------- batched weight packing
 // One launch packs every conv weight of an encoder: desc[i] names a float32 [K][C][RS] source and
 // its two destinations; block ranges [blk0, blk0+nblk) are assigned per tensor.

@@ -14,6 +14,19 @@ int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_pa
              int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
+// direct (implicit-GEMM) stem: layout.hip (padded NHWC4 input, row-wise weights), gather.hip (table),
+// conv_igemm.hip (forward), conv_wgrad.hip (weight gradient)
+size_t stem_pad_bytes(int dtype, int n_img, int H, int W);
+int stem_taps(int dtype);
+int stem_ic(int dtype);
+int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st);
+int pack_stem_rows(int dtype, const float* w, void* wp, int cin, hipStream_t st);
+int conv_stem_tiles_m(int dtype, int n_img, int H, int W);
+int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
+                  int W, int Cin, hipStream_t st);
+size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W);
+int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
+                    void* ws, size_t ws_bytes, hipStream_t st);
 // conv_wgrad.hip
 size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS);
 int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K,

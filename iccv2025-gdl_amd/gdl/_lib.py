@@ -34,6 +34,16 @@ SIGNATURES = {
     "gdl_stem_im2col": ("i", "ipp" + "iiiii" + "p"),
     "gdl_pack_stem_weight": ("i", "ippip"),
     "gdl_stem_wgrad": ("i", "ipppp" + "ii" + "pzp"),
+    "gdl_stem_pad_bytes": ("z", "iiii"),
+    "gdl_stem_weight_bytes": ("z", "i"),
+    "gdl_stem_table_bytes": ("z", "iii"),
+    "gdl_stem_pad": ("i", "ippiiiii" + "p"),
+    "gdl_pack_stem_rows": ("i", "ippi" + "p"),
+    "gdl_stem_build_table": ("i", "iiiip" + "p"),
+    "gdl_stem_conv_bn_tiles": ("i", "iiii"),
+    "gdl_stem_conv_fwd": ("i", "ippppp" + "iiii" + "p"),
+    "gdl_stem_conv_wgrad_workspace_bytes": ("z", "iii"),
+    "gdl_stem_conv_wgrad": ("i", "ipppp" + "iiii" + "pz" + "p"),
     "gdl_nhwc_to_nchw_f32": ("i", "ipp" + "iiii" + "p"),
     "gdl_nchw_f32_to_nhwc": ("i", "ipp" + "iiii" + "p"),
     "gdl_bn_stats_tiles": ("i", "i"),

@@ -94,6 +94,29 @@ GDL_API int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, v
 GDL_API int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, const void* table, int M, int Cin,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* Direct (implicit-GEMM) stem -- what the encoder engine runs; the im2col entry points above remain for
+ * callers that want the matrix.  The reference's input tensor (same as gdl_stem_im2col) is copied once
+ * into a zero-padded channels-last image with 4 channels per pixel,
+ *     xp [B*T][H+6][W+8][4] dtype   (gdl_stem_pad_bytes bytes),
+ * in which a filter row of an output pixel is 8 consecutive pixels (64 bytes bf16 / 128 bytes f32).
+ * gdl_pack_stem_rows: float32 [64][Cin][7][7] -> dtype [64][taps][IC] (gdl_stem_weight_bytes bytes;
+ * one 128-byte K-step = one filter row in f32, two in bf16; padding slots are zero).
+ * gdl_stem_build_table: the gather table of the stem (gdl_stem_table_bytes bytes), built once per shape.
+ * gdl_stem_conv_fwd: y NHWC [B*T][P][Q][64] dtype (+ BatchNorm partials as gdl_conv_fwd,
+ *   tiles = gdl_stem_conv_bn_tiles).  gdl_stem_conv_wgrad: dw [64][Cin][7][7] float32 from dy [M][64]. */
+GDL_API size_t gdl_stem_pad_bytes(int dtype, int n_img, int H, int W);
+GDL_API size_t gdl_stem_weight_bytes(int dtype);
+GDL_API size_t gdl_stem_table_bytes(int n_img, int H, int W);
+GDL_API int gdl_stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, void* stream);
+GDL_API int gdl_pack_stem_rows(int dtype, const float* w, void* wp, int Cin, void* stream);
+GDL_API int gdl_stem_build_table(int dtype, int n_img, int H, int W, void* table, void* stream);
+GDL_API int gdl_stem_conv_bn_tiles(int dtype, int n_img, int H, int W);
+GDL_API int gdl_stem_conv_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table,
+                              int n_img, int H, int W, int Cin, void* stream);
+GDL_API size_t gdl_stem_conv_wgrad_workspace_bytes(int n_img, int H, int W);
+GDL_API int gdl_stem_conv_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H,
+                                int W, int Cin, void* ws, size_t ws_bytes, void* stream);
+
 /* layout conversion at the module boundary: NHWC dtype <-> NCHW float32 */
 GDL_API int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream);
 GDL_API int gdl_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, int C, void* stream);

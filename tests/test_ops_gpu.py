@@ -153,6 +153,50 @@ def test_stem(case, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("case", [("audio", 2, 1, 1, 65, 47), ("visual", 2, 3, 2, 40, 36), ("visual_odd", 1, 3, 3, 33, 29)])
+def test_stem_direct(case, dt):
+    """7x7/2 stem as an implicit GEMM over the padded NHWC4 input (what the engine runs): forward with BatchNorm
+    partials and weight gradient against the oracle's direct conv."""
+    _, B, Cin, T, H, W = case
+    lib = L.load()
+    x = rng.standard_normal((B, Cin, T, H, W), dtype=np.float32)
+    w = (rng.standard_normal((64, Cin, 7, 7), dtype=np.float32) * 0.1).astype(np.float32)
+    xq, wq = quant(x, dt), quant(w, dt)  # the padded copy / the packed weights round to the storage type
+    x4 = np.ascontiguousarray(xq.transpose(0, 2, 1, 3, 4)).reshape(B * T, Cin, H, W)
+    ref = orc.conv2d_fwd(x4, wq, 2, 3)
+    n_img, P, Q = B * T, ref.shape[2], ref.shape[3]
+    M = n_img * P * Q
+    st = L.cur_stream()
+    xp = torch.empty(lib.gdl_stem_pad_bytes(dt, n_img, H, W), dtype=torch.uint8, device=DEV)
+    wp = torch.empty(lib.gdl_stem_weight_bytes(dt), dtype=torch.uint8, device=DEV)
+    tab = torch.empty(lib.gdl_stem_table_bytes(n_img, H, W), dtype=torch.uint8, device=DEV)
+    y = empty((n_img, P, Q, 64), dt)
+    tiles = lib.gdl_stem_conv_bn_tiles(dt, n_img, H, W)
+    part = torch.full((tiles, 64, 2), float("nan"), device=DEV)
+    xd, wd = dev(x), dev(w)
+    L.call("gdl_stem_pad", dt, L.ptr(xd), L.ptr(xp), B, Cin, T, H, W, st)
+    L.call("gdl_pack_stem_rows", dt, L.ptr(wd), L.ptr(wp), Cin, st)
+    L.call("gdl_stem_build_table", dt, n_img, H, W, L.ptr(tab), st)
+    L.call("gdl_stem_conv_fwd", dt, L.ptr(xp), L.ptr(wp), L.ptr(y), L.ptr(part), L.ptr(tab), n_img, H, W, Cin, st)
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert relerr(got, ref) < tol(dt, 2e-6, 3e-3), relerr(got, ref)
+    # partials are the per-channel sum / sum of squares of the STORED values
+    s = part.sum(0).cpu().numpy()
+    gq = got.transpose(1, 0, 2, 3).reshape(64, -1).astype(np.float64)
+    assert np.allclose(s[:, 0], gq.sum(1), rtol=1e-4, atol=1e-2) and np.allclose(s[:, 1], (gq * gq).sum(1), rtol=1e-4, atol=1e-2)
+    dy = quant(rng.standard_normal((n_img, 64, P, Q), dtype=np.float32), dt)
+    refw = orc.conv2d_bwd_weight(dy, x4, (64, Cin, 7, 7), 2, 3)
+    dyd = to_nhwc(dy, dt)
+    nbytes = lib.gdl_stem_conv_wgrad_workspace_bytes(n_img, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
+    L.call("gdl_stem_conv_wgrad", dt, L.ptr(dyd), L.ptr(xp), L.ptr(dw), L.ptr(tab), n_img, H, W, Cin, L.ptr(ws), nbytes, st)
+    torch.cuda.synchronize()
+    assert relerr(dw.cpu().numpy(), refw) < 2e-5, relerr(dw.cpu().numpy(), refw)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C,N,H,W", [(64, 3, 9, 7), (128, 2, 17, 12), (512, 4, 3, 2)])
 def test_bn_forward_backward(C, N, H, W, dt):
     x = quant(rng.standard_normal((N, C, H, W), dtype=np.float32) * 1.7 + 0.3, dt)
