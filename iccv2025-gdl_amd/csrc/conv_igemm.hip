@@ -699,7 +699,9 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
         slab_bm = e ? atoi(e) : 0;
     }
     if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
-        for (int bm : {256, 128}) {
+        // Measured end to end (bench.py, four streams sharing the CUs): the 128-row tile (48 KB of LDS, three
+        // blocks per CU) beats the 256-row one (64 KB, two) by ~1 %, although they tie when run alone.
+        for (int bm : {128, 256}) {
             if (slab_bm && bm != slab_bm) continue;
             const size_t lds = slab_lds_bytes(bm, W, IC, dtype);
             const long blocks = (long)((M + bm - 1) / bm) * (OC / 64);
