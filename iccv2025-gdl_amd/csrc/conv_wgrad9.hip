@@ -298,7 +298,9 @@ static W9Plan plan_w9(int M, int C, int K) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("GDL_WGRAD9_BLOCKS");  // tuning aid
-        target = e ? atoi(e) : 512;
+        // 512 blocks win when the kernel runs alone (tools/bench_conv.py); inside the step, where four
+        // streams share the CUs and every block leaves 144 KB of partials, 256 do (bench.py: -2 % step time)
+        target = e ? atoi(e) : 256;
     }
     // every block leaves 144 KB of partials: at least W9_MIN_STAGES stages of work per block
     static int min_st = -1;
