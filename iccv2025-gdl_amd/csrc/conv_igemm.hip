@@ -26,6 +26,8 @@
 #include "gather.h"
 #include "prof.h"
 
+#include <hip/hip_ext.h>
+
 namespace gdl {
 
 struct ConvArgs {
@@ -655,8 +657,8 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, WM, WN, MODE);
-    ProfScope prof(pname, PROF_MFMA, st, a.flops);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, a);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv_igemm_kernel");
     return GDL_OK;
 }
@@ -674,8 +676,8 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
     const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / 64);
     static char pname[96] = "";
     if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d>", prof_tname<T>(), BM, MODE);
-    ProfScope prof(pname, PROF_MFMA, st, a.flops);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, a);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
     return GDL_OK;
 }

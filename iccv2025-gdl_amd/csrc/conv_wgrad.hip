@@ -21,6 +21,8 @@
 #include "gather.h"
 #include "prof.h"
 
+#include <hip/hip_ext.h>
+
 namespace gdl {
 
 struct WgradArgs {
@@ -415,8 +417,8 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     static char pname[96] = "";
     if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv_wgrad_kernel<%s, %d, %d>", prof_tname<T>(), TK, TC);
-    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.K * a.C * a.RS);
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, a);
+    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.K * a.C * a.RS, true);
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv_wgrad_kernel");
     return GDL_OK;
 }

@@ -26,6 +26,8 @@
 #include "gather.h"
 #include "prof.h"
 
+#include <hip/hip_ext.h>
+
 namespace gdl {
 
 struct Wgrad9Args {
@@ -381,8 +383,8 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     const int per_slice = a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     {
-        ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9);
-        hipLaunchKernelGGL(conv_wgrad9_kernel, dim3(grid), dim3(256), lds, st, a);
+        ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true);
+        hipExtLaunchKernelGGL(conv_wgrad9_kernel, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
     }
     const size_t total4 = (size_t)K * C * 9 / 4;

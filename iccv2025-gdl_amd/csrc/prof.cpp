@@ -25,7 +25,14 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 
 bool prof_enabled() { return g_on; }
 
-int prof_begin(const char* name, int bound, hipStream_t st) {
+void prof_events(int token, hipEvent_t* e0, hipEvent_t* e1) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (token < 0 || token >= (int)g_recs.size()) return;
+    *e0 = g_recs[token].e0;
+    *e1 = g_recs[token].e1;
+}
+
+int prof_begin(const char* name, int bound, hipStream_t st, bool ext) {
     if (!g_on) return -1;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_filter.empty() && g_filter != name) return -1;
@@ -49,15 +56,15 @@ int prof_begin(const char* name, int bound, hipStream_t st) {
     } else {
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
     }
-    (void)hipEventRecord(r.e0, st);
+    if (!ext) (void)hipEventRecord(r.e0, st);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
 }
 
-void prof_end(int token, hipStream_t st, double work) {
+void prof_end(int token, hipStream_t st, double work, bool ext) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (token < 0 || token >= (int)g_recs.size()) return;
-    (void)hipEventRecord(g_recs[token].e1, st);
+    if (!ext) (void)hipEventRecord(g_recs[token].e1, st);
     g_recs[token].work = work;
 }
 

@@ -22,18 +22,35 @@ inline const char* prof_tname<bf16>() {
 }
 
 bool prof_enabled();
-// `name` must be a string with static lifetime; returns a token (>= 0) when enabled, -1 otherwise
-int prof_begin(const char* name, int bound, hipStream_t st);
+// `name` must be a string with static lifetime; returns a token (>= 0) when enabled, -1 otherwise.
+// ext: the caller passes the two events to hipExtLaunchKernelGGL, which stamps them with the kernel's own
+// begin / end times (what rocprofv3 reports); otherwise the events are recorded on the stream around the
+// launch, which on a device shared by several streams also counts the wait for free CUs.
+int prof_begin(const char* name, int bound, hipStream_t st, bool ext = false);
 // work: algorithmic flops (MFMA-bound kernels) or algorithmic bytes (HBM-bound kernels)
-void prof_end(int token, hipStream_t st, double work);
+void prof_end(int token, hipStream_t st, double work, bool ext = false);
+void prof_events(int token, hipEvent_t* e0, hipEvent_t* e1);
 
 struct ProfScope {
     int tok;
     hipStream_t st;
     double work;
-    ProfScope(const char* name, int bound, hipStream_t s, double w) : tok(prof_begin(name, bound, s)), st(s), work(w) {}
+    bool ext;
+    ProfScope(const char* name, int bound, hipStream_t s, double w, bool ext_launch = false)
+        : tok(prof_begin(name, bound, s, ext_launch)), st(s), work(w), ext(ext_launch) {}
     ~ProfScope() {
-        if (tok >= 0) prof_end(tok, st, work);
+        if (tok >= 0) prof_end(tok, st, work, ext);
+    }
+    // events for hipExtLaunchKernelGGL (null when the tap is off: a plain launch)
+    hipEvent_t e0() const {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (tok >= 0 && ext) prof_events(tok, &a, &b);
+        return a;
+    }
+    hipEvent_t e1() const {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (tok >= 0 && ext) prof_events(tok, &a, &b);
+        return b;
     }
 };
 
