@@ -181,8 +181,17 @@ def main():
         lib.gdl_prof_enable(0)
         d = [k for k in collect(a.steps) if k["kernel"] == dominant][0]
         lib.gdl_prof_set_filter(None)
+        # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes
+        # (tools/pmc_wgrad9.sh), so the committed measurement is read back here; null if it is not for this kernel
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(d["kernel"])
+            if pm and a.dtype == "bf16" and B == 64:
+                traffic = round(pm["bytes_per_launch"])
+        except (OSError, ValueError):
+            pass
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
-                else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": None, "kernel": d["kernel"],
+                else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
                 "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
     phases = None
     if a.phases and rank == 0:
