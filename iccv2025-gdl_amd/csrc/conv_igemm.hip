@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 template <int MI, int NI>
 __device__ __forceinline__ void slab_reads(uint4 (&px)[MI], uint4 (&wf)[NI], const unsigned (&pb)[MI], unsigned wb) {
     static_assert(MI == 2 || MI == 4, "MI");
-    static_assert(NI == 4, "NI");
+    static_assert(NI == 4 || NI == 8, "NI");
     px[0] = lds_read16_asm_off<0>(pb[0]);
     px[1] = lds_read16_asm_off<2048>(pb[1]);
     if constexpr (MI == 4) {
@@ -418,12 +418,18 @@ __device__ __forceinline__ void slab_reads(uint4 (&px)[MI], uint4 (&wf)[NI], con
     wf[1] = lds_read16_asm_off<2048>(wb);
     wf[2] = lds_read16_asm_off<4096>(wb);
     wf[3] = lds_read16_asm_off<6144>(wb);
+    if constexpr (NI == 8) {
+        wf[4] = lds_read16_asm_off<8192>(wb);
+        wf[5] = lds_read16_asm_off<10240>(wb);
+        wf[6] = lds_read16_asm_off<12288>(wb);
+        wf[7] = lds_read16_asm_off<14336>(wb);
+    }
 }
 
-template <typename T, int BM, int MODE>
+template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BN = 64, WM = 4, WN = 1;
+    constexpr int WM = 4, WN = 1;
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
     constexpr int BROWS = BN / 32;
@@ -449,13 +455,16 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     const int slab_bytes = nins * 1024;
     const unsigned smem_base = lds_addr(smem);
     const unsigned slab_base = smem_base + 2 * WSTAGE;
-    const unsigned zrow = slab_base + (kpt > 1 ? 2 : 1) * slab_bytes;
+    // zero row for masked (padding) taps: the rows of slab 0 past slab_rows (its last DMA piece is only partly
+    // used; the out-of-range lanes deposit zeros) when there are any, else 1 KiB after the slabs
+    const bool spare_row = (a.slab_rows & 7) != 0;
+    const unsigned zrow = spare_row ? slab_base + a.slab_rows * 128 : slab_base + (kpt > 1 ? 2 : 1) * slab_bytes;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
 
     // zero row: an out-of-range LDS-DMA deposits zeros (1 KiB, one wave instruction) -- no LDS store, no barrier
-    if (wave == 0) dma16(rin, smem + (zrow - smem_base), (int)0x80000000);
+    if (wave == 0 && !spare_row) dma16(rin, smem + (zrow - smem_base), (int)0x80000000);
 
     // per-lane validity masks of the MI pixel fragments this wave multiplies
     const int frow = lane & 15, fg = lane >> 4;
@@ -560,6 +569,7 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MI; ++m) pb[m] ^= 64u;
             slab_reads<MI, NI>(px[1], wf[1], pb, wb1);
+            // (lgkmcnt counts at most 15: with 8 weight fragments the second half's 10 reads are all that may remain)
             lds_wait_n<MI + NI>();
             TSEG(acc_rd)
 #pragma unroll
@@ -600,12 +610,12 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
 #endif
 }
 
-static size_t slab_lds_bytes(int BM, int W, int IC, int dtype) {
+static size_t slab_lds_bytes(int BM, int BN, int W, int IC, int dtype) {
     const int bke = dtype == GDL_BF16 ? 64 : 32, esz = dtype == GDL_BF16 ? 2 : 4;
     const int rows = BM + 2 * W + 2;
     const size_t slab = (size_t)((rows + 7) / 8) * 1024;
-    const size_t main = 2 * 64 * 128 + (IC / bke > 1 ? 2 : 1) * slab + 1024;
-    const size_t epi = (size_t)BM * (64 * esz + 16) + 4 * 64 * 2 * 4;
+    const size_t main = 2 * (size_t)BN * 128 + (IC / bke > 1 ? 2 : 1) * slab + ((rows & 7) ? 0 : 1024);
+    const size_t epi = (size_t)BM * (BN * esz + 16) + 4 * (size_t)BN * 2 * 4;
     return main > epi ? main : epi;
 }
 
@@ -663,19 +673,19 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     return GDL_OK;
 }
 
-template <typename T, int BM, int MODE>
+template <typename T, int BM, int BN, int MODE>
 static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, BM);
-    auto kfn = conv3x3_slab_kernel<T, BM, MODE>;
+    auto kfn = conv3x3_slab_kernel<T, BM, BN, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_slab)");
         attr_set = true;
     }
-    const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / 64);
+    const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / BN);
     static char pname[96] = "";
-    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d>", prof_tname<T>(), BM, MODE);
+    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d, %d>", prof_tname<T>(), BM, BN, MODE);
     ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
@@ -688,6 +698,14 @@ struct ConvPlan {
     int bm, bn;
     size_t lds;
 };
+static long slab_bn128_min() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_SLAB_BN128_MIN");  // tuning aid: fewest blocks for which the 128-channel tile is used
+        v = e ? atol(e) : 100;
+    }
+    return v;
+}
 static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad) {
     ConvPlan p{};
     static int noslab = -1;
@@ -703,9 +721,27 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
         // Measured end to end (bench.py, four streams sharing the CUs): the 128-row tile (48 KB of LDS, three
         // blocks per CU) beats the 256-row one (64 KB, two) by ~1 %, although they tie when run alone.
+        static int slab_bn = -1;
+        if (slab_bn < 0) {
+            const char* e = getenv("GDL_SLAB_BN");  // tuning aid: 64 = never use the 128-channel tile
+            slab_bn = e ? atoi(e) : 0;
+        }
+        // 128 x 128 tile when the layer is wide enough and still yields a block per CU: the slab is fetched
+        // once per 128 output channels and a K-step carries twice the MFMAs for the same barrier / DMA issue
+        if (!slab_bm && slab_bn != 64 && OC % 128 == 0) {
+            const size_t lds = slab_lds_bytes(128, 128, W, IC, dtype);
+            const long blocks = (long)((M + 127) / 128) * (OC / 128);
+            if (lds <= 80 * 1024 && blocks >= slab_bn128_min()) {
+                p.slab = 1;
+                p.bm = 128;
+                p.bn = 128;
+                p.lds = lds;
+                return p;
+            }
+        }
         for (int bm : {128, 256}) {
             if (slab_bm && bm != slab_bm) continue;
-            const size_t lds = slab_lds_bytes(bm, W, IC, dtype);
+            const size_t lds = slab_lds_bytes(bm, 64, W, IC, dtype);
             const long blocks = (long)((M + bm - 1) / bm) * (OC / 64);
             if (lds <= 80 * 1024 && (blocks >= 160 || bm == 128)) {
                 p.slab = 1;
@@ -726,8 +762,9 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
 template <typename T, int MODE>
 static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
     if (pl.slab) {
-        if (pl.bm == 256) return launch_slab<T, 256, MODE>(a, pl.lds, st);
-        return launch_slab<T, 128, MODE>(a, pl.lds, st);
+        if (pl.bn == 128) return launch_slab<T, 128, 128, MODE>(a, pl.lds, st);
+        if (pl.bm == 256) return launch_slab<T, 256, 64, MODE>(a, pl.lds, st);
+        return launch_slab<T, 128, 64, MODE>(a, pl.lds, st);
     }
     if (pl.bm == 256) return launch_one<T, 256, 64, 4, 1, MODE>(a, st);
     if (pl.bm == 128) return launch_one<T, 128, 64, 2, 2, MODE>(a, st);
