@@ -208,6 +208,13 @@ int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const fl
     return head_concat_bwd(x, y, W, g_x_out, g_y_out, g_out, out_reaches_xy, uni_in_dw, dx, dy, dW, db, B, n_classes,
                            (hipStream_t)stream);
 }
+int gdl_eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n_classes,
+                   int64_t* num, int64_t* acc, int64_t* acc_a, int64_t* acc_v, void* stream) {
+    GDL_REQUIRE(out && labels && num && acc && B > 0 && n_classes > 0, "eval_count: bad arguments");
+    GDL_REQUIRE((out_a != nullptr) == (acc_a != nullptr) && (out_v != nullptr) == (acc_v != nullptr),
+                "eval_count: a unimodal logit set needs its counter array and vice versa");
+    return eval_count(out, out_a, out_v, labels, B, n_classes, num, acc, acc_a, acc_v, (hipStream_t)stream);
+}
 int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
                    int n_classes, void* stream) {
     GDL_REQUIRE(logits && labels && loss && B > 0 && n_classes > 0, "softmax_ce: bad arguments");

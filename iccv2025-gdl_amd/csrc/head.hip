@@ -152,6 +152,42 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
 }
+// valid() of /root/reference/main_dgl.py:206-219 without its per-sample host loop: for every sample the
+// arg-max of the three logit sets (softmax is monotone, np.argmax takes the first maximum) is compared with
+// the label and four per-class counters are bumped: num[label]++, acc*[label] += (argmax == label).
+// Integer atomics: the result does not depend on the order.
+__global__ __launch_bounds__(256) void eval_count_kernel(const float* __restrict__ out, const float* __restrict__ out_a,
+                                                         const float* __restrict__ out_v, const int64_t* __restrict__ labels,
+                                                         int B, int n, unsigned long long* num, unsigned long long* acc,
+                                                         unsigned long long* acc_a, unsigned long long* acc_v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const int lab = (int)labels[i];
+    if (lab < 0 || lab >= n) return;  // (the reference would raise an IndexError)
+    const float* rows[3] = {out + (size_t)i * n, out_a ? out_a + (size_t)i * n : nullptr, out_v ? out_v + (size_t)i * n : nullptr};
+    unsigned long long* cnt[3] = {acc, acc_a, acc_v};
+    atomicAdd(&num[lab], 1ULL);
+    for (int h = 0; h < 3; ++h) {
+        if (!rows[h] || !cnt[h]) continue;
+        int best = 0;
+        float bv = rows[h][0];
+        for (int c = 1; c < n; ++c)
+            if (rows[h][c] > bv) {  // strict: first maximum wins, like np.argmax
+                bv = rows[h][c];
+                best = c;
+            }
+        if (best == lab) atomicAdd(&cnt[h][lab], 1ULL);
+    }
+}
+int eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n, int64_t* num,
+               int64_t* acc, int64_t* acc_a, int64_t* acc_v, hipStream_t st) {
+    hipLaunchKernelGGL(eval_count_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, st, out, out_a, out_v, labels, B, n,
+                       (unsigned long long*)num, (unsigned long long*)acc, (unsigned long long*)acc_a,
+                       (unsigned long long*)acc_v);
+    GDL_CHECK_LAUNCH("eval_count_kernel");
+    return GDL_OK;
+}
+
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
                hipStream_t st) {
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, scale, loss, dlogits, B, n);

@@ -198,6 +198,40 @@ class DGLTrainer:
             e.record(stream)
             self.phase_events.append((name, e))
 
+    # ------------------------------------------------------------------ validation (main_dgl.py:168-222)
+    def valid(self, batches):
+        """The reference's valid(): eval-mode forward (BatchNorm running statistics) of every (spec, image, label)
+        batch, arg-max of the three logit sets and per-class counters -- all on the device, one host copy at the
+        end instead of 3*B per batch.  Returns (acc, acc_a, acc_v) = sum(acc*)/sum(num) as main_dgl.py:222."""
+        n = self.n_classes
+        cnt = torch.zeros((4, n), dtype=torch.int64, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        for spec, image, label in batches:
+            self._prepare(spec, image)
+            self._bind()
+            audio = spec.unsqueeze(1)
+            label = label.contiguous()
+            ev = main.record_event()
+            self.s_a.wait_event(ev)
+            self.s_v.wait_event(ev)
+            with torch.cuda.stream(self.s_v):
+                self.eng_v.forward(image, False, feat_out=self.fv)
+            with torch.cuda.stream(self.s_a):
+                self.eng_a.forward(audio, False, feat_out=self.fa)
+            main.wait_stream(self.s_a)
+            main.wait_stream(self.s_v)
+            st = main.cuda_stream
+            dgl = self.mode == "dgl"
+            L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.pviews[0]), L.ptr(self.pviews[1]),
+                   L.ptr(self.out), L.ptr(self.out_a) if dgl else None, L.ptr(self.out_v) if dgl else None, self.B, n, st)
+            L.call("gdl_eval_count", L.ptr(self.out), L.ptr(self.out_a) if dgl else None, L.ptr(self.out_v) if dgl else None,
+                   L.ptr(label), self.B, n, cnt[0].data_ptr(), cnt[1].data_ptr(), cnt[2].data_ptr() if dgl else None,
+                   cnt[3].data_ptr() if dgl else None, st)
+        c = cnt.cpu().numpy().astype("float64")
+        self.valid_counts = c
+        tot = max(c[0].sum(), 1.0)
+        return c[1].sum() / tot, c[2].sum() / tot, c[3].sum() / tot
+
     # ------------------------------------------------------------------ results (host sync)
     def read(self):
         """Synchronises and returns the quantities the reference prints / logs per step."""

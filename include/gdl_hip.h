@@ -200,6 +200,13 @@ GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, 
                                 float* dy, float* dW, float* db, int B, int n_classes, void* stream);
 GDL_API int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
                            int n_classes, void* stream);
+/* valid() (main_dgl.py:185-222) without its per-sample host loop: per-class counters (int64[n_classes] each, the
+ * caller zeroes them once and accumulates over the batches of the validation set):
+ *   num[label[i]] += 1;  acc[label[i]] += (argmax(out[i]) == label[i]);  likewise acc_a / acc_v from out_a / out_v
+ * (first maximum wins, like np.argmax; softmax is monotone so it is not evaluated).  out_a/acc_a and out_v/acc_v
+ * may be NULL together.  Accuracies are sum(acc)/sum(num) etc. as in main_dgl.py:222. */
+GDL_API int gdl_eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B,
+                           int n_classes, int64_t* num, int64_t* acc, int64_t* acc_a, int64_t* acc_v, void* stream);
 
 /* ------------------------------------------------------------------ clip + grad stats + SGD
  * clip_grad_norm_(params, 40, 2) (main_dgl.py:129), the logged

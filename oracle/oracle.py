@@ -204,6 +204,28 @@ def softmax_ce(logits, labels, scale=1.0):
     return float(loss), d
 
 
+def valid_counts(out, out_a, out_v, labels, n_classes):
+    """Per-class counters of valid() (/root/reference/main_dgl.py:188-219), one batch: softmax, np.argmax per
+    sample, num[label] += 1 and acc*[label] += 1 where the prediction equals the label."""
+    num, acc, acc_a, acc_v = (np.zeros(n_classes, dtype=np.int64) for _ in range(4))
+
+    def softmax(z):
+        e = np.exp(z - z.max(axis=1, keepdims=True))
+        return e / e.sum(axis=1, keepdims=True)
+
+    pred, pa, pv = softmax(out), softmax(out_a), softmax(out_v)
+    for i in range(out.shape[0]):
+        lab = int(labels[i])
+        num[lab] += 1
+        if int(np.argmax(pred[i])) == lab:
+            acc[lab] += 1
+        if int(np.argmax(pv[i])) == lab:
+            acc_v[lab] += 1
+        if int(np.argmax(pa[i])) == lab:
+            acc_a[lab] += 1
+    return num, acc, acc_a, acc_v
+
+
 def sumsq(g):
     g = _c(g)
     return float(lib().orc_sumsq(_p(g), ctypes.c_size_t(g.size)))

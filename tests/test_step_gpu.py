@@ -92,6 +92,27 @@ def test_softmax_ce(B, n):
 
 
 # ------------------------------------------------------------------ fused clip + stats + SGD
+@pytest.mark.parametrize("B,n", [(64, 6), (7, 34), (513, 309)])
+def test_eval_count(B, n):
+    """Device-side counters of valid() against the numpy restatement of main_dgl.py:206-219 (ties included)."""
+    from oracle import oracle as orc
+
+    rs = np.random.default_rng(B * 1000 + n)
+    outs = [np.round(rs.standard_normal((B, n)).astype(np.float32) * 2, 1) for _ in range(3)]  # coarse grid: ties happen
+    labels = rs.integers(0, n, B).astype(np.int64)
+    ref = orc.valid_counts(outs[0], outs[1], outs[2], labels, n)
+    d = [torch.from_numpy(o).to(DEV) for o in outs]
+    lab = torch.from_numpy(labels).to(DEV)
+    cnt = torch.zeros((4, n), dtype=torch.int64, device=DEV)
+    for _ in range(2):  # counters accumulate over calls
+        L.call("gdl_eval_count", L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]), L.ptr(lab), B, n, cnt[0].data_ptr(), cnt[1].data_ptr(),
+               cnt[2].data_ptr(), cnt[3].data_ptr(), L.cur_stream())
+    torch.cuda.synchronize()
+    got = cnt.cpu().numpy()
+    for k in range(4):
+        np.testing.assert_array_equal(got[k], 2 * ref[k])
+
+
 @pytest.mark.parametrize("scale", [0.01, 10.0])  # below / above the clipping threshold
 def test_optim(scale):
     sizes = [6144, 6, 3136, 64, 64, 36864, 9, 147456, 8193]
@@ -273,6 +294,17 @@ def test_native_step_golden(name, dtype):
     ev = o[0] if cfg["mode"] == "dgl" else o[2]
     et = (1e-2 if cfg["steps"] > 1 else 2e-3) if f32 else (0.2 if tiny else 5e-2)
     np.testing.assert_allclose(ev.cpu().numpy(), g["eval.out"], rtol=et, atol=et)
+    # valid() on the device: the same eval-mode forward + the per-class counters, against the oracle's counting
+    # of the golden eval logits (classes whose top-2 golden logits are closer than the tolerance are skipped)
+    if cfg["mode"] == "dgl":
+        acc = tr.valid([(spec, image, label)])
+        go, ga, gv = g["eval.out"], g["eval.out_a"], g["eval.out_v"]
+        ref = orc.valid_counts(go, ga, gv, label.cpu().numpy(), cfg["n_classes"])
+        srt = np.sort(go, axis=1)
+        if np.all(srt[:, -1] - srt[:, -2] > 4 * et * np.abs(srt[:, -1]) + 4 * et):
+            assert abs(acc[0] - ref[1].sum() / ref[0].sum()) < 1e-12
+        np.testing.assert_array_equal(tr.valid_counts[0], ref[0])
+        assert all(0.0 <= a <= 1.0 for a in acc)
 
 
 def _bufnames(g, pre):
