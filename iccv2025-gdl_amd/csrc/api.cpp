@@ -208,6 +208,21 @@ int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const fl
     return head_concat_bwd(x, y, W, g_x_out, g_y_out, g_out, out_reaches_xy, uni_in_dw, dx, dy, dW, db, B, n_classes,
                            (hipStream_t)stream);
 }
+int gdl_head_sum_fwd(const float* x, const float* y, const float* Wx, const float* bx, const float* Wy, const float* by,
+                     float* out, float* x_out, float* y_out, int B, int n_classes, void* stream) {
+    GDL_REQUIRE(x && y && Wx && bx && Wy && by && out && B > 0 && n_classes > 0, "head_sum_fwd: bad arguments");
+    return head_sum_fwd(x, y, Wx, bx, Wy, by, out, x_out, y_out, B, n_classes, (hipStream_t)stream);
+}
+int gdl_head_sum_bwd(const float* x, const float* y, const float* Wx, const float* Wy, const float* g_x_out,
+                     const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy,
+                     float* dWx, float* dbx, float* dWy, float* dby, int B, int n_classes, void* stream) {
+    GDL_REQUIRE(x && y && Wx && Wy && B > 0 && n_classes > 0, "head_sum_bwd: bad arguments");
+    GDL_REQUIRE((dx != nullptr) == (dy != nullptr), "head_sum_bwd: dx/dy come in pairs");
+    GDL_REQUIRE((dWx != nullptr) == (dbx != nullptr) && (dWy != nullptr) == (dby != nullptr) && (dWx != nullptr) == (dWy != nullptr),
+                "head_sum_bwd: dWx/dbx/dWy/dby come together");
+    return head_sum_bwd(x, y, Wx, Wy, g_x_out, g_y_out, g_out, out_reaches_xy, uni_in_dw, dx, dy, dWx, dbx, dWy, dby, B,
+                        n_classes, (hipStream_t)stream);
+}
 int gdl_eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n_classes,
                    int64_t* num, int64_t* acc, int64_t* acc_a, int64_t* acc_v, void* stream) {
     GDL_REQUIRE(out && labels && num && acc && B > 0 && n_classes > 0, "eval_count: bad arguments");

@@ -14,9 +14,18 @@ namespace gdl {
 
 constexpr int HD = 512;  // features per modality
 
+// The two linear maps of a head and their biases.  ConcatFusion(_DGL): one [n][1024] matrix, Wx = W,
+// Wy = W + 512, ldw = 1024, one bias used by all three logit sets.  SumFusion_DGL (fusion_modules.py:16-30):
+// two [n][512] matrices fc_x / fc_y with their own biases; `output` carries bx + by.
+struct HeadW {
+    const float *Wx, *Wy;
+    int ldw;
+    const float *bx, *by;
+    int sum_bias;  // 1: out gets bx + by (sum head), 0: out gets bx (== by, concat head)
+};
+
 // grid = B; each wave handles classes j = wave, wave+4, ...; lanes split the 512-long dots.
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                       const float* __restrict__ W, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, HeadW w,
                                                        float* __restrict__ out, float* __restrict__ x_out,
                                                        float* __restrict__ y_out, int n) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -27,12 +36,13 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         yv[i] = y[(size_t)b * HD + lane + 64 * i];
     }
     for (int j = wave; j < n; j += 4) {
-        const float* w = W + (size_t)j * 2 * HD;
+        const float* wx = w.Wx + (size_t)j * w.ldw;
+        const float* wy = w.Wy + (size_t)j * w.ldw;
         float pa = 0.f, pv = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            pa += w[lane + 64 * i] * xv[i];
-            pv += w[HD + lane + 64 * i] * yv[i];
+            pa += wx[lane + 64 * i] * xv[i];
+            pv += wy[lane + 64 * i] * yv[i];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -40,22 +50,30 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
             pv += __shfl_xor(pv, o);
         }
         if (lane == 0) {
-            const float bj = bias[j];
-            out[(size_t)b * n + j] = pa + pv + bj;
-            if (x_out) x_out[(size_t)b * n + j] = pa + bj;
-            if (y_out) y_out[(size_t)b * n + j] = pv + bj;
+            const float bxj = w.bx[j], byj = w.by[j];
+            out[(size_t)b * n + j] = pa + pv + (w.sum_bias ? bxj + byj : bxj);
+            if (x_out) x_out[(size_t)b * n + j] = pa + bxj;
+            if (y_out) y_out[(size_t)b * n + j] = pv + byj;
         }
     }
 }
 int head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out,
                     int B, int n, hipStream_t st) {
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, st, x, y, W, b, out, x_out, y_out, n);
+    const HeadW w{W, W + HD, 2 * HD, b, b, 0};
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, st, x, y, w, out, x_out, y_out, n);
+    GDL_CHECK_LAUNCH("head_fwd_kernel");
+    return GDL_OK;
+}
+int head_sum_fwd(const float* x, const float* y, const float* Wx, const float* bx, const float* Wy, const float* by, float* out,
+                 float* x_out, float* y_out, int B, int n, hipStream_t st) {
+    const HeadW w{Wx, Wy, HD, bx, by, 1};
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, st, x, y, w, out, x_out, y_out, n);
     GDL_CHECK_LAUNCH("head_fwd_kernel");
     return GDL_OK;
 }
 
-// dx[b][i] = sum_j gx[b][j] * W[j][i]  (gx = g_x_out (+ g_out)), same for dy with W[j][512+i]
-__global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float* __restrict__ W, const float* __restrict__ g_x_out,
+// dx[b][i] = sum_j gx[b][j] * Wx[j][i]  (gx = g_x_out (+ g_out)), same for dy with Wy
+__global__ __launch_bounds__(256) void head_bwd_feat_kernel(HeadW w, const float* __restrict__ g_x_out,
                                                             const float* __restrict__ g_y_out,
                                                             const float* __restrict__ g_out, int out_reaches_xy,
                                                             float* __restrict__ dx, float* __restrict__ dy, int n) {
@@ -63,25 +81,29 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float* __restr
     for (int i = threadIdx.x; i < 2 * HD; i += 256) {
         const bool is_y = i >= HD;
         const float* gu = is_y ? g_y_out : g_x_out;
+        const float* W = is_y ? w.Wy : w.Wx;
+        const int fi = is_y ? i - HD : i;
         float s = 0.f;
         for (int j = 0; j < n; ++j) {
             float g = gu ? gu[(size_t)b * n + j] : 0.f;
             if (out_reaches_xy && g_out) g += g_out[(size_t)b * n + j];
-            s += g * W[(size_t)j * 2 * HD + i];
+            s += g * W[(size_t)j * w.ldw + fi];
         }
         if (is_y)
-            dy[(size_t)b * HD + (i - HD)] = s;
+            dy[(size_t)b * HD + fi] = s;
         else
-            dx[(size_t)b * HD + i] = s;
+            dx[(size_t)b * HD + fi] = s;
     }
 }
-// dW[j][i] = sum_b gw[b][j] * feat[b][i]; gw = g_out (+ g_x_out on the x half, + g_y_out on the y half if uni_in_dw)
-// db[j] = sum_b (g_out + uni*(g_x_out + g_y_out))[b][j].   grid = n classes.
+// dWx[j][i] = sum_b gw[b][j] * x[b][i], gw = g_out (+ g_x_out if uni_in_dw); dWy likewise with y / g_y_out.
+// concat head: one bias, db = sum_b (g_out + uni*(g_x_out + g_y_out)); sum head: dbx = sum_b (g_out + uni*g_x_out),
+// dby likewise.   grid = n classes.
 __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ g_x_out,
                                                          const float* __restrict__ g_y_out, const float* __restrict__ g_out,
-                                                         int uni_in_dw, float* __restrict__ dW, float* __restrict__ db,
-                                                         int B, int n) {
+                                                         int uni_in_dw, float* __restrict__ dWx, float* __restrict__ dWy,
+                                                         int ldw, float* __restrict__ dbx, float* __restrict__ dby, int B,
+                                                         int n) {
     const int j = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * HD; i += 256) {
         const bool is_y = i >= HD;
@@ -94,32 +116,53 @@ __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict
             if (uni_in_dw && gu) g += gu[(size_t)b * n + j];
             s += g * feat[(size_t)b * HD + fi];
         }
-        dW[(size_t)j * 2 * HD + i] = s;
+        (is_y ? dWy : dWx)[(size_t)j * ldw + fi] = s;
     }
     if (threadIdx.x == 0) {
-        float s = 0.f;
+        float so = 0.f, sx = 0.f, sy = 0.f;
         for (int b = 0; b < B; ++b) {
-            float g = g_out ? g_out[(size_t)b * n + j] : 0.f;
+            so += g_out ? g_out[(size_t)b * n + j] : 0.f;
             if (uni_in_dw) {
-                if (g_x_out) g += g_x_out[(size_t)b * n + j];
-                if (g_y_out) g += g_y_out[(size_t)b * n + j];
+                if (g_x_out) sx += g_x_out[(size_t)b * n + j];
+                if (g_y_out) sy += g_y_out[(size_t)b * n + j];
             }
-            s += g;
         }
-        db[j] = s;
+        if (dby) {  // sum head: two biases
+            dbx[j] = so + sx;
+            dby[j] = so + sy;
+        } else {
+            dbx[j] = so + sx + sy;
+        }
     }
 }
 int head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
                     const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db,
                     int B, int n, hipStream_t st) {
     if (dx && dy) {
-        hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(B), dim3(256), 0, st, W, g_x_out, g_y_out, g_out, out_reaches_xy, dx,
-                           dy, n);
+        const HeadW w{W, W + HD, 2 * HD, nullptr, nullptr, 0};
+        hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(B), dim3(256), 0, st, w, g_x_out, g_y_out, g_out, out_reaches_xy, dx, dy,
+                           n);
         GDL_CHECK_LAUNCH("head_bwd_feat_kernel");
     }
     if (dW && db) {
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dW, db, B,
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dW, dW + HD,
+                           2 * HD, db, (float*)nullptr, B, n);
+        GDL_CHECK_LAUNCH("head_bwd_w_kernel");
+    }
+    return GDL_OK;
+}
+int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* Wy, const float* g_x_out, const float* g_y_out,
+                 const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dWx, float* dbx,
+                 float* dWy, float* dby, int B, int n, hipStream_t st) {
+    if (dx && dy) {
+        const HeadW w{Wx, Wy, HD, nullptr, nullptr, 1};
+        hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(B), dim3(256), 0, st, w, g_x_out, g_y_out, g_out, out_reaches_xy, dx, dy,
                            n);
+        GDL_CHECK_LAUNCH("head_bwd_feat_kernel");
+    }
+    if (dWx && dWy) {
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dWx, dWy, HD,
+                           dbx, dby, B, n);
         GDL_CHECK_LAUNCH("head_bwd_w_kernel");
     }
     return GDL_OK;

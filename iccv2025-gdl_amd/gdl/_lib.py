@@ -63,6 +63,8 @@ SIGNATURES = {
     "gdl_head_concat_fwd": ("i", "ppppppp" + "ii" + "p"),
     "gdl_head_concat_bwd": ("i", "pppppp" + "ii" + "pppp" + "ii" + "p"),
     "gdl_softmax_ce": ("i", "ppf" + "pp" + "ii" + "p"),
+    "gdl_head_sum_fwd": ("i", "ppppppppp" + "ii" + "p"),
+    "gdl_head_sum_bwd": ("i", "ppppppp" + "ii" + "pppppp" + "ii" + "p"),
     "gdl_eval_count": ("i", "pppp" + "ii" + "pppp" + "p"),
     "gdl_optim_create": ("i", "pppi"),
     "gdl_optim_destroy": (None, "p"),

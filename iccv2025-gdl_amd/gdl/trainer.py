@@ -36,12 +36,23 @@ class DGLTrainer:
         self.pg = process_group
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
         head = model.fusion_module
-        self.device = head.fc_out.weight.device
+        # head kind: concat (fc_out [n,1024]; ConcatFusion / ConcatFusion_DGL) or sum (fc_x, fc_y [n,512]; SumFusion_DGL)
+        self.head = "sum" if hasattr(head, "fc_x") else "concat"
+        first = head.fc_x if self.head == "sum" else head.fc_out
+        self.device = first.weight.device
         if self.device.type != "cuda":
             raise L.GdlError("DGLTrainer: the model must live on an MI355X (cuda) device; there is no CPU path")
-        self.n_classes = head.fc_out.weight.shape[0]
-        # ---- flat arenas: [fc_out.weight, fc_out.bias | audio_net (60) | visual_net (60)]
-        named = [("fusion_module.fc_out.weight", head.fc_out.weight), ("fusion_module.fc_out.bias", head.fc_out.bias)]
+        if self.head == "sum" and mode != "dgl":
+            raise L.GdlError("DGLTrainer: the sum head is built for the DGL step only")
+        self.n_classes = first.weight.shape[0]
+        # ---- flat arenas: [trained fusion-head tensors | audio_net (60) | visual_net (60)]
+        # (ConcatFusion_DGL's fc_auxi never receives a gradient, SURVEY G1: it stays outside the arena)
+        if self.head == "sum":
+            named = [("fusion_module.fc_x.weight", head.fc_x.weight), ("fusion_module.fc_x.bias", head.fc_x.bias),
+                     ("fusion_module.fc_y.weight", head.fc_y.weight), ("fusion_module.fc_y.bias", head.fc_y.bias)]
+        else:
+            named = [("fusion_module.fc_out.weight", head.fc_out.weight), ("fusion_module.fc_out.bias", head.fc_out.bias)]
+        nf = self.nf = len(named)
         named += [("audio_net." + n, p) for n, p in model.audio_net.named_parameters()]
         named += [("visual_net." + n, p) for n, p in model.visual_net.named_parameters()]
         self.names = [n for n, _ in named]
@@ -51,7 +62,7 @@ class DGLTrainer:
             offs.append(o)
         self.offsets = offs
         self.total = o
-        group = [0, 0] + [1] * 60 + [2] * 60
+        group = [0] * nf + [1] * 60 + [2] * 60
         self.params = torch.empty(o, device=self.device)
         self.grads = torch.zeros(o, device=self.device)
         self.momentum = torch.zeros(o, device=self.device)
@@ -62,7 +73,7 @@ class DGLTrainer:
             p.data = v  # the module now aliases the arena: state_dict / eval see the trained weights
             self.pviews.append(v)
             self.gviews.append(self.grads[offs[i]:offs[i + 1]].view(p.shape))
-        self.bucket = {"fusion": (0, offs[2]), "audio": (offs[2], offs[62]), "visual": (offs[62], offs[122])}
+        self.bucket = {"fusion": (0, offs[nf]), "audio": (offs[nf], offs[nf + 60]), "visual": (offs[nf + 60], offs[nf + 120])}
         self.reducer = None
         self.world = 1
         if process_group is not None:
@@ -135,7 +146,7 @@ class DGLTrainer:
         audio = spec.unsqueeze(1)  # main_dgl.py:100
         label = label.contiguous()
         B, n = self.B, self.n_classes
-        W, b = self.pviews[0], self.pviews[1]
+        nf = self.nf
         self._mark(main, "start")
         ev = main.record_event()
         self.s_a.wait_event(ev)
@@ -151,19 +162,26 @@ class DGLTrainer:
         self._mark(main, "fwd_done")
         st = main.cuda_stream
         dgl = self.mode == "dgl"
-        L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), L.ptr(b), L.ptr(self.out),
-               L.ptr(self.out_a) if dgl else None, L.ptr(self.out_v) if dgl else None, B, n, st)
+        self._head_forward(dgl, st)
         lp = self.losses.data_ptr()
         L.call("gdl_softmax_ce", L.ptr(self.out), L.ptr(label), 1.0, lp, L.ptr(self.g_f), B, n, st)
         if dgl:
             L.call("gdl_softmax_ce", L.ptr(self.out_a), L.ptr(label), self.alpha, lp + 4, L.ptr(self.g_a), B, n, st)
             L.call("gdl_softmax_ce", L.ptr(self.out_v), L.ptr(label), self.alpha, lp + 8, L.ptr(self.g_v), B, n, st)
-            L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), L.ptr(self.g_a), L.ptr(self.g_v),
-                   L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]),
-                   L.ptr(self.gviews[1]), B, n, st)
+            # DGL truncation: `out` is computed from detached features (flag 0) and the head gradients of the
+            # unimodal losses are dropped before loss_f.backward() (flag 0)   (main_dgl.py:110-122)
+            if self.head == "sum":
+                pv, gv = self.pviews, self.gviews
+                L.call("gdl_head_sum_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[2]), L.ptr(self.g_a),
+                       L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(gv[0]), L.ptr(gv[1]),
+                       L.ptr(gv[2]), L.ptr(gv[3]), B, n, st)
+            else:
+                L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.pviews[0]), L.ptr(self.g_a),
+                       L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]),
+                       L.ptr(self.gviews[1]), B, n, st)
         else:  # BASELINE config 1: ConcatFusion + one CE loss (main.py:161-175)
-            L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(W), None, None, L.ptr(self.g_f), 1, 0,
-                   L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]), L.ptr(self.gviews[1]), B, n, st)
+            L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.pviews[0]), None, None, L.ptr(self.g_f),
+                   1, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]), L.ptr(self.gviews[1]), B, n, st)
         self._mark(main, "head_done")
         red = self.reducer
         if red is not None:
@@ -172,11 +190,11 @@ class DGLTrainer:
         self.s_a.wait_event(ev2)
         self.s_v.wait_event(ev2)
         with torch.cuda.stream(self.s_v):
-            self.eng_v.backward(self.gviews[62:122], dfeat=self.dfv)
+            self.eng_v.backward(self.gviews[nf + 60:nf + 120], dfeat=self.dfv)
             if red is not None:
                 red.launch("visual")
         with torch.cuda.stream(self.s_a):
-            self.eng_a.backward(self.gviews[2:62], dfeat=self.dfa)
+            self.eng_a.backward(self.gviews[nf:nf + 60], dfeat=self.dfa)
             if red is not None:
                 red.launch("audio")
         main.wait_stream(self.s_a)
@@ -191,6 +209,17 @@ class DGLTrainer:
                L.ptr(self.stats), gs, self.lr, self.mu, self.wd, st)
         self._mark(main, "end")
         self.steps += 1
+
+    def _head_forward(self, dgl, st):
+        """(out, out_a, out_v) from the pooled features self.fa / self.fv."""
+        pv, B, n = self.pviews, self.B, self.n_classes
+        oa, ov = (L.ptr(self.out_a), L.ptr(self.out_v)) if dgl else (None, None)
+        if self.head == "sum":  # fusion_modules.py:22-30
+            L.call("gdl_head_sum_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(pv[2]), L.ptr(pv[3]),
+                   L.ptr(self.out), oa, ov, B, n, st)
+        else:  # fusion_modules.py:38-42 / 51-59
+            L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(self.out), oa, ov,
+                   B, n, st)
 
     def _mark(self, stream, name):
         if self.phase_events is not None:
@@ -222,8 +251,7 @@ class DGLTrainer:
             main.wait_stream(self.s_v)
             st = main.cuda_stream
             dgl = self.mode == "dgl"
-            L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.pviews[0]), L.ptr(self.pviews[1]),
-                   L.ptr(self.out), L.ptr(self.out_a) if dgl else None, L.ptr(self.out_v) if dgl else None, self.B, n, st)
+            self._head_forward(dgl, st)
             L.call("gdl_eval_count", L.ptr(self.out), L.ptr(self.out_a) if dgl else None, L.ptr(self.out_v) if dgl else None,
                    L.ptr(label), self.B, n, cnt[0].data_ptr(), cnt[1].data_ptr(), cnt[2].data_ptr() if dgl else None,
                    cnt[3].data_ptr() if dgl else None, st)

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .backbone import resnet18
-from .fusion_modules import ConcatFusion, ConcatFusion_DGL  # noqa: F401
+from .fusion_modules import ConcatFusion, ConcatFusion_DGL, SumFusion_DGL  # noqa: F401
 
 N_CLASSES = {'VGGSound': 309, 'KineticSound': 34, 'kinect400': 400, 'CREMAD': 6, 'AVE': 28}  # basic_model.py:15-26
 
@@ -22,10 +22,12 @@ class AVClassifier_DGL(nn.Module):
         if args.dataset not in N_CLASSES:
             raise NotImplementedError('Incorrect dataset name {}'.format(args.dataset))
         n_classes = N_CLASSES[args.dataset]
-        if fusion == 'concat':
+        if fusion == 'sum':
+            self.fusion_module = SumFusion_DGL(output_dim=n_classes)
+        elif fusion == 'concat':
             self.fusion_module = ConcatFusion_DGL(output_dim=n_classes)
-        elif fusion in ('sum', 'film', 'gated'):
-            raise NotImplementedError('gdl: fusion method {!r} of the reference is not built yet (concat only)'.format(fusion))
+        elif fusion in ('film', 'gated'):
+            raise NotImplementedError('gdl: fusion method {!r} of the reference is not built yet (concat and sum only)'.format(fusion))
         else:
             raise NotImplementedError('Incorrect fusion method: {}!'.format(fusion))
         if args.modality != 'full':

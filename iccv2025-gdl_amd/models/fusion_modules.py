@@ -66,6 +66,48 @@ class _ConcatFn(torch.autograd.Function):
         return dx, dy, dW, db
 
 
+class _SumDGLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, Wx, bx, Wy, by):
+        x, y, Wx, bx, Wy, by = (_f32c(t) for t in (x, y, Wx, bx, Wy, by))
+        B, n = x.shape[0], Wx.shape[0]
+        if x.shape[1] != 512 or y.shape[1] != 512 or Wx.shape[1] != 512 or Wy.shape[1] != 512:
+            raise RuntimeError("gdl: SumFusion_DGL expects 512-d audio and visual features")
+        out, x_out, y_out = (torch.empty((B, n), device=x.device) for _ in range(3))
+        L.call("gdl_head_sum_fwd", L.ptr(x), L.ptr(y), L.ptr(Wx), L.ptr(bx), L.ptr(Wy), L.ptr(by), L.ptr(out), L.ptr(x_out),
+               L.ptr(y_out), B, n, L.cur_stream())
+        ctx.save_for_backward(x, y, Wx, Wy)
+        return x_out, y_out, out
+
+    @staticmethod
+    def backward(ctx, g_x_out, g_y_out, g_out):
+        x, y, Wx, Wy = ctx.saved_tensors
+        B, n = x.shape[0], Wx.shape[0]
+        gx = _f32c(g_x_out) if g_x_out is not None else None
+        gy = _f32c(g_y_out) if g_y_out is not None else None
+        go = _f32c(g_out) if g_out is not None else None
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        dWx, dWy = torch.empty_like(Wx), torch.empty_like(Wy)
+        dbx, dby = torch.empty(n, device=x.device), torch.empty(n, device=x.device)
+        # `output` was computed from x.detach() / y.detach() (fusion_modules.py:27-29): it never reaches x / y
+        L.call("gdl_head_sum_bwd", L.ptr(x), L.ptr(y), L.ptr(Wx), L.ptr(Wy), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 1, L.ptr(dx),
+               L.ptr(dy), L.ptr(dWx), L.ptr(dbx), L.ptr(dWy), L.ptr(dby), B, n, L.cur_stream())
+        return dx, dy, dWx, dbx, dWy, dby
+
+
+class SumFusion_DGL(nn.Module):
+    """fusion_modules.py:16-30: outx = fc_x(x), outy = fc_y(y), output = fc_x(x.detach()) + fc_y(y.detach())."""
+
+    def __init__(self, input_dim=512, output_dim=100):
+        super(SumFusion_DGL, self).__init__()
+        self.fc_x = nn.Linear(input_dim, output_dim)
+        self.fc_y = nn.Linear(input_dim, output_dim)
+
+    def forward(self, x, y):
+        outx, outy, output = _SumDGLFn.apply(x, y, self.fc_x.weight, self.fc_x.bias, self.fc_y.weight, self.fc_y.bias)
+        return outx, outy, output
+
+
 class ConcatFusion(nn.Module):
     def __init__(self, input_dim=1024, output_dim=100):
         super(ConcatFusion, self).__init__()

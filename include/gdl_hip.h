@@ -198,6 +198,15 @@ GDL_API int gdl_head_concat_fwd(const float* x, const float* y, const float* W, 
 GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out,
                                 const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
                                 float* dy, float* dW, float* db, int B, int n_classes, void* stream);
+/* SumFusion_DGL (fusion_modules.py:16-30; SURVEY next row N2): fc_x, fc_y: Linear(512, n).
+ *   x_out = fc_x(x), y_out = fc_y(y), out = fc_x(x.detach()) + fc_y(y.detach()).
+ * Same flag meaning as the concat head; the sum head has two weight matrices [n][512] and two biases
+ * (dbx = sum_b (g_out + uni*g_x_out), dby likewise). */
+GDL_API int gdl_head_sum_fwd(const float* x, const float* y, const float* Wx, const float* bx, const float* Wy,
+                             const float* by, float* out, float* x_out, float* y_out, int B, int n_classes, void* stream);
+GDL_API int gdl_head_sum_bwd(const float* x, const float* y, const float* Wx, const float* Wy, const float* g_x_out,
+                             const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
+                             float* dy, float* dWx, float* dbx, float* dWy, float* dby, int B, int n_classes, void* stream);
 GDL_API int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
                            int n_classes, void* stream);
 /* valid() (main_dgl.py:185-222) without its per-sample host loop: per-class counters (int64[n_classes] each, the

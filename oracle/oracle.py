@@ -375,6 +375,40 @@ def concat_dgl_bwd(x, y, W, g_x_out, g_y_out, g_out):
     return dx, dy, dW, db
 
 
+def sum_dgl_fwd(x, y, Wx, bx, Wy, by):
+    """SumFusion_DGL.forward, fusion_modules.py:22-30 -> (outx, outy, output)."""
+    outx = linear_fwd(x, Wx, bx)  # :24
+    outy = linear_fwd(y, Wy, by)  # :25
+    out = linear_fwd(x, Wx, bx) + linear_fwd(y, Wy, by)  # :27-29 (detached inputs)
+    return outx, outy, out
+
+
+def sum_dgl_bwd(x, y, Wx, Wy, g_x_out, g_y_out, g_out):
+    """Autograd of the four Linear calls above for upstream gradients on (outx, outy, output); any may be None.
+    `output` sees detached inputs: it contributes to the weights / biases only."""
+    dx, dy = np.zeros_like(x), np.zeros_like(y)
+    dWx, dWy = np.zeros_like(Wx), np.zeros_like(Wy)
+    dbx, dby = np.zeros(Wx.shape[0], np.float32), np.zeros(Wy.shape[0], np.float32)
+    if g_x_out is not None:
+        d, w, b = linear_bwd(g_x_out, x, Wx)
+        dx += d
+        dWx += w
+        dbx += b
+    if g_y_out is not None:
+        d, w, b = linear_bwd(g_y_out, y, Wy)
+        dy += d
+        dWy += w
+        dby += b
+    if g_out is not None:
+        _, w, b = linear_bwd(g_out, x, Wx)
+        dWx += w
+        dbx += b
+        _, w, b = linear_bwd(g_out, y, Wy)
+        dWy += w
+        dby += b
+    return dx, dy, dWx, dbx, dWy, dby
+
+
 def concat_fwd(x, y, W, b):
     """ConcatFusion.forward, fusion_modules.py:38-42 -> output."""
     return linear_fwd(np.concatenate([x, y], 1), W, b)
@@ -408,6 +442,11 @@ class AVModel:
         self.a_map_shape, self.v_map_shape, self.BT = a.shape, v.shape, (B, T)
         self.fa = avgpool_fwd(a, B, 1)  # :78
         self.fv = avgpool_fwd(v, B, T)  # :73-79
+        if "fusion_module.fc_x.weight" in self.P:  # SumFusion_DGL (basic_model.py:29-30)
+            P = self.P
+            a_out, v_out, out = sum_dgl_fwd(self.fa, self.fv, P["fusion_module.fc_x.weight"], P["fusion_module.fc_x.bias"],
+                                            P["fusion_module.fc_y.weight"], P["fusion_module.fc_y.bias"])
+            return out, a_out, v_out
         W, b = self.P["fusion_module.fc_out.weight"], self.P["fusion_module.fc_out.bias"]
         if self.mode == "dgl":
             a_out, v_out, out = concat_dgl_fwd(self.fa, self.fv, W, b)
@@ -419,10 +458,24 @@ class AVModel:
         P = self.P
         B, T = image.shape[0], image.shape[2]
         out, out_a, out_v = self.forward(spec, image, True)
-        W = P["fusion_module.fc_out.weight"]
         r = {"out": out}
         G = {}
-        if self.mode == "dgl":
+        sum_head = "fusion_module.fc_x.weight" in P
+        W = None if sum_head else P["fusion_module.fc_out.weight"]
+        if sum_head:
+            Wx, Wy = P["fusion_module.fc_x.weight"], P["fusion_module.fc_y.weight"]
+            loss_v, g_v = softmax_ce(out_v, label, alpha)
+            loss_a, g_a = softmax_ce(out_a, label, alpha)
+            loss_f, g_f = softmax_ce(out, label, 1.0)
+            # phase 1 (:110): encoders get alpha*d(CE(outx)+CE(outy)); every fusion_module.* gradient is then dropped
+            dfa, dfv, dWx_u, dbx_u, dWy_u, dby_u = sum_dgl_bwd(self.fa, self.fv, Wx, Wy, g_a, g_v, None)
+            r["dropped_head_gradnorm"] = float(np.sqrt(sumsq(dWx_u) + sumsq(dbx_u) + sumsq(dWy_u) + sumsq(dby_u)))
+            # phase 2 (:122): loss_f reaches fc_x / fc_y parameters only (detached features)
+            _, _, dWx, dbx, dWy, dby = sum_dgl_bwd(self.fa, self.fv, Wx, Wy, None, None, g_f)
+            r.update(out_a=out_a, out_v=out_v, loss_a=loss_a, loss_v=loss_v)
+            G["fusion_module.fc_x.weight"], G["fusion_module.fc_x.bias"] = dWx, dbx
+            G["fusion_module.fc_y.weight"], G["fusion_module.fc_y.bias"] = dWy, dby
+        elif self.mode == "dgl":
             loss_v, g_v = softmax_ce(out_v, label, alpha)  # :102,108
             loss_a, g_a = softmax_ce(out_a, label, alpha)  # :103,108
             loss_f, g_f = softmax_ce(out, label, 1.0)  # :104
@@ -436,7 +489,8 @@ class AVModel:
             loss_f, g_f = softmax_ce(out, label, 1.0)
             dfa, dfv, dW, db = concat_bwd(self.fa, self.fv, W, g_f)
         r["loss_f"] = loss_f
-        G["fusion_module.fc_out.weight"], G["fusion_module.fc_out.bias"] = dW, db
+        if not sum_head:
+            G["fusion_module.fc_out.weight"], G["fusion_module.fc_out.bias"] = dW, db
         G.update(self.audio.backward(avgpool_bwd(dfa, self.a_map_shape, B, 1)))
         G.update(self.visual.backward(avgpool_bwd(dfv, self.v_map_shape, B, T)))
         # clip_grad_norm_(model.parameters(), 40, 2)  (:129); fc_auxi has no grad

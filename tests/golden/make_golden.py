@@ -100,14 +100,14 @@ def _summ(t):
 
 
 def run_step_case(name, bm, bb, fm, dataset, spec_hw, frames, image_hw, batch, alpha, steps, mode="dgl", seed=0,
-                  lr=2e-3):
+                  lr=2e-3, fusion="concat"):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     n_classes = fx.N_CLASSES[dataset]
     if mode == "dgl":
-        args = argparse.Namespace(fusion_method="concat", dataset=dataset, modality="full", batch_size=batch)
+        args = argparse.Namespace(fusion_method=fusion, dataset=dataset, modality="full", batch_size=batch)
         model = bm.AVClassifier_DGL(args)
-        _load(model, n_classes, "concat_dgl")
+        _load(model, n_classes, fusion + "_dgl")
     else:
         model = _ConcatAV(bb, fm, n_classes)
         _load(model, n_classes, "concat")
@@ -119,7 +119,7 @@ def run_step_case(name, bm, bb, fm, dataset, spec_hw, frames, image_hw, batch, a
     out_d = {}
     cfg = dict(name=name, dataset=dataset, n_classes=n_classes, spec_hw=list(spec_hw), frames=frames,
                image_hw=list(image_hw), batch=batch, alpha=alpha, steps=steps, mode=mode, seed=seed, lr=lr,
-               momentum=0.9, weight_decay=1e-4, max_norm=40.0, torch=torch.__version__)
+               momentum=0.9, weight_decay=1e-4, max_norm=40.0, torch=torch.__version__, fusion=fusion)
     out_d["config"] = np.array(json.dumps(cfg))
     model.train()
     for st in range(steps):
@@ -277,6 +277,35 @@ def run_head_case(name, fm, cls, n_classes, batch=4):
     print(name, "ok")
 
 
+def run_sum_head_case(name, fm, n_classes, batch=4):
+    """SumFusion_DGL (fusion_modules.py:16-30): forward + both backward phases of main_dgl.py:110-122."""
+    head = fm.SumFusion_DGL(output_dim=n_classes)
+    shapes = {"fc_x.weight": (n_classes, 512), "fc_x.bias": (n_classes,), "fc_y.weight": (n_classes, 512),
+              "fc_y.bias": (n_classes,)}
+    st = fx.make_state({"fusion_module." + k: v for k, v in shapes.items()})
+    head.load_state_dict({k[len("fusion_module."):]: torch.from_numpy(v.copy()) for k, v in st.items()})
+    r = np.random.default_rng([92, n_classes])
+    x = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    y = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    g = [r.standard_normal((batch, n_classes), dtype=np.float32) for _ in range(3)]
+    x_out, y_out, out = head(x, y)
+    d = {"x": x.detach().numpy(), "y": y.detach().numpy(), "x_out": x_out.detach().numpy(), "y_out": y_out.detach().numpy(),
+         "out": out.detach().numpy(), "g_x_out": g[0], "g_y_out": g[1], "g_out": g[2]}
+    (x_out * torch.from_numpy(g[0])).sum().add((y_out * torch.from_numpy(g[1])).sum()).backward(retain_graph=True)
+    d.update(dx=x.grad.numpy().copy(), dy=y.grad.numpy().copy())
+    for n, p in head.named_parameters():
+        d["uni." + n] = p.grad.numpy().copy()
+        p.grad = None
+    x.grad = None
+    y.grad = None
+    (out * torch.from_numpy(g[2])).sum().backward()
+    for n, p in head.named_parameters():
+        d["f." + n] = p.grad.numpy().copy()
+    d["dx_after_f_is_none"] = np.int8(x.grad is None)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -295,6 +324,9 @@ def main():
                                                4.0, 1),
         "dgl_ks_b2": lambda: run_step_case("dgl_ks_b2", bm, bb, fm, "KineticSound", (129, 626), 3, (224, 224), 2, 2.0,
                                            1),
+        "head_sum_dgl_c6": lambda: run_sum_head_case("head_sum_dgl_c6", fm, 6),
+        "dgl_sum_tiny_b4": lambda: run_step_case("dgl_sum_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
+                                                 fusion="sum"),
         "concat_cremad_b2": lambda: run_step_case("concat_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224),
                                                   2, 0.0, 1, mode="concat"),
     }

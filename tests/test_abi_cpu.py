@@ -113,7 +113,14 @@ def test_mirror_keeps_reference_interface():
     sd = m.state_dict()
     assert "audio_net.bn1.num_batches_tracked" in sd and "visual_net.layer4.1.bn2.running_var" in sd
     assert isinstance(m.fusion_module, ConcatFusion_DGL) and isinstance(AVClassifier(args).fusion_module, ConcatFusion)
-    for method in ("sum", "film", "gated"):
+    from models.fusion_modules import SumFusion_DGL
+
+    ms = AVClassifier_DGL(argparse.Namespace(fusion_method="sum", dataset="KineticSound", modality="full"))
+    assert isinstance(ms.fusion_module, SumFusion_DGL)
+    assert [n for n, _ in ms.named_parameters()][:4] == ["fusion_module.fc_x.weight", "fusion_module.fc_x.bias",
+                                                         "fusion_module.fc_y.weight", "fusion_module.fc_y.bias"]
+    assert ms.fusion_module.fc_x.weight.shape == (34, 512)
+    for method in ("film", "gated"):
         with pytest.raises(NotImplementedError):
             AVClassifier_DGL(argparse.Namespace(fusion_method=method, dataset="CREMAD", modality="full"))
     # no CPU fallback: CPU tensors are refused loudly

@@ -37,6 +37,25 @@ def test_head_dgl(golden_dir, name, ncls):
     assert int(g["auxi_grad_is_none"]) == 1
 
 
+def test_head_sum_dgl(golden_dir):
+    """SumFusion_DGL (fusion_modules.py:16-30): forward and both backward phases of main_dgl.py:110-122."""
+    g = _load(golden_dir, "head_sum_dgl_c6")
+    st = fx.make_state({"fusion_module.fc_x.weight": (6, 512), "fusion_module.fc_x.bias": (6,),
+                        "fusion_module.fc_y.weight": (6, 512), "fusion_module.fc_y.bias": (6,)})
+    Wx, bx, Wy, by = (st["fusion_module." + k] for k in ("fc_x.weight", "fc_x.bias", "fc_y.weight", "fc_y.bias"))
+    x_out, y_out, out = orc.sum_dgl_fwd(g["x"], g["y"], Wx, bx, Wy, by)
+    for a, k in ((x_out, "x_out"), (y_out, "y_out"), (out, "out")):
+        np.testing.assert_allclose(a, g[k], rtol=RTOL, atol=ATOL)
+    dx, dy, dWx, dbx, dWy, dby = orc.sum_dgl_bwd(g["x"], g["y"], Wx, Wy, g["g_x_out"], g["g_y_out"], None)
+    for a, k in ((dx, "dx"), (dy, "dy"), (dWx, "uni.fc_x.weight"), (dbx, "uni.fc_x.bias"), (dWy, "uni.fc_y.weight"),
+                 (dby, "uni.fc_y.bias")):
+        np.testing.assert_allclose(a, g[k], rtol=RTOL, atol=1e-4)
+    dx2, dy2, dWx, dbx, dWy, dby = orc.sum_dgl_bwd(g["x"], g["y"], Wx, Wy, None, None, g["g_out"])
+    assert not dx2.any() and not dy2.any() and int(g["dx_after_f_is_none"]) == 1  # detached: nothing reaches the encoders
+    for a, k in ((dWx, "f.fc_x.weight"), (dbx, "f.fc_x.bias"), (dWy, "f.fc_y.weight"), (dby, "f.fc_y.bias")):
+        np.testing.assert_allclose(a, g[k], rtol=RTOL, atol=1e-4)
+
+
 def test_head_concat(golden_dir):
     g = _load(golden_dir, "head_concat_c6")
     st = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
@@ -109,11 +128,12 @@ def check_step_against_golden(g, model_step, cfg, steps, rtol_logits=1e-3, rtol_
             assert abs(got - gn[i]) <= rtol_gn * gn[i] + 1e-6 * float(g[pre + "total_norm"]), (n, got, gn[i])
 
 
-@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2"])
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2",
+                                  "dgl_sum_tiny_b4"])
 def test_step(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = json.loads(str(g["config"]))
-    fusion = "concat_dgl" if cfg["mode"] == "dgl" else "concat"
+    fusion = cfg.get("fusion", "concat") + "_dgl" if cfg["mode"] == "dgl" else "concat"
     P, Bf = fx.model_state(cfg["n_classes"], fusion)
     model = orc.AVModel(P, Bf, cfg["mode"])
 

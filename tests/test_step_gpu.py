@@ -60,6 +60,41 @@ def test_head_dgl_golden(name, n):
     np.testing.assert_allclose(db.cpu().numpy(), g["db_f"], rtol=1e-4, atol=1e-4)
 
 
+def test_head_sum_dgl_golden():
+    """SumFusion_DGL (fusion_modules.py:16-30) through the C ABI against the reference's golden (both backward phases)."""
+    g = _gold("head_sum_dgl_c6")
+    n = 6
+    st = fx.make_state({"fusion_module.fc_x.weight": (n, 512), "fusion_module.fc_x.bias": (n,),
+                        "fusion_module.fc_y.weight": (n, 512), "fusion_module.fc_y.bias": (n,)})
+    Wx, bx, Wy, by = (dev(st["fusion_module." + k]) for k in ("fc_x.weight", "fc_x.bias", "fc_y.weight", "fc_y.bias"))
+    x, y = dev(g["x"]), dev(g["y"])
+    B = x.shape[0]
+    out, xo, yo = (torch.empty(B, n, device=DEV) for _ in range(3))
+    s = L.cur_stream()
+    L.call("gdl_head_sum_fwd", L.ptr(x), L.ptr(y), L.ptr(Wx), L.ptr(bx), L.ptr(Wy), L.ptr(by), L.ptr(out), L.ptr(xo), L.ptr(yo),
+           B, n, s)
+    torch.cuda.synchronize()
+    for a, k in ((xo, "x_out"), (yo, "y_out"), (out, "out")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=2e-4, atol=2e-5)
+    gx, gy, go = dev(g["g_x_out"]), dev(g["g_y_out"]), dev(g["g_out"])
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    dWx, dWy = torch.empty_like(Wx), torch.empty_like(Wy)
+    dbx, dby = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    # phase 1: unimodal losses only, plain autograd (head gradients are produced, the script then drops them)
+    L.call("gdl_head_sum_bwd", L.ptr(x), L.ptr(y), L.ptr(Wx), L.ptr(Wy), L.ptr(gx), L.ptr(gy), None, 0, 1, L.ptr(dx), L.ptr(dy),
+           L.ptr(dWx), L.ptr(dbx), L.ptr(dWy), L.ptr(dby), B, n, s)
+    torch.cuda.synchronize()
+    for a, k in ((dx, "dx"), (dy, "dy"), (dWx, "uni.fc_x.weight"), (dbx, "uni.fc_x.bias"), (dWy, "uni.fc_y.weight"),
+                 (dby, "uni.fc_y.bias")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=2e-4, atol=1e-4)
+    # phase 2: loss_f only -> weights / biases only
+    L.call("gdl_head_sum_bwd", L.ptr(x), L.ptr(y), L.ptr(Wx), L.ptr(Wy), None, None, L.ptr(go), 0, 0, None, None, L.ptr(dWx),
+           L.ptr(dbx), L.ptr(dWy), L.ptr(dby), B, n, s)
+    torch.cuda.synchronize()
+    for a, k in ((dWx, "f.fc_x.weight"), (dbx, "f.fc_x.bias"), (dWy, "f.fc_y.weight"), (dby, "f.fc_y.bias")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=2e-4, atol=1e-4)
+
+
 def test_head_concat_golden():
     g = _gold("head_concat_c6")
     st_ = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
@@ -207,10 +242,11 @@ def test_encoder_golden(name, modality, dtype):
 def _make_model(cfg, dtype):
     from models.basic_model import AVClassifier, AVClassifier_DGL
 
-    args = argparse.Namespace(fusion_method="concat", dataset=cfg["dataset"], modality="full", batch_size=cfg["batch"])
+    fusion = cfg.get("fusion", "concat")
+    args = argparse.Namespace(fusion_method=fusion, dataset=cfg["dataset"], modality="full", batch_size=cfg["batch"])
     dgl = cfg["mode"] == "dgl"
     model = AVClassifier_DGL(args) if dgl else AVClassifier(args)
-    P, Bf = fx.model_state(cfg["n_classes"], "concat_dgl" if dgl else "concat")
+    P, Bf = fx.model_state(cfg["n_classes"], fusion + "_dgl" if dgl else "concat")
     _load_state(model, {**P, **Bf})
     model = model.to(DEV)
     model.audio_net.gdl_dtype = dtype
@@ -224,7 +260,7 @@ def _batch(cfg, st):
     return dev(spec), dev(image), torch.from_numpy(label).to(DEV)
 
 
-STEP_CASES = ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2"]
+STEP_CASES = ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2", "dgl_sum_tiny_b4"]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -278,8 +314,8 @@ def test_native_step_golden(name, dtype):
         got = sd[n].double().abs().sum().item()
         np.testing.assert_allclose(got, ps[i][1], rtol=2e-5 if (f32 and cfg["steps"] == 1) else 1e-3, err_msg=n)
     # fc_auxi untouched (grad None -> SGD skips it)
-    P0, _ = fx.model_state(cfg["n_classes"], "concat_dgl" if cfg["mode"] == "dgl" else "concat")
-    if cfg["mode"] == "dgl":
+    P0, _ = fx.model_state(cfg["n_classes"], cfg.get("fusion", "concat") + "_dgl" if cfg["mode"] == "dgl" else "concat")
+    if cfg["mode"] == "dgl" and cfg.get("fusion", "concat") == "concat":
         np.testing.assert_array_equal(sd["fusion_module.fc_auxi.weight"].cpu().numpy(), P0["fusion_module.fc_auxi.weight"])
     for k in _bufnames(g, last):
         tolr, tola = (2e-3, 1e-4) if f32 else (5e-2, 3e-2)
@@ -311,7 +347,7 @@ def _bufnames(g, pre):
     return [k[len(pre + "buf."):] for k in g.files if k.startswith(pre + "buf.")]
 
 
-@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2"])
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2", "dgl_sum_tiny_b4"])
 def test_dropin_autograd_step_golden(name):
     """The reference's own step body (main_dgl.py:97-154) run UNCHANGED on the drop-in modules:
     torch autograd with retain_graph, grad=None on the head, second backward, torch clip + SGD."""
@@ -347,7 +383,8 @@ def test_dropin_autograd_step_golden(name):
     np.testing.assert_allclose(total.item(), g["s0.total_norm"], rtol=3e-3)
     np.testing.assert_allclose(audio_grad_sum, g["s0.audio_grad_sum"], rtol=6e-3)
     np.testing.assert_allclose(visual_grad_sum, g["s0.visual_grad_sum"], rtol=6e-3)
-    assert model.module.fusion_module.fc_auxi.weight.grad is None
+    if hasattr(model.module.fusion_module, "fc_auxi"):
+        assert model.module.fusion_module.fc_auxi.weight.grad is None
     names = [str(n) for n in g["s0.grad_names"]]
     ps = g["s0.param_sums"]
     sd = model.module.state_dict()
