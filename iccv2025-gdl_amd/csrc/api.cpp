@@ -223,6 +223,24 @@ int gdl_head_sum_bwd(const float* x, const float* y, const float* Wx, const floa
     return head_sum_bwd(x, y, Wx, Wy, g_x_out, g_y_out, g_out, out_reaches_xy, uni_in_dw, dx, dy, dWx, dbx, dWy, dby, B,
                         n_classes, (hipStream_t)stream);
 }
+int gdl_head_gated_fwd(const float* x, const float* y, const float* W1, const float* b1, const float* W2, const float* b2,
+                       const float* Wo, const float* bo, float* hx, float* hy, float* out, float* x_out, float* y_out, int B,
+                       int n_classes, void* stream) {
+    GDL_REQUIRE(x && y && W1 && b1 && W2 && b2 && Wo && bo && hx && hy && out && B > 0 && n_classes > 0,
+                "head_gated_fwd: bad arguments");
+    return head_gated_fwd(x, y, W1, b1, W2, b2, Wo, bo, hx, hy, out, x_out, y_out, B, n_classes, (hipStream_t)stream);
+}
+int gdl_head_gated_bwd(const float* x, const float* y, const float* hx, const float* hy, const float* W1, const float* W2,
+                       const float* Wo, const float* g_x_out, const float* g_y_out, const float* g_out, int uni_in_dw,
+                       float* dx, float* dy, float* dW1, float* db1, float* dW2, float* db2, float* dWo, float* dbo, float* ws,
+                       int B, int n_classes, void* stream) {
+    GDL_REQUIRE(x && y && hx && hy && W1 && W2 && Wo && ws && B > 0 && n_classes > 0, "head_gated_bwd: bad arguments");
+    GDL_REQUIRE((dx != nullptr) == (dy != nullptr) && (dWo != nullptr) == (dbo != nullptr), "head_gated_bwd: dx/dy, dWo/dbo pairs");
+    GDL_REQUIRE((dW1 != nullptr) == (db1 != nullptr) && (dW1 != nullptr) == (dW2 != nullptr) && (dW1 != nullptr) == (db2 != nullptr),
+                "head_gated_bwd: dW1/db1/dW2/db2 come together");
+    return head_gated_bwd(x, y, hx, hy, W1, W2, Wo, g_x_out, g_y_out, g_out, uni_in_dw, dx, dy, dW1, db1, dW2, db2, dWo, dbo, ws, B,
+                          n_classes, (hipStream_t)stream);
+}
 int gdl_eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n_classes,
                    int64_t* num, int64_t* acc, int64_t* acc_a, int64_t* acc_v, void* stream) {
     GDL_REQUIRE(out && labels && num && acc && B > 0 && n_classes > 0, "eval_count: bad arguments");

@@ -195,6 +195,197 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
     if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
 }
+// ---------------------------------------------------------------- GatedFusion_DGL (fusion_modules.py:213-250)
+//   hx = fc_x(x), hy = fc_y(y)                              (Linear(512, 512) each)
+//   output = fc_out(sigmoid(hx.detach()) * hy.detach())     (x_gate = True, basic_model.py:38)
+//   out_x  = fc_out(sigmoid(hx) * hx),  out_y = fc_out(sigmoid(hy) * hy)       (the "gate" of each unimodal
+//   logit set is the modality's own hidden vector: h * sigmoid(h))
+// B x 512 x 512 products: tiny (33 MFLOP), latency bound, plain FMA kernels.
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// grid = (B, 2): which = 0 -> hx = x W1^T + b1, 1 -> hy = y W2^T + b2.  Waves own outputs j = wave, wave+4, ..
+__global__ __launch_bounds__(256) void gated_hidden_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ W1, const float* __restrict__ b1,
+                                                           const float* __restrict__ W2, const float* __restrict__ b2,
+                                                           float* __restrict__ hx, float* __restrict__ hy) {
+    const int b = blockIdx.x, which = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* in = (which ? y : x) + (size_t)b * HD;
+    const float* W = which ? W2 : W1;
+    const float* bias = which ? b2 : b1;
+    float* h = (which ? hy : hx) + (size_t)b * HD;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = in[lane + 64 * i];
+    for (int j = wave; j < HD; j += 4) {
+        const float* w = W + (size_t)j * HD;
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p += w[lane + 64 * i] * v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        if (lane == 0) h[j] = p + bias[j];
+    }
+}
+// grid = B: the three logit sets from the hidden vectors
+__global__ __launch_bounds__(256) void gated_out_kernel(const float* __restrict__ hx, const float* __restrict__ hy,
+                                                        const float* __restrict__ Wo, const float* __restrict__ bo,
+                                                        float* __restrict__ out, float* __restrict__ x_out,
+                                                        float* __restrict__ y_out, int n) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sx[8], sy[8], gz[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = hx[(size_t)b * HD + lane + 64 * i], c = hy[(size_t)b * HD + lane + 64 * i];
+        const float ga = sigmoidf_(a);
+        sx[i] = ga * a;
+        sy[i] = sigmoidf_(c) * c;
+        gz[i] = ga * c;
+    }
+    for (int j = wave; j < n; j += 4) {
+        const float* w = Wo + (size_t)j * HD;
+        float px = 0.f, py = 0.f, pz = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float wv = w[lane + 64 * i];
+            px += wv * sx[i];
+            py += wv * sy[i];
+            pz += wv * gz[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            px += __shfl_xor(px, o);
+            py += __shfl_xor(py, o);
+            pz += __shfl_xor(pz, o);
+        }
+        if (lane == 0) {
+            const float bj = bo[j];
+            out[(size_t)b * n + j] = pz + bj;
+            if (x_out) x_out[(size_t)b * n + j] = px + bj;
+            if (y_out) y_out[(size_t)b * n + j] = py + bj;
+        }
+    }
+}
+int head_gated_fwd(const float* x, const float* y, const float* W1, const float* b1, const float* W2, const float* b2,
+                   const float* Wo, const float* bo, float* hx, float* hy, float* out, float* x_out, float* y_out, int B, int n,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(gated_hidden_kernel, dim3(B, 2), dim3(256), 0, st, x, y, W1, b1, W2, b2, hx, hy);
+    GDL_CHECK_LAUNCH("gated_hidden_kernel");
+    hipLaunchKernelGGL(gated_out_kernel, dim3(B), dim3(256), 0, st, hx, hy, Wo, bo, out, x_out, y_out, n);
+    GDL_CHECK_LAUNCH("gated_out_kernel");
+    return GDL_OK;
+}
+
+// grid = (B, 2): d_h[b][j] = (sum_c g[b][c] Wo[c][j]) * swish'(h[b][j]),  swish'(h) = s (1 + h (1 - s)), s = sigmoid(h)
+__global__ __launch_bounds__(256) void gated_dh_kernel(const float* __restrict__ hx, const float* __restrict__ hy,
+                                                       const float* __restrict__ Wo, const float* __restrict__ g_x_out,
+                                                       const float* __restrict__ g_y_out, float* __restrict__ dhx,
+                                                       float* __restrict__ dhy, int n) {
+    const int b = blockIdx.x, which = blockIdx.y;
+    const float* g = which ? g_y_out : g_x_out;
+    const float* h = (which ? hy : hx) + (size_t)b * HD;
+    float* dh = (which ? dhy : dhx) + (size_t)b * HD;
+    for (int j = threadIdx.x; j < HD; j += 256) {
+        float s = 0.f;
+        if (g)
+            for (int c = 0; c < n; ++c) s += g[(size_t)b * n + c] * Wo[(size_t)c * HD + j];
+        const float hv = h[j], sg = sigmoidf_(hv);
+        dh[j] = s * sg * (1.f + hv * (1.f - sg));
+    }
+}
+// grid = (B, 2): dx[b][i] = sum_j dhx[b][j] W1[j][i]   (threads along i: coalesced rows of W1)
+__global__ __launch_bounds__(256) void gated_dx_kernel(const float* __restrict__ dhx, const float* __restrict__ dhy,
+                                                       const float* __restrict__ W1, const float* __restrict__ W2,
+                                                       float* __restrict__ dx, float* __restrict__ dy) {
+    __shared__ float dh[HD];
+    const int b = blockIdx.x, which = blockIdx.y;
+    const float* src = (which ? dhy : dhx) + (size_t)b * HD;
+    const float* W = which ? W2 : W1;
+    float* dst = (which ? dy : dx) + (size_t)b * HD;
+    for (int j = threadIdx.x; j < HD; j += 256) dh[j] = src[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < HD; i += 256) {
+        float s = 0.f;
+        for (int j = 0; j < HD; ++j) s += dh[j] * W[(size_t)j * HD + i];
+        dst[i] = s;
+    }
+}
+// grid = n: dWo[c][j] = sum_b ( g_out[b][c] * sig(hx)*hy  +  uni * (g_x_out[b][c] * swish(hx) + g_y_out[b][c] * swish(hy)) )
+__global__ __launch_bounds__(256) void gated_dwo_kernel(const float* __restrict__ hx, const float* __restrict__ hy,
+                                                        const float* __restrict__ g_x_out, const float* __restrict__ g_y_out,
+                                                        const float* __restrict__ g_out, int uni_in_dw,
+                                                        float* __restrict__ dWo, float* __restrict__ dbo, int B, int n) {
+    const int c = blockIdx.x;
+    for (int j = threadIdx.x; j < HD; j += 256) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float a = hx[(size_t)b * HD + j], v = hy[(size_t)b * HD + j];
+            const float ga = sigmoidf_(a);
+            if (g_out) s += g_out[(size_t)b * n + c] * ga * v;
+            if (uni_in_dw) {
+                if (g_x_out) s += g_x_out[(size_t)b * n + c] * ga * a;
+                if (g_y_out) s += g_y_out[(size_t)b * n + c] * sigmoidf_(v) * v;
+            }
+        }
+        dWo[(size_t)c * HD + j] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            if (g_out) s += g_out[(size_t)b * n + c];
+            if (uni_in_dw) {
+                if (g_x_out) s += g_x_out[(size_t)b * n + c];
+                if (g_y_out) s += g_y_out[(size_t)b * n + c];
+            }
+        }
+        dbo[c] = s;
+    }
+}
+// grid = (512, 2): dW1[j][i] = sum_b dhx[b][j] x[b][i], db1[j] = sum_b dhx[b][j]   (plain-autograd callers only)
+__global__ __launch_bounds__(256) void gated_dw1_kernel(const float* __restrict__ dhx, const float* __restrict__ dhy,
+                                                        const float* __restrict__ x, const float* __restrict__ y,
+                                                        float* __restrict__ dW1, float* __restrict__ db1,
+                                                        float* __restrict__ dW2, float* __restrict__ db2, int B) {
+    const int j = blockIdx.x, which = blockIdx.y;
+    const float* dh = which ? dhy : dhx;
+    const float* in = which ? y : x;
+    float* dW = which ? dW2 : dW1;
+    float* db = which ? db2 : db1;
+    for (int i = threadIdx.x; i < HD; i += 256) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dh[(size_t)b * HD + j] * in[(size_t)b * HD + i];
+        dW[(size_t)j * HD + i] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dh[(size_t)b * HD + j];
+        db[j] = s;
+    }
+}
+// ws: 2 * B * 512 floats (d hx, d hy)
+int head_gated_bwd(const float* x, const float* y, const float* hx, const float* hy, const float* W1, const float* W2,
+                   const float* Wo, const float* g_x_out, const float* g_y_out, const float* g_out, int uni_in_dw, float* dx,
+                   float* dy, float* dW1, float* db1, float* dW2, float* db2, float* dWo, float* dbo, float* ws, int B, int n,
+                   hipStream_t st) {
+    float *dhx = ws, *dhy = ws + (size_t)B * HD;
+    if ((dx && dy) || dW1) {
+        hipLaunchKernelGGL(gated_dh_kernel, dim3(B, 2), dim3(256), 0, st, hx, hy, Wo, g_x_out, g_y_out, dhx, dhy, n);
+        GDL_CHECK_LAUNCH("gated_dh_kernel");
+    }
+    if (dx && dy) {
+        hipLaunchKernelGGL(gated_dx_kernel, dim3(B, 2), dim3(256), 0, st, dhx, dhy, W1, W2, dx, dy);
+        GDL_CHECK_LAUNCH("gated_dx_kernel");
+    }
+    if (dW1) {
+        hipLaunchKernelGGL(gated_dw1_kernel, dim3(HD, 2), dim3(256), 0, st, dhx, dhy, x, y, dW1, db1, dW2, db2, B);
+        GDL_CHECK_LAUNCH("gated_dw1_kernel");
+    }
+    if (dWo && dbo) {
+        hipLaunchKernelGGL(gated_dwo_kernel, dim3(n), dim3(256), 0, st, hx, hy, g_x_out, g_y_out, g_out, uni_in_dw, dWo, dbo, B, n);
+        GDL_CHECK_LAUNCH("gated_dwo_kernel");
+    }
+    return GDL_OK;
+}
+
 // valid() of /root/reference/main_dgl.py:206-219 without its per-sample host loop: for every sample the
 // arg-max of the three logit sets (softmax is monotone, np.argmax takes the first maximum) is compared with
 // the label and four per-class counters are bumped: num[label]++, acc*[label] += (argmax == label).

@@ -84,6 +84,13 @@ int head_sum_fwd(const float* x, const float* y, const float* Wx, const float* b
 int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* Wy, const float* g_x_out, const float* g_y_out,
                  const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dWx, float* dbx,
                  float* dWy, float* dby, int B, int n, hipStream_t st);
+int head_gated_fwd(const float* x, const float* y, const float* W1, const float* b1, const float* W2, const float* b2,
+                   const float* Wo, const float* bo, float* hx, float* hy, float* out, float* x_out, float* y_out, int B, int n,
+                   hipStream_t st);
+int head_gated_bwd(const float* x, const float* y, const float* hx, const float* hy, const float* W1, const float* W2,
+                   const float* Wo, const float* g_x_out, const float* g_y_out, const float* g_out, int uni_in_dw, float* dx,
+                   float* dy, float* dW1, float* db1, float* dW2, float* db2, float* dWo, float* dbo, float* ws, int B, int n,
+                   hipStream_t st);
 int eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n, int64_t* num,
                int64_t* acc, int64_t* acc_a, int64_t* acc_v, hipStream_t st);
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "gdl_softmax_ce": ("i", "ppf" + "pp" + "ii" + "p"),
     "gdl_head_sum_fwd": ("i", "ppppppppp" + "ii" + "p"),
     "gdl_head_sum_bwd": ("i", "ppppppp" + "ii" + "pppppp" + "ii" + "p"),
+    "gdl_head_gated_fwd": ("i", "p" * 13 + "ii" + "p"),
+    "gdl_head_gated_bwd": ("i", "p" * 10 + "i" + "p" * 9 + "ii" + "p"),
     "gdl_eval_count": ("i", "pppp" + "ii" + "pppp" + "p"),
     "gdl_optim_create": ("i", "pppi"),
     "gdl_optim_destroy": (None, "p"),

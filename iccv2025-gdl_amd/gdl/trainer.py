@@ -37,14 +37,19 @@ class DGLTrainer:
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
         head = model.fusion_module
         # head kind: concat (fc_out [n,1024]; ConcatFusion / ConcatFusion_DGL) or sum (fc_x, fc_y [n,512]; SumFusion_DGL)
-        self.head = "sum" if hasattr(head, "fc_x") else "concat"
+        # or gated (fc_x, fc_y [512,512] + fc_out [n,512]; GatedFusion_DGL -- the step never gives fc_x / fc_y a
+        # gradient (main_dgl.py:114-122 drops phase 1's, loss_f sees detached hidden vectors), so like fc_auxi they stay
+        # outside the optimised arena)
+        self.head = ("gated" if hasattr(head, "fc_out") else "sum") if hasattr(head, "fc_x") else "concat"
         first = head.fc_x if self.head == "sum" else head.fc_out
         self.device = first.weight.device
         if self.device.type != "cuda":
             raise L.GdlError("DGLTrainer: the model must live on an MI355X (cuda) device; there is no CPU path")
-        if self.head == "sum" and mode != "dgl":
-            raise L.GdlError("DGLTrainer: the sum head is built for the DGL step only")
-        self.n_classes = first.weight.shape[0]
+        if self.head != "concat" and mode != "dgl":
+            raise L.GdlError("DGLTrainer: the sum / gated heads are built for the DGL step only")
+        if self.head == "gated" and not getattr(head, "x_gate", True):
+            raise L.GdlError("DGLTrainer: GatedFusion_DGL is built for x_gate=True (basic_model.py:38)")
+        self.n_classes = (head.fc_out if self.head == "gated" else first).weight.shape[0]
         # ---- flat arenas: [trained fusion-head tensors | audio_net (60) | visual_net (60)]
         # (ConcatFusion_DGL's fc_auxi never receives a gradient, SURVEY G1: it stays outside the arena)
         if self.head == "sum":
@@ -126,6 +131,9 @@ class DGLTrainer:
         n, d = self.n_classes, self.device
         self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
         self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
+        if self.head == "gated":  # hidden vectors (saved for the backward) + its scratch
+            self.hx, self.hy = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
+            self.head_ws = torch.empty(2 * B * 512, device=d)
         self.out, self.out_a, self.out_v = (torch.empty((B, n), device=d) for _ in range(3))
         self.g_f, self.g_a, self.g_v = (torch.empty((B, n), device=d) for _ in range(3))
         self.B = B
@@ -170,7 +178,13 @@ class DGLTrainer:
             L.call("gdl_softmax_ce", L.ptr(self.out_v), L.ptr(label), self.alpha, lp + 8, L.ptr(self.g_v), B, n, st)
             # DGL truncation: `out` is computed from detached features (flag 0) and the head gradients of the
             # unimodal losses are dropped before loss_f.backward() (flag 0)   (main_dgl.py:110-122)
-            if self.head == "sum":
+            if self.head == "gated":
+                fm = self.model.fusion_module
+                L.call("gdl_head_gated_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.hx), L.ptr(self.hy),
+                       L.ptr(fm.fc_x.weight), L.ptr(fm.fc_y.weight), L.ptr(self.pviews[0]), L.ptr(self.g_a), L.ptr(self.g_v),
+                       L.ptr(self.g_f), 0, L.ptr(self.dfa), L.ptr(self.dfv), None, None, None, None, L.ptr(self.gviews[0]),
+                       L.ptr(self.gviews[1]), L.ptr(self.head_ws), B, n, st)
+            elif self.head == "sum":
                 pv, gv = self.pviews, self.gviews
                 L.call("gdl_head_sum_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[2]), L.ptr(self.g_a),
                        L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(gv[0]), L.ptr(gv[1]),
@@ -214,7 +228,12 @@ class DGLTrainer:
         """(out, out_a, out_v) from the pooled features self.fa / self.fv."""
         pv, B, n = self.pviews, self.B, self.n_classes
         oa, ov = (L.ptr(self.out_a), L.ptr(self.out_v)) if dgl else (None, None)
-        if self.head == "sum":  # fusion_modules.py:22-30
+        if self.head == "gated":  # fusion_modules.py:232-250
+            fm = self.model.fusion_module
+            L.call("gdl_head_gated_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(fm.fc_x.weight), L.ptr(fm.fc_x.bias),
+                   L.ptr(fm.fc_y.weight), L.ptr(fm.fc_y.bias), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(self.hx), L.ptr(self.hy),
+                   L.ptr(self.out), oa, ov, B, n, st)
+        elif self.head == "sum":  # fusion_modules.py:22-30
             L.call("gdl_head_sum_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(pv[2]), L.ptr(pv[3]),
                    L.ptr(self.out), oa, ov, B, n, st)
         else:  # fusion_modules.py:38-42 / 51-59

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .backbone import resnet18
-from .fusion_modules import ConcatFusion, ConcatFusion_DGL, SumFusion_DGL  # noqa: F401
+from .fusion_modules import ConcatFusion, ConcatFusion_DGL, GatedFusion_DGL, SumFusion_DGL  # noqa: F401
 
 N_CLASSES = {'VGGSound': 309, 'KineticSound': 34, 'kinect400': 400, 'CREMAD': 6, 'AVE': 28}  # basic_model.py:15-26
 
@@ -26,8 +26,10 @@ class AVClassifier_DGL(nn.Module):
             self.fusion_module = SumFusion_DGL(output_dim=n_classes)
         elif fusion == 'concat':
             self.fusion_module = ConcatFusion_DGL(output_dim=n_classes)
-        elif fusion in ('film', 'gated'):
-            raise NotImplementedError('gdl: fusion method {!r} of the reference is not built yet (concat and sum only)'.format(fusion))
+        elif fusion == 'gated':
+            self.fusion_module = GatedFusion_DGL(output_dim=n_classes, x_gate=True)
+        elif fusion == 'film':
+            raise NotImplementedError("gdl: fusion method 'film' of the reference (a 134 M-parameter bilinear head) is not built yet")
         else:
             raise NotImplementedError('Incorrect fusion method: {}!'.format(fusion))
         if args.modality != 'full':

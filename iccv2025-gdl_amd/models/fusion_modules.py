@@ -108,6 +108,60 @@ class SumFusion_DGL(nn.Module):
         return outx, outy, output
 
 
+class _GatedDGLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, W1, b1, W2, b2, Wo, bo):
+        x, y, W1, b1, W2, b2, Wo, bo = (_f32c(t) for t in (x, y, W1, b1, W2, b2, Wo, bo))
+        B, n = x.shape[0], Wo.shape[0]
+        if x.shape[1] != 512 or y.shape[1] != 512 or W1.shape != (512, 512) or W2.shape != (512, 512) or Wo.shape[1] != 512:
+            raise RuntimeError("gdl: GatedFusion_DGL expects 512-d features and dim = 512")
+        hx, hy = torch.empty((B, 512), device=x.device), torch.empty((B, 512), device=x.device)
+        out, x_out, y_out = (torch.empty((B, n), device=x.device) for _ in range(3))
+        L.call("gdl_head_gated_fwd", L.ptr(x), L.ptr(y), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(Wo), L.ptr(bo),
+               L.ptr(hx), L.ptr(hy), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B, n, L.cur_stream())
+        ctx.save_for_backward(x, y, hx, hy, W1, W2, Wo)
+        return x_out, y_out, out
+
+    @staticmethod
+    def backward(ctx, g_x_out, g_y_out, g_out):
+        x, y, hx, hy, W1, W2, Wo = ctx.saved_tensors
+        B, n = x.shape[0], Wo.shape[0]
+        gx = _f32c(g_x_out) if g_x_out is not None else None
+        gy = _f32c(g_y_out) if g_y_out is not None else None
+        go = _f32c(g_out) if g_out is not None else None
+        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        dW1, dW2, dWo = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wo)
+        db1, db2, dbo = torch.empty(512, device=x.device), torch.empty(512, device=x.device), torch.empty(n, device=x.device)
+        ws = torch.empty(2 * B * 512, device=x.device)
+        L.call("gdl_head_gated_bwd", L.ptr(x), L.ptr(y), L.ptr(hx), L.ptr(hy), L.ptr(W1), L.ptr(W2), L.ptr(Wo), L.ptr(gx),
+               L.ptr(gy), L.ptr(go), 1, L.ptr(dx), L.ptr(dy), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), L.ptr(dWo),
+               L.ptr(dbo), L.ptr(ws), B, n, L.cur_stream())
+        if gx is None and gy is None:
+            # `output` alone (detached hidden vectors, fusion_modules.py:237-243) leaves fc_x / fc_y without a gradient:
+            # autograd must see None, not zeros (SGD skips grad-less parameters, weight decay included)
+            return None, None, None, None, None, None, dWo, dbo
+        return dx, dy, dW1, db1, dW2, db2, dWo, dbo
+
+
+class GatedFusion_DGL(nn.Module):
+    """fusion_modules.py:213-250 (x_gate=True, the only setting basic_model.py:38 constructs)."""
+
+    def __init__(self, input_dim=512, dim=512, output_dim=100, x_gate=True):
+        super(GatedFusion_DGL, self).__init__()
+        if not x_gate:
+            raise NotImplementedError("gdl: GatedFusion_DGL is built for x_gate=True (basic_model.py:38)")
+        self.fc_x = nn.Linear(input_dim, dim)
+        self.fc_y = nn.Linear(input_dim, dim)
+        self.fc_out = nn.Linear(dim, output_dim)
+        self.x_gate = x_gate
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x, y):
+        out_x, out_y, output = _GatedDGLFn.apply(x, y, self.fc_x.weight, self.fc_x.bias, self.fc_y.weight, self.fc_y.bias,
+                                                 self.fc_out.weight, self.fc_out.bias)
+        return out_x, out_y, output
+
+
 class ConcatFusion(nn.Module):
     def __init__(self, input_dim=1024, output_dim=100):
         super(ConcatFusion, self).__init__()

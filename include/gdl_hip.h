@@ -198,6 +198,19 @@ GDL_API int gdl_head_concat_fwd(const float* x, const float* y, const float* W, 
 GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out,
                                 const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
                                 float* dy, float* dW, float* db, int B, int n_classes, void* stream);
+/* GatedFusion_DGL (fusion_modules.py:213-250, x_gate = True; SURVEY next row N2): fc_x, fc_y: Linear(512, 512),
+ * fc_out: Linear(512, n).  hx = fc_x(x), hy = fc_y(y) ([B][512], returned: saved for the backward);
+ *   out = fc_out(sigmoid(hx.detach()) * hy.detach()),  x_out = fc_out(sigmoid(hx) * hx),  y_out = fc_out(sigmoid(hy) * hy).
+ * Backward for upstream gradients on (x_out, y_out, out), any may be NULL: dx, dy (through fc_x / fc_y; `out` never
+ * reaches them), dWo / dbo = out's contribution (+ the unimodal ones if uni_in_dw), optionally dW1, db1, dW2, db2
+ * (NULL in the DGL step, whose script drops them and whose loss_f does not reach fc_x / fc_y).  ws: 2*B*512 floats. */
+GDL_API int gdl_head_gated_fwd(const float* x, const float* y, const float* W1, const float* b1, const float* W2,
+                               const float* b2, const float* Wo, const float* bo, float* hx, float* hy, float* out,
+                               float* x_out, float* y_out, int B, int n_classes, void* stream);
+GDL_API int gdl_head_gated_bwd(const float* x, const float* y, const float* hx, const float* hy, const float* W1,
+                               const float* W2, const float* Wo, const float* g_x_out, const float* g_y_out,
+                               const float* g_out, int uni_in_dw, float* dx, float* dy, float* dW1, float* db1, float* dW2,
+                               float* db2, float* dWo, float* dbo, float* ws, int B, int n_classes, void* stream);
 /* SumFusion_DGL (fusion_modules.py:16-30; SURVEY next row N2): fc_x, fc_y: Linear(512, n).
  *   x_out = fc_x(x), y_out = fc_y(y), out = fc_x(x.detach()) + fc_y(y.detach()).
  * Same flag meaning as the concat head; the sum head has two weight matrices [n][512] and two biases

@@ -130,6 +130,13 @@ def model_param_shapes(n_classes, fusion="concat_dgl"):
         out["fusion_module.fc_x.bias"] = (n_classes,)
         out["fusion_module.fc_y.weight"] = (n_classes, 512)
         out["fusion_module.fc_y.bias"] = (n_classes,)
+    elif fusion == "gated_dgl":  # fusion_modules.py:219-224
+        out["fusion_module.fc_x.weight"] = (512, 512)
+        out["fusion_module.fc_x.bias"] = (512,)
+        out["fusion_module.fc_y.weight"] = (512, 512)
+        out["fusion_module.fc_y.bias"] = (512,)
+        out["fusion_module.fc_out.weight"] = (n_classes, 512)
+        out["fusion_module.fc_out.bias"] = (n_classes,)
     elif fusion == "concat":  # fusion_modules.py:33-36
         out["fusion_module.fc_out.weight"] = (n_classes, 1024)
         out["fusion_module.fc_out.bias"] = (n_classes,)

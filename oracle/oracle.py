@@ -409,6 +409,51 @@ def sum_dgl_bwd(x, y, Wx, Wy, g_x_out, g_y_out, g_out):
     return dx, dy, dWx, dbx, dWy, dby
 
 
+def _sigmoid(v):
+    return (1.0 / (1.0 + np.exp(-v.astype(np.float64)))).astype(np.float32)
+
+
+def gated_dgl_fwd(x, y, W1, b1, W2, b2, Wo, bo):
+    """GatedFusion_DGL.forward with x_gate=True, fusion_modules.py:232-250 -> (out_x, out_y, output, hx, hy)."""
+    hx = linear_fwd(x, W1, b1)  # :234
+    hy = linear_fwd(y, W2, b2)  # :235
+    out = linear_fwd(_sigmoid(hx) * hy, Wo, bo)  # :241-243 on detached hx, hy
+    ox = linear_fwd(_sigmoid(hx) * hx, Wo, bo)  # :246-247
+    oy = linear_fwd(_sigmoid(hy) * hy, Wo, bo)  # :248-249
+    return ox, oy, out, hx, hy
+
+
+def gated_dgl_bwd(x, y, hx, hy, W1, W2, Wo, g_x_out, g_y_out, g_out):
+    """Autograd of the above for upstream gradients on (out_x, out_y, output); any may be None.  `output` uses
+    detached hidden vectors: it reaches fc_out only.  Returns dx, dy, {fc_x, fc_y, fc_out gradients}."""
+    B = x.shape[0]
+    dx, dy = np.zeros_like(x), np.zeros_like(y)
+    G = {"fc_x.weight": np.zeros_like(W1), "fc_x.bias": np.zeros(W1.shape[0], np.float32),
+         "fc_y.weight": np.zeros_like(W2), "fc_y.bias": np.zeros(W2.shape[0], np.float32),
+         "fc_out.weight": np.zeros_like(Wo), "fc_out.bias": np.zeros(Wo.shape[0], np.float32)}
+
+    def uni(g, h, inp, W, kx):
+        s = _sigmoid(h)
+        dz, dWo, dbo = linear_bwd(g, (s * h).astype(np.float32), Wo)  # fc_out applied to swish(h)
+        G["fc_out.weight"] += dWo
+        G["fc_out.bias"] += dbo
+        dh = (dz * (s * (1.0 + h * (1.0 - s)))).astype(np.float32)
+        d, dW, db = linear_bwd(dh, inp, W)
+        G[kx + ".weight"] += dW
+        G[kx + ".bias"] += db
+        return d
+
+    if g_x_out is not None:
+        dx += uni(g_x_out, hx, x, W1, "fc_x")
+    if g_y_out is not None:
+        dy += uni(g_y_out, hy, y, W2, "fc_y")
+    if g_out is not None:
+        _, dWo, dbo = linear_bwd(g_out, (_sigmoid(hx) * hy).astype(np.float32), Wo)
+        G["fc_out.weight"] += dWo
+        G["fc_out.bias"] += dbo
+    return dx, dy, G
+
+
 def concat_fwd(x, y, W, b):
     """ConcatFusion.forward, fusion_modules.py:38-42 -> output."""
     return linear_fwd(np.concatenate([x, y], 1), W, b)
@@ -442,6 +487,12 @@ class AVModel:
         self.a_map_shape, self.v_map_shape, self.BT = a.shape, v.shape, (B, T)
         self.fa = avgpool_fwd(a, B, 1)  # :78
         self.fv = avgpool_fwd(v, B, T)  # :73-79
+        if "fusion_module.fc_x.weight" in self.P and "fusion_module.fc_out.weight" in self.P:  # GatedFusion_DGL
+            P = self.P
+            a_out, v_out, out, self.hx, self.hy = gated_dgl_fwd(
+                self.fa, self.fv, P["fusion_module.fc_x.weight"], P["fusion_module.fc_x.bias"], P["fusion_module.fc_y.weight"],
+                P["fusion_module.fc_y.bias"], P["fusion_module.fc_out.weight"], P["fusion_module.fc_out.bias"])
+            return out, a_out, v_out
         if "fusion_module.fc_x.weight" in self.P:  # SumFusion_DGL (basic_model.py:29-30)
             P = self.P
             a_out, v_out, out = sum_dgl_fwd(self.fa, self.fv, P["fusion_module.fc_x.weight"], P["fusion_module.fc_x.bias"],
@@ -460,9 +511,23 @@ class AVModel:
         out, out_a, out_v = self.forward(spec, image, True)
         r = {"out": out}
         G = {}
-        sum_head = "fusion_module.fc_x.weight" in P
+        gated = "fusion_module.fc_x.weight" in P and "fusion_module.fc_out.weight" in P
+        sum_head = "fusion_module.fc_x.weight" in P and not gated
         W = None if sum_head else P["fusion_module.fc_out.weight"]
-        if sum_head:
+        if gated:
+            W1, W2 = P["fusion_module.fc_x.weight"], P["fusion_module.fc_y.weight"]
+            loss_v, g_v = softmax_ce(out_v, label, alpha)
+            loss_a, g_a = softmax_ce(out_a, label, alpha)
+            loss_f, g_f = softmax_ce(out, label, 1.0)
+            # phase 1 (:110): encoders get the unimodal gradients through fc_out, swish and fc_x / fc_y; every
+            # fusion_module.* gradient is then dropped (:114-119)
+            dfa, dfv, Gu = gated_dgl_bwd(self.fa, self.fv, self.hx, self.hy, W1, W2, W, g_a, g_v, None)
+            r["dropped_head_gradnorm"] = float(np.sqrt(sum(sumsq(v) for v in Gu.values())))
+            # phase 2 (:122): loss_f reaches fc_out only -- fc_x / fc_y keep grad None and are never updated
+            _, _, Gf = gated_dgl_bwd(self.fa, self.fv, self.hx, self.hy, W1, W2, W, None, None, g_f)
+            r.update(out_a=out_a, out_v=out_v, loss_a=loss_a, loss_v=loss_v)
+            dW, db = Gf["fc_out.weight"], Gf["fc_out.bias"]
+        elif sum_head:
             Wx, Wy = P["fusion_module.fc_x.weight"], P["fusion_module.fc_y.weight"]
             loss_v, g_v = softmax_ce(out_v, label, alpha)
             loss_a, g_a = softmax_ce(out_a, label, alpha)

@@ -306,6 +306,44 @@ def run_sum_head_case(name, fm, n_classes, batch=4):
     print(name, "ok")
 
 
+def run_gated_head_case(name, fm, n_classes, batch=4):
+    """GatedFusion_DGL(x_gate=True) (fusion_modules.py:213-250): forward + both backward phases of main_dgl.py:110-122."""
+    head = fm.GatedFusion_DGL(output_dim=n_classes, x_gate=True)
+    shapes = {"fc_x.weight": (512, 512), "fc_x.bias": (512,), "fc_y.weight": (512, 512), "fc_y.bias": (512,),
+              "fc_out.weight": (n_classes, 512), "fc_out.bias": (n_classes,)}
+    st = fx.make_state({"fusion_module." + k: v for k, v in shapes.items()})
+    head.load_state_dict({k[len("fusion_module."):]: torch.from_numpy(v.copy()) for k, v in st.items()})
+    r = np.random.default_rng([93, n_classes])
+    x = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    y = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    g = [r.standard_normal((batch, n_classes), dtype=np.float32) for _ in range(3)]
+    x_out, y_out, out = head(x, y)
+    d = {"x": x.detach().numpy(), "y": y.detach().numpy(), "x_out": x_out.detach().numpy(), "y_out": y_out.detach().numpy(),
+         "out": out.detach().numpy(), "g_x_out": g[0], "g_y_out": g[1], "g_out": g[2]}
+    (x_out * torch.from_numpy(g[0])).sum().add((y_out * torch.from_numpy(g[1])).sum()).backward(retain_graph=True)
+    d.update(dx=x.grad.numpy().copy(), dy=y.grad.numpy().copy())
+    def store(key, a):  # the 512x512 gradients: L2 norm + every 97th element keep the fixture small
+        if a.size <= 10000:
+            d[key] = a.copy()
+        else:
+            d[key + ".norm"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+            d[key + ".sample97"] = a.reshape(-1)[::97].copy()
+
+    for n, p in head.named_parameters():
+        store("uni." + n, p.grad.numpy())
+        p.grad = None
+    x.grad = None
+    y.grad = None
+    (out * torch.from_numpy(g[2])).sum().backward()
+    for n, p in head.named_parameters():
+        d["f_is_none." + n] = np.int8(p.grad is None)
+        if p.grad is not None:
+            store("f." + n, p.grad.numpy())
+    d["dx_after_f_is_none"] = np.int8(x.grad is None)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "ok", {n: int(d["f_is_none." + n]) for n, _ in head.named_parameters()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -327,6 +365,9 @@ def main():
         "head_sum_dgl_c6": lambda: run_sum_head_case("head_sum_dgl_c6", fm, 6),
         "dgl_sum_tiny_b4": lambda: run_step_case("dgl_sum_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                  fusion="sum"),
+        "head_gated_dgl_c6": lambda: run_gated_head_case("head_gated_dgl_c6", fm, 6),
+        "dgl_gated_tiny_b4": lambda: run_step_case("dgl_gated_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
+                                                   fusion="gated"),
         "concat_cremad_b2": lambda: run_step_case("concat_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224),
                                                   2, 0.0, 1, mode="concat"),
     }

@@ -120,7 +120,12 @@ def test_mirror_keeps_reference_interface():
     assert [n for n, _ in ms.named_parameters()][:4] == ["fusion_module.fc_x.weight", "fusion_module.fc_x.bias",
                                                          "fusion_module.fc_y.weight", "fusion_module.fc_y.bias"]
     assert ms.fusion_module.fc_x.weight.shape == (34, 512)
-    for method in ("film", "gated"):
+    mg = AVClassifier_DGL(argparse.Namespace(fusion_method="gated", dataset="CREMAD", modality="full"))
+    assert [n for n, _ in mg.named_parameters()][:6] == ["fusion_module.fc_x.weight", "fusion_module.fc_x.bias",
+                                                         "fusion_module.fc_y.weight", "fusion_module.fc_y.bias",
+                                                         "fusion_module.fc_out.weight", "fusion_module.fc_out.bias"]
+    assert mg.fusion_module.fc_out.weight.shape == (6, 512) and mg.fusion_module.x_gate is True
+    for method in ("film",):
         with pytest.raises(NotImplementedError):
             AVClassifier_DGL(argparse.Namespace(fusion_method=method, dataset="CREMAD", modality="full"))
     # no CPU fallback: CPU tensors are refused loudly

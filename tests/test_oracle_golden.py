@@ -56,6 +56,38 @@ def test_head_sum_dgl(golden_dir):
         np.testing.assert_allclose(a, g[k], rtol=RTOL, atol=1e-4)
 
 
+def _close_big(got, g, key, rtol=RTOL, atol=1e-4):
+    """Compare with a golden stored whole (small tensors) or as norm + every 97th element (the 512x512 ones)."""
+    if key in g.files:
+        np.testing.assert_allclose(got, g[key], rtol=rtol, atol=atol, err_msg=key)
+    else:
+        np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), float(g[key + ".norm"]), rtol=rtol, err_msg=key)
+        np.testing.assert_allclose(got.reshape(-1)[::97], g[key + ".sample97"], rtol=rtol, atol=atol, err_msg=key)
+
+
+def test_head_gated_dgl(golden_dir):
+    """GatedFusion_DGL(x_gate=True) (fusion_modules.py:213-250): forward and both backward phases."""
+    g = _load(golden_dir, "head_gated_dgl_c6")
+    names = ("fc_x.weight", "fc_x.bias", "fc_y.weight", "fc_y.bias", "fc_out.weight", "fc_out.bias")
+    st = fx.make_state({"fusion_module." + k: s for k, s in zip(names, ((512, 512), (512,), (512, 512), (512,), (6, 512), (6,)))})
+    W1, b1, W2, b2, Wo, bo = (st["fusion_module." + k] for k in names)
+    ox, oy, out, hx, hy = orc.gated_dgl_fwd(g["x"], g["y"], W1, b1, W2, b2, Wo, bo)
+    for a, k in ((ox, "x_out"), (oy, "y_out"), (out, "out")):
+        np.testing.assert_allclose(a, g[k], rtol=RTOL, atol=1e-4)
+    dx, dy, G = orc.gated_dgl_bwd(g["x"], g["y"], hx, hy, W1, W2, Wo, g["g_x_out"], g["g_y_out"], None)
+    np.testing.assert_allclose(dx, g["dx"], rtol=RTOL, atol=1e-4)
+    np.testing.assert_allclose(dy, g["dy"], rtol=RTOL, atol=1e-4)
+    for k in names:
+        _close_big(G[k], g, "uni." + k, atol=2e-4)
+    dx2, dy2, G2 = orc.gated_dgl_bwd(g["x"], g["y"], hx, hy, W1, W2, Wo, None, None, g["g_out"])
+    assert not dx2.any() and not dy2.any() and int(g["dx_after_f_is_none"]) == 1
+    for k in names:
+        if int(g["f_is_none." + k]):  # fc_x / fc_y: loss_f never reaches them (detached hidden vectors)
+            assert not G2[k].any(), k
+        else:
+            _close_big(G2[k], g, "f." + k)
+
+
 def test_head_concat(golden_dir):
     g = _load(golden_dir, "head_concat_c6")
     st = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
@@ -129,7 +161,7 @@ def check_step_against_golden(g, model_step, cfg, steps, rtol_logits=1e-3, rtol_
 
 
 @pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2",
-                                  "dgl_sum_tiny_b4"])
+                                  "dgl_sum_tiny_b4", "dgl_gated_tiny_b4"])
 def test_step(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = json.loads(str(g["config"]))

@@ -95,6 +95,54 @@ def test_head_sum_dgl_golden():
         np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=2e-4, atol=1e-4)
 
 
+def test_head_gated_dgl_golden():
+    """GatedFusion_DGL through the C ABI against the reference's golden (both backward phases of the DGL step)."""
+    g = _gold("head_gated_dgl_c6")
+    n = 6
+    names = ("fc_x.weight", "fc_x.bias", "fc_y.weight", "fc_y.bias", "fc_out.weight", "fc_out.bias")
+    st = fx.make_state({"fusion_module." + k: sh for k, sh in zip(names, ((512, 512), (512,), (512, 512), (512,), (n, 512), (n,)))})
+    W1, b1, W2, b2, Wo, bo = (dev(st["fusion_module." + k]) for k in names)
+    x, y = dev(g["x"]), dev(g["y"])
+    B = x.shape[0]
+    hx, hy = torch.empty(B, 512, device=DEV), torch.empty(B, 512, device=DEV)
+    out, xo, yo = (torch.empty(B, n, device=DEV) for _ in range(3))
+    s = L.cur_stream()
+    L.call("gdl_head_gated_fwd", L.ptr(x), L.ptr(y), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(Wo), L.ptr(bo), L.ptr(hx),
+           L.ptr(hy), L.ptr(out), L.ptr(xo), L.ptr(yo), B, n, s)
+    torch.cuda.synchronize()
+    for a, k in ((xo, "x_out"), (yo, "y_out"), (out, "out")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=2e-4, atol=1e-4)
+    gx, gy, go = dev(g["g_x_out"]), dev(g["g_y_out"]), dev(g["g_out"])
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    G = {k: torch.empty_like(t) for k, t in zip(names, (W1, b1, W2, b2, Wo, bo))}
+    ws = torch.empty(2 * B * 512, device=DEV)
+
+    def close(got, key):
+        got = got.cpu().numpy()
+        if key in g.files:
+            np.testing.assert_allclose(got, g[key], rtol=2e-4, atol=2e-4, err_msg=key)
+        else:
+            np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), float(g[key + ".norm"]), rtol=2e-4)
+            np.testing.assert_allclose(got.reshape(-1)[::97], g[key + ".sample97"], rtol=2e-4, atol=2e-4, err_msg=key)
+
+    # phase 1: the unimodal losses, plain autograd (every head gradient is produced; the script then drops them)
+    L.call("gdl_head_gated_bwd", L.ptr(x), L.ptr(y), L.ptr(hx), L.ptr(hy), L.ptr(W1), L.ptr(W2), L.ptr(Wo), L.ptr(gx), L.ptr(gy), None,
+           1, L.ptr(dx), L.ptr(dy), L.ptr(G["fc_x.weight"]), L.ptr(G["fc_x.bias"]), L.ptr(G["fc_y.weight"]), L.ptr(G["fc_y.bias"]),
+           L.ptr(G["fc_out.weight"]), L.ptr(G["fc_out.bias"]), L.ptr(ws), B, n, s)
+    torch.cuda.synchronize()
+    close(dx, "dx")
+    close(dy, "dy")
+    for k in names:
+        close(G[k], "uni." + k)
+    # phase 2: loss_f reaches fc_out only
+    L.call("gdl_head_gated_bwd", L.ptr(x), L.ptr(y), L.ptr(hx), L.ptr(hy), L.ptr(W1), L.ptr(W2), L.ptr(Wo), None, None, L.ptr(go), 0,
+           None, None, None, None, None, None, L.ptr(G["fc_out.weight"]), L.ptr(G["fc_out.bias"]), L.ptr(ws), B, n, s)
+    torch.cuda.synchronize()
+    close(G["fc_out.weight"], "f.fc_out.weight")
+    close(G["fc_out.bias"], "f.fc_out.bias")
+    assert int(g["f_is_none.fc_x.weight"]) == 1 and int(g["f_is_none.fc_y.bias"]) == 1
+
+
 def test_head_concat_golden():
     g = _gold("head_concat_c6")
     st_ = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
@@ -260,7 +308,8 @@ def _batch(cfg, st):
     return dev(spec), dev(image), torch.from_numpy(label).to(DEV)
 
 
-STEP_CASES = ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2", "dgl_sum_tiny_b4"]
+STEP_CASES = ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2", "dgl_sum_tiny_b4",
+              "dgl_gated_tiny_b4"]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -347,7 +396,7 @@ def _bufnames(g, pre):
     return [k[len(pre + "buf."):] for k in g.files if k.startswith(pre + "buf.")]
 
 
-@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2", "dgl_sum_tiny_b4"])
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2", "dgl_sum_tiny_b4", "dgl_gated_tiny_b4"])
 def test_dropin_autograd_step_golden(name):
     """The reference's own step body (main_dgl.py:97-154) run UNCHANGED on the drop-in modules:
     torch autograd with retain_graph, grad=None on the head, second backward, torch clip + SGD."""
