@@ -147,17 +147,20 @@ def main():
     torch.cuda.synchronize()
     prof = (not a.no_prof) and rank == 0
     kernels, dominant = None, None
-    if prof:
+    if not a.no_prof:
         # untimed calibration: every launch tapped (costs ~10 % throughput), gives the per-kernel table and
-        # names the dominant kernel; the timed region then taps ONLY that kernel's launches
-        lib.gdl_prof_set_filter(None)
-        lib.gdl_prof_enable(1)
+        # names the dominant kernel; the timed region then taps ONLY that kernel's launches.  Every rank runs
+        # the three steps (they contain the gradient all-reduces); only rank 0 taps.
+        if prof:
+            lib.gdl_prof_set_filter(None)
+            lib.gdl_prof_enable(1)
         for _ in range(3):
             tr.step(spec, image, label)
-        lib.gdl_prof_enable(0)
-        kernels = collect(3)
-        dominant = kernels[0]["kernel"]
-        lib.gdl_prof_set_filter(dominant.encode())
+        if prof:
+            lib.gdl_prof_enable(0)
+            kernels = collect(3)
+            dominant = kernels[0]["kernel"]
+            lib.gdl_prof_set_filter(dominant.encode())
     barrier()
     if prof:
         lib.gdl_prof_enable(1)
@@ -194,7 +197,7 @@ def main():
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
                 "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
     phases = None
-    if a.phases and rank == 0:
+    if a.phases:  # (every rank runs the extra steps: they contain collectives)
         tr.phase_events = []
         for _ in range(5):
             tr.step(spec, image, label)

@@ -205,12 +205,15 @@ class DGLTrainer:
         self.s_v.wait_event(ev2)
         with torch.cuda.stream(self.s_v):
             self.eng_v.backward(self.gviews[nf + 60:nf + 120], dfeat=self.dfv)
-            if red is not None:
-                red.launch("visual")
         with torch.cuda.stream(self.s_a):
             self.eng_a.backward(self.gviews[nf:nf + 60], dfeat=self.dfa)
             if red is not None:
+                # collectives of one communicator run in issue order: the audio bucket (its backward is the
+                # shorter one) goes first so that it overlaps the rest of the visual backward
                 red.launch("audio")
+        if red is not None:
+            with torch.cuda.stream(self.s_v):
+                red.launch("visual")
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_v)
         if red is not None:
