@@ -80,6 +80,11 @@ def main():
         raise SystemExit("bench.py: for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
+    # test plumbing (tests/test_ddp_gpu.py): GDL_BENCH_BACKEND=gloo with GDL_BENCH_ONE_DEVICE=1 runs the N-rank
+    # control flow on a box with a single GPU (RCCL refuses two ranks on one device); never used for numbers
+    backend = os.environ.get("GDL_BENCH_BACKEND", "nccl")
+    if os.environ.get("GDL_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -87,7 +92,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from gdl import _lib as L
@@ -116,7 +124,7 @@ def main():
         if world > 1:
             import torch.distributed as dist
 
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
 
     import ctypes
 
@@ -211,6 +219,11 @@ def main():
             for k in range(4):
                 acc.setdefault(names[k] + "->" + names[k + 1], []).append(es[k].elapsed_time(es[k + 1]))
         phases = {k: round(sum(v) / len(v), 3) for k, v in acc.items()}
+    if world > 1:
+        import torch.distributed as dist
+
+        barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     value = world * B * a.steps / elapsed

@@ -98,3 +98,23 @@ def test_two_rank_step_matches_oracle():
         buf = np.zeros_like(p)
         orc.sgd_(p, g, buf, 2e-3, 0.9, 1e-4, True)
         np.testing.assert_allclose(got, p, rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_bench_two_rank_control_flow():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"):
+    every rank must take part in every collective-bearing step (warm-up, calibration, timed region) -- a rank-0-only
+    step would hang here.  Two ranks on the one device over gloo (test plumbing of bench.py); the number is meaningless."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, GDL_BENCH_BACKEND="gloo", GDL_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert d["roofline"] and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
