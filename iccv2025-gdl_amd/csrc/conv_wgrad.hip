@@ -10,11 +10,13 @@
 // no transpose.
 //
 // Block = 256 threads (2x2 waves), tile TK x TC output channels for ONE tap and ONE
-// slice of the pixel range (split-K); LDS stages of 64 pixels, double buffered,
-// register staged.  Partial tiles go to a workspace [split][K][R*S][C] f32; a second
-// kernel folds the splits in a fixed order and writes the reference's [K][C][R][S]
-// gradient layout.  Tap is the fastest-varying index among blocks that share an XCD,
-// so the 9 taps of one pixel slice reuse dy / x from that XCD's L2.
+// slice of the pixel range (split-K); LDS stages of 64 pixels, double buffered, filled by
+// LDS-DMA (buffer_load ... lds) through the forward gather table.  Partial tiles go to a
+// workspace [split][K][R*S][C] f32; a second kernel folds the splits in a fixed order and
+// writes the reference's [K][C][R][S] gradient layout.  Tap is the fastest-varying index
+// among blocks that share an XCD, so the taps of one pixel slice reuse dy / x from that
+// XCD's L2.  This is the general kernel (stride-2 3x3, 1x1, the direct stem in `split` mode);
+// the 3x3 stride-1 convolutions run on conv_wgrad9.hip, which handles all nine taps per block.
 #include <stdlib.h>
 
 #include "common.h"
