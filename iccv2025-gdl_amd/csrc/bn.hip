@@ -92,7 +92,7 @@ __device__ __forceinline__ double block_sum_double(double v, double* sh) {
 // Column sums of a [rows][C][2] float array in double, FIN_CH channels per block: thread (rl, cl) adds
 // rows rl, rl+FIN_RL, .. of channel c0+cl (16 lanes read one 128-byte line; 8 rows in flight), the FIN_RL
 // row-lanes are then folded through LDS in a fixed order.  Returns the two sums to the threads rl == 0.
-constexpr int FIN_CH = 16, FIN_RL = 64;  // block = 1024 threads
+constexpr int FIN_CH = 8, FIN_RL = 128;  // block = 1024 threads; 8 channels = one 64-byte segment of a partial row
 __device__ __forceinline__ void fin_colsum(const float* __restrict__ partial, int rows, int C, int c, double& s, double& q) {
     __shared__ double sh[FIN_RL][FIN_CH][2];
     const int rl = threadIdx.x / FIN_CH, cl = threadIdx.x % FIN_CH;
@@ -117,12 +117,17 @@ __device__ __forceinline__ void fin_colsum(const float* __restrict__ partial, in
     sh[rl][cl][0] = s;
     sh[rl][cl][1] = q;
     __syncthreads();
-    if (rl == 0) {
-        for (int r = 1; r < FIN_RL; ++r) {
-            s += sh[r][cl][0];
-            q += sh[r][cl][1];
+    // fixed binary tree over the row-lanes (deterministic; a serial fold by one thread cost ~3 us)
+#pragma unroll
+    for (int st = FIN_RL / 2; st > 0; st >>= 1) {
+        if (rl < st) {
+            sh[rl][cl][0] += sh[rl + st][cl][0];
+            sh[rl][cl][1] += sh[rl + st][cl][1];
         }
+        __syncthreads();
     }
+    s = sh[0][cl][0];
+    q = sh[0][cl][1];
 }
 
 __global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_finalize_train_kernel(
