@@ -69,9 +69,15 @@ __device__ __forceinline__ void w9_wait() {
 // 32-byte granule swizzle of a 128-byte [pixel][64 channels] row (same as conv_wgrad.hip's wg_swz<128>)
 __device__ __forceinline__ int w9_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// NG = 1: one group of 4 waves per block.  NG = 2: two groups (8 waves) that own alternate 64-pixel stages, each with
+// its own double-buffered LDS stages, and fold their accumulators through LDS before the block leaves ONE partial
+// tile: two waves per SIMD (one group multiplies while the other issues its DMA / waits for LDS) at the partial
+// traffic of half as many blocks.
+template <int NG>
+__global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = NG == 1 ? 0 : (wave_all >> 2), wave = wave_all & 3;
     const int g = lane >> 4, li = lane & 15;
 
     // block -> (slice, ktile, ctile); the tiles of one pixel slice are neighbours on one XCD
@@ -85,16 +91,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     const int k0 = kt * 64, c0 = ct * 64;
     const int m_begin = slice * a.chunk;
     const int m_end = min(a.M, m_begin + a.chunk);
-    const int nst = (m_end - m_begin + W9_BP - 1) / W9_BP;
+    const int nst_all = (m_end - m_begin + W9_BP - 1) / W9_BP;
+    const int nit = (nst_all + NG - 1) / NG;               // loop trips (every wave of the block takes part in the barrier)
+    const int nst = (nst_all - grp + NG - 1) / NG;         // stages of this group: grp, grp + NG, ...
 
     const int nins = (a.slab_rows + 7) >> 3;        // 1 KiB DMA pieces of the slab
     const int STAGE = W9_BP * 128 + nins * 1024;    // dy tile + slab
+    unsigned char* smem = smem_all + grp * 2 * STAGE;  // this group's two stage buffers
     const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned zrow = smem_base + 2 * STAGE;    // 1 KiB of zeros
+    const unsigned zrow = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem_all + NG * 2 * STAGE;
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-    if (wave == 0) w9_dma16(rx, smem + 2 * STAGE, (int)0x80000000);  // zero row (out-of-range DMA deposits zeros)
+    if (wave_all == 0) w9_dma16(rx, smem_all + NG * 2 * STAGE, (int)0x80000000);  // zero row (out-of-range DMA deposits zeros)
 
     // ---- DMA bookkeeping.  A piece = 8 rows x 128 B; lane L -> row L>>3, physical 16-byte chunk L&7;
     // the source chunk is the one whose swizzled position that is.
@@ -105,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     for (int i = 0; i < 2; ++i) {
         const int row = (wave + 4 * i) * 8 + prow;
         const int ch = (((pch >> 1) ^ w9_swz(row)) << 1) | (pch & 1);
-        dy_off[i] = (m_begin + row) * (a.K * 2) + k0 * 2 + ch * 16;
+        dy_off[i] = (m_begin + grp * W9_BP + row) * (a.K * 2) + k0 * 2 + ch * 16;
     }
-    int ld_m = m_begin;  // first pixel of the next stage to load
+    int ld_m = m_begin + grp * W9_BP;  // first pixel of the next stage to load
     auto load_stage = [&](int buf) {
         unsigned char* Ks = smem + buf * STAGE;
         unsigned char* Xs = Ks + W9_BP * 128;
@@ -115,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
         for (int i = 0; i < 2; ++i) {
             const int m = ld_m + (wave + 4 * i) * 8 + prow;
             w9_dma16(rdy, Ks + (wave + 4 * i) * 1024, m < m_end ? dy_off[i] : (int)0x80000000);
-            dy_off[i] += W9_BP * a.K * 2;
+            dy_off[i] += NG * W9_BP * a.K * 2;
         }
         for (int jj = wave; jj < nins; jj += 4) {
             const int sr = jj * 8 + prow;
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
             const int ch = (((pch >> 1) ^ w9_swz(sr)) << 1) | (pch & 1);
             w9_dma16(rx, Xs + jj * 1024, ok ? pix * (a.C * 2) + c0 * 2 + ch * 16 : (int)0x80000000);
         }
-        ld_m += W9_BP;
+        ld_m += NG * W9_BP;
     };
 
     // ---- per-lane LDS read addresses (stage buffer 0; the other buffer is +STAGE).
@@ -169,16 +178,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
 
     if (nst > 0) {
         load_stage(0);
-        load_masks(m_begin, pmask);
+        load_masks(m_begin + grp * W9_BP, pmask);
     }
-    for (int st = 0; st < nst; ++st) {
+    for (int st = 0; st < nit; ++st) {
         // the stage issued one iteration ago (and the masks) have landed; every wave is done with the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (st >= nst) continue;  // (NG = 2, odd stage count: the second group idles through the last trip)
         if (st + 1 < nst) {
             load_stage((st + 1) & 1);
-            load_masks(m_begin + (st + 1) * W9_BP, nmask);
+            load_masks(m_begin + (NG * (st + 1) + grp) * W9_BP, nmask);
         }
         // ---- two K-steps of 32 pixels (the second one 32 rows = 4096 bytes further: instruction offset)
 #pragma unroll
@@ -231,6 +241,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int h = 0; h < 2; ++h) pmask[ks][h] = nmask[ks][h];
+    }
+    if (NG == 2) {
+        // fold the second group's accumulators into the first's through LDS (the stage buffers are dead: barrier first)
+        float4* xch = (float4*)smem_all + (size_t)wave * 36 * 64 + lane;
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xch[(t * 4 + i) * 64] = make_float4(acc[t][i][0], acc[t][i][1], acc[t][i][2], acc[t][i][3]);
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = xch[(t * 4 + i) * 64];
+                acc[t][i][0] += v.x;
+                acc[t][i][1] += v.y;
+                acc[t][i][2] += v.z;
+                acc[t][i][3] += v.w;
+            }
     }
     // ---- partial tile in fragment order: [slice][kt][ct][wave][tap][i][lane][4]
     float4* part = (float4*)a.partial + ((((size_t)slice * per_slice + rem) * 4 + wave) * 36) * 64;
@@ -336,15 +370,29 @@ size_t conv_wgrad9_ws_bytes(int M, int C, int K) {
     return (size_t)p.nsplit * K * 9 * C * sizeof(float);
 }
 
-static size_t w9_lds_bytes(int W) {
+static int w9_groups() {
+    static int v = -1;
+    if (v < 0) {
+        // Measured on MI355X: two groups are 1.25x faster when the kernel runs alone (tools/bench_conv.py: 0.071 vs
+        // 0.090 ms on the layer-1 shape at 256 blocks) but 4 % SLOWER inside the step (bench.py: 7.36 vs 7.05 ms) --
+        // their 124-160 KB of LDS keep the other streams' blocks off the CU.  Default: one group.
+        const char* e = getenv("GDL_WGRAD9_NG");  // tuning aid: 2 = 8-wave blocks
+        v = e ? atoi(e) : 1;
+        if (v != 2) v = 1;
+    }
+    return v;
+}
+static size_t w9_lds_bytes(int W, int ng) {
     const int rows = W9_BP + 2 * W + 2;
-    return 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024;
+    const size_t stages = ng * 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024;
+    const size_t fold = ng == 2 ? (size_t)4 * 36 * 64 * 16 : 0;  // accumulator exchange of the two groups
+    return stages > fold ? stages : fold;
 }
 
 // true if this geometry runs on the 9-tap kernel
 bool conv_wgrad9_ok(int dtype, int W, int C, int K, int R, int S, int stride, int pad) {
     return conv_wgrad9_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 64 == 0 &&
-           K % 64 == 0 && w9_lds_bytes(W) <= 80 * 1024;
+           K % 64 == 0 && w9_lds_bytes(W, 1) <= 80 * 1024;
 }
 
 int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K, void* ws,
@@ -373,10 +421,13 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
         return GDL_ERR_WORKSPACE;
     }
     a.partial = (float*)ws;
-    const size_t lds = w9_lds_bytes(W);
+    const int ng = (w9_groups() == 2 && w9_lds_bytes(W, 2) <= 160 * 1024) ? 2 : 1;
+    const size_t lds = w9_lds_bytes(W, ng);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad9)");
         attr_set = true;
     }
@@ -384,7 +435,10 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     {
         ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true);
-        hipExtLaunchKernelGGL(conv_wgrad9_kernel, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
+        if (ng == 2)
+            hipExtLaunchKernelGGL(conv_wgrad9_kernel<2>, dim3(grid), dim3(512), lds, st, prof.e0(), prof.e1(), 0, a);
+        else
+            hipExtLaunchKernelGGL(conv_wgrad9_kernel<1>, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
     }
     const size_t total4 = (size_t)K * C * 9 / 4;
