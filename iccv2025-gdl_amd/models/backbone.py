@@ -16,15 +16,22 @@ from gdl import _lib as L
 from gdl.encoder import EncoderEngine
 
 
+def _weights_only_conv(cin, cout, k, stride, pad):
+    """An nn.Conv2d used purely as a named, correctly shaped and initialised weight holder (bias-free, as every
+    convolution of the reference backbone); the arithmetic happens in csrc/."""
+    return nn.Conv2d(cin, cout, (k, k), stride=(stride, stride), padding=(pad, pad), bias=False)
+
+
 def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
-    """3x3 convolution with padding (backbone.py:20-23) -- parameter container."""
-    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation, groups=groups, bias=False,
-                     dilation=dilation)
+    """Same call signature as backbone.py:20-23; the engine implements groups = dilation = 1 only."""
+    if (groups, dilation) != (1, 1):
+        raise NotImplementedError("gdl: grouped / dilated 3x3 convolutions are not used by the reference and not built")
+    return _weights_only_conv(in_planes, out_planes, 3, stride, 1)
 
 
 def conv1x1(in_planes, out_planes, stride=1):
-    """1x1 convolution (backbone.py:26-28) -- parameter container."""
-    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+    """Same call signature as backbone.py:26-28 (the downsample shortcut)."""
+    return _weights_only_conv(in_planes, out_planes, 1, stride, 0)
 
 
 class BasicBlock(nn.Module):
@@ -33,19 +40,17 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64, dilation=1,
                  norm_layer=None):
-        super(BasicBlock, self).__init__()
-        if norm_layer is None:
-            norm_layer = nn.BatchNorm2d
-        if groups != 1 or base_width != 64:
-            raise ValueError('BasicBlock only supports groups=1 and base_width=64')
+        super().__init__()
+        bn = nn.BatchNorm2d if norm_layer is None else norm_layer
+        if (groups, base_width) != (1, 64):
+            raise ValueError('BasicBlock only supports groups=1 and base_width=64')  # same error as the reference
         if dilation > 1:
             raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
-        self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn1 = norm_layer(planes)
-        self.relu = nn.ReLU(inplace=True)
-        self.conv2 = conv3x3(planes, planes)
-        self.bn2 = norm_layer(planes)
-        self.downsample = downsample
+        # registration order = state_dict / named_parameters order of the reference block:
+        # conv1, bn1, (relu), conv2, bn2, downsample
+        for name, mod in (("conv1", conv3x3(inplanes, planes, stride)), ("bn1", bn(planes)), ("relu", nn.ReLU(inplace=True)),
+                          ("conv2", conv3x3(planes, planes)), ("bn2", bn(planes)), ("downsample", downsample)):
+            setattr(self, name, mod)
         self.stride = stride
 
     def forward(self, x):
@@ -93,67 +98,58 @@ class ResNet(nn.Module):
 
     def __init__(self, args, block, layers, modality, num_classes=1000, pool='avgpool', zero_init_residual=False,
                  groups=1, width_per_group=64, replace_stride_with_dilation=None, norm_layer=None):
-        super(ResNet, self).__init__()
-        self.modality = modality
-        self.pool = pool
-        if norm_layer is None:
-            norm_layer = nn.BatchNorm2d
-        if norm_layer is not nn.BatchNorm2d or block is not BasicBlock or list(layers) != [2, 2, 2, 2]:
-            raise NotImplementedError("gdl: the MI355X engine implements resnet18 (BasicBlock [2,2,2,2], BatchNorm2d)")
-        self._norm_layer = norm_layer
-        self.inplanes = 64
-        self.dilation = 1
-        if replace_stride_with_dilation is None:
-            replace_stride_with_dilation = [False, False, False]
-        if len(replace_stride_with_dilation) != 3:
+        super().__init__()
+        bn = nn.BatchNorm2d if norm_layer is None else norm_layer
+        rswd = [False] * 3 if replace_stride_with_dilation is None else list(replace_stride_with_dilation)
+        if len(rswd) != 3:
             raise ValueError("replace_stride_with_dilation should be None "
                              "or a 3-element tuple, got {}".format(replace_stride_with_dilation))
-        if any(replace_stride_with_dilation) or groups != 1 or width_per_group != 64:
+        if bn is not nn.BatchNorm2d or block is not BasicBlock or list(layers) != [2, 2, 2, 2]:
+            raise NotImplementedError("gdl: the MI355X engine implements resnet18 (BasicBlock [2,2,2,2], BatchNorm2d)")
+        if any(rswd) or (groups, width_per_group) != (1, 64):
             raise NotImplementedError("gdl: dilation / groups are not used by the reference and not implemented")
-        self.groups = groups
-        self.base_width = width_per_group
-        if modality == 'audio':
-            self.conv1 = nn.Conv2d(1, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
-        elif modality == 'visual':
-            self.conv1 = nn.Conv2d(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias=False)
-        else:
+        stem_in = {'audio': 1, 'visual': 3}  # backbone.py:96-101
+        if modality not in stem_in:
             raise NotImplementedError('Incorrect modality, should be audio or visual but got {}'.format(modality))
-        self.bn1 = norm_layer(self.inplanes)
+        self.modality, self.pool, self.args = modality, pool, args
+        self._norm_layer, self.groups, self.base_width, self.dilation = bn, groups, width_per_group, 1
+        # modules in the reference's registration order: conv1, bn1, relu, maxpool, layer1..4
+        self.inplanes = 64
+        self.conv1 = _weights_only_conv(stem_in[modality], 64, 7, 2, 3)
+        self.bn1 = bn(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
-        self.args = args
-        for m in self.modules():  # backbone.py:117-122
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
-                nn.init.normal_(m.weight, mean=1, std=0.02)
-                nn.init.constant_(m.bias, 0)
+        for idx, (width, stride) in enumerate(((64, 1), (128, 2), (256, 2), (512, 2))):
+            setattr(self, "layer%d" % (idx + 1), self._make_layer(block, width, layers[idx], stride=stride))
+        # constructor-time initialisation (backbone.py:117-127): it consumes the global RNG in module order, which
+        # seeded runs of the reference depend on, so it is reproduced call for call even though the DGL script
+        # re-initialises everything through utils.weight_init afterwards
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(mod, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.normal_(mod.weight, mean=1, std=0.02)
+                nn.init.zeros_(mod.bias)
         if zero_init_residual:
-            for m in self.modules():
-                if isinstance(m, BasicBlock):
-                    nn.init.constant_(m.bn2.weight, 0)
+            for mod in self.modules():
+                if isinstance(mod, BasicBlock):
+                    nn.init.zeros_(mod.bn2.weight)
         # engine state (not part of state_dict)
         self.gdl_dtype = os.environ.get("GDL_DTYPE", "bf16")
         self._engines = {}
 
     def _make_layer(self, block, planes, blocks, stride=1, dilate=False):
-        norm_layer = self._norm_layer
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = nn.Sequential(
-                conv1x1(self.inplanes, planes * block.expansion, stride),
-                norm_layer(planes * block.expansion),
-            )
-        layers = [block(self.inplanes, planes, stride, downsample, self.groups, self.base_width, 1, norm_layer)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes, groups=self.groups, base_width=self.base_width,
-                                dilation=self.dilation, norm_layer=norm_layer))
-        return nn.Sequential(*layers)
+        """A stage of `blocks` BasicBlocks; the first one changes resolution / width and then carries the
+        conv1x1 + BatchNorm shortcut (backbone.py:134-156)."""
+        width = planes * block.expansion
+        shortcut = None
+        if stride != 1 or self.inplanes != width:
+            shortcut = nn.Sequential(conv1x1(self.inplanes, width, stride), self._norm_layer(width))
+        stage = [block(self.inplanes, planes, stride, shortcut, self.groups, self.base_width, 1, self._norm_layer)]
+        self.inplanes = width
+        stage += [block(width, planes, groups=self.groups, base_width=self.base_width, dilation=self.dilation,
+                        norm_layer=self._norm_layer) for _ in range(blocks - 1)]
+        return nn.Sequential(*stage)
 
     # ------------------------------------------------------------------ engine plumbing
     def _bn_layers(self):

@@ -344,6 +344,25 @@ def run_gated_head_case(name, fm, n_classes, batch=4):
     print(name, "ok", {n: int(d["f_is_none." + n]) for n, _ in head.named_parameters()})
 
 
+def run_seeded_init_case(name, bm):
+    """`setup_seed(0)` -> `AVClassifier_DGL(args)` -> `.apply(weight_init)` (main_dgl.py:226-238) for every fusion head
+    this build provides: per-tensor (sum, sum|.|) of the resulting state_dict.  Pins constructor order, constructor-time
+    RNG consumption and weight_init of the drop-in modules."""
+    import utils.utils as ut  # the reference's (REF is first on sys.path)
+
+    d = {}
+    for fusion in ("concat", "sum", "gated"):
+        ut.setup_seed(0)
+        args = argparse.Namespace(fusion_method=fusion, dataset="CREMAD", modality="full", batch_size=2)
+        model = bm.AVClassifier_DGL(args)
+        model.apply(ut.weight_init)
+        sd = model.state_dict()
+        d[fusion + ".keys"] = np.array(list(sd.keys()))
+        d[fusion + ".sums"] = np.stack([_summ(v.float()) for v in sd.values()])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -362,6 +381,7 @@ def main():
                                                4.0, 1),
         "dgl_ks_b2": lambda: run_step_case("dgl_ks_b2", bm, bb, fm, "KineticSound", (129, 626), 3, (224, 224), 2, 2.0,
                                            1),
+        "seeded_init": lambda: run_seeded_init_case("seeded_init", bm),
         "head_sum_dgl_c6": lambda: run_sum_head_case("head_sum_dgl_c6", fm, 6),
         "dgl_sum_tiny_b4": lambda: run_step_case("dgl_sum_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                  fusion="sum"),

@@ -131,3 +131,22 @@ def test_mirror_keeps_reference_interface():
     # no CPU fallback: CPU tensors are refused loudly
     with pytest.raises(Exception):
         m(torch.zeros(1, 1, 257, 188), torch.zeros(1, 3, 3, 224, 224))
+
+
+def test_seeded_init_matches_reference():
+    """setup_seed(0) + AVClassifier_DGL(args) + apply(weight_init) gives the reference's initial weights (golden
+    captured from the imported reference: per-tensor sum and sum of magnitudes), for every head this build provides."""
+    import numpy as np
+
+    from models.basic_model import AVClassifier_DGL
+    from utils.utils import setup_seed, weight_init
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "seeded_init.npz"))
+    for fusion in ("concat", "sum", "gated"):
+        setup_seed(0)
+        m = AVClassifier_DGL(argparse.Namespace(fusion_method=fusion, dataset="CREMAD", modality="full", batch_size=2))
+        m.apply(weight_init)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [str(k) for k in g[fusion + ".keys"]]
+        got = np.stack([[v.double().sum().item(), v.double().abs().sum().item()] for v in sd.values()])
+        np.testing.assert_allclose(got, g[fusion + ".sums"], rtol=1e-12, atol=1e-12)
