@@ -35,3 +35,18 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries():
+    """The HIP library and the oracle's C restatement are build products (git-ignored): build them when a fresh
+    checkout runs the suite before `__graft_entry__.build()` did (hipcc cross-compiles gfx950 without a GPU).  An
+    existing library is left alone -- on the GPU box the pre-built one travels with the snapshot."""
+    import subprocess
+
+    so = os.path.join(PKG, "csrc", "build", "libgdl_hip.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc"), "-j8"])
+    from oracle import oracle as orc
+
+    orc.build()
