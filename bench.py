@@ -235,7 +235,8 @@ def main():
         "config": {"workload": "CREMA-D DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x257x188 + frames "
                                "3x3x224x224, alpha=4, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "buckets": "audio_net / visual_net / fusion fc_out, RCCL all-reduce" if world > 1 else "none"},
+                   "buckets": "fusion head | audio layer4 | audio rest | visual layer4 | visual rest, RCCL all-reduce, layer4 "
+                              "buckets overlapped with the rest of the backward" if world > 1 else "none"},
         "samples_per_sec_per_gpu": round(value / world, 2),
         "step_tflops": round(value * TRAIN_GFLOP_PER_SAMPLE / 1e3, 2),
         "mfma_frac_end_to_end": round(value / world * TRAIN_GFLOP_PER_SAMPLE / 1e3 / MFMA_PEAK_TFLOPS[a.dtype], 4),

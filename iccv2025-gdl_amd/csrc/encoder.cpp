@@ -78,6 +78,9 @@ struct gdl_encoder {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side[2] = {nullptr, nullptr};
     bool side_pending[2] = {false, false};
+    // gdl_encoder_backward_phase: state carried from phase 1 (layer4) to phase 2 (the rest)
+    void *bw_dz = nullptr, *bw_spare = nullptr;
+    long bw_serial = -1;  // serial of the forward whose phase 1 ran
     ~gdl_encoder() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -506,24 +509,44 @@ static int bn_backward(gdl_encoder* e, BN& n, const void* g, const void* y, int 
                         st);
 }
 
-int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfmap_nchw, float* const* grads,
-                         void* stream) {
+// phase 0: the whole backward.  phase 1: the upstream gradient and layer4 (blocks 7, 6) -- afterwards the last 15
+// gradient tensors (8.4 M of the 11.2 M parameters) are final on `stream`, so a data-parallel caller can start
+// their all-reduce while phase 2 (layer3 .. layer1 and the stem) runs.
+static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float* dfmap_nchw, float* const* grads,
+                                 void* stream, int phase) {
     GDL_REQUIRE(e && grads, "encoder_backward: null");
-    GDL_REQUIRE((dfeat != nullptr) != (dfmap_nchw != nullptr), "encoder_backward: pass exactly one of dfeat / dfmap_nchw");
+    GDL_REQUIRE(phase >= 0 && phase <= 2, "encoder_backward: phase %d", phase);
+    if (phase != 2)
+        GDL_REQUIRE((dfeat != nullptr) != (dfmap_nchw != nullptr), "encoder_backward: pass exactly one of dfeat / dfmap_nchw");
     if (!e->have_train_fwd) {
         set_error("encoder_backward: no training-mode forward to differentiate");
+        return GDL_ERR_STATE;
+    }
+    if (phase == 2 && e->bw_serial != (long)e->serial) {
+        set_error("encoder_backward: phase 2 without phase 1 of the same forward");
         return GDL_ERR_STATE;
     }
     for (int i = 0; i < GDL_ENC_NPARAMS; ++i) GDL_REQUIRE(grads[i], "encoder_backward: grads[%d] null", i);
     hipStream_t st = (hipStream_t)stream;
     const int dt = e->dtype;
-    // upstream gradient on the layer4 map -> gA
-    if (dfeat)
-        RC(avgpool_bwd(dt, dfeat, e->gA, e->B, e->T, e->hf * e->wf, 512, st));
-    else
-        RC(nchw_f32_to_nhwc(dt, dfmap_nchw, e->gA, e->n_img, e->hf, e->wf, 512, st));
-    void* dz = e->gA;    // gradient w.r.t. the current block's output
-    void* spare = e->gE;  // receives the gradient w.r.t. the block's input
+    const int nblk = (int)e->blocks.size();
+    const int bi_first = phase == 2 ? nblk - 3 : nblk - 1;  // blocks run from bi_first down to bi_last
+    const int bi_last = phase == 1 ? nblk - 2 : 0;
+    void* dz;     // gradient w.r.t. the current block's output
+    void* spare;  // receives the gradient w.r.t. the block's input
+    if (phase != 2) {
+        // upstream gradient on the layer4 map -> gA
+        if (dfeat)
+            RC(avgpool_bwd(dt, dfeat, e->gA, e->B, e->T, e->hf * e->wf, 512, st));
+        else
+            RC(nchw_f32_to_nhwc(dt, dfmap_nchw, e->gA, e->n_img, e->hf, e->wf, 512, st));
+        dz = e->gA;
+        spare = e->gE;
+        e->side_pending[0] = e->side_pending[1] = false;
+    } else {
+        dz = e->bw_dz;
+        spare = e->bw_spare;
+    }
     // weight gradients: forked onto the side stream (sw) once their dy exists on st
     hipStream_t sw = e->side ? e->side : st;
     auto fork = [&]() -> int {  // sw waits for everything enqueued on st so far
@@ -532,8 +555,7 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
         if (he == hipSuccess) he = hipStreamWaitEvent(e->side, e->ev_fork, 0);
         return he == hipSuccess ? GDL_OK : check_hip(he, "encoder_backward: fork");
     };
-    e->side_pending[0] = e->side_pending[1] = false;
-    for (int bi = (int)e->blocks.size() - 1; bi >= 0; --bi) {
+    for (int bi = bi_first; bi >= bi_last; --bi) {
         Block& k = e->blocks[bi];
         const size_t Mo = (size_t)k.n * k.p * k.q;
         const int par = bi & 1;
@@ -594,6 +616,19 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
         }
         dz = dxin;
     }
+    if (phase == 1) {  // hand over to phase 2; the layer4 gradients must be complete on st
+        e->bw_dz = dz;
+        e->bw_spare = spare;
+        e->bw_serial = (long)e->serial;
+        if (e->side) {
+            hipError_t he = hipEventRecord(e->ev_join, e->side);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);
+            if (he != hipSuccess) return check_hip(he, "encoder_backward: phase join");
+            e->side_pending[0] = e->side_pending[1] = false;
+        }
+        return GDL_OK;
+    }
+    e->bw_serial = -1;
     // stem: maxpool -> relu -> bn1 -> conv1 weight gradient (the input needs no gradient)
     RC(maxpool_bwd(dt, dz, e->idx, e->g0, e->n_img, e->h0, e->w0, 64, st));
     RC(bn_backward(e, e->bn0, e->g0, e->y0, 1, e->g0, (size_t)e->m0, grads, st));
@@ -606,6 +641,16 @@ int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfma
         e->side_pending[0] = e->side_pending[1] = false;
     }
     return GDL_OK;
+}
+
+int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfmap_nchw, float* const* grads,
+                         void* stream) {
+    return encoder_backward_impl(e, dfeat, dfmap_nchw, grads, stream, 0);
+}
+int gdl_encoder_backward_phase(gdl_encoder_t* e, int phase, const float* dfeat, const float* dfmap_nchw,
+                               float* const* grads, void* stream) {
+    GDL_REQUIRE(phase == 1 || phase == 2, "encoder_backward_phase: phase must be 1 or 2");
+    return encoder_backward_impl(e, dfeat, dfmap_nchw, grads, stream, phase);
 }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ SIGNATURES = {
     "gdl_encoder_create": ("i", "piiiiii"),
     "gdl_encoder_destroy": (None, "p"),
     "gdl_encoder_side_stream": ("i", "pi"),
+    "gdl_encoder_backward_phase": ("i", "pippp" + "p"),
     "gdl_encoder_workspace_bytes": ("z", "p"),
     "gdl_encoder_param_numel": ("i", "pp"),
     "gdl_encoder_out_shape": ("i", "pppp"),

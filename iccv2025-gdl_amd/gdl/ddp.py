@@ -2,15 +2,16 @@
 
 Stock DistributedDataParallel is wrong for this step: fc_out receives gradients in
 both backward passes of the reference, so DDP either raises or silently skips the fusion head's
-reduction.  Here the gradients live in one flat arena with three disjoint buckets
+reduction.  Here the gradients live in one flat arena with disjoint buckets (DGLTrainer)
 
-    fusion  : fusion_module.fc_out.{weight,bias}       (6 150 elements for CREMA-D)
-    audio   : audio_net.*                              (11 170 240)
-    visual  : visual_net.*                             (11 176 512)
+    fusion              : the trained fusion-head tensors       (6 150 elements for CREMA-D / concat)
+    audio_l4, audio_rest   : audio_net.layer4.* (8.39 M) / the rest of audio_net (2.78 M)
+    visual_l4, visual_rest : the same split of visual_net
 
-and each bucket is summed across ranks exactly once per step, as soon as it is final:
-the fusion bucket right after the head backward, each encoder bucket right after that
-encoder's backward on its own stream -- overlapping the other encoder's backward.  The
+and each bucket is summed across ranks exactly once per step, as soon as it is final: the
+fusion bucket right after the head backward, an encoder's layer4 bucket after the first
+phase of its backward (gdl_encoder_backward_phase) -- three quarters of the bytes travel
+while layer3 .. stem are still being differentiated -- and the rest after the second.  The
 1/world averaging is folded into the clip / SGD kernels (grad_scale).  `fc_auxi` never has a
 gradient and is not part of any bucket.  BatchNorm statistics stay per rank, as with the
 reference's nn.DataParallel replicas.

@@ -86,12 +86,17 @@ class EncoderEngine:
     def serial(self):
         return self.lib.gdl_encoder_forward_serial(self.h)
 
-    def backward(self, grads, dfeat=None, dfmap=None):
-        """grads: 60 float32 CUDA tensors (overwritten)."""
+    def backward(self, grads, dfeat=None, dfmap=None, phase=0):
+        """grads: 60 float32 CUDA tensors (overwritten).  phase 0 = everything; 1 = upstream gradient + layer4 (the last
+        15 gradient tensors are then final: their all-reduce can start), 2 = the rest (no dfeat / dfmap)."""
         if dfeat is not None:
             dfeat = dfeat.float().contiguous()
         if dfmap is not None:
             dfmap = dfmap.float().contiguous()
         G = (ctypes.c_void_p * L.ENC_NPARAMS)(*[g.data_ptr() for g in grads])
-        L.call("gdl_encoder_backward", self.h, L.ptr(dfeat), L.ptr(dfmap), G, L.cur_stream())
-        self._keep_b = (dfeat, dfmap)
+        if phase == 0:
+            L.call("gdl_encoder_backward", self.h, L.ptr(dfeat), L.ptr(dfmap), G, L.cur_stream())
+        else:
+            L.call("gdl_encoder_backward_phase", self.h, phase, L.ptr(dfeat), L.ptr(dfmap), G, L.cur_stream())
+        if phase != 2:
+            self._keep_b = (dfeat, dfmap)

@@ -291,6 +291,11 @@ GDL_API int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, 
  * is non-NULL.  grads: 60 device pointers (float32, reference layouts), overwritten. */
 GDL_API int gdl_encoder_backward(gdl_encoder_t* e, const float* dfeat, const float* dfmap_nchw, float* const* grads,
                                  void* stream);
+/* The same backward in two calls, for data-parallel callers: phase 1 = the upstream gradient and layer4 -- when it
+ * returns (in stream order) the last 15 gradient tensors, 8.4 M of the 11.2 M parameters, are final and their
+ * all-reduce can overlap phase 2 (layer3 .. layer1 and the stem).  Phase 2 takes no dfeat / dfmap (pass NULL). */
+GDL_API int gdl_encoder_backward_phase(gdl_encoder_t* e, int phase, const float* dfeat, const float* dfmap_nchw,
+                                       float* const* grads, void* stream);
 /* serial number of the last training forward (to detect stale activations) */
 GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
 

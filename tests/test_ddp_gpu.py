@@ -117,4 +117,4 @@ def test_bench_two_rank_control_flow():
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
-    assert d["roofline"] and d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    assert d["roofline"] and d["roofline"]["achieved"] > 0 and d["cpu_baseline"] is None

@@ -286,6 +286,44 @@ def test_encoder_golden(name, modality, dtype):
     assert relerr(ye.cpu().numpy(), g["y_eval"]) < (2e-4 if f32 else 4e-2)
 
 
+@pytest.mark.parametrize("modality,shape", [("audio", (2, 1, 65, 47)), ("visual", (2, 3, 2, 64, 64))])
+def test_encoder_backward_phases(modality, shape):
+    """gdl_encoder_backward_phase 1 + 2 == gdl_encoder_backward, bit for bit (same kernels, same order), with and
+    without the weight-gradient side stream; phase 2 without phase 1 is refused."""
+    from gdl.encoder import EncoderEngine
+
+    x = torch.randn(*shape, device=DEV)
+    B = shape[0]
+    T = shape[2] if modality == "visual" else 1
+    H, W = shape[-2], shape[-1]
+    res = []
+    for side in (False, True):
+        eng = EncoderEngine(modality, "bf16", B, T, H, W, DEV)
+        if side:
+            eng.side_stream(True)
+        sh = fx.resnet18_param_shapes("", 1 if modality == "audio" else 3)
+        P = [dev(v) for v in fx.make_state(sh).values()]
+        bs = fx.make_state(fx.resnet18_buffer_shapes(""))
+        rm = [dev(v) for k, v in bs.items() if k.endswith("running_mean")]
+        rv = [dev(v) for k, v in bs.items() if k.endswith("running_var")]
+        nb = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in rm]
+        eng.set_params(P, rm, rv, nb)
+        dfeat = torch.randn(B, 512, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        for phases in ((0,), (1, 2)):
+            eng.forward(x, True)
+            grads = [torch.full_like(p, float("nan")) for p in P]
+            for ph in phases:
+                eng.backward(grads, dfeat=dfeat if ph != 2 else None, phase=ph)
+            torch.cuda.synchronize()
+            res.append([g.clone() for g in grads])
+        with pytest.raises(L.GdlError):
+            eng.forward(x, True)
+            eng.backward(grads, phase=2)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------ whole DGL step vs reference goldens
 def _make_model(cfg, dtype):
     from models.basic_model import AVClassifier, AVClassifier_DGL
