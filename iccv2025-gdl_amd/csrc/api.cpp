@@ -241,6 +241,23 @@ int gdl_head_gated_bwd(const float* x, const float* y, const float* hx, const fl
     return head_gated_bwd(x, y, hx, hy, W1, W2, Wo, g_x_out, g_y_out, g_out, uni_in_dw, dx, dy, dW1, db1, dW2, db2, dWo, dbo, ws, B,
                           n_classes, (hipStream_t)stream);
 }
+size_t gdl_head_film_workspace_bytes(int B) { return (B >= 1 && B <= 64) ? head_film_ws_bytes(B) : 0; }
+int gdl_head_film_fwd(const float* x, const float* y, const float* Wfc, const float* bfc, const float* Wo, const float* bo,
+                      float* hidden, float* out, float* x_out, float* y_out, int B, int n_classes, void* ws, size_t ws_bytes,
+                      void* stream) {
+    GDL_REQUIRE(x && y && Wfc && bfc && Wo && bo && hidden && out && n_classes > 0, "head_film_fwd: bad arguments");
+    return head_film_fwd(x, y, Wfc, bfc, Wo, bo, hidden, out, x_out, y_out, B, n_classes, ws, ws_bytes, (hipStream_t)stream);
+}
+int gdl_head_film_bwd(const float* x, const float* y, const float* Wfc, const float* Wo, const float* hidden,
+                      const float* g_x_out, const float* g_y_out, const float* g_out, int uni_in_dw, float* dx, float* dy,
+                      float* dWfc, float* dbfc, float* dWo, float* dbo, int B, int n_classes, void* ws, size_t ws_bytes,
+                      void* stream) {
+    GDL_REQUIRE(x && y && Wfc && Wo && hidden && n_classes > 0, "head_film_bwd: bad arguments");
+    GDL_REQUIRE((dx != nullptr) == (dy != nullptr) && (dWfc != nullptr) == (dbfc != nullptr) && (dWo != nullptr) == (dbo != nullptr),
+                "head_film_bwd: dx/dy, dWfc/dbfc, dWo/dbo come in pairs");
+    return head_film_bwd(x, y, Wfc, Wo, hidden, g_x_out, g_y_out, g_out, uni_in_dw, dx, dy, dWfc, dbfc, dWo, dbo, B, n_classes,
+                         ws, ws_bytes, (hipStream_t)stream);
+}
 int gdl_eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n_classes,
                    int64_t* num, int64_t* acc, int64_t* acc_a, int64_t* acc_v, void* stream) {
     GDL_REQUIRE(out && labels && num && acc && B > 0 && n_classes > 0, "eval_count: bad arguments");

@@ -91,6 +91,13 @@ int head_gated_bwd(const float* x, const float* y, const float* hx, const float*
                    const float* Wo, const float* g_x_out, const float* g_y_out, const float* g_out, int uni_in_dw, float* dx,
                    float* dy, float* dW1, float* db1, float* dW2, float* db2, float* dWo, float* dbo, float* ws, int B, int n,
                    hipStream_t st);
+// head_film.hip: FiLM_DGL (B <= 64 per call); hidden = [3][B][512] (h_x, h_f, h_y)
+size_t head_film_ws_bytes(int B);
+int head_film_fwd(const float* x, const float* y, const float* Wfc, const float* bfc, const float* Wo, const float* bo,
+                  float* hidden, float* out, float* x_out, float* y_out, int B, int n, void* ws, size_t ws_bytes, hipStream_t st);
+int head_film_bwd(const float* x, const float* y, const float* Wfc, const float* Wo, const float* hidden,
+                  const float* g_x_out, const float* g_y_out, const float* g_out, int uni, float* dx, float* dy, float* dWfc,
+                  float* dbfc, float* dWo, float* dbo, int B, int n, void* ws, size_t ws_bytes, hipStream_t st);
 int eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n, int64_t* num,
                int64_t* acc, int64_t* acc_a, int64_t* acc_v, hipStream_t st);
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,

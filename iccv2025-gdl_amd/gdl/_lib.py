@@ -67,6 +67,9 @@ SIGNATURES = {
     "gdl_head_sum_bwd": ("i", "ppppppp" + "ii" + "pppppp" + "ii" + "p"),
     "gdl_head_gated_fwd": ("i", "p" * 13 + "ii" + "p"),
     "gdl_head_gated_bwd": ("i", "p" * 10 + "i" + "p" * 9 + "ii" + "p"),
+    "gdl_head_film_workspace_bytes": ("z", "i"),
+    "gdl_head_film_fwd": ("i", "p" * 10 + "ii" + "pz" + "p"),
+    "gdl_head_film_bwd": ("i", "p" * 8 + "i" + "p" * 6 + "ii" + "pz" + "p"),
     "gdl_eval_count": ("i", "pppp" + "ii" + "pppp" + "p"),
     "gdl_optim_create": ("i", "pppi"),
     "gdl_optim_destroy": (None, "p"),

@@ -198,6 +198,21 @@ GDL_API int gdl_head_concat_fwd(const float* x, const float* y, const float* W, 
 GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out,
                                 const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
                                 float* dy, float* dW, float* db, int B, int n_classes, void* stream);
+/* FiLM_DGL (fusion_modules.py:126-178; SURVEY next row N2): fc: Linear(512*512, 512) -- a 134 M-parameter bilinear
+ * form per output, h[b][k] = u_b^T W_k v_b + bias_k -- and fc_out: Linear(512, n):
+ *   out = fc_out(fc(x.detach() (x) y.detach())),  x_out = fc_out(fc(x (x) x)),  y_out = fc_out(fc(y (x) y)).
+ * The outer products are never materialised; the contractions over fc.weight (537 MB) run as 1x1 convolutions /
+ * weight gradients of this library in exact-f32 mode.  B <= 64 per call.  hidden: [3][B][512] float32 (h_x, h_f,
+ * h_y), produced by fwd and consumed, with the SAME untouched workspace, by bwd.  bwd: any upstream gradient may
+ * be NULL; dx/dy, dWfc/dbfc, dWo/dbo are optional pairs; uni_in_dw as for the other heads (0 in the DGL step). */
+GDL_API size_t gdl_head_film_workspace_bytes(int B);
+GDL_API int gdl_head_film_fwd(const float* x, const float* y, const float* Wfc, const float* bfc, const float* Wo,
+                              const float* bo, float* hidden, float* out, float* x_out, float* y_out, int B, int n_classes,
+                              void* ws, size_t ws_bytes, void* stream);
+GDL_API int gdl_head_film_bwd(const float* x, const float* y, const float* Wfc, const float* Wo, const float* hidden,
+                              const float* g_x_out, const float* g_y_out, const float* g_out, int uni_in_dw, float* dx,
+                              float* dy, float* dWfc, float* dbfc, float* dWo, float* dbo, int B, int n_classes, void* ws,
+                              size_t ws_bytes, void* stream);
 /* GatedFusion_DGL (fusion_modules.py:213-250, x_gate = True; SURVEY next row N2): fc_x, fc_y: Linear(512, 512),
  * fc_out: Linear(512, n).  hx = fc_x(x), hy = fc_y(y) ([B][512], returned: saved for the backward);
  *   out = fc_out(sigmoid(hx.detach()) * hy.detach()),  x_out = fc_out(sigmoid(hx) * hx),  y_out = fc_out(sigmoid(hy) * hy).

@@ -137,6 +137,11 @@ def model_param_shapes(n_classes, fusion="concat_dgl"):
         out["fusion_module.fc_y.bias"] = (512,)
         out["fusion_module.fc_out.weight"] = (n_classes, 512)
         out["fusion_module.fc_out.bias"] = (n_classes,)
+    elif fusion == "film_dgl":  # fusion_modules.py:132-138
+        out["fusion_module.fc.weight"] = (512, 512 * 512)
+        out["fusion_module.fc.bias"] = (512,)
+        out["fusion_module.fc_out.weight"] = (n_classes, 512)
+        out["fusion_module.fc_out.bias"] = (n_classes,)
     elif fusion == "concat":  # fusion_modules.py:33-36
         out["fusion_module.fc_out.weight"] = (n_classes, 1024)
         out["fusion_module.fc_out.bias"] = (n_classes,)

@@ -454,6 +454,57 @@ def gated_dgl_bwd(x, y, hx, hy, W1, W2, Wo, g_x_out, g_y_out, g_out):
     return dx, dy, G
 
 
+def film_dgl_fwd(x, y, Wfc, bfc, Wo, bo):
+    """FiLM_DGL.forward, fusion_modules.py:140-178 -> (z_x, z_y, output, (hx, hf, hy)).  fc acts on the flattened
+    outer product: fc(flatten(u (x) v))[k] = u^T W_k v + b_k with W_k = Wfc[k].reshape(512, 512)."""
+    A = Wfc.reshape(512 * 512, 512)  # row (k, i), column j
+    Tx = (A @ x.T).reshape(512, 512, -1)  # [k][i][b] = (W_k x_b)[i]
+    Ty = (A @ y.T).reshape(512, 512, -1)
+    hf = np.einsum("bi,kib->bk", x, Ty) + bfc  # :153-158, detached x, y
+    hx = np.einsum("bi,kib->bk", x, Tx) + bfc  # :160-163
+    hy = np.einsum("bi,kib->bk", y, Ty) + bfc  # :165-168
+    hx, hf, hy = (h.astype(np.float32) for h in (hx, hf, hy))
+    return linear_fwd(hx, Wo, bo), linear_fwd(hy, Wo, bo), linear_fwd(hf, Wo, bo), (hx, hf, hy)
+
+
+def film_dgl_bwd(x, y, Wfc, Wo, hidden, g_x_out, g_y_out, g_out, want_fc=True):
+    """Autograd of the above for upstream gradients on (z_x, z_y, output); any may be None.  `output` uses detached
+    features: it reaches fc / fc_out only.  Returns dx, dy, {fc, fc_out gradients}."""
+    hx, hf, hy = hidden
+    W3 = Wfc.reshape(512, 512, 512)
+    dx, dy = np.zeros_like(x), np.zeros_like(y)
+    G = {"fc_out.weight": np.zeros_like(Wo), "fc_out.bias": np.zeros(Wo.shape[0], np.float32)}
+    if want_fc:
+        G["fc.weight"] = np.zeros_like(Wfc)
+        G["fc.bias"] = np.zeros(512, np.float32)
+
+    def through(g, h, u, v, reach_u, reach_v):
+        dh, dWo, dbo = linear_bwd(g, h, Wo)
+        G["fc_out.weight"] += dWo
+        G["fc_out.bias"] += dbo
+        du, dv = np.zeros_like(u), np.zeros_like(v)
+        for b in range(u.shape[0]):
+            Mb = np.tensordot(dh[b], W3, axes=(0, 0))  # sum_k dh[b,k] W_k
+            if reach_u:
+                du[b] = Mb @ v[b]
+            if reach_v:
+                dv[b] = Mb.T @ u[b]
+        if want_fc:
+            G["fc.weight"] += np.einsum("bk,bi,bj->kij", dh, u, v, optimize=True).reshape(512, -1).astype(np.float32)
+            G["fc.bias"] += dh.sum(0)
+        return du, dv
+
+    if g_x_out is not None:
+        du, dv = through(g_x_out, hx, x, x, True, True)
+        dx += du + dv
+    if g_y_out is not None:
+        du, dv = through(g_y_out, hy, y, y, True, True)
+        dy += du + dv
+    if g_out is not None:
+        through(g_out, hf, x, y, False, False)
+    return dx, dy, G
+
+
 def concat_fwd(x, y, W, b):
     """ConcatFusion.forward, fusion_modules.py:38-42 -> output."""
     return linear_fwd(np.concatenate([x, y], 1), W, b)

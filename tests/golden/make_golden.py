@@ -363,6 +363,42 @@ def run_seeded_init_case(name, bm):
     print(name, "ok")
 
 
+def run_film_head_case(name, fm, n_classes, batch=3):
+    """FiLM_DGL (fusion_modules.py:126-178): forward + both backward phases of main_dgl.py:110-122."""
+    head = fm.FiLM_DGL(output_dim=n_classes, x_film=True)
+    shapes = {"fc.weight": (512, 512 * 512), "fc.bias": (512,), "fc_out.weight": (n_classes, 512), "fc_out.bias": (n_classes,)}
+    st = fx.make_state({"fusion_module." + k: v for k, v in shapes.items()})
+    head.load_state_dict({k[len("fusion_module."):]: torch.from_numpy(v.copy()) for k, v in st.items()})
+    r = np.random.default_rng([94, n_classes])
+    x = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    y = torch.from_numpy(r.standard_normal((batch, 512), dtype=np.float32)).requires_grad_()
+    g = [r.standard_normal((batch, n_classes), dtype=np.float32) for _ in range(3)]
+    x_out, y_out, out = head(x, y)
+    d = {"x": x.detach().numpy(), "y": y.detach().numpy(), "x_out": x_out.detach().numpy(), "y_out": y_out.detach().numpy(),
+         "out": out.detach().numpy(), "g_x_out": g[0], "g_y_out": g[1], "g_out": g[2]}
+
+    def store(key, a):
+        if a.size <= 10000:
+            d[key] = a.copy()
+        else:
+            d[key + ".norm"] = np.float64(np.sqrt((a.astype(np.float64) ** 2).sum()))
+            d[key + ".sample97"] = a.reshape(-1)[::9973].copy() if a.size > 10 ** 7 else a.reshape(-1)[::97].copy()
+
+    (x_out * torch.from_numpy(g[0])).sum().add((y_out * torch.from_numpy(g[1])).sum()).backward(retain_graph=True)
+    d.update(dx=x.grad.numpy().copy(), dy=y.grad.numpy().copy())
+    for n, p in head.named_parameters():
+        store("uni." + n, p.grad.numpy())
+        p.grad = None
+    x.grad = None
+    y.grad = None
+    (out * torch.from_numpy(g[2])).sum().backward()
+    for n, p in head.named_parameters():
+        store("f." + n, p.grad.numpy())
+    d["dx_after_f_is_none"] = np.int8(x.grad is None)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "ok")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -385,6 +421,7 @@ def main():
         "head_sum_dgl_c6": lambda: run_sum_head_case("head_sum_dgl_c6", fm, 6),
         "dgl_sum_tiny_b4": lambda: run_step_case("dgl_sum_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                  fusion="sum"),
+        "head_film_dgl_c6": lambda: run_film_head_case("head_film_dgl_c6", fm, 6),
         "head_gated_dgl_c6": lambda: run_gated_head_case("head_gated_dgl_c6", fm, 6),
         "dgl_gated_tiny_b4": lambda: run_step_case("dgl_gated_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                    fusion="gated"),

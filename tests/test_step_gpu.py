@@ -143,6 +143,57 @@ def test_head_gated_dgl_golden():
     assert int(g["f_is_none.fc_x.weight"]) == 1 and int(g["f_is_none.fc_y.bias"]) == 1
 
 
+def test_head_film_dgl_golden():
+    """FiLM_DGL through the C ABI (bilinear contractions over the 537 MB fc.weight as f32 1x1 convolutions / weight
+    gradients of this library) against the reference's golden: forward and both backward phases of the DGL step."""
+    g = _gold("head_film_dgl_c6")
+    n = 6
+    lib = L.load()
+    names = ("fc.weight", "fc.bias", "fc_out.weight", "fc_out.bias")
+    st = fx.make_state({"fusion_module." + k: sh for k, sh in zip(names, ((512, 512 * 512), (512,), (n, 512), (n,)))})
+    Wfc, bfc, Wo, bo = (dev(st["fusion_module." + k]) for k in names)
+    x, y = dev(g["x"]), dev(g["y"])
+    B = x.shape[0]
+    nb = lib.gdl_head_film_workspace_bytes(B)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hidden = torch.empty(3, B, 512, device=DEV)
+    out, xo, yo = (torch.empty(B, n, device=DEV) for _ in range(3))
+    s = L.cur_stream()
+    L.call("gdl_head_film_fwd", L.ptr(x), L.ptr(y), L.ptr(Wfc), L.ptr(bfc), L.ptr(Wo), L.ptr(bo), L.ptr(hidden), L.ptr(out),
+           L.ptr(xo), L.ptr(yo), B, n, L.ptr(ws), nb, s)
+    torch.cuda.synchronize()
+    for a, k in ((xo, "x_out"), (yo, "y_out"), (out, "out")):
+        np.testing.assert_allclose(a.cpu().numpy(), g[k], rtol=1e-3, atol=1e-3)
+    gx, gy, go = dev(g["g_x_out"]), dev(g["g_y_out"]), dev(g["g_out"])
+    dx, dy = torch.empty_like(x), torch.empty_like(y)
+    G = {k: torch.empty_like(t) for k, t in zip(names, (Wfc, bfc, Wo, bo))}
+
+    def close(got, key):
+        got = got.cpu().numpy()
+        if key in g.files:
+            np.testing.assert_allclose(got, g[key], rtol=1e-3, atol=1e-3, err_msg=key)
+        else:
+            step = 9973 if got.size > 10 ** 7 else 97
+            np.testing.assert_allclose(np.sqrt((got.astype(np.float64) ** 2).sum()), float(g[key + ".norm"]), rtol=1e-3)
+            np.testing.assert_allclose(got.reshape(-1)[::step], g[key + ".sample97"], rtol=1e-3, atol=1e-3, err_msg=key)
+
+    # phase 1: the unimodal losses, plain autograd (every head gradient is produced; the script then drops them)
+    L.call("gdl_head_film_bwd", L.ptr(x), L.ptr(y), L.ptr(Wfc), L.ptr(Wo), L.ptr(hidden), L.ptr(gx), L.ptr(gy), None, 1, L.ptr(dx),
+           L.ptr(dy), L.ptr(G["fc.weight"]), L.ptr(G["fc.bias"]), L.ptr(G["fc_out.weight"]), L.ptr(G["fc_out.bias"]), B, n,
+           L.ptr(ws), nb, s)
+    torch.cuda.synchronize()
+    close(dx, "dx")
+    close(dy, "dy")
+    for k in names:
+        close(G[k], "uni." + k)
+    # phase 2: loss_f on detached features reaches fc and fc_out only
+    L.call("gdl_head_film_bwd", L.ptr(x), L.ptr(y), L.ptr(Wfc), L.ptr(Wo), L.ptr(hidden), None, None, L.ptr(go), 0, None, None,
+           L.ptr(G["fc.weight"]), L.ptr(G["fc.bias"]), L.ptr(G["fc_out.weight"]), L.ptr(G["fc_out.bias"]), B, n, L.ptr(ws), nb, s)
+    torch.cuda.synchronize()
+    for k in names:
+        close(G[k], "f." + k)
+
+
 def test_head_concat_golden():
     g = _gold("head_concat_c6")
     st_ = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
