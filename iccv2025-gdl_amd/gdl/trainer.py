@@ -40,19 +40,24 @@ class DGLTrainer:
         # or gated (fc_x, fc_y [512,512] + fc_out [n,512]; GatedFusion_DGL -- the step never gives fc_x / fc_y a
         # gradient (main_dgl.py:114-122 drops phase 1's, loss_f sees detached hidden vectors), so like fc_auxi they stay
         # outside the optimised arena)
-        self.head = ("gated" if hasattr(head, "fc_out") else "sum") if hasattr(head, "fc_x") else "concat"
+        # or film (fc [512, 262144] + fc_out [n,512]; FiLM_DGL: all four tensors are trained by loss_f)
+        self.head = ("gated" if hasattr(head, "fc_out") else "sum") if hasattr(head, "fc_x") else \
+            ("film" if hasattr(head, "fc") else "concat")
         first = head.fc_x if self.head == "sum" else head.fc_out
         self.device = first.weight.device
         if self.device.type != "cuda":
             raise L.GdlError("DGLTrainer: the model must live on an MI355X (cuda) device; there is no CPU path")
         if self.head != "concat" and mode != "dgl":
-            raise L.GdlError("DGLTrainer: the sum / gated heads are built for the DGL step only")
+            raise L.GdlError("DGLTrainer: the sum / gated / film heads are built for the DGL step only")
         if self.head == "gated" and not getattr(head, "x_gate", True):
             raise L.GdlError("DGLTrainer: GatedFusion_DGL is built for x_gate=True (basic_model.py:38)")
         self.n_classes = (head.fc_out if self.head == "gated" else first).weight.shape[0]
         # ---- flat arenas: [trained fusion-head tensors | audio_net (60) | visual_net (60)]
         # (ConcatFusion_DGL's fc_auxi never receives a gradient, SURVEY G1: it stays outside the arena)
-        if self.head == "sum":
+        if self.head == "film":
+            named = [("fusion_module.fc.weight", head.fc.weight), ("fusion_module.fc.bias", head.fc.bias),
+                     ("fusion_module.fc_out.weight", head.fc_out.weight), ("fusion_module.fc_out.bias", head.fc_out.bias)]
+        elif self.head == "sum":
             named = [("fusion_module.fc_x.weight", head.fc_x.weight), ("fusion_module.fc_x.bias", head.fc_x.bias),
                      ("fusion_module.fc_y.weight", head.fc_y.weight), ("fusion_module.fc_y.bias", head.fc_y.bias)]
         else:
@@ -137,6 +142,11 @@ class DGLTrainer:
         n, d = self.n_classes, self.device
         self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
         self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
+        if self.head == "film":
+            if B > 64:
+                raise L.GdlError("DGLTrainer: the FiLM head handles at most 64 samples per step")
+            self.hidden = torch.empty((3, B, 512), device=d)
+            self.head_ws = torch.empty(self.lib.gdl_head_film_workspace_bytes(B), dtype=torch.uint8, device=d)
         if self.head == "gated":  # hidden vectors (saved for the backward) + its scratch
             self.hx, self.hy = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
             self.head_ws = torch.empty(2 * B * 512, device=d)
@@ -184,7 +194,12 @@ class DGLTrainer:
             L.call("gdl_softmax_ce", L.ptr(self.out_v), L.ptr(label), self.alpha, lp + 8, L.ptr(self.g_v), B, n, st)
             # DGL truncation: `out` is computed from detached features (flag 0) and the head gradients of the
             # unimodal losses are dropped before loss_f.backward() (flag 0)   (main_dgl.py:110-122)
-            if self.head == "gated":
+            if self.head == "film":
+                pv, gv = self.pviews, self.gviews
+                L.call("gdl_head_film_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[2]), L.ptr(self.hidden),
+                       L.ptr(self.g_a), L.ptr(self.g_v), L.ptr(self.g_f), 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(gv[0]),
+                       L.ptr(gv[1]), L.ptr(gv[2]), L.ptr(gv[3]), B, n, L.ptr(self.head_ws), self.head_ws.numel(), st)
+            elif self.head == "gated":
                 fm = self.model.fusion_module
                 L.call("gdl_head_gated_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.hx), L.ptr(self.hy),
                        L.ptr(fm.fc_x.weight), L.ptr(fm.fc_y.weight), L.ptr(self.pviews[0]), L.ptr(self.g_a), L.ptr(self.g_v),
@@ -249,7 +264,10 @@ class DGLTrainer:
         """(out, out_a, out_v) from the pooled features self.fa / self.fv."""
         pv, B, n = self.pviews, self.B, self.n_classes
         oa, ov = (L.ptr(self.out_a), L.ptr(self.out_v)) if dgl else (None, None)
-        if self.head == "gated":  # fusion_modules.py:232-250
+        if self.head == "film":  # fusion_modules.py:140-178
+            L.call("gdl_head_film_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(pv[2]), L.ptr(pv[3]),
+                   L.ptr(self.hidden), L.ptr(self.out), oa, ov, B, n, L.ptr(self.head_ws), self.head_ws.numel(), st)
+        elif self.head == "gated":  # fusion_modules.py:232-250
             fm = self.model.fusion_module
             L.call("gdl_head_gated_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(fm.fc_x.weight), L.ptr(fm.fc_x.bias),
                    L.ptr(fm.fc_y.weight), L.ptr(fm.fc_y.bias), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(self.hx), L.ptr(self.hy),

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .backbone import resnet18
-from .fusion_modules import ConcatFusion, ConcatFusion_DGL, GatedFusion_DGL, SumFusion_DGL  # noqa: F401
+from .fusion_modules import ConcatFusion, ConcatFusion_DGL, FiLM_DGL, GatedFusion_DGL, SumFusion_DGL  # noqa: F401
 
 N_CLASSES = {'VGGSound': 309, 'KineticSound': 34, 'kinect400': 400, 'CREMAD': 6, 'AVE': 28}  # basic_model.py:15-26
 
@@ -29,7 +29,7 @@ class AVClassifier_DGL(nn.Module):
         elif fusion == 'gated':
             self.fusion_module = GatedFusion_DGL(output_dim=n_classes, x_gate=True)
         elif fusion == 'film':
-            raise NotImplementedError("gdl: fusion method 'film' of the reference (a 134 M-parameter bilinear head) is not built yet")
+            self.fusion_module = FiLM_DGL(output_dim=n_classes, x_film=True)
         else:
             raise NotImplementedError('Incorrect fusion method: {}!'.format(fusion))
         if args.modality != 'full':

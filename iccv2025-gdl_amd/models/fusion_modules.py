@@ -162,6 +162,59 @@ class GatedFusion_DGL(nn.Module):
         return out_x, out_y, output
 
 
+class _FiLMDGLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, Wfc, bfc, Wo, bo):
+        x, y, Wfc, bfc, Wo, bo = (_f32c(t) for t in (x, y, Wfc, bfc, Wo, bo))
+        B, n = x.shape[0], Wo.shape[0]
+        if x.shape[1] != 512 or y.shape[1] != 512 or Wfc.shape != (512, 512 * 512) or Wo.shape[1] != 512:
+            raise RuntimeError("gdl: FiLM_DGL expects 512-d features and dim = 512")
+        if B > 64:
+            raise RuntimeError("gdl: FiLM_DGL handles at most 64 samples per call")
+        nb = L.load().gdl_head_film_workspace_bytes(B)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)  # keeps W_k v_b for the backward
+        hidden = torch.empty((3, B, 512), device=x.device)
+        out, x_out, y_out = (torch.empty((B, n), device=x.device) for _ in range(3))
+        L.call("gdl_head_film_fwd", L.ptr(x), L.ptr(y), L.ptr(Wfc), L.ptr(bfc), L.ptr(Wo), L.ptr(bo), L.ptr(hidden), L.ptr(out),
+               L.ptr(x_out), L.ptr(y_out), B, n, L.ptr(ws), nb, L.cur_stream())
+        ctx.save_for_backward(x, y, Wfc, Wo, hidden, ws)
+        return x_out, y_out, out
+
+    @staticmethod
+    def backward(ctx, g_x_out, g_y_out, g_out):
+        x, y, Wfc, Wo, hidden, ws = ctx.saved_tensors
+        B, n = x.shape[0], Wo.shape[0]
+        gx = _f32c(g_x_out) if g_x_out is not None else None
+        gy = _f32c(g_y_out) if g_y_out is not None else None
+        go = _f32c(g_out) if g_out is not None else None
+        uni_only_out = gx is None and gy is None  # `output` alone never reaches x / y (detached, fusion_modules.py:150-158)
+        dx = None if uni_only_out else torch.empty_like(x)
+        dy = None if uni_only_out else torch.empty_like(y)
+        dWfc, dbfc = torch.empty_like(Wfc), torch.empty(512, device=x.device)
+        dWo, dbo = torch.empty_like(Wo), torch.empty(n, device=x.device)
+        L.call("gdl_head_film_bwd", L.ptr(x), L.ptr(y), L.ptr(Wfc), L.ptr(Wo), L.ptr(hidden), L.ptr(gx), L.ptr(gy), L.ptr(go), 1,
+               L.ptr(dx), L.ptr(dy), L.ptr(dWfc), L.ptr(dbfc), L.ptr(dWo), L.ptr(dbo), B, n, L.ptr(ws), ws.numel(),
+               L.cur_stream())
+        return dx, dy, dWfc, dbfc, dWo, dbo
+
+
+class FiLM_DGL(nn.Module):
+    """fusion_modules.py:126-178: fc = Linear(dim*dim, dim) applied to flattened outer products (a bilinear form per
+    output), fc_out = Linear(dim, n).  134 M parameters.  `x_film` is accepted and, as in the reference, unused."""
+
+    def __init__(self, input_dim=512, dim=512, output_dim=100, x_film=True):
+        super(FiLM_DGL, self).__init__()
+        if input_dim != 512 or dim != 512:
+            raise NotImplementedError("gdl: FiLM_DGL is built for input_dim = dim = 512 (basic_model.py:36)")
+        self.fc = nn.Linear(dim * dim, dim)
+        self.fc_out = nn.Linear(dim, output_dim)
+        self.x_film = x_film
+
+    def forward(self, x, y):
+        z_x, z_y, output = _FiLMDGLFn.apply(x, y, self.fc.weight, self.fc.bias, self.fc_out.weight, self.fc_out.bias)
+        return z_x, z_y, output
+
+
 class ConcatFusion(nn.Module):
     def __init__(self, input_dim=1024, output_dim=100):
         super(ConcatFusion, self).__init__()

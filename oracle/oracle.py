@@ -538,6 +538,12 @@ class AVModel:
         self.a_map_shape, self.v_map_shape, self.BT = a.shape, v.shape, (B, T)
         self.fa = avgpool_fwd(a, B, 1)  # :78
         self.fv = avgpool_fwd(v, B, T)  # :73-79
+        if "fusion_module.fc.weight" in self.P:  # FiLM_DGL
+            P = self.P
+            a_out, v_out, out, self.film_hidden = film_dgl_fwd(self.fa, self.fv, P["fusion_module.fc.weight"],
+                                                               P["fusion_module.fc.bias"], P["fusion_module.fc_out.weight"],
+                                                               P["fusion_module.fc_out.bias"])
+            return out, a_out, v_out
         if "fusion_module.fc_x.weight" in self.P and "fusion_module.fc_out.weight" in self.P:  # GatedFusion_DGL
             P = self.P
             a_out, v_out, out, self.hx, self.hy = gated_dgl_fwd(
@@ -562,10 +568,26 @@ class AVModel:
         out, out_a, out_v = self.forward(spec, image, True)
         r = {"out": out}
         G = {}
+        film = "fusion_module.fc.weight" in P
         gated = "fusion_module.fc_x.weight" in P and "fusion_module.fc_out.weight" in P
         sum_head = "fusion_module.fc_x.weight" in P and not gated
         W = None if sum_head else P["fusion_module.fc_out.weight"]
-        if gated:
+        if film:
+            Wfc = P["fusion_module.fc.weight"]
+            loss_v, g_v = softmax_ce(out_v, label, alpha)
+            loss_a, g_a = softmax_ce(out_a, label, alpha)
+            loss_f, g_f = softmax_ce(out, label, 1.0)
+            # phase 1 (:110): encoders get the unimodal gradients through fc_out and the quadratic forms u^T W_k u; the
+            # head gradients it produces (incl. the 134 M of fc.weight) are dropped (:114-119) -- only their norm is kept
+            dfa, dfv, Gu = film_dgl_bwd(self.fa, self.fv, Wfc, W, self.film_hidden, g_a, g_v, None)
+            r["dropped_head_gradnorm"] = float(np.sqrt(sum(sumsq(v) for v in Gu.values())))
+            del Gu
+            # phase 2 (:122): loss_f on detached features reaches fc and fc_out
+            _, _, Gf = film_dgl_bwd(self.fa, self.fv, Wfc, W, self.film_hidden, None, None, g_f)
+            r.update(out_a=out_a, out_v=out_v, loss_a=loss_a, loss_v=loss_v)
+            G["fusion_module.fc.weight"], G["fusion_module.fc.bias"] = Gf["fc.weight"], Gf["fc.bias"]
+            dW, db = Gf["fc_out.weight"], Gf["fc_out.bias"]
+        elif gated:
             W1, W2 = P["fusion_module.fc_x.weight"], P["fusion_module.fc_y.weight"]
             loss_v, g_v = softmax_ce(out_v, label, alpha)
             loss_a, g_a = softmax_ce(out_a, label, alpha)

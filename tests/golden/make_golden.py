@@ -351,7 +351,7 @@ def run_seeded_init_case(name, bm):
     import utils.utils as ut  # the reference's (REF is first on sys.path)
 
     d = {}
-    for fusion in ("concat", "sum", "gated"):
+    for fusion in ("concat", "sum", "gated", "film"):
         ut.setup_seed(0)
         args = argparse.Namespace(fusion_method=fusion, dataset="CREMAD", modality="full", batch_size=2)
         model = bm.AVClassifier_DGL(args)
@@ -421,6 +421,8 @@ def main():
         "head_sum_dgl_c6": lambda: run_sum_head_case("head_sum_dgl_c6", fm, 6),
         "dgl_sum_tiny_b4": lambda: run_step_case("dgl_sum_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                  fusion="sum"),
+        "dgl_film_tiny_b4": lambda: run_step_case("dgl_film_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
+                                                  fusion="film"),
         "head_film_dgl_c6": lambda: run_film_head_case("head_film_dgl_c6", fm, 6),
         "head_gated_dgl_c6": lambda: run_gated_head_case("head_gated_dgl_c6", fm, 6),
         "dgl_gated_tiny_b4": lambda: run_step_case("dgl_gated_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,

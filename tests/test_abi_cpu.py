@@ -125,7 +125,7 @@ def test_mirror_keeps_reference_interface():
                                                          "fusion_module.fc_y.weight", "fusion_module.fc_y.bias",
                                                          "fusion_module.fc_out.weight", "fusion_module.fc_out.bias"]
     assert mg.fusion_module.fc_out.weight.shape == (6, 512) and mg.fusion_module.x_gate is True
-    for method in ("film",):
+    for method in ("film_like", "attention"):
         with pytest.raises(NotImplementedError):
             AVClassifier_DGL(argparse.Namespace(fusion_method=method, dataset="CREMAD", modality="full"))
     # no CPU fallback: CPU tensors are refused loudly
@@ -142,7 +142,7 @@ def test_seeded_init_matches_reference():
     from utils.utils import setup_seed, weight_init
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "seeded_init.npz"))
-    for fusion in ("concat", "sum", "gated"):
+    for fusion in ("concat", "sum", "gated", "film"):
         setup_seed(0)
         m = AVClassifier_DGL(argparse.Namespace(fusion_method=fusion, dataset="CREMAD", modality="full", batch_size=2))
         m.apply(weight_init)

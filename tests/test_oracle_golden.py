@@ -183,7 +183,7 @@ def check_step_against_golden(g, model_step, cfg, steps, rtol_logits=1e-3, rtol_
 
 
 @pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2",
-                                  "dgl_sum_tiny_b4", "dgl_gated_tiny_b4"])
+                                  "dgl_sum_tiny_b4", "dgl_gated_tiny_b4", "dgl_film_tiny_b4"])
 def test_step(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = json.loads(str(g["config"]))

@@ -398,7 +398,7 @@ def _batch(cfg, st):
 
 
 STEP_CASES = ["dgl_tiny_b4", "dgl_tiny_t1_b2", "dgl_cremad_b2", "dgl_ks_b2", "concat_cremad_b2", "dgl_sum_tiny_b4",
-              "dgl_gated_tiny_b4"]
+              "dgl_gated_tiny_b4", "dgl_film_tiny_b4"]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -485,7 +485,7 @@ def _bufnames(g, pre):
     return [k[len(pre + "buf."):] for k in g.files if k.startswith(pre + "buf.")]
 
 
-@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2", "dgl_sum_tiny_b4", "dgl_gated_tiny_b4"])
+@pytest.mark.parametrize("name", ["dgl_tiny_b4", "dgl_cremad_b2", "dgl_sum_tiny_b4", "dgl_gated_tiny_b4", "dgl_film_tiny_b4"])
 def test_dropin_autograd_step_golden(name):
     """The reference's own step body (main_dgl.py:97-154) run UNCHANGED on the drop-in modules:
     torch autograd with retain_graph, grad=None on the head, second backward, torch clip + SGD."""
