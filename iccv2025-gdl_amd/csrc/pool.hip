@@ -18,14 +18,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                                                               int Q) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
-    const size_t total = (size_t)N * P * Q * cpr;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int vc = (int)(i % cpr);
-        size_t t = i / cpr;
-        const int q = (int)(t % Q);
-        t /= Q;
-        const int p = (int)(t % P);
-        const int n = (int)(t / P);
+    // a block walks whole output rows (n,p): one 32-bit division per row instead of three 64-bit ones per element
+    const int rows = N * P, per_row = Q * cpr;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+      const int n = row / P, p = row - n * P;
+      for (int jj = threadIdx.x; jj < per_row; jj += blockDim.x) {
+        const int q = jj / cpr, vc = jj - q * cpr;
+        const size_t i = (size_t)row * per_row + jj;
         float sc[EPC], sf[EPC], best[EPC];
         int bi[EPC];
 #pragma unroll
@@ -69,6 +68,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
         } else {
             *(uint32_t*)ip = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
         }
+      }
     }
 }
 int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
@@ -77,7 +77,7 @@ int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const floa
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     GDL_REQUIRE(C % epc == 0, "maxpool: C=%d", C);
     const size_t total = (size_t)N * P * Q * (C / epc);
-    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    const int grid = N * P > 8192 ? 8192 : N * P;
     // read the stem output once, write pooled values + 1-byte indices
     ProfScope prof(dtype == GDL_BF16 ? "gdl::bn_relu_maxpool_kernel<gdl::bf16>" : "gdl::bn_relu_maxpool_kernel<float>", PROF_HBM, st, (double)N * H * W * C * (16.0 / epc) + (double)total * (16.0 + epc));
     if (dtype == GDL_BF16)
@@ -98,14 +98,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                                                           T* __restrict__ dx, int N, int H, int W, int C, int P, int Q) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
-    const size_t total = (size_t)N * H * W * cpr;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int vc = (int)(i % cpr);
-        size_t t = i / cpr;
-        const int w = (int)(t % W);
-        t /= W;
-        const int h = (int)(t % H);
-        const int n = (int)(t / H);
+    const int rows = N * H, per_row = W * cpr;  // a block walks whole input rows (n,h)
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+      const int n = row / H, h = row - n * H;
+      for (int jj = threadIdx.x; jj < per_row; jj += blockDim.x) {
+        const int w = jj / cpr, vc = jj - w * cpr;
+        const size_t i = (size_t)row * per_row + jj;
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
@@ -144,13 +142,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
             }
         }
         *(uint4*)(dx + i * EPC) = pack16<T>(acc);
+      }
     }
 }
 int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, hipStream_t st) {
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     const size_t total = (size_t)N * H * W * (C / epc);
-    const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    const int grid = N * H > 16384 ? 16384 : N * H;
     ProfScope prof(dtype == GDL_BF16 ? "gdl::maxpool_bwd_kernel<gdl::bf16>" : "gdl::maxpool_bwd_kernel<float>", PROF_HBM, st, (double)total * 16.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H,
