@@ -312,13 +312,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int wrow = (tid >> 6) * 8;  // first tile row this wave's DMA instruction covers (plus 32*i)
 
     int ld_tap = tapset ? __builtin_ctz(tapset) : a.ntaps, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
+    // Pixel shift of that tap, fetched (scalar loads from the kernel arguments) when ld_tap changes, i.e. one tile
+    // ahead of its use.  Indexing a.delta[] / a.delta_hi[] by lane inside load_tile made it a VECTOR load whose
+    // latency sat between the barrier and the DMA issue of every K-step.
+    int d_lo = a.delta[ld_tap < a.ntaps ? ld_tap : 0], d_hi = a.split ? a.delta_hi[ld_tap < a.ntaps ? ld_tap : 0] : 0;
     // Every call issues exactly AROWS+BROWS DMA instructions per wave (the counted s_waitcnt below
     // relies on it); past the last K-step they are all out of range: no memory traffic, zeros into
     // a ring slot nobody reads.
     auto load_tile = [&](int buf) {
         const bool live = ld_tap < a.ntaps;
         const int tap = live ? ld_tap : 0;
-        const int ua = (a_hi ? a.delta_hi[tap] : a.delta[tap]) + ld_kc * 128;  // uniform unless split
+        const int ua = (a_hi ? d_hi : d_lo) + ld_kc * 128;  // uniform unless split
         const int ub = (tap * a.IC) * esz + ld_kc * 128;  // uniform
         unsigned char* As = smem + buf * SM::STAGE;
         unsigned char* Bs = As + BM * 128;
@@ -333,6 +337,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             ld_kc = 0;
             const unsigned rest = ld_tap + 1 < 32 ? tapset >> (ld_tap + 1) : 0u;
             ld_tap = rest ? ld_tap + 1 + __builtin_ctz(rest) : a.ntaps;  // next tap of the set
+            const int nt = ld_tap < a.ntaps ? ld_tap : 0;
+            d_lo = a.delta[nt];
+            if (a.split) d_hi = a.delta_hi[nt];
         }
     };
 

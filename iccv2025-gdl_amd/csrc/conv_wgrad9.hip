@@ -17,6 +17,12 @@
 // per tap, three taps ahead of the MFMAs (counted lgkmcnt).  All LDS addresses are precomputed per
 // lane (the swizzle of a shifted slab row does not change from stage to stage); a padding tap is a
 // per-lane select of the zero row, driven by the forward gather table's tap mask of the lane's pixel.
+//
+// Memory pipeline (see the kernel): every load of the loop is an LDS-DMA (the pixels' tap masks included:
+// 4 bytes per lane into a 256-byte mask stage) and every wait is explicit -- with an ordinary global load
+// in the loop the compiler, which cannot count the variable number of DMA instructions, put
+// `s_waitcnt vmcnt(0)` in front of the first use of the masks, right after the next stage had been issued.
+// Four extra waves per block do nothing but issue the DMA, because issuing it blocks a wave.
 // Partials go to the workspace in fragment order ([slice][tile][wave][tap][kfrag][lane][4], 16-byte
 // stores, 1 KiB per wave instruction); wgrad9_reduce_kernel folds the slices in a fixed order and
 // scatters to the reference's [K][C][3][3] layout (deterministic, no atomics).
@@ -40,7 +46,13 @@ struct Wgrad9Args {
     int tiles_k, tiles_c;
     int slab_rows;             // 64 + 2W + 2
     unsigned dy_bytes, x_bytes;
+#ifdef GDL_TIMING
+    unsigned long long* dbg;
+#endif
 };
+#ifdef GDL_TIMING
+extern unsigned long long* g_timing_buf;
+#endif
 
 constexpr int W9_BP = 64;  // pixels per stage
 
@@ -52,6 +64,22 @@ __device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned c
     (void)lds_base;
     (void)voffset;
 #endif
+}
+// 4 bytes per lane into LDS (tap masks)
+__device__ __forceinline__ void w9_dma4(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_base, 4, voffset, 0, 0, 0);
+#else
+    (void)rsrc;
+    (void)lds_base;
+    (void)voffset;
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ unsigned w9_lds32(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
 }
 // transpose read hidden from the compiler (see conv_wgrad.hip), with an instruction byte offset
 template <int OFF>
@@ -69,15 +97,18 @@ __device__ __forceinline__ void w9_wait() {
 // 32-byte granule swizzle of a 128-byte [pixel][64 channels] row (same as conv_wgrad.hip's wg_swz<128>)
 __device__ __forceinline__ int w9_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-// NG = 1: one group of 4 waves per block.  NG = 2: two groups (8 waves) that own alternate 64-pixel stages, each with
-// its own double-buffered LDS stages, and fold their accumulators through LDS before the block leaves ONE partial
-// tile: two waves per SIMD (one group multiplies while the other issues its DMA / waits for LDS) at the partial
-// traffic of half as many blocks.
-template <int NG>
-__global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+// SPEC: 8 waves -- waves 0-3 (workers) multiply, waves 4-7 (loaders) do nothing but issue the LDS-DMA of the next
+// stage.  An LDS-DMA instruction blocks the issuing wave (~200 clk per 1 KiB piece for a lone wave, measured with
+// the -DGDL_TIMING probes: 2 500 clk of issue beside 1 900 clk of MFMA work per stage when the same four waves did
+// both), so the load of stage s+1 only overlaps the MFMAs of stage s if OTHER waves issue it; one loader and one
+// worker share each SIMD and the LDS footprint stays that of two stages.  !SPEC: the four waves do both (kept as a
+// tuning aid, GDL_WGRAD9_SPEC=0).
+template <bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_kernel(Wgrad9Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = NG == 1 ? 0 : (wave_all >> 2), wave = wave_all & 3;
+    const int wave = wave_all & 3;
+    const bool loader = !SPEC || wave_all >= 4, worker = !SPEC || wave_all < 4;
     const int g = lane >> 4, li = lane & 15;
 
     // block -> (slice, ktile, ctile); the tiles of one pixel slice are neighbours on one XCD
@@ -91,49 +122,48 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) 
     const int k0 = kt * 64, c0 = ct * 64;
     const int m_begin = slice * a.chunk;
     const int m_end = min(a.M, m_begin + a.chunk);
-    const int nst_all = (m_end - m_begin + W9_BP - 1) / W9_BP;
-    const int nit = (nst_all + NG - 1) / NG;               // loop trips (every wave of the block takes part in the barrier)
-    const int nst = (nst_all - grp + NG - 1) / NG;         // stages of this group: grp, grp + NG, ...
+    const int nst = (m_end - m_begin + W9_BP - 1) / W9_BP;
 
     const int nins = (a.slab_rows + 7) >> 3;        // 1 KiB DMA pieces of the slab
     const int STAGE = W9_BP * 128 + nins * 1024;    // dy tile + slab
-    unsigned char* smem = smem_all + grp * 2 * STAGE;  // this group's two stage buffers
     const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned zrow = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem_all + NG * 2 * STAGE;
+    unsigned char* zero_p = smem + 2 * STAGE;       // 1 KiB zero row
+    unsigned char* mask_st = zero_p + 1024;         // two 256-byte mask stages
+    const unsigned zrow = smem_base + 2 * STAGE;
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-    if (wave_all == 0) w9_dma16(rx, smem_all + NG * 2 * STAGE, (int)0x80000000);  // zero row (out-of-range DMA deposits zeros)
+    const __amdgpu_buffer_rsrc_t rtab =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.table, 0, (unsigned)a.M * (unsigned)sizeof(GatherEntry), 0x00020000);
+    if (loader && wave == 0) w9_dma16(rx, zero_p, (int)0x80000000);  // zero row (out-of-range DMA deposits zeros)
 
     // ---- DMA bookkeeping.  A piece = 8 rows x 128 B; lane L -> row L>>3, physical 16-byte chunk L&7;
-    // the source chunk is the one whose swizzled position that is.
+    // the source chunk is the one whose swizzled position that is.  Pieces of a stage: 8 of dy, `nins` of
+    // the slab, 1 of tap masks (4 bytes per lane: the second word of the pixels' gather entries; past the
+    // slice: zeros); loader wave w takes pieces w, w+4, ...
     const int prow = lane >> 3, pch = lane & 7;
-    // dy tile: 8 pieces, wave w takes pieces w and w+4
-    int dy_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave + 4 * i) * 8 + prow;
-        const int ch = (((pch >> 1) ^ w9_swz(row)) << 1) | (pch & 1);
-        dy_off[i] = (m_begin + grp * W9_BP + row) * (a.K * 2) + k0 * 2 + ch * 16;
-    }
-    int ld_m = m_begin + grp * W9_BP;  // first pixel of the next stage to load
+    const int npieces = 8 + nins + 1;
+    int ld_m = m_begin;  // first pixel of the next stage to load
     auto load_stage = [&](int buf) {
         unsigned char* Ks = smem + buf * STAGE;
         unsigned char* Xs = Ks + W9_BP * 128;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = ld_m + (wave + 4 * i) * 8 + prow;
-            w9_dma16(rdy, Ks + (wave + 4 * i) * 1024, m < m_end ? dy_off[i] : (int)0x80000000);
-            dy_off[i] += NG * W9_BP * a.K * 2;
+        for (int p = wave; p < npieces; p += 4) {
+            if (p < 8) {
+                const int row = p * 8 + prow, m = ld_m + row;
+                const int ch = (((pch >> 1) ^ w9_swz(row)) << 1) | (pch & 1);
+                w9_dma16(rdy, Ks + p * 1024, m < m_end ? m * (a.K * 2) + k0 * 2 + ch * 16 : (int)0x80000000);
+            } else if (p < 8 + nins) {
+                const int jj = p - 8, sr = jj * 8 + prow;
+                const int pix = ld_m - (a.W + 1) + sr;
+                const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.M;
+                const int ch = (((pch >> 1) ^ w9_swz(sr)) << 1) | (pch & 1);
+                w9_dma16(rx, Xs + jj * 1024, ok ? pix * (a.C * 2) + c0 * 2 + ch * 16 : (int)0x80000000);
+            } else {
+                const int m = ld_m + lane;
+                w9_dma4(rtab, mask_st + buf * 256, m < m_end ? m * (int)sizeof(GatherEntry) + 4 : (int)0x80000000);
+            }
         }
-        for (int jj = wave; jj < nins; jj += 4) {
-            const int sr = jj * 8 + prow;
-            const int pix = ld_m - (a.W + 1) + sr;
-            const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.M;
-            const int ch = (((pch >> 1) ^ w9_swz(sr)) << 1) | (pch & 1);
-            w9_dma16(rx, Xs + jj * 1024, ok ? pix * (a.C * 2) + c0 * 2 + ch * 16 : (int)0x80000000);
-        }
-        ld_m += NG * W9_BP;
+        ld_m += W9_BP;
     };
 
     // ---- per-lane LDS read addresses (stage buffer 0; the other buffer is +STAGE).
@@ -158,17 +188,8 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) 
         }
     }
     const unsigned zaddr = zrow + (li & 3) * 8;  // any 8 bytes of the zero KiB (K-step 1 reads at +4096: pre-biased there)
-    // tap masks of this lane's 4 pixels of a stage: [ks][h]
-    unsigned pmask[2][2], nmask[2][2];
-    auto load_masks = [&](int mbase, unsigned (&mk)[2][2]) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = mbase + ks * 32 + lrow + h * 4;
-                mk[ks][h] = m < m_end ? a.table[m].mask : 0u;
-            }
-    };
+    // tap masks of this lane's 4 pixels of a stage ([ks][h]: pixel ks*32 + lrow + h*4) come from the mask stage
+    const unsigned maddr = zrow + 1024 + lrow * 4;
 
     f32x4_t acc[9][4];
 #pragma unroll
@@ -176,20 +197,45 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (nst > 0) {
-        load_stage(0);
-        load_masks(m_begin + grp * W9_BP, pmask);
-    }
-    for (int st = 0; st < nit; ++st) {
-        // the stage issued one iteration ago (and the masks) have landed; every wave is done with the other buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef GDL_TIMING
+    unsigned long long t_entry = __builtin_amdgcn_s_memtime(), t_wait = 0, t_issue = 0, t_mask = 0, t_a, t_b;
+#endif
+    if (loader && nst > 0) load_stage(0);
+#ifdef GDL_TIMING
+    unsigned long long t_first = __builtin_amdgcn_s_memtime();
+#endif
+    for (int st = 0; st < nst; ++st) {
+#ifdef GDL_TIMING
+        t_a = __builtin_amdgcn_s_memtime();
+#endif
+        // the stage issued one iteration ago has landed in every loader's part; every worker is done with the
+        // other buffer
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (st >= nst) continue;  // (NG = 2, odd stage count: the second group idles through the last trip)
-        if (st + 1 < nst) {
-            load_stage((st + 1) & 1);
-            load_masks(m_begin + (NG * (st + 1) + grp) * W9_BP, nmask);
+#ifdef GDL_TIMING
+        t_b = __builtin_amdgcn_s_memtime();
+        t_wait += t_b - t_a;
+#endif
+        if (loader && st + 1 < nst) load_stage((st + 1) & 1);
+#ifdef GDL_TIMING
+        t_a = __builtin_amdgcn_s_memtime();
+        t_issue += t_a - t_b;
+#endif
+        if (!worker) continue;
+        unsigned pmask[2][2];
+        {
+            const unsigned ma = maddr + (st & 1) * 256;
+            pmask[0][0] = w9_lds32<0>(ma);
+            pmask[0][1] = w9_lds32<16>(ma);
+            pmask[1][0] = w9_lds32<128>(ma);
+            pmask[1][1] = w9_lds32<144>(ma);
+            w9_wait<0>();
         }
+#ifdef GDL_TIMING
+        t_b = __builtin_amdgcn_s_memtime();
+        t_mask += t_b - t_a;
+#endif
         // ---- two K-steps of 32 pixels (the second one 32 rows = 4096 bytes further: instruction offset)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -237,35 +283,21 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) 
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int h = 0; h < 2; ++h) baddr[t][h] += dlt;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) pmask[ks][h] = nmask[ks][h];
     }
-    if (NG == 2) {
-        // fold the second group's accumulators into the first's through LDS (the stage buffers are dead: barrier first)
-        float4* xch = (float4*)smem_all + (size_t)wave * 36 * 64 + lane;
-        __syncthreads();
-        if (grp == 1) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xch[(t * 4 + i) * 64] = make_float4(acc[t][i][0], acc[t][i][1], acc[t][i][2], acc[t][i][3]);
-        }
-        __syncthreads();
-        if (grp == 1) return;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = xch[(t * 4 + i) * 64];
-                acc[t][i][0] += v.x;
-                acc[t][i][1] += v.y;
-                acc[t][i][2] += v.z;
-                acc[t][i][3] += v.w;
-            }
+#ifdef GDL_TIMING
+    unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
+    if (a.dbg && lane == 0) {  // one record per wave: [block][wave]
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 8 + wave_all) * 8;
+        d[0] = t_entry;
+        d[1] = t_first - t_entry;
+        d[2] = t_wait;
+        d[3] = t_issue;
+        d[4] = (t_loop_end - t_first) - t_wait - t_issue - t_mask;
+        d[6] = nst;
+        d[7] = t_mask;
     }
+#endif
+    if (!worker) return;  // (a loader's last DMA was waited for at the top of the last iteration)
     // ---- partial tile in fragment order: [slice][kt][ct][wave][tap][i][lane][4]
     float4* part = (float4*)a.partial + ((((size_t)slice * per_slice + rem) * 4 + wave) * 36) * 64;
 #pragma unroll
@@ -273,6 +305,9 @@ __global__ __launch_bounds__(256 * NG, 2) void conv_wgrad9_kernel(Wgrad9Args a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             part[(t * 4 + i) * 64 + lane] = make_float4(acc[t][i][0], acc[t][i][1], acc[t][i][2], acc[t][i][3]);
+#ifdef GDL_TIMING
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 8 + wave_all) * 8 + 5] = __builtin_amdgcn_s_memtime() - t_loop_end;
+#endif
 }
 
 // out[k][c][r][s] = sum_slice partial[slice][tile][wave][tap][i][lane][e], fixed order.
@@ -370,34 +405,36 @@ size_t conv_wgrad9_ws_bytes(int M, int C, int K) {
     return (size_t)p.nsplit * K * 9 * C * sizeof(float);
 }
 
-static int w9_groups() {
+static bool w9_spec() {
     static int v = -1;
     if (v < 0) {
-        // Measured on MI355X: two groups are 1.25x faster when the kernel runs alone (tools/bench_conv.py: 0.071 vs
-        // 0.090 ms on the layer-1 shape at 256 blocks) but 4 % SLOWER inside the step (bench.py: 7.36 vs 7.05 ms) --
-        // their 124-160 KB of LDS keep the other streams' blocks off the CU.  Default: one group.
-        const char* e = getenv("GDL_WGRAD9_NG");  // tuning aid: 2 = 8-wave blocks
-        v = e ? atoi(e) : 1;
-        if (v != 2) v = 1;
+        // Measured on MI355X: alone the 8-wave form is 1.2-1.3x faster on three of the four layer shapes
+        // (tools/bench_conv.py: 0.069 vs 0.086 ms at 64x56x56) but the step is 4 % SLOWER with it (bench.py, same box:
+        // 8 900 vs 9 280 samples/s) -- 8 waves x 220 VGPRs fill the CU's register file, so the blocks of the kernels
+        // on the other streams no longer fit beside it.  Default: four waves that load and multiply.
+        const char* e = getenv("GDL_WGRAD9_SPEC");  // tuning aid: 1 = 4 worker + 4 loader waves
+        v = e ? atoi(e) : 0;
     }
-    return v;
+    return v != 0;
 }
-static size_t w9_lds_bytes(int W, int ng) {
+static size_t w9_lds_bytes(int W) {
     const int rows = W9_BP + 2 * W + 2;
-    const size_t stages = ng * 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024;
-    const size_t fold = ng == 2 ? (size_t)4 * 36 * 64 * 16 : 0;  // accumulator exchange of the two groups
-    return stages > fold ? stages : fold;
+    // two stages (dy tile + slab) + zero row + two mask stages
+    return 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024 + 512;
 }
 
 // true if this geometry runs on the 9-tap kernel
 bool conv_wgrad9_ok(int dtype, int W, int C, int K, int R, int S, int stride, int pad) {
     return conv_wgrad9_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 64 == 0 &&
-           K % 64 == 0 && w9_lds_bytes(W, 1) <= 80 * 1024;
+           K % 64 == 0 && w9_lds_bytes(W) <= 80 * 1024;
 }
 
 int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K, void* ws,
                 size_t ws_bytes, hipStream_t st) {
     Wgrad9Args a{};
+#ifdef GDL_TIMING
+    a.dbg = g_timing_buf;
+#endif
     a.dy = dy;
     a.x = x;
     a.table = (const GatherEntry*)table;
@@ -421,13 +458,12 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
         return GDL_ERR_WORKSPACE;
     }
     a.partial = (float*)ws;
-    const int ng = (w9_groups() == 2 && w9_lds_bytes(W, 2) <= 160 * 1024) ? 2 : 1;
-    const size_t lds = w9_lds_bytes(W, ng);
+    const size_t lds = w9_lds_bytes(W);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad9)");
         attr_set = true;
     }
@@ -435,10 +471,10 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     {
         ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true);
-        if (ng == 2)
-            hipExtLaunchKernelGGL(conv_wgrad9_kernel<2>, dim3(grid), dim3(512), lds, st, prof.e0(), prof.e1(), 0, a);
+        if (w9_spec())
+            hipExtLaunchKernelGGL(conv_wgrad9_kernel<true>, dim3(grid), dim3(512), lds, st, prof.e0(), prof.e1(), 0, a);
         else
-            hipExtLaunchKernelGGL(conv_wgrad9_kernel<1>, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
+            hipExtLaunchKernelGGL(conv_wgrad9_kernel<false>, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
     }
     const size_t total4 = (size_t)K * C * 9 / 4;

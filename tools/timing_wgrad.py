@@ -40,11 +40,18 @@ for shape in sys.argv[1:]:
     e1.record()
     torch.cuda.synchronize()
     L.call("gdl_debug_timing_buffer", None)
-    d = dbg.cpu().numpy()
-    d = d[d[:, 0] != 0]
-    nst = d[:, 6].mean()
-    print(f"wgrad {shape}: {e0.elapsed_time(e1) * 1e3:.1f} us (kernel+reduce), {len(d)} blocks, {nst:.1f} stages/block")
-    for i, nm in ((1, "prologue"), (2, "wait+barrier"), (3, "issue"), (4, "compute"), (5, "epilogue")):
-        v = d[:, i]
-        per = f" ({v.mean() / nst:7.0f} / stage)" if i in (2, 3, 4) else ""
-        print(f"   {nm:>13s}: mean {v.mean():9.0f} p10 {np.percentile(v, 10):9.0f} p90 {np.percentile(v, 90):9.0f}{per}")
+    dall = dbg.cpu().numpy()
+    # the 9-tap kernel leaves one record per wave ([block][8 waves]: 4 workers, 4 loaders), the per-tap one per block
+    groups = [("all", dall)]
+    if R == 3 and stride == 1 and os.environ.get("GDL_WGRAD9", "1") != "0":
+        groups = [("worker waves", dall.reshape(-1, 8, 8)[:, :4].reshape(-1, 8)), ("loader waves", dall.reshape(-1, 8, 8)[:, 4:].reshape(-1, 8))]
+    print(f"wgrad {shape}: {e0.elapsed_time(e1) * 1e3:.1f} us (kernel+reduce)")
+    for gname, d in groups:
+        d = d[d[:, 0] != 0]
+        nst = d[:, 6].mean()
+        span = (d[:, 0].max() - d[:, 0].min()) / 100.0  # s_memtime ticks at 100 MHz
+        print(f"  {gname}: {len(d)} records, {nst:.1f} stages each, entry spread {span:.1f} us")
+        for i, nm in ((1, "prologue"), (2, "wait+barrier"), (3, "issue"), (7, "masks"), (4, "compute"), (5, "epilogue")):
+            v = d[:, i]
+            per = f" ({v.mean() / nst:7.1f} / stage)" if i in (2, 3, 4, 7) else ""
+            print(f"   {nm:>13s}: mean {v.mean():9.0f} p10 {np.percentile(v, 10):9.0f} p90 {np.percentile(v, 90):9.0f}{per}")
