@@ -265,6 +265,23 @@ int gdl_eval_count(const float* out, const float* out_a, const float* out_v, con
                 "eval_count: a unimodal logit set needs its counter array and vice versa");
     return eval_count(out, out_a, out_v, labels, B, n_classes, num, acc, acc_a, acc_v, (hipStream_t)stream);
 }
+int gdl_logspec_frames(int n_samples, int hop) {
+    if (n_samples <= 0 || hop <= 0) return 0;
+    return logspec_frames(n_samples, hop);
+}
+int gdl_logspec(const float* wave, int B, int n_samples, int n_fft, int hop, int pad_mode, float* out, void* stream) {
+    GDL_REQUIRE(wave && out && B > 0 && n_samples > 0 && hop > 0, "logspec: bad arguments");
+    GDL_REQUIRE(n_fft >= 16 && n_fft <= 2048 && (n_fft & (n_fft - 1)) == 0, "logspec: n_fft must be a power of two in [16, 2048]");
+    GDL_REQUIRE(pad_mode == GDL_PAD_CONSTANT || pad_mode == GDL_PAD_REFLECT, "logspec: pad_mode must be GDL_PAD_CONSTANT or GDL_PAD_REFLECT");
+    GDL_REQUIRE(pad_mode == GDL_PAD_CONSTANT || n_samples > n_fft / 2, "logspec: reflect padding needs more than n_fft/2 samples");
+    return logspec(wave, B, n_samples, n_fft, hop, pad_mode == GDL_PAD_REFLECT, out, (hipStream_t)stream);
+}
+int gdl_frames_normalize(const uint8_t* frames, int64_t n_img, int H, int W, const float* mean, const float* std, float* out,
+                         void* stream) {
+    GDL_REQUIRE(frames && out && mean && std && n_img > 0 && H > 0 && W > 0, "frames_normalize: bad arguments");
+    GDL_REQUIRE(std[0] != 0.f && std[1] != 0.f && std[2] != 0.f, "frames_normalize: zero std");
+    return frames_normalize(frames, (size_t)n_img, H, W, mean, std, out, (hipStream_t)stream);
+}
 int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
                    int n_classes, void* stream) {
     GDL_REQUIRE(logits && labels && loss && B > 0 && n_classes > 0, "softmax_ce: bad arguments");

@@ -98,6 +98,11 @@ int head_film_fwd(const float* x, const float* y, const float* Wfc, const float*
 int head_film_bwd(const float* x, const float* y, const float* Wfc, const float* Wo, const float* hidden,
                   const float* g_x_out, const float* g_y_out, const float* g_out, int uni, float* dx, float* dy, float* dWfc,
                   float* dbfc, float* dWo, float* dbo, int B, int n, void* ws, size_t ws_bytes, hipStream_t st);
+// input.hip
+int logspec_frames(int L, int hop);
+int logspec(const float* wave, int B, int L, int n_fft, int hop, int reflect, float* out, hipStream_t st);
+int frames_normalize(const unsigned char* in, size_t n_img, int H, int W, const float* mean, const float* std, float* out,
+                     hipStream_t st);
 int eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n, int64_t* num,
                int64_t* acc, int64_t* acc_a, int64_t* acc_v, hipStream_t st);
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,

@@ -70,6 +70,9 @@ SIGNATURES = {
     "gdl_head_film_workspace_bytes": ("z", "i"),
     "gdl_head_film_fwd": ("i", "p" * 10 + "ii" + "pz" + "p"),
     "gdl_head_film_bwd": ("i", "p" * 8 + "i" + "p" * 6 + "ii" + "pz" + "p"),
+    "gdl_logspec_frames": ("i", "ii"),
+    "gdl_logspec": ("i", "p" + "iiiii" + "pp"),
+    "gdl_frames_normalize": ("i", "p" + "lii" + "ppp" + "p"),
     "gdl_eval_count": ("i", "pppp" + "ii" + "pppp" + "p"),
     "gdl_optim_create": ("i", "pppi"),
     "gdl_optim_destroy": (None, "p"),

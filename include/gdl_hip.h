@@ -245,6 +245,23 @@ GDL_API int gdl_softmax_ce(const float* logits, const int64_t* labels, float sca
 GDL_API int gdl_eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B,
                            int n_classes, int64_t* num, int64_t* acc, int64_t* acc_a, int64_t* acc_v, void* stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * The device-side stages of the datasets' __getitem__:
+ *   gdl_logspec: clip to [-1, 1], librosa.stft(n_fft, hop_length) with librosa's defaults (periodic Hann window of
+ *     n_fft samples, center=True), log(|X| + 1e-7)  (dataset/CramedDataset.py:62-66: n_fft 512, hop 353;
+ *     KSDataset.py:144-149 / VGGSoundDataset.py:117-122: 256 / 128).  wave: float32 [B][n_samples] (already resampled
+ *     and tiled / cropped to its fixed length by the host); out: float32 [B][n_fft/2+1][gdl_logspec_frames()], the
+ *     tensor the DataLoader yields.  pad_mode: how the n_fft/2 samples either side are made up -- librosa >= 0.10
+ *     pads with zeros (GDL_PAD_CONSTANT), older releases reflect (GDL_PAD_REFLECT); the reference does not pin a version.
+ *   gdl_frames_normalize: transforms.ToTensor() + Normalize(mean, std) (CramedDataset.py:77-81): uint8 [n_img][H][W][3]
+ *     -> float32 [n_img][3][H][W], ((x / 255) - mean[c]) / std[c]; mean / std: 3 host floats each. */
+#define GDL_PAD_CONSTANT 0
+#define GDL_PAD_REFLECT 1
+GDL_API int gdl_logspec_frames(int n_samples, int hop);
+GDL_API int gdl_logspec(const float* wave, int B, int n_samples, int n_fft, int hop, int pad_mode, float* out, void* stream);
+GDL_API int gdl_frames_normalize(const uint8_t* frames, int64_t n_img, int H, int W, const float* mean, const float* std,
+                                 float* out, void* stream);
+
 /* ------------------------------------------------------------------ clip + grad stats + SGD
  * clip_grad_norm_(params, 40, 2) (main_dgl.py:129), the logged
  * sum_p mean|grad_p| per encoder (:132-143) and optim.SGD(momentum, weight_decay)

@@ -226,6 +226,31 @@ def valid_counts(out, out_a, out_v, labels, n_classes):
     return num, acc, acc_a, acc_v
 
 
+def log_spectrogram(wave, n_fft, hop, pad_mode="constant"):
+    """The datasets' audio feature (dataset/CramedDataset.py:62-66, KSDataset.py:144-149): clip to [-1, 1],
+    librosa.stft(n_fft, hop_length=hop), log(|X| + 1e-7).  librosa is not vendored in the reference and is absent
+    here; this restates its published algorithm (librosa.stft with its defaults: win_length = n_fft, periodic Hann
+    window, center=True with `pad_mode` padding of n_fft//2 samples -- 'constant' since librosa 0.10, 'reflect' before)
+    in float64.  wave: [B][L] float; returns float32 [B][n_fft//2+1][1 + L//hop].  Pinned against torch.stft
+    (an independent implementation) by tests/test_oracle_golden.py::test_log_spectrogram_vs_torch."""
+    w = np.clip(np.asarray(wave, dtype=np.float64), -1.0, 1.0)
+    pad = n_fft // 2
+    wp = np.pad(w, ((0, 0), (pad, pad)), mode=pad_mode)
+    frames = 1 + w.shape[1] // hop
+    idx = np.arange(frames)[:, None] * hop + np.arange(n_fft)[None, :]
+    hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)
+    X = np.fft.rfft(wp[:, idx] * hann, axis=-1)  # [B][frames][bins]
+    return np.log(np.abs(X) + 1e-7).transpose(0, 2, 1).astype(np.float32)
+
+
+def normalize_frames(frames_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """transforms.ToTensor() + transforms.Normalize(mean, std) (dataset/CramedDataset.py:77-81) on decoded uint8
+    frames [N][H][W][3] -> float32 [N][3][H][W]; the same fp32 operations in the same order as torchvision."""
+    x = np.asarray(frames_u8).astype(np.float32) / np.float32(255.0)
+    x = (x - np.asarray(mean, dtype=np.float32)) / np.asarray(std, dtype=np.float32)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
 def sumsq(g):
     g = _c(g)
     return float(lib().orc_sumsq(_p(g), ctypes.c_size_t(g.size)))

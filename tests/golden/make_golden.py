@@ -399,10 +399,39 @@ def run_film_head_case(name, fm, n_classes, batch=3):
     print(name, "ok")
 
 
+def run_input_pipeline_case(name):
+    """Input pipeline.  The reference's datasets need librosa and torchvision, neither of which is
+    installed here, so these vectors come from the independent implementations that ARE: torch.stft with librosa's
+    defaults spelled out (periodic Hann of n_fft samples, center=True, pad_mode constant / reflect) and the torch
+    operations torchvision's ToTensor / Normalize are documented to perform."""
+    g = torch.Generator().manual_seed(20250824)
+    out = {}
+    for tag, n_fft, hop, n in (("cremad", 512, 353, 3000), ("ks", 256, 128, 2000)):
+        wave = torch.randn(2, n, generator=g) * 0.6  # some samples exceed +-1: the clip matters
+        out[f"{tag}.wave"] = wave.numpy()
+        for pm in ("constant", "reflect"):
+            X = torch.stft(wave.clamp(-1.0, 1.0).double(), n_fft, hop_length=hop, win_length=n_fft,
+                           window=torch.hann_window(n_fft, periodic=True, dtype=torch.float64), center=True, pad_mode=pm,
+                           return_complex=True)
+            out[f"{tag}.{pm}"] = torch.log(X.abs() + 1e-7).float().numpy()
+    frames = torch.randint(0, 256, (2, 3, 12, 10, 3), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    t = frames.permute(0, 1, 4, 2, 3).float().div(255)                      # ToTensor
+    t = t.sub(mean.view(1, 1, 3, 1, 1)).div(std.view(1, 1, 3, 1, 1))        # Normalize
+    out["frames.u8"] = frames.numpy()
+    out["frames.norm"] = t.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: {len(out)} arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     a = ap.parse_args()
+    if not a.only or a.only in "input_pipeline":
+        run_input_pipeline_case("input_pipeline")  # (needs no reference import)
+        if a.only:
+            return
     bm, bb, fm = _import_reference()
     cases = {
         "head_dgl_c6": lambda: run_head_case("head_dgl_c6", fm, "ConcatFusion_DGL", 6),

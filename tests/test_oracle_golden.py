@@ -230,3 +230,39 @@ def test_sgd_matches_torch():
         opt.step()
         orc.sgd_(p, g, buf, 2e-3, 0.9, 1e-4, i == 0)
         np.testing.assert_allclose(p, tp.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ input pipeline
+@pytest.mark.parametrize("tag,n_fft,hop", [("cremad", 512, 353), ("ks", 256, 128)])
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_log_spectrogram_golden(golden_dir, tag, n_fft, hop, pad_mode):
+    """The float64 restatement of librosa.stft + log against the committed torch.stft vectors (librosa itself is
+    neither vendored in the reference nor installed here).  Tolerance: both sides are float64 rounded to float32."""
+    g = np.load(os.path.join(golden_dir, "input_pipeline.npz"))
+    got = orc.log_spectrogram(g[f"{tag}.wave"], n_fft, hop, pad_mode)
+    want = g[f"{tag}.{pad_mode}"]
+    assert got.shape == want.shape == (2, n_fft // 2 + 1, 1 + g[f"{tag}.wave"].shape[1] // hop)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_log_spectrogram_vs_torch():
+    """Same check live, at the reference's full clip lengths (3 s at 22 050 Hz -> [257, 188]; 5 s at 16 kHz -> [129, 626])."""
+    import torch
+
+    rs = np.random.default_rng(5)
+    for n_fft, hop, n, shape in ((512, 353, 22050 * 3, (257, 188)), (256, 128, 16000 * 5, (129, 626))):
+        wave = (rs.standard_normal((1, n)) * 0.5).astype(np.float32)
+        got = orc.log_spectrogram(wave, n_fft, hop, "constant")
+        assert got.shape[1:] == shape  # the spectrogram shapes of BASELINE.json's configs
+        X = torch.stft(torch.from_numpy(wave).clamp(-1, 1).double(), n_fft, hop_length=hop,
+                       window=torch.hann_window(n_fft, periodic=True, dtype=torch.float64), center=True, pad_mode="constant",
+                       return_complex=True)
+        np.testing.assert_allclose(got, torch.log(X.abs() + 1e-7).float().numpy(), rtol=0, atol=2e-6)
+
+
+def test_normalize_frames_golden(golden_dir):
+    """ToTensor + Normalize: bit-exact (the same fp32 operations in the same order)."""
+    g = np.load(os.path.join(golden_dir, "input_pipeline.npz"))
+    u8 = g["frames.u8"]
+    got = orc.normalize_frames(u8.reshape(-1, *u8.shape[2:])).reshape(g["frames.norm"].shape)
+    np.testing.assert_array_equal(got, g["frames.norm"])

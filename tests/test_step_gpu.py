@@ -557,3 +557,76 @@ def test_full_size_properties():
     # clipping: post-clip global norm == min(total, 40)
     post = np.sqrt(sum(v * v for v in r0["grad_norm"].values()))
     np.testing.assert_allclose(post, min(r0["total_norm"], 40.0), rtol=1e-4)
+
+
+# ------------------------------------------------------------------ input pipeline
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_log_spectrogram_golden(golden_dir, pad_mode):
+    """gdl_logspec against the committed torch.stft vectors.  fp32 direct DFT vs a float64 transform: the magnitudes
+    agree to 2e-5 of the largest one, the log values to 1e-3 wherever |X| >= 1e-2 (below that the log of a
+    near-cancelled sum is ill-conditioned in any fp32 implementation, librosa's included)."""
+    from gdl import data as gd
+
+    g = np.load(os.path.join(golden_dir, "input_pipeline.npz"))
+    for tag, n_fft, hop in (("cremad", 512, 353), ("ks", 256, 128)):
+        got = gd.log_spectrogram(torch.from_numpy(g[f"{tag}.wave"]).to(DEV), n_fft, hop, pad_mode).cpu().numpy()
+        want = g[f"{tag}.{pad_mode}"]
+        assert got.shape == want.shape
+        _check_logspec(got, want)
+
+
+def _check_logspec(got, want):
+    mg, mw = np.exp(got.astype(np.float64)) - 1e-7, np.exp(want.astype(np.float64)) - 1e-7
+    assert np.abs(mg - mw).max() <= 2e-5 * max(1.0, mw.max())
+    big = mw >= 1e-2
+    np.testing.assert_allclose(got[big], want[big], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("n_fft,hop,n,B", [(512, 353, 22050 * 3, 64), (256, 128, 16000 * 5, 8), (512, 256, 700, 3),
+                                           (256, 128, 100, 2), (64, 16, 1000, 1)])
+def test_log_spectrogram_oracle(n_fft, hop, n, B):
+    """Full-size batches of BASELINE.json's configs (CREMA-D B=64: [64, 257, 188]; Kinetics-Sounds: [8, 129, 626]) and
+    the ragged cases: a clip shorter than one window, a length that is not a multiple of the hop, loud samples that the
+    clip flattens, a silent clip (log(1e-7) everywhere)."""
+    from gdl import data as gd
+    from oracle import oracle as orc
+
+    rs = np.random.default_rng(n_fft + n)
+    wave = (rs.standard_normal((B, n)) * 0.7).astype(np.float32)
+    wave[0, : n // 3] *= 4.0  # well beyond +-1
+    if B > 1:
+        wave[-1] = 0.0  # silence
+    for pad_mode in ("constant", "reflect"):
+        if pad_mode == "reflect" and n <= n_fft // 2:
+            with pytest.raises(L.GdlError):
+                gd.log_spectrogram(torch.from_numpy(wave).to(DEV), n_fft, hop, pad_mode)
+            continue
+        got = gd.log_spectrogram(torch.from_numpy(wave).to(DEV), n_fft, hop, pad_mode).cpu().numpy()
+        want = orc.log_spectrogram(wave, n_fft, hop, pad_mode)
+        assert got.shape == (B, n_fft // 2 + 1, 1 + n // hop)
+        _check_logspec(got, want)
+        if B > 1:
+            np.testing.assert_allclose(got[-1], np.log(np.float32(1e-7)), rtol=0, atol=1e-5)
+    # a 1-D waveform gives one spectrogram; bad arguments are reported, not computed
+    one = gd.log_spectrogram(torch.from_numpy(wave[0]).to(DEV), n_fft, hop)
+    assert one.shape == (n_fft // 2 + 1, 1 + n // hop)
+    with pytest.raises(ValueError):
+        gd.log_spectrogram(torch.from_numpy(wave), n_fft, hop)  # host tensor: there is no CPU path
+    with pytest.raises(L.GdlError):
+        gd.log_spectrogram(torch.from_numpy(wave).to(DEV), 500, hop)  # not a power of two
+
+
+def test_normalize_frames(golden_dir):
+    """ToTensor + Normalize on the device: bit-exact against the committed vectors and, at the batch shape of the
+    CREMA-D step ([64, 3, 224, 224, 3] uint8), against the oracle."""
+    from gdl import data as gd
+    from oracle import oracle as orc
+
+    g = np.load(os.path.join(golden_dir, "input_pipeline.npz"))
+    got = gd.normalize_frames(torch.from_numpy(g["frames.u8"]).to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(got, g["frames.norm"])
+    rs = np.random.default_rng(9)
+    u8 = rs.integers(0, 256, (64, 3, 224, 224, 3), dtype=np.uint8)
+    got = gd.normalize_frames(torch.from_numpy(u8).to(DEV)).cpu().numpy()
+    assert got.shape == (64, 3, 3, 224, 224)
+    np.testing.assert_array_equal(got.reshape(-1, 3, 224, 224), orc.normalize_frames(u8.reshape(-1, 224, 224, 3)))
