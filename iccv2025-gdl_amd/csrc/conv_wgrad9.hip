@@ -311,24 +311,32 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
 }
 
 // out[k][c][r][s] = sum_slice partial[slice][tile][wave][tap][i][lane][e], fixed order.
-// Block = 256 threads = 16 consecutive float4 outputs x 16 split-lanes (lane l sums slices l, l+16, ..);
+// Block = 256 threads = 256/SL consecutive float4 outputs x SL split-lanes (lane l sums slices l, l+SL, ..., four loads
+// in flight); thread = l * (256/SL) + o, so the 256/SL threads of one split-lane read one contiguous run of a slice.
+// SL = 4 when there are at most 4 slices (the 512-channel layers: no idle split-lanes), else 16.
 // D[i][j] fragment layout: k = 16i + (lane>>4)*4 + e, c = 16*wave + (lane&15).
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float4* __restrict__ partial, float* __restrict__ out,
                                                             int nsplit, int K, int C, int tiles_k, int tiles_c) {
-    __shared__ float4 red[16][16];
+    constexpr int OPB = 256 / SL;
+    __shared__ float4 red[SL][OPB];
     const size_t total4 = (size_t)K * C * 9 / 4;  // float4 elements per slice
-    const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
-    const size_t idx = blockIdx.x * (size_t)16 + o;
+    const int o = threadIdx.x % OPB, l = threadIdx.x / OPB;
+    const size_t idx = blockIdx.x * (size_t)OPB + o;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < total4) {
+        const float4* p = partial + idx;
         int sp = l;
-        for (; sp + 16 < nsplit; sp += 32) {  // two slices in flight
-            const float4 v0 = partial[(size_t)sp * total4 + idx], v1 = partial[(size_t)(sp + 16) * total4 + idx];
+        for (; sp + 3 * SL < nsplit; sp += 4 * SL) {
+            const float4 v0 = p[(size_t)sp * total4], v1 = p[(size_t)(sp + SL) * total4];
+            const float4 v2 = p[(size_t)(sp + 2 * SL) * total4], v3 = p[(size_t)(sp + 3 * SL) * total4];
             s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
             s.x += v1.x, s.y += v1.y, s.z += v1.z, s.w += v1.w;
+            s.x += v2.x, s.y += v2.y, s.z += v2.z, s.w += v2.w;
+            s.x += v3.x, s.y += v3.y, s.z += v3.z, s.w += v3.w;
         }
-        if (sp < nsplit) {
-            const float4 v0 = partial[(size_t)sp * total4 + idx];
+        for (; sp < nsplit; sp += SL) {
+            const float4 v0 = p[(size_t)sp * total4];
             s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
         }
     }
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) void wgrad9_reduce_kernel(const float4* __rest
     __syncthreads();
     if (l == 0 && idx < total4) {
 #pragma unroll
-        for (int jj = 1; jj < 16; ++jj) {
+        for (int jj = 1; jj < SL; ++jj) {
             const float4 v = red[jj][o];
             s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
         }
@@ -479,8 +487,12 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     }
     const size_t total4 = (size_t)K * C * 9 / 4;
     ProfScope prof("gdl::wgrad9_reduce_kernel", PROF_HBM, st, (double)total4 * 16.0 * (p.nsplit + 1));
-    hipLaunchKernelGGL(wgrad9_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, (const float4*)a.partial, dw,
-                       p.nsplit, K, C, a.tiles_k, a.tiles_c);
+    if (p.nsplit <= 4)
+        hipLaunchKernelGGL(wgrad9_reduce_kernel<4>, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float4*)a.partial,
+                           dw, p.nsplit, K, C, a.tiles_k, a.tiles_c);
+    else
+        hipLaunchKernelGGL(wgrad9_reduce_kernel<16>, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st,
+                           (const float4*)a.partial, dw, p.nsplit, K, C, a.tiles_k, a.tiles_c);
     GDL_CHECK_LAUNCH("wgrad9_reduce_kernel");
     return GDL_OK;
 }
