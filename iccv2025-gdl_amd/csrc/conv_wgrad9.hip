@@ -248,7 +248,11 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
             auto issue_b = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const unsigned ad = ((pmask[ks][h] >> t) & 1u) ? baddr[t][h] : (ks ? zaddr - 4096u : zaddr);
+                    // bit t of the mask, sign-extended, selects between the slab row and the zero row (bfe + bfi)
+                    // (two VALU instructions; the compiler's own select takes three: and, compare, cndmask)
+                    unsigned sel, ad;
+                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(pmask[ks][h]), "n"(t));
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(sel), "v"(baddr[t][h]), "v"(ks ? zaddr - 4096u : zaddr));
                     bf[t % 3][h] = ks ? w9_tr<4096>(ad) : w9_tr<0>(ad);
                 }
             };
