@@ -54,7 +54,8 @@ struct Wgrad9Args {
 extern unsigned long long* g_timing_buf;
 #endif
 
-constexpr int W9_BP = 64;  // pixels per stage
+constexpr int W9_BP = 64;        // pixels per stage
+constexpr int W9_RING = 32768;   // bytes of the slab ring (256 rows)
 
 __device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, int voffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -103,7 +104,14 @@ __device__ __forceinline__ int w9_swz(int row) { return ((row >> 1) & 1) | (((ro
 // both), so the load of stage s+1 only overlaps the MFMAs of stage s if OTHER waves issue it; one loader and one
 // worker share each SIMD and the LDS footprint stays that of two stages.  !SPEC: the four waves do both (kept as a
 // tuning aid, GDL_WGRAD9_SPEC=0).
-template <bool SPEC>
+//
+// RING: consecutive stages' slabs overlap in 2W+2 of their 64+2W+2 rows, so the slab lives in a ring of 256 rows
+// (32 KiB at LDS offset 0, pixel p at row (p - p0) mod 256) and a stage only loads its 64 NEW rows: 17-18 DMA pieces
+// per stage instead of 32 at W = 56 (25 at W = 28).  A read address advances by 64 rows per stage and wraps with one
+// AND; the second K-step's +4096 instruction offset may run past the ring's end, so rows 0..31 are mirrored behind it
+// (4 extra pieces every fourth stage).  Used where it saves at least 6 pieces per stage (W >= 24); the narrow layers
+// keep the plain double buffer, whose LDS footprint is smaller there.
+template <bool SPEC, bool RING>
 __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,11 +133,17 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
     const int nst = (m_end - m_begin + W9_BP - 1) / W9_BP;
 
     const int nins = (a.slab_rows + 7) >> 3;        // 1 KiB DMA pieces of the slab
-    const int STAGE = W9_BP * 128 + nins * 1024;    // dy tile + slab
+    // plain: [stage 0: dy tile + slab][stage 1][zero row][mask stages]
+    // RING:  [ring 32 KiB][mirror of rows 0..31, 4 KiB][dy tile 0][dy tile 1][zero row][mask stages]
+    const int STAGE = RING ? W9_BP * 128 : W9_BP * 128 + nins * 1024;
+    const int DY0 = RING ? W9_RING + 4096 : 0;      // byte offset of dy tile 0
+    const int ZOFF = RING ? DY0 + 2 * STAGE : 2 * STAGE;
     const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
-    unsigned char* zero_p = smem + 2 * STAGE;       // 1 KiB zero row
+    if (RING && (smem_base & (W9_RING - 1)) != 0) __builtin_trap();  // the wrap-by-AND needs the ring at a 32 KiB boundary
+    unsigned char* zero_p = smem + ZOFF;            // 1 KiB zero row
     unsigned char* mask_st = zero_p + 1024;         // two 256-byte mask stages
-    const unsigned zrow = smem_base + 2 * STAGE;
+    const unsigned zrow = smem_base + ZOFF;
+    const int ringT = ((2 * a.W + 2 + 63) >> 6) << 6;  // ring row of the first new row of stage 0's successor block
 
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -142,17 +156,38 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
     // the slab, 1 of tap masks (4 bytes per lane: the second word of the pixels' gather entries; past the
     // slice: zeros); loader wave w takes pieces w, w+4, ...
     const int prow = lane >> 3, pch = lane & 7;
-    const int npieces = 8 + nins + 1;
     int ld_m = m_begin;  // first pixel of the next stage to load
+    int ld_s = 0;        // its index
     auto load_stage = [&](int buf) {
-        unsigned char* Ks = smem + buf * STAGE;
+        unsigned char* Ks = smem + DY0 + buf * STAGE;
         unsigned char* Xs = Ks + W9_BP * 128;
-        for (int p = wave; p < npieces; p += 4) {
+        // RING: stage 0 fills ring rows [0, ringT + 64) with pixels p0 + row, p0 = m_begin - (W+1) - (ringT - 2W - 2);
+        // stage s > 0 brings pixels m_s + (W+1) + [0, 64) into block (s + ringT/64) mod 4 (and its first 32 rows
+        // into the mirror when that is block 0)
+        const int blk = (ld_s + (ringT >> 6)) & 3;
+        const int nx = !RING ? nins : (ld_s == 0 ? (ringT >> 3) + 8 : (blk == 0 ? 12 : 8));
+        const int np = 8 + nx + 1;
+        for (int p = wave; p < np; p += 4) {
             if (p < 8) {
                 const int row = p * 8 + prow, m = ld_m + row;
                 const int ch = (((pch >> 1) ^ w9_swz(row)) << 1) | (pch & 1);
                 w9_dma16(rdy, Ks + p * 1024, m < m_end ? m * (a.K * 2) + k0 * 2 + ch * 16 : (int)0x80000000);
-            } else if (p < 8 + nins) {
+            } else if (RING && p < 8 + nx) {
+                int jj = p - 8;  // piece: 8 ring rows
+                int pix, dst;
+                if (ld_s == 0) {
+                    pix = m_begin - (a.W + 1) - (ringT - 2 * a.W - 2) + jj * 8 + prow;
+                    dst = jj * 1024;
+                } else {
+                    const bool mir = jj >= 8;  // second copy of the block's first 4 pieces
+                    if (mir) jj -= 8;
+                    pix = ld_m + (a.W + 1) + jj * 8 + prow;
+                    dst = mir ? W9_RING + jj * 1024 : blk * 8192 + jj * 1024;
+                }
+                const int sr = jj * 8 + prow;  // bits 1 and 3 of the ring row (blocks are 64 rows: they do not change them)
+                const int ch = (((pch >> 1) ^ w9_swz(sr)) << 1) | (pch & 1);
+                w9_dma16(rx, smem + dst, (unsigned)pix < (unsigned)a.M ? pix * (a.C * 2) + c0 * 2 + ch * 16 : (int)0x80000000);
+            } else if (!RING && p < 8 + nins) {
                 const int jj = p - 8, sr = jj * 8 + prow;
                 const int pix = ld_m - (a.W + 1) + sr;
                 const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.M;
@@ -164,6 +199,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
             }
         }
         ld_m += W9_BP;
+        ld_s += 1;
     };
 
     // ---- per-lane LDS read addresses (stage buffer 0; the other buffer is +STAGE).
@@ -175,7 +211,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
     for (int h = 0; h < 2; ++h) {
         const int row = lrow + h * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) aaddr[i][h] = smem_base + row * 128 + ((i ^ w9_swz(row)) << 5) + (li & 3) * 8;
+        for (int i = 0; i < 4; ++i) aaddr[i][h] = smem_base + DY0 + row * 128 + ((i ^ w9_swz(row)) << 5) + (li & 3) * 8;
     }
     unsigned baddr[9][2];  // x fragment of tap t (this wave's 16 channels), half h
 #pragma unroll
@@ -183,8 +219,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
         const int sh = (t / 3 - 1) * a.W + (t % 3 - 1);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int sr = lrow + h * 4 + (a.W + 1) + sh;
-            baddr[t][h] = smem_base + W9_BP * 128 + sr * 128 + ((wave ^ w9_swz(sr)) << 5) + (li & 3) * 8;
+            // plain: slab row of stage buffer 0; RING: ring row of stage 0 (the ring starts ringT - (2W+2) pixels early)
+            const int sr = lrow + h * 4 + (a.W + 1) + sh + (RING ? ringT - 2 * a.W - 2 : 0);
+            baddr[t][h] = smem_base + (RING ? 0 : W9_BP * 128) + sr * 128 + ((wave ^ w9_swz(sr)) << 5) + (li & 3) * 8;
         }
     }
     const unsigned zaddr = zrow + (li & 3) * 8;  // any 8 bytes of the zero KiB (K-step 1 reads at +4096: pre-biased there)
@@ -286,7 +323,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) baddr[t][h] += dlt;
+            for (int h = 0; h < 2; ++h) baddr[t][h] = RING ? ((baddr[t][h] + 8192u) & (unsigned)(W9_RING - 1)) : baddr[t][h] + dlt;
     }
 #ifdef GDL_TIMING
     unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
@@ -429,7 +466,16 @@ static bool w9_spec() {
     }
     return v != 0;
 }
+static bool w9_ring(int W) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_WGRAD9_RING");  // tuning aid: 0 = plain double buffer everywhere
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0 && W >= 24 && 2 * W + 2 <= 128;
+}
 static size_t w9_lds_bytes(int W) {
+    if (w9_ring(W)) return (size_t)W9_RING + 4096 + 2 * W9_BP * 128 + 1024 + 512;  // ring + mirror + dy tiles + zero row + masks
     const int rows = W9_BP + 2 * W + 2;
     // two stages (dy tile + slab) + zero row + two mask stages
     return 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024 + 512;
@@ -471,22 +517,20 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     }
     a.partial = (float*)ws;
     const size_t lds = w9_lds_bytes(W);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)conv_wgrad9_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    const bool ring = w9_ring(W), spec = w9_spec();
+    auto kern = spec ? (ring ? conv_wgrad9_kernel<true, true> : conv_wgrad9_kernel<true, false>)
+                     : (ring ? conv_wgrad9_kernel<false, true> : conv_wgrad9_kernel<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[spec * 2 + ring]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad9)");
-        attr_set = true;
+        attr_set[spec * 2 + ring] = true;
     }
     const int per_slice = a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     {
         ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true);
-        if (w9_spec())
-            hipExtLaunchKernelGGL(conv_wgrad9_kernel<true>, dim3(grid), dim3(512), lds, st, prof.e0(), prof.e1(), 0, a);
-        else
-            hipExtLaunchKernelGGL(conv_wgrad9_kernel<false>, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(spec ? 512 : 256), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
     }
     const size_t total4 = (size_t)K * C * 9 / 4;
