@@ -91,7 +91,12 @@ WGRAD_SHAPES = [
     (2, 128, 9, 6, 64, 3, 1, 1),     # TK=64, TC=128
     (2, 128, 12, 10, 256, 3, 1, 1),  # 128x128
     (2, 64, 9, 6, 128, 1, 2, 0),     # 1x1 stride 2
-    (3, 64, 56, 56, 64, 3, 1, 1),    # many splits
+    (3, 64, 56, 56, 64, 3, 1, 1),    # many splits; slab ring (W >= 24)
+    (1, 64, 5, 24, 64, 3, 1, 1),     # narrowest ring geometry, M = 120 (ragged last stage)
+    (1, 64, 5, 23, 64, 3, 1, 1),     # widest plain double buffer below it
+    (2, 64, 3, 63, 128, 3, 1, 1),    # widest ring geometry (2W+2 = 128)
+    (2, 64, 2, 64, 64, 3, 1, 1),     # just past it: plain
+    (1, 128, 40, 47, 64, 3, 1, 1),   # audio layer-1 width: the ring wraps several times per slice
 ]
 
 
