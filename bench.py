@@ -27,7 +27,18 @@ sys.path.insert(0, os.path.join(ROOT, "iccv2025-gdl_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-TRAIN_GFLOP_PER_SAMPLE = 42.567  # BASELINE.md section 2 (CREMA-D, T=3; 2*MAC, convs only)
+# the workloads of BASELINE.json's configs: configs[1] (the metric's own, default) and configs[2] (Kinetics-Sounds shapes;
+# 34 logits as the reference builds it, basic_model.py:17 -- BASELINE says 31, the cost difference is nil)
+WORKLOADS = {
+    "cremad": {"dataset": "CREMAD", "n_classes": 6, "spec": (257, 188), "alpha": 4.0, "gflop": 42.567,
+               "name": "CREMA-D DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x257x188 + frames 3x3x224x224, "
+                       "alpha=4, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
+               "metric": "audio-visual samples/sec, CREMA-D DGL train step (whole job)"},
+    "ks": {"dataset": "KineticSound", "n_classes": 34, "spec": (129, 626), "alpha": 2.0, "gflop": 50.563,
+           "name": "Kinetics-Sounds DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x129x626 + frames 3x3x224x224, "
+                   "34 logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
+           "metric": "audio-visual samples/sec, Kinetics-Sounds DGL train step (whole job)"},
+}
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
 HBM_PEAK_GBS = 8000.0
 
@@ -39,6 +50,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="cremad", choices=sorted(WORKLOADS),
+                    help="cremad = BASELINE configs[1] (the metric's configuration); ks = configs[2] shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="samples in the CPU oracle step (about 10-20 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
@@ -47,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch, threads):
+def cpu_baseline(batch, threads, wl):
     """The CPU oracle's DGL step (kind 'port') on a bounded sample: one warm-up + one timed step."""
     from oracle import fixtures as fx
     from oracle import oracle as orc
@@ -55,17 +68,17 @@ def cpu_baseline(batch, threads):
     cores = os.cpu_count() or 1
     thr = threads if threads > 0 else min(cores, 64)
     orc.set_num_threads(thr)
-    P, Bf = fx.model_state(6, "concat_dgl")
+    P, Bf = fx.model_state(wl["n_classes"], "concat_dgl")
     model = orc.AVModel(P, Bf, "dgl")
-    spec, image, label = fx.make_batch(0, batch, (257, 188), 3, (224, 224), 6)
+    spec, image, label = fx.make_batch(0, batch, wl["spec"], 3, (224, 224), wl["n_classes"])
     t0 = time.time()
-    model.train_step(spec, image, label, 4.0, 2e-3)
+    model.train_step(spec, image, label, wl["alpha"], 2e-3)
     t1 = time.time()
-    model.train_step(spec, image, label, 4.0, 2e-3)
+    model.train_step(spec, image, label, wl["alpha"], 2e-3)
     t2 = time.time()
     dt = t2 - t1
     return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": thr, "kind": "port",
-            "sample": f"oracle/ C port, CREMA-D T=3 DGL step, B={batch}, fp32, 1 warm-up ({t1 - t0:.1f} s) + 1 timed "
+            "sample": f"oracle/ C port, {wl['dataset']} T=3 DGL step, B={batch}, fp32, 1 warm-up ({t1 - t0:.1f} s) + 1 timed "
                       f"step ({dt:.1f} s) on {thr} of {cores} host threads"}
 
 
@@ -106,19 +119,20 @@ def main():
     lib = L.load()
     # model exactly as main_dgl.py:230-246 builds it (random init; identical on every rank via the seed)
     setup_seed(0)
-    args = argparse.Namespace(fusion_method="concat", dataset="CREMAD", modality="full", batch_size=a.batch)
+    wl = WORKLOADS[a.workload]
+    args = argparse.Namespace(fusion_method="concat", dataset=wl["dataset"], modality="full", batch_size=a.batch)
     model = AVClassifier_DGL(args)
     model.apply(weight_init)
     model.to(dev)
     model.train()
-    tr = DGLTrainer(model, lr=2e-3, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype,
+    tr = DGLTrainer(model, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype,
                     process_group=pg)
     # synthetic CREMA-D batch, seed 1234 + rank, resident on the device
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B = a.batch
-    spec = torch.randn(B, 257, 188, generator=g).to(dev)
+    spec = torch.randn(B, *wl["spec"], generator=g).to(dev)
     image = torch.randn(B, 3, 3, 224, 224, generator=g).to(dev)
-    label = torch.randint(0, 6, (B,), generator=g).to(dev)
+    label = torch.randint(0, wl["n_classes"], (B,), generator=g).to(dev)
 
     def barrier():
         if world > 1:
@@ -197,7 +211,7 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(d["kernel"])
-            if pm and a.dtype == "bf16" and B == 64:
+            if pm and a.dtype == "bf16" and B == 64 and a.workload == "cremad":
                 traffic = round(pm["bytes_per_launch"])
         except (OSError, ValueError):
             pass
@@ -228,24 +242,23 @@ def main():
         return
     value = world * B * a.steps / elapsed
     out = {
-        "metric": "audio-visual samples/sec, CREMA-D DGL train step (whole job)",
+        "metric": wl["metric"],
         "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "CREMA-D DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x257x188 + frames "
-                               "3x3x224x224, alpha=4, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
+        "config": {"workload": wl["name"],
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                    "buckets": "fusion head | audio layer4 | audio rest | visual layer4 | visual rest, RCCL all-reduce, layer4 "
                               "buckets overlapped with the rest of the backward" if world > 1 else "none"},
         "samples_per_sec_per_gpu": round(value / world, 2),
-        "step_tflops": round(value * TRAIN_GFLOP_PER_SAMPLE / 1e3, 2),
-        "mfma_frac_end_to_end": round(value / world * TRAIN_GFLOP_PER_SAMPLE / 1e3 / MFMA_PEAK_TFLOPS[a.dtype], 4),
+        "step_tflops": round(value * wl["gflop"] / 1e3, 2),
+        "mfma_frac_end_to_end": round(value / world * wl["gflop"] / 1e3 / MFMA_PEAK_TFLOPS[a.dtype], 4),
         "loss_f": round(res["loss_f"], 5), "loss_a": round(res["loss_a"], 5), "loss_v": round(res["loss_v"], 5),
         "total_norm": round(res["total_norm"], 4),
         "roofline": roof, "kernels": kernels, "phases_ms": phases,
     }
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_threads)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_threads, wl)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
