@@ -89,37 +89,39 @@ __device__ __forceinline__ double block_sum_double(double v, double* sh) {
     return r;
 }
 
-// Column sums of a [rows][C][2] float array in double, FIN_CH channels per block: thread (rl, cl) adds
-// rows rl, rl+FIN_RL, .. of channel c0+cl (16 lanes read one 128-byte line; 8 rows in flight), the FIN_RL
-// row-lanes are then folded through LDS in a fixed order.  Returns the two sums to the threads rl == 0.
-constexpr int FIN_CH = 8, FIN_RL = 128;  // block = 1024 threads; 8 channels = one 64-byte segment of a partial row
+// Column sums of a [rows][C][2] float array in double, CH channels per block of 256 threads: thread (rl, cl) adds
+// rows rl, rl+RL, .. of channel c0+cl, eight loads in flight, the RL = 256/CH row-lanes are then folded through LDS
+// in a fixed order.  Returns the two sums to every thread (of its channel).  These kernels sit between two dependent
+// kernels of a chain 80 times per step and cost the step their full duration (skipping them: -0.56 ms of 6.97), so
+// CH is picked for ~64 blocks (fin_ch).
+constexpr int FIN_THREADS = 256;  // (1024-thread blocks waited for a CU with 16 free wave slots: ~8 us even for 74 rows)
+template <int CH>
 __device__ __forceinline__ void fin_colsum(const float* __restrict__ partial, int rows, int C, int c, double& s, double& q) {
-    __shared__ double sh[FIN_RL][FIN_CH][2];
-    const int rl = threadIdx.x / FIN_CH, cl = threadIdx.x % FIN_CH;
+    constexpr int RL = FIN_THREADS / CH;
+    __shared__ double sh[RL][CH][2];
+    const int rl = threadIdx.x / CH, cl = threadIdx.x % CH;
     const float2* __restrict__ p2 = (const float2*)partial;
     s = 0.0, q = 0.0;
-    int t = c < C ? rl : rows;  // channels past C (C not a multiple of FIN_CH) only take part in the barrier
-    for (; t + 7 * FIN_RL < rows; t += 8 * FIN_RL) {
+    // (channels past C, when C is not a multiple of CH, only take part in the barriers)
+    for (int t = c < C ? rl : rows; t < rows; t += 8 * RL) {
         float2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p2[(size_t)(t + u * FIN_RL) * C + c];
+        for (int u = 0; u < 8; ++u) {
+            const int r = t + u * RL;
+            v[u] = r < rows ? p2[(size_t)r * C + c] : make_float2(0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             s += (double)v[u].x;
             q += (double)v[u].y;
         }
     }
-    for (; t < rows; t += FIN_RL) {
-        const float2 v = p2[(size_t)t * C + c];
-        s += (double)v.x;
-        q += (double)v.y;
-    }
     sh[rl][cl][0] = s;
     sh[rl][cl][1] = q;
     __syncthreads();
     // fixed binary tree over the row-lanes (deterministic; a serial fold by one thread cost ~3 us)
 #pragma unroll
-    for (int st = FIN_RL / 2; st > 0; st >>= 1) {
+    for (int st = RL / 2; st > 0; st >>= 1) {
         if (rl < st) {
             sh[rl][cl][0] += sh[rl + st][cl][0];
             sh[rl][cl][1] += sh[rl + st][cl][1];
@@ -129,15 +131,17 @@ __device__ __forceinline__ void fin_colsum(const float* __restrict__ partial, in
     s = sh[0][cl][0];
     q = sh[0][cl][1];
 }
+static int fin_ch(int C) { return C >= 512 ? 8 : (C >= 256 ? 4 : (C >= 128 ? 2 : 1)); }
 
-__global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_finalize_train_kernel(
+template <int CH>
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_train_kernel(
     const float* __restrict__ partial, int tiles, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
     float* save_mean, float* save_rstd, float* scale, float* shift) {
-    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const int c = blockIdx.x * CH + threadIdx.x % CH;
     double s, q;
-    fin_colsum(partial, tiles, C, c, s, q);
-    if (threadIdx.x < FIN_CH && c < C) {
+    fin_colsum<CH>(partial, tiles, C, c, s, q);
+    if (threadIdx.x < CH && c < C) {
         const double mean = s / count;
         double var = q / count - mean * mean;  // biased
         if (var < 0.0) var = 0.0;
@@ -158,8 +162,11 @@ __global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_finalize_train_kernel(
 int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
                       float* scale, float* shift, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_RL), 0, st, partial, tiles, C, count,
-                       gamma, beta, eps, momentum, rm, rv, nbt, save_mean, save_rstd, scale, shift);
+    const int ch = fin_ch(C);
+    auto kern = ch == 8 ? bn_finalize_train_kernel<8>
+                        : (ch == 4 ? bn_finalize_train_kernel<4> : (ch == 2 ? bn_finalize_train_kernel<2> : bn_finalize_train_kernel<1>));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(C, ch)), dim3(FIN_THREADS), 0, st, partial, tiles, C, count, gamma, beta, eps, momentum,
+                       rm, rv, nbt, save_mean, save_rstd, scale, shift);
     GDL_CHECK_LAUNCH("bn_finalize_train_kernel");
     return GDL_OK;
 }
@@ -529,13 +536,14 @@ int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, c
 }
 
 // dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M
-__global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
+template <int CH>
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
                                                                          double count, float* dgamma, float* dbeta,
                                                                          float* coef) {
-    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const int c = blockIdx.x * CH + threadIdx.x % CH;
     double a, b;
-    fin_colsum(partial, blocks, C, c, a, b);
-    if (threadIdx.x < FIN_CH && c < C) {
+    fin_colsum<CH>(partial, blocks, C, c, a, b);
+    if (threadIdx.x < CH && c < C) {
         dbeta[c] = (float)a;
         dgamma[c] = (float)b;
         coef[c] = (float)(a / count);
@@ -544,8 +552,10 @@ __global__ __launch_bounds__(FIN_CH* FIN_RL) void bn_bwd_finalize_kernel(const f
 }
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                     hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_CH)), dim3(FIN_CH * FIN_RL), 0, st, partial, blocks, C, count, dgamma,
-                       dbeta, coef);
+    const int ch = fin_ch(C);
+    auto kern = ch == 8 ? bn_bwd_finalize_kernel<8>
+                        : (ch == 4 ? bn_bwd_finalize_kernel<4> : (ch == 2 ? bn_bwd_finalize_kernel<2> : bn_bwd_finalize_kernel<1>));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(C, ch)), dim3(FIN_THREADS), 0, st, partial, blocks, C, count, dgamma, dbeta, coef);
     GDL_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     return GDL_OK;
 }
