@@ -11,6 +11,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "ops.h"
 #include "prof.h"
 
 namespace gdl {
@@ -133,42 +134,50 @@ __device__ __forceinline__ void fin_colsum(const float* __restrict__ partial, in
 }
 static int fin_ch(int C) { return C >= 512 ? 8 : (C >= 256 ? 4 : (C >= 128 ? 2 : 1)); }
 
+// (grid.y = 1 or 2: two independent BatchNorms -- bn2 and the downsample BatchNorm of a block -- share one launch)
 template <int CH>
-__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_train_kernel(
-    const float* __restrict__ partial, int tiles, int C, double count, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt,
-    float* save_mean, float* save_rstd, float* scale, float* shift) {
+__global__ __launch_bounds__(FIN_THREADS) void bn_finalize_train_kernel(BnFinTrain a0, BnFinTrain a1, float eps, float momentum) {
+    const BnFinTrain& a = blockIdx.y ? a1 : a0;
+    const int C = a.C;
     const int c = blockIdx.x * CH + threadIdx.x % CH;
     double s, q;
-    fin_colsum<CH>(partial, tiles, C, c, s, q);
+    fin_colsum<CH>(a.partial, a.tiles, C, c, s, q);
     if (threadIdx.x < CH && c < C) {
+        const double count = a.count;
         const double mean = s / count;
         double var = q / count - mean * mean;  // biased
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
-        const float sc = (float)((double)gamma[c] * rstd);
-        save_mean[c] = (float)mean;
-        save_rstd[c] = (float)rstd;
-        scale[c] = sc;
-        shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * rstd);
-        if (running_mean) {
+        const float sc = (float)((double)a.gamma[c] * rstd);
+        a.save_mean[c] = (float)mean;
+        a.save_rstd[c] = (float)rstd;
+        a.scale[c] = sc;
+        a.shift[c] = (float)((double)a.beta[c] - mean * (double)a.gamma[c] * rstd);
+        if (a.running_mean) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+            a.running_mean[c] = (float)((1.0 - (double)momentum) * (double)a.running_mean[c] + (double)momentum * mean);
+            a.running_var[c] = (float)((1.0 - (double)momentum) * (double)a.running_var[c] + (double)momentum * unb);
         }
-        if (nbt && c == 0) *nbt += 1;
+        if (a.nbt && c == 0) *a.nbt += 1;
     }
+}
+static int launch_fin_train(const BnFinTrain& a0, const BnFinTrain& a1, int n, float eps, float momentum, hipStream_t st) {
+    const int ch = fin_ch(a0.C);
+    auto kern = ch == 8 ? bn_finalize_train_kernel<8>
+                        : (ch == 4 ? bn_finalize_train_kernel<4> : (ch == 2 ? bn_finalize_train_kernel<2> : bn_finalize_train_kernel<1>));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a0.C, ch), n), dim3(FIN_THREADS), 0, st, a0, a1, eps, momentum);
+    GDL_CHECK_LAUNCH("bn_finalize_train_kernel");
+    return GDL_OK;
 }
 int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
                       float* scale, float* shift, hipStream_t st) {
-    const int ch = fin_ch(C);
-    auto kern = ch == 8 ? bn_finalize_train_kernel<8>
-                        : (ch == 4 ? bn_finalize_train_kernel<4> : (ch == 2 ? bn_finalize_train_kernel<2> : bn_finalize_train_kernel<1>));
-    hipLaunchKernelGGL(kern, dim3(ceil_div(C, ch)), dim3(FIN_THREADS), 0, st, partial, tiles, C, count, gamma, beta, eps, momentum,
-                       rm, rv, nbt, save_mean, save_rstd, scale, shift);
-    GDL_CHECK_LAUNCH("bn_finalize_train_kernel");
-    return GDL_OK;
+    const BnFinTrain a{partial, tiles, C, count, gamma, beta, rm, rv, nbt, save_mean, save_rstd, scale, shift};
+    return launch_fin_train(a, a, 1, eps, momentum, st);
+}
+int bn_finalize_train_pair(const BnFinTrain& a, const BnFinTrain& b, float eps, float momentum, hipStream_t st) {
+    GDL_REQUIRE(a.C == b.C, "bn_finalize_train_pair: channel counts differ (%d, %d)", a.C, b.C);
+    return launch_fin_train(a, b, 2, eps, momentum, st);
 }
 
 __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
@@ -537,27 +546,35 @@ int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, c
 
 // dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M
 template <int CH>
-__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int C,
-                                                                         double count, float* dgamma, float* dbeta,
-                                                                         float* coef) {
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(BnFinBwd a0, BnFinBwd a1) {
+    const BnFinBwd& p = blockIdx.y ? a1 : a0;
+    const int C = p.C;
     const int c = blockIdx.x * CH + threadIdx.x % CH;
     double a, b;
-    fin_colsum<CH>(partial, blocks, C, c, a, b);
+    fin_colsum<CH>(p.partial, p.blocks, C, c, a, b);
     if (threadIdx.x < CH && c < C) {
-        dbeta[c] = (float)a;
-        dgamma[c] = (float)b;
-        coef[c] = (float)(a / count);
-        coef[C + c] = (float)(b / count);
+        p.dbeta[c] = (float)a;
+        p.dgamma[c] = (float)b;
+        p.coef[c] = (float)(a / p.count);
+        p.coef[C + c] = (float)(b / p.count);
     }
+}
+static int launch_fin_bwd(const BnFinBwd& a0, const BnFinBwd& a1, int n, hipStream_t st) {
+    const int ch = fin_ch(a0.C);
+    auto kern = ch == 8 ? bn_bwd_finalize_kernel<8>
+                        : (ch == 4 ? bn_bwd_finalize_kernel<4> : (ch == 2 ? bn_bwd_finalize_kernel<2> : bn_bwd_finalize_kernel<1>));
+    hipLaunchKernelGGL(kern, dim3(ceil_div(a0.C, ch), n), dim3(FIN_THREADS), 0, st, a0, a1);
+    GDL_CHECK_LAUNCH("bn_bwd_finalize_kernel");
+    return GDL_OK;
 }
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                     hipStream_t st) {
-    const int ch = fin_ch(C);
-    auto kern = ch == 8 ? bn_bwd_finalize_kernel<8>
-                        : (ch == 4 ? bn_bwd_finalize_kernel<4> : (ch == 2 ? bn_bwd_finalize_kernel<2> : bn_bwd_finalize_kernel<1>));
-    hipLaunchKernelGGL(kern, dim3(ceil_div(C, ch)), dim3(FIN_THREADS), 0, st, partial, blocks, C, count, dgamma, dbeta, coef);
-    GDL_CHECK_LAUNCH("bn_bwd_finalize_kernel");
-    return GDL_OK;
+    const BnFinBwd a{partial, blocks, C, count, dgamma, dbeta, coef};
+    return launch_fin_bwd(a, a, 1, st);
+}
+int bn_bwd_finalize_pair(const BnFinBwd& a, const BnFinBwd& b, hipStream_t st) {
+    GDL_REQUIRE(a.C == b.C, "bn_bwd_finalize_pair: channel counts differ (%d, %d)", a.C, b.C);
+    return launch_fin_bwd(a, b, 2, st);
 }
 
 // pass 2: dy = gamma*rstd*(g' - coef0 - xhat*coef1)

@@ -88,7 +88,7 @@ struct gdl_encoder {
             if (ev_side[p]) (void)hipEventDestroy(ev_side[p]);
         if (side) (void)hipStreamDestroy(side);
     }
-    float *bn_partial = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr, *dw0p = nullptr;
+    float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr, *dw0p = nullptr;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
     size_t ws_bytes = 0;
@@ -220,6 +220,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     bn_partial_floats = max_tiles_c * 2;
     bnb_partial_floats = max_bnb * 2;
     bn_partial = (float*)b.take(bn_partial_floats * sizeof(float));
+    bn_partial2 = (float*)b.take(bn_partial_floats * sizeof(float));
     bnb_partial = (float*)b.take(bnb_partial_floats * sizeof(float));
     bnb_partial2 = (float*)b.take(bnb_partial_floats * sizeof(float));
     wg_ws_bytes = wg;
@@ -405,12 +406,17 @@ static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double co
     return bn_finalize_eval(n.c, gamma, beta, 1e-5f, e->rmean[n.bidx], e->rvar[n.bidx], n.scale, n.shift, st);
 }
 
-static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st) {
+static bool separate_stats() {
     static int sep = -1;
     if (sep < 0) {
         const char* env = getenv("GDL_SEPARATE_STATS");  // tuning aid: statistics by a separate pass over y
         sep = env ? atoi(env) : 0;
     }
+    return sep != 0;
+}
+
+static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st) {
+    const bool sep = separate_stats();
     if (sep && training) {
         RC(conv_fwd(e->dtype, x, c.w_krsc, y, nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st));
         const int M = nimg * c.p * c.q;
@@ -482,6 +488,22 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         const size_t Mo = (size_t)k.n * k.p * k.q;
         RC(conv_bn(e, k.c1, k.b1, k.xin, k.y1, k.n, training, st));
         RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st));
+        if (k.has_ds && training && !separate_stats()) {
+            // bn2 and the downsample BatchNorm are independent: both convolutions first, ONE finalize launch for the two
+            // (a finalize kernel costs the chain its whole ~6 us; 80 of them were 0.56 ms of the step)
+            auto fin = [&](const Conv& c, BN& n, const float* partial) {
+                return BnFinTrain{partial, conv_tiles_m(dt, k.n, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad), n.c,
+                                  (double)Mo, e->params[n.pidx], e->params[n.pidx + 1], e->rmean[n.bidx], e->rvar[n.bidx],
+                                  e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift};
+            };
+            RC(conv_fwd(dt, k.a1, k.c2.w_krsc, k.y2, e->bn_partial, k.c2.tab_fwd, k.n, k.c2.h, k.c2.w, k.c2.cin, k.c2.cout,
+                        k.c2.r, k.c2.s, k.c2.stride, k.c2.pad, st));
+            RC(conv_fwd(dt, k.xin, k.cd.w_krsc, k.yd, e->bn_partial2, k.cd.tab_fwd, k.n, k.cd.h, k.cd.w, k.cd.cin, k.cd.cout,
+                        k.cd.r, k.cd.s, k.cd.stride, k.cd.pad, st));
+            RC(bn_finalize_train_pair(fin(k.c2, k.b2, e->bn_partial), fin(k.cd, k.bd, e->bn_partial2), 1e-5f, 0.1f, st));
+            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st));
+            continue;
+        }
         RC(conv_bn(e, k.c2, k.b2, k.a1, k.y2, k.n, training, st));
         if (k.has_ds) {
             RC(conv_bn(e, k.cd, k.bd, k.xin, k.yd, k.n, training, st));
@@ -572,13 +594,17 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                             k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st));
         {
             const int blocks = bn_bwd_blocks(Mo, k.cout);
-            RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef,
-                               st));
+            if (k.has_ds)  // one finalize launch for bn2 and the downsample BatchNorm
+                RC(bn_bwd_finalize_pair(
+                    BnFinBwd{e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef},
+                    BnFinBwd{e->bnb_partial2, blocks, k.cout, (double)Mo, grads[k.bd.pidx], grads[k.bd.pidx + 1], k.bd.coef},
+                    st));
+            else
+                RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1],
+                                   k.b2.coef, st));
             RC(bn_bwd_apply(dt, do2, k.y2, k.b2.scale, k.b2.shift, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, 0,
                             gB, Mo, k.cout, st));  // gB = dy2
             if (k.has_ds) {
-                RC(bn_bwd_finalize(e->bnb_partial2, blocks, k.cout, (double)Mo, grads[k.bd.pidx], grads[k.bd.pidx + 1],
-                                   k.bd.coef, st));
                 RC(bn_bwd_apply(dt, do2, k.yd, k.bd.scale, k.bd.shift, k.bd.mean, k.bd.rstd, e->params[k.bd.pidx],
                                 k.bd.coef, 0, gD, Mo, k.cout, st));  // gD = dyd
             }

@@ -48,6 +48,24 @@ int nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, in
 // bn.hip
 int bn_stats_tiles(int M);
 int bn_stats(int dtype, const void* y, float* partial, int M, int C, hipStream_t st);
+// argument sets of the finalize kernels (the *_pair forms finalize two BatchNorms of equal width in one launch)
+struct BnFinTrain {
+    const float* partial;
+    int tiles, C;
+    double count;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    int64_t* nbt;
+    float *save_mean, *save_rstd, *scale, *shift;
+};
+struct BnFinBwd {
+    const float* partial;
+    int blocks, C;
+    double count;
+    float *dgamma, *dbeta, *coef;
+};
+int bn_finalize_train_pair(const BnFinTrain& a, const BnFinTrain& b, float eps, float momentum, hipStream_t st);
+int bn_bwd_finalize_pair(const BnFinBwd& a, const BnFinBwd& b, hipStream_t st);
 int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
                       float* scale, float* shift, hipStream_t st);
