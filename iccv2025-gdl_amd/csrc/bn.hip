@@ -646,6 +646,68 @@ static int bn_bwd_apply_t(const void* g, const void* y, const float* scale, cons
     GDL_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return GDL_OK;
 }
+// The two BatchNorms that share one upstream gradient (bn2 and the downsample BatchNorm of a block): g is read once,
+//   dyA = gammaA*rstdA*(g - kA1 - xhatA*kA2),  dyB likewise from yB.  No ReLU mask (g is already masked by the block).
+struct BnApplySide {
+    const void* y;
+    const float *mean, *rstd, *gamma, *coef;
+    void* dy;
+};
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply2_kernel(const T* __restrict__ g, BnApplySide A, BnApplySide B,
+                                                                   size_t nvec, int C, size_t stride_vec) {
+    constexpr int EPC = TT<T>::EPC;
+    size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
+    if (i >= nvec) return;
+    const int c0 = (int)((i * EPC) % C);
+    float mu[2][EPC], rs[2][EPC], gr[2][EPC], k1[2][EPC], k2[2][EPC];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const BnApplySide& P = s ? B : A;
+        ld_chan<EPC>(P.mean, c0, mu[s]);
+        ld_chan<EPC>(P.rstd, c0, rs[s]);
+        ld_chan<EPC>(P.gamma, c0, gr[s]);
+        ld_chan<EPC>(P.coef, c0, k1[s]);
+        ld_chan<EPC>(P.coef + C, c0, k2[s]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) gr[s][e] *= rs[s][e];
+    }
+    const T *ya = (const T*)A.y, *yb = (const T*)B.y;
+    T *da = (T*)A.dy, *db = (T*)B.dy;
+    for (; i < nvec; i += stride_vec) {
+        const uint4 gq = *(const uint4*)(g + i * EPC), aq = *(const uint4*)(ya + i * EPC), bq = *(const uint4*)(yb + i * EPC);
+        float gv[EPC], yv[EPC], o[EPC];
+        unpack16<T>(gq, gv);
+        unpack16<T>(aq, yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = gr[0][e] * (gv[e] - k1[0][e] - (yv[e] - mu[0][e]) * rs[0][e] * k2[0][e]);
+        *(uint4*)(da + i * EPC) = pack16<T>(o);
+        unpack16<T>(bq, yv);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o[e] = gr[1][e] * (gv[e] - k1[1][e] - (yv[e] - mu[1][e]) * rs[1][e] * k2[1][e]);
+        *(uint4*)(db + i * EPC) = pack16<T>(o);
+    }
+}
+int bn_bwd_apply2(int dtype, const void* g, const void* yA, const float* meanA, const float* rstdA, const float* gammaA,
+                  const float* coefA, void* dyA, const void* yB, const float* meanB, const float* rstdB, const float* gammaB,
+                  const float* coefB, void* dyB, size_t M, int C, hipStream_t st) {
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    const size_t nvec = M * (size_t)C / epc;
+    int blocks;
+    size_t stride;
+    ew_grid(nvec, C / epc, blocks, stride);
+    const BnApplySide A{yA, meanA, rstdA, gammaA, coefA, dyA}, B{yB, meanB, rstdB, gammaB, coefB, dyB};
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::bn_bwd_apply2_kernel<gdl::bf16>" : "gdl::bn_bwd_apply2_kernel<float>", PROF_HBM, st,
+                   (double)nvec * 16.0 * 5);
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply2_kernel<bf16>, dim3(blocks), dim3(BN_THREADS), 0, st, (const bf16*)g, A, B, nvec, C, stride);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply2_kernel<float>, dim3(blocks), dim3(BN_THREADS), 0, st, (const float*)g, A, B, nvec, C,
+                           stride);
+    GDL_CHECK_LAUNCH("bn_bwd_apply2_kernel");
+    return GDL_OK;
+}
+
 int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                  const float* rstd, const float* gamma, const float* coef, int relu_mask, void* dy, size_t M, int C,
                  hipStream_t st) {

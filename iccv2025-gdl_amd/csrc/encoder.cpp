@@ -602,12 +602,12 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             else
                 RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1],
                                    k.b2.coef, st));
-            RC(bn_bwd_apply(dt, do2, k.y2, k.b2.scale, k.b2.shift, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, 0,
-                            gB, Mo, k.cout, st));  // gB = dy2
-            if (k.has_ds) {
-                RC(bn_bwd_apply(dt, do2, k.yd, k.bd.scale, k.bd.shift, k.bd.mean, k.bd.rstd, e->params[k.bd.pidx],
-                                k.bd.coef, 0, gD, Mo, k.cout, st));  // gD = dyd
-            }
+            if (k.has_ds)  // gB = dy2 and gD = dyd from one pass over do2
+                RC(bn_bwd_apply2(dt, do2, k.y2, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, gB, k.yd, k.bd.mean,
+                                 k.bd.rstd, e->params[k.bd.pidx], k.bd.coef, gD, Mo, k.cout, st));
+            else
+                RC(bn_bwd_apply(dt, do2, k.y2, k.b2.scale, k.b2.shift, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef,
+                                0, gB, Mo, k.cout, st));  // gB = dy2
         }
         RC(fork());  // dy2 (and dyd) exist
         RC(conv_wgrad(dt, gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,

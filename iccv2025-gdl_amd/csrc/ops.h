@@ -65,6 +65,9 @@ struct BnFinBwd {
     float *dgamma, *dbeta, *coef;
 };
 int bn_finalize_train_pair(const BnFinTrain& a, const BnFinTrain& b, float eps, float momentum, hipStream_t st);
+int bn_bwd_apply2(int dtype, const void* g, const void* yA, const float* meanA, const float* rstdA, const float* gammaA,
+                  const float* coefA, void* dyA, const void* yB, const float* meanB, const float* rstdB, const float* gammaB,
+                  const float* coefB, void* dyB, size_t M, int C, hipStream_t st);
 int bn_bwd_finalize_pair(const BnFinBwd& a, const BnFinBwd& b, hipStream_t st);
 int bn_finalize_train(const float* partial, int tiles, int C, double count, const float* gamma, const float* beta,
                       float eps, float momentum, float* rm, float* rv, int64_t* nbt, float* save_mean, float* save_rstd,
