@@ -282,6 +282,15 @@ int gdl_frames_normalize(const uint8_t* frames, int64_t n_img, int H, int W, con
     GDL_REQUIRE(std[0] != 0.f && std[1] != 0.f && std[2] != 0.f, "frames_normalize: zero std");
     return frames_normalize(frames, (size_t)n_img, H, W, mean, std, out, (hipStream_t)stream);
 }
+int gdl_softmax_ce3(const float* logits0, const float* logits1, const float* logits2, const int64_t* labels, float scale0,
+                    float scale1, float scale2, float* losses, float* dlogits0, float* dlogits1, float* dlogits2, int B,
+                    int n_classes, void* stream) {
+    GDL_REQUIRE(logits0 && logits1 && logits2 && labels && losses && B > 0 && n_classes > 0, "softmax_ce3: bad arguments");
+    const float* lg[3] = {logits0, logits1, logits2};
+    float* dl[3] = {dlogits0, dlogits1, dlogits2};
+    const float sc[3] = {scale0, scale1, scale2};
+    return softmax_ce_multi(3, lg, labels, sc, losses, dl, B, n_classes, (hipStream_t)stream);
+}
 int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
                    int n_classes, void* stream) {
     GDL_REQUIRE(logits && labels && loss && B > 0 && n_classes > 0, "softmax_ce: bad arguments");

@@ -98,27 +98,38 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(HeadW w, const float
 // dWx[j][i] = sum_b gw[b][j] * x[b][i], gw = g_out (+ g_x_out if uni_in_dw); dWy likewise with y / g_y_out.
 // concat head: one bias, db = sum_b (g_out + uni*(g_x_out + g_y_out)); sum head: dbx = sum_b (g_out + uni*g_x_out),
 // dby likewise.   grid = n classes.
+// grid = (n classes, 2*HD/256): one thread per weight-gradient element (six blocks looping over 8 x 64 dependent
+// iterations took 77 us -- in front of both encoders' backward passes); the batch's logit gradients of class j are staged
+// in LDS, the sum over the batch runs in index order (bit-identical to the serial form).
 __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ g_x_out,
                                                          const float* __restrict__ g_y_out, const float* __restrict__ g_out,
                                                          int uni_in_dw, float* __restrict__ dWx, float* __restrict__ dWy,
                                                          int ldw, float* __restrict__ dbx, float* __restrict__ dby, int B,
                                                          int n) {
+    __shared__ float gs[256];
     const int j = blockIdx.x;
-    for (int i = threadIdx.x; i < 2 * HD; i += 256) {
-        const bool is_y = i >= HD;
-        const float* feat = is_y ? y : x;
-        const float* gu = is_y ? g_y_out : g_x_out;
-        const int fi = is_y ? i - HD : i;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) {
+    const int i = blockIdx.y * 256 + threadIdx.x;  // 0 .. 2*HD-1 (HD is a multiple of 256: a block is all-x or all-y)
+    const bool is_y = i >= HD;
+    const float* feat = is_y ? y : x;
+    const float* gu = is_y ? g_y_out : g_x_out;
+    const int fi = is_y ? i - HD : i;
+    float s = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int nb = min(256, B - b0);
+        __syncthreads();
+        if ((int)threadIdx.x < nb) {
+            const int b = b0 + threadIdx.x;
             float g = g_out ? g_out[(size_t)b * n + j] : 0.f;
             if (uni_in_dw && gu) g += gu[(size_t)b * n + j];
-            s += g * feat[(size_t)b * HD + fi];
+            gs[threadIdx.x] = g;
         }
-        (is_y ? dWy : dWx)[(size_t)j * ldw + fi] = s;
+        __syncthreads();
+#pragma unroll 8
+        for (int b = 0; b < nb; ++b) s += gs[b] * feat[(size_t)(b0 + b) * HD + fi];
     }
-    if (threadIdx.x == 0) {
+    (is_y ? dWy : dWx)[(size_t)j * ldw + fi] = s;
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
         float so = 0.f, sx = 0.f, sy = 0.f;
         for (int b = 0; b < B; ++b) {
             so += g_out ? g_out[(size_t)b * n + j] : 0.f;
@@ -135,6 +146,7 @@ __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float* __restrict
         }
     }
 }
+static_assert(HD % 256 == 0, "head_bwd_w_kernel: a block must not straddle the two feature vectors");
 int head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
                     const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db,
                     int B, int n, hipStream_t st) {
@@ -145,7 +157,7 @@ int head_concat_bwd(const float* x, const float* y, const float* W, const float*
         GDL_CHECK_LAUNCH("head_bwd_feat_kernel");
     }
     if (dW && db) {
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dW, dW + HD,
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n, 2 * HD / 256), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dW, dW + HD,
                            2 * HD, db, (float*)nullptr, B, n);
         GDL_CHECK_LAUNCH("head_bwd_w_kernel");
     }
@@ -161,7 +173,7 @@ int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* W
         GDL_CHECK_LAUNCH("head_bwd_feat_kernel");
     }
     if (dWx && dWy) {
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dWx, dWy, HD,
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3(n, 2 * HD / 256), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out, uni_in_dw, dWx, dWy, HD,
                            dbx, dby, B, n);
         GDL_CHECK_LAUNCH("head_bwd_w_kernel");
     }
@@ -169,7 +181,7 @@ int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* W
 }
 
 // loss = mean_b ( logsumexp(l_b) - l_b[label_b] ); dlogits = scale*(softmax - onehot)/B.  One block.
-__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+__device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                          float scale, float* __restrict__ loss, float* __restrict__ dlogits,
                                                          int B, int n) {
     __shared__ float part[256];
@@ -422,11 +434,32 @@ int eval_count(const float* out, const float* out_a, const float* out_v, const i
     return GDL_OK;
 }
 
-int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
-               hipStream_t st) {
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, st, logits, labels, scale, loss, dlogits, B, n);
+// one block per loss: the three cross-entropies of the DGL step (main_dgl.py:102-104) are ONE launch
+struct CeSets {
+    const float* logits[4];
+    float* dlogits[4];
+    float scale[4];
+};
+__global__ __launch_bounds__(256) void softmax_ce_kernel(CeSets s, const int64_t* __restrict__ labels, float* __restrict__ loss,
+                                                         int B, int n) {
+    const int k = blockIdx.x;
+    softmax_ce_block(s.logits[k], labels, s.scale[k], loss + k, s.dlogits[k], B, n);
+}
+int softmax_ce_multi(int nsets, const float* const* logits, const int64_t* labels, const float* scales, float* losses,
+                     float* const* dlogits, int B, int n, hipStream_t st) {
+    CeSets s{};
+    for (int k = 0; k < nsets; ++k) {
+        s.logits[k] = logits[k];
+        s.dlogits[k] = dlogits ? dlogits[k] : nullptr;
+        s.scale[k] = scales[k];
+    }
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(nsets), dim3(256), 0, st, s, labels, losses, B, n);
     GDL_CHECK_LAUNCH("softmax_ce_kernel");
     return GDL_OK;
+}
+int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
+               hipStream_t st) {
+    return softmax_ce_multi(1, &logits, labels, &scale, loss, &dlogits, B, n, st);
 }
 
 }  // namespace gdl

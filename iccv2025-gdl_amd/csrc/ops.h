@@ -126,6 +126,8 @@ int frames_normalize(const unsigned char* in, size_t n_img, int H, int W, const 
                      hipStream_t st);
 int eval_count(const float* out, const float* out_a, const float* out_v, const int64_t* labels, int B, int n, int64_t* num,
                int64_t* acc, int64_t* acc_a, int64_t* acc_v, hipStream_t st);
+int softmax_ce_multi(int nsets, const float* const* logits, const int64_t* labels, const float* scales, float* losses,
+                     float* const* dlogits, int B, int n, hipStream_t st);
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
                hipStream_t st);
 

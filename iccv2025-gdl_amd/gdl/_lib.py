@@ -63,6 +63,7 @@ SIGNATURES = {
     "gdl_head_concat_fwd": ("i", "ppppppp" + "ii" + "p"),
     "gdl_head_concat_bwd": ("i", "pppppp" + "ii" + "pppp" + "ii" + "p"),
     "gdl_softmax_ce": ("i", "ppf" + "pp" + "ii" + "p"),
+    "gdl_softmax_ce3": ("i", "pppp" + "fff" + "pppp" + "ii" + "p"),
     "gdl_head_sum_fwd": ("i", "ppppppppp" + "ii" + "p"),
     "gdl_head_sum_bwd": ("i", "ppppppp" + "ii" + "pppppp" + "ii" + "p"),
     "gdl_head_gated_fwd": ("i", "p" * 13 + "ii" + "p"),

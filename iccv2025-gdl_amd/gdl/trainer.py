@@ -188,10 +188,12 @@ class DGLTrainer:
         dgl = self.mode == "dgl"
         self._head_forward(dgl, st)
         lp = self.losses.data_ptr()
-        L.call("gdl_softmax_ce", L.ptr(self.out), L.ptr(label), 1.0, lp, L.ptr(self.g_f), B, n, st)
+        if dgl:  # loss_f, alpha*loss_a, alpha*loss_v (main_dgl.py:102-108) in one launch
+            L.call("gdl_softmax_ce3", L.ptr(self.out), L.ptr(self.out_a), L.ptr(self.out_v), L.ptr(label), 1.0, self.alpha,
+                   self.alpha, lp, L.ptr(self.g_f), L.ptr(self.g_a), L.ptr(self.g_v), B, n, st)
+        else:
+            L.call("gdl_softmax_ce", L.ptr(self.out), L.ptr(label), 1.0, lp, L.ptr(self.g_f), B, n, st)
         if dgl:
-            L.call("gdl_softmax_ce", L.ptr(self.out_a), L.ptr(label), self.alpha, lp + 4, L.ptr(self.g_a), B, n, st)
-            L.call("gdl_softmax_ce", L.ptr(self.out_v), L.ptr(label), self.alpha, lp + 8, L.ptr(self.g_v), B, n, st)
             # DGL truncation: `out` is computed from detached features (flag 0) and the head gradients of the
             # unimodal losses are dropped before loss_f.backward() (flag 0)   (main_dgl.py:110-122)
             if self.head == "film":

@@ -235,6 +235,11 @@ GDL_API int gdl_head_sum_fwd(const float* x, const float* y, const float* Wx, co
 GDL_API int gdl_head_sum_bwd(const float* x, const float* y, const float* Wx, const float* Wy, const float* g_x_out,
                              const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
                              float* dy, float* dWx, float* dbx, float* dWy, float* dby, int B, int n_classes, void* stream);
+/* the three losses of the DGL step (loss_f, loss_a, loss_v; main_dgl.py:102-104) in one launch: losses[k] and dlogits_k
+ * as gdl_softmax_ce would leave them for (logits_k, scale_k); any dlogits_k may be NULL */
+GDL_API int gdl_softmax_ce3(const float* logits0, const float* logits1, const float* logits2, const int64_t* labels,
+                            float scale0, float scale1, float scale2, float* losses, float* dlogits0, float* dlogits1,
+                            float* dlogits2, int B, int n_classes, void* stream);
 GDL_API int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B,
                            int n_classes, void* stream);
 /* valid() (main_dgl.py:185-222) without its per-sample host loop: per-class counters (int64[n_classes] each, the

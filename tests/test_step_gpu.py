@@ -225,6 +225,25 @@ def test_softmax_ce(B, n):
     np.testing.assert_allclose(d.cpu().numpy(), d_ref, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,n", [(64, 6), (5, 34)])
+def test_softmax_ce3(B, n):
+    """The three losses of the DGL step in one launch: each set as gdl_softmax_ce leaves it; a NULL dlogits is allowed."""
+    lgs = [(3 * rng.standard_normal((B, n))).astype(np.float32) for _ in range(3)]
+    lab = rng.integers(0, n, B).astype(np.int64)
+    scales = (1.0, 4.0, 0.5)
+    refs = [orc.softmax_ce(lg, lab, sc) for lg, sc in zip(lgs, scales)]
+    lgd, labd = [dev(lg) for lg in lgs], torch.from_numpy(lab).to(DEV)
+    loss = torch.zeros(3, device=DEV)
+    d = [torch.empty((B, n), device=DEV), torch.empty((B, n), device=DEV), None]
+    L.call("gdl_softmax_ce3", L.ptr(lgd[0]), L.ptr(lgd[1]), L.ptr(lgd[2]), L.ptr(labd), *scales, L.ptr(loss), L.ptr(d[0]),
+           L.ptr(d[1]), None, B, n, L.cur_stream())
+    torch.cuda.synchronize()
+    for k in range(3):
+        np.testing.assert_allclose(loss[k].item(), refs[k][0], rtol=1e-5)
+        if d[k] is not None:
+            np.testing.assert_allclose(d[k].cpu().numpy(), refs[k][1], rtol=1e-4, atol=1e-7)
+
+
 # ------------------------------------------------------------------ fused clip + stats + SGD
 @pytest.mark.parametrize("B,n", [(64, 6), (7, 34), (513, 309)])
 def test_eval_count(B, n):
