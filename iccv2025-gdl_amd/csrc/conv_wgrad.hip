@@ -516,10 +516,194 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
     out[i] = acc;
 }
 
+// ---- bf16 stem weight gradient, row-slab form.  The per-tap kernel above fetches, per 64 output pixels and tap, a
+// dy tile and a GATHERED x tile (64 x 128 B) -- 64 LDS-DMA pieces per 32 MFMAs, and it ran at the end of every encoder
+// backward with nothing beside it (switching it off: -0.40 ms of a 6.7 ms step).  Here a stage is 64 consecutive output
+// pixels of ONE output row: their dy rows are one contiguous 8 KiB run and the 8 padded-input rows they touch are 8
+// contiguous runs of 134 pixels (1 072 B), stored in LDS at a pitch of 1 088 B -- 17 pieces per stage for the same 32
+// MFMAs, no masks (the padding is materialised in xp), every LDS read address static per lane:
+//   B fragment of tap t (filter rows 2t, 2t+1), wave w (columns 16w..16w+15 = row 2t+(w>>1), filter pixels 4(w&1)..+3):
+//   output pixel m reads input pixels 2m + 4(w&1) + {0..3} of slab row 2t+(w>>1): 8 bytes per lane, transpose read.
+// Rows wider than 64 pixels take ceil(Q/64) stages; the last one starts at Q-64 and the pixels it shares with its
+// predecessor are loaded as zeros (dy out of range).  Partials: [slice][k][tap][c], folded by stem_wgrad_reduce_kernel.
+struct StemRowsArgs {
+    const void* dy;      // [n_img*P*Q][64] bf16
+    const void* xp;      // [n_img][Hp][Wp][4] bf16
+    float* partial;      // [nsplit][64][4][64]
+    int P, Q, Hp, Wp, nseg;
+    int stages, chunk, nsplit;  // stages = n_img*P*nseg, chunk = stages per slice
+    unsigned dy_bytes, x_bytes;
+};
+constexpr int SR_PITCH = 1088, SR_XBYTES = 9 * 1024, SR_STAGE = 8192 + SR_XBYTES;
+template <int OFF>
+__device__ __forceinline__ uint2 sr_tr(unsigned addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void sr_wait() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__global__ __launch_bounds__(256) void stem_wgrad_rows_kernel(StemRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int slice = blockIdx.x;
+    const int s_begin = slice * a.chunk, s_end = min(a.stages, s_begin + a.chunk);
+    const int nst = s_end - s_begin;
+    const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.xp, 0, a.x_bytes, 0x00020000);
+
+    // ---- DMA bookkeeping: dy pieces p = wave, wave+4 (8 rows x 128 B each, 32-byte-granule swizzle as in the kernels
+    // above); x pieces p = wave, wave+4, wave+8 (< 9): lane L of piece p lands at linear byte 1024p + 16L of the
+    // [8][1088] slab, i.e. slab row (1024p+16L)/1088, byte (1024p+16L)%1088 of that row's 1072-byte run.
+    const int prow = lane >> 3, pch = lane & 7;
+    int dy_rel[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 4 * i) * 8 + prow;
+        const int ch = (((pch >> 1) ^ wg_swz<128>(row)) << 1) | (pch & 1);
+        dy_rel[i] = row * 128 + ch * 16;
+    }
+    int x_rel[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = wave + 4 * i, off = 1024 * p + 16 * lane;
+        const int row = off / SR_PITCH, col = off % SR_PITCH;
+        x_rel[i] = (p < 9 && row < 8 && col < 1072) ? row * a.Wp * 8 + col : -1;
+    }
+    int ld_s = s_begin;
+    auto load_stage = [&](int buf) {
+        unsigned char* Ks = smem + buf * SR_STAGE;
+        unsigned char* Xs = Ks + 8192;
+        const int sg = ld_s % a.nseg, R = ld_s / a.nseg;  // R = n*P + oh
+        const int n = R / a.P, oh = R - n * a.P;
+        const int ow0 = min(64 * sg, a.Q - 64), first = 64 * sg - ow0;  // tile rows < first belong to the previous stage
+        const int dy_base = (R * a.Q + ow0) * 128;
+        const int x_base = ((n * a.Hp + 2 * oh) * a.Wp + 2 * ow0) * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave + 4 * i) * 8 + prow;
+            wg_dma16(rdy, Ks + (wave + 4 * i) * 1024, row >= first ? dy_base + dy_rel[i] : (int)0x80000000);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (wave + 4 * i < 9) wg_dma16(rx, Xs + (wave + 4 * i) * 1024, x_rel[i] >= 0 ? x_base + x_rel[i] : (int)0x80000000);
+        ld_s += 1;
+    };
+
+    // ---- per-lane LDS read addresses (stage buffer 0)
+    const int lrow = g * 8 + (li >> 2);  // + h*4 + ks*32
+    unsigned aaddr[4][2], baddr[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = lrow + h * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aaddr[i][h] = smem_base + row * 128 + ((i ^ wg_swz<128>(row)) << 5) + (li & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            baddr[t][h] = smem_base + 8192 + (2 * t + (wave >> 1)) * SR_PITCH + (2 * row + 4 * (wave & 1) + (li & 3)) * 8;
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) load_stage(0);
+    for (int st = 0; st < nst; ++st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < nst) load_stage((st + 1) & 1);
+        // two K-steps of 32 pixels: dy rows +32 (4096 B), x pixels +64 (512 B): instruction offsets
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint2 af[4][2], bf[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) af[i][h] = ks ? sr_tr<4096>(aaddr[i][h]) : sr_tr<0>(aaddr[i][h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bf[t][h] = ks ? sr_tr<512>(baddr[t][h]) : sr_tr<0>(baddr[t][h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t == 0)
+                    sr_wait<6>();
+                else if (t == 1)
+                    sr_wait<4>();
+                else if (t == 2)
+                    sr_wait<2>();
+                else
+                    sr_wait<0>();
+                const uint4 fb = make_uint4(bf[t][0].x, bf[t][0].y, bf[t][1].x, bf[t][1].y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 fa = make_uint4(af[i][0].x, af[i][0].y, af[i][1].x, af[i][1].y);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                       __builtin_bit_cast(bf16x8_t, fb), acc[t][i], 0, 0, 0);
+                }
+            }
+        }
+        const int dlt = (st & 1) ? -SR_STAGE : SR_STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aaddr[i][h] += dlt;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) baddr[t][h] += dlt;
+        }
+    }
+    // D[i][j]: k = 16i + (lane>>4)*4 + e, c = 16*wave + (lane&15);  partial[slice][k][tap][c]
+    float* part = a.partial + (size_t)slice * (64 * 4 * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[((16 * i + g * 4 + e) * 4 + t) * 64 + 16 * wave + li] = acc[t][i][e];
+}
+struct StemRowsPlan {
+    int nseg, stages, chunk, nsplit;
+};
+static bool stem_rows_ok(int dtype, int W) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_STEM_ROWS");  // tuning aid: 0 = per-tap kernel
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0 && dtype == GDL_BF16 && (W - 1) / 2 + 1 >= 64;
+}
+static StemRowsPlan plan_stem_rows(int n_img, int H, int W) {
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+    StemRowsPlan p;
+    p.nseg = (Q + 63) / 64;
+    p.stages = n_img * P * p.nseg;
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("GDL_STEM_ROWS_BLOCKS");  // tuning aid
+        target = e ? atoi(e) : 512;
+    }
+    int ns = target;
+    if (ns > (p.stages + 3) / 4) ns = (p.stages + 3) / 4;  // at least 4 stages per 64 KB partial tile
+    if (ns < 1) ns = 1;
+    p.chunk = (p.stages + ns - 1) / ns;
+    p.nsplit = (p.stages + p.chunk - 1) / p.chunk;
+    return p;
+}
+
 static WgradPlan plan_stem_wgrad(int M) { return plan_wgrad(M, 64, 64, 4); }
 size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W) {
     const int M = n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
-    return (size_t)plan_stem_wgrad(M).nsplit * 64 * 4 * 64 * sizeof(float);
+    int ns = plan_stem_wgrad(M).nsplit;
+    if ((W - 1) / 2 + 1 >= 64) ns = max(ns, plan_stem_rows(n_img, H, W).nsplit);  // (either kernel may run: dtype decides)
+    return (size_t)ns * 64 * 4 * 64 * sizeof(float);
 }
 int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
                     void* ws, size_t ws_bytes, hipStream_t st) {
@@ -527,6 +711,33 @@ int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const 
     GDL_REQUIRE(dy && xp && dw && table, "stem wgrad: null pointer");
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
     const int esz = dtype == GDL_BF16 ? 2 : 4, pix = 4 * esz;
+    if (stem_rows_ok(dtype, W)) {
+        const StemRowsPlan p = plan_stem_rows(n_img, H, W);
+        const size_t need = (size_t)p.nsplit * 64 * 4 * 64 * sizeof(float);
+        if (ws_bytes < need || !ws) {
+            set_error("stem wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+            return GDL_ERR_WORKSPACE;
+        }
+        GDL_REQUIRE((size_t)n_img * P * Q * 128 < (1UL << 31) && (size_t)n_img * Hp * Wp * 8 < (1UL << 31), "stem wgrad: tensor exceeds 2 GiB");
+        StemRowsArgs r{};
+        r.dy = dy;
+        r.xp = xp;
+        r.partial = (float*)ws;
+        r.P = P, r.Q = Q, r.Hp = Hp, r.Wp = Wp, r.nseg = p.nseg;
+        r.stages = p.stages, r.chunk = p.chunk, r.nsplit = p.nsplit;
+        r.dy_bytes = (unsigned)((size_t)n_img * P * Q * 128);
+        r.x_bytes = (unsigned)((size_t)n_img * Hp * Wp * 8);
+        {
+            ProfScope prof("gdl::stem_wgrad_rows_kernel", PROF_MFMA, st, 2.0 * (double)n_img * P * Q * 64 * 49 * Cin, true);
+            hipExtLaunchKernelGGL(stem_wgrad_rows_kernel, dim3(p.nsplit), dim3(256), 2 * SR_STAGE, st, prof.e0(), prof.e1(), 0, r);
+            GDL_CHECK_LAUNCH("stem_wgrad_rows_kernel");
+        }
+        ProfScope prof("gdl::stem_wgrad_reduce_kernel", PROF_HBM, st, (double)64 * Cin * 49 * 4.0 * (p.nsplit + 1));
+        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(64 * Cin * 49, 256)), dim3(256), 0, st, r.partial, dw, p.nsplit,
+                           Cin);
+        GDL_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
+        return GDL_OK;
+    }
     WgradArgs a{};
 #ifdef GDL_TIMING
     a.dbg = nullptr;

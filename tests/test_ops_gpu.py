@@ -158,7 +158,9 @@ def test_stem(case, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("case", [("audio", 2, 1, 1, 65, 47), ("visual", 2, 3, 2, 40, 36), ("visual_odd", 1, 3, 3, 33, 29)])
+@pytest.mark.parametrize("case", [("audio", 2, 1, 1, 65, 47), ("visual", 2, 3, 2, 40, 36), ("visual_odd", 1, 3, 3, 33, 29),
+                                  # output rows of >= 64 pixels: the bf16 weight gradient runs on the row-slab kernel
+                                  ("row64", 1, 3, 2, 12, 128), ("row95_odd_h", 2, 1, 1, 9, 190), ("row135", 2, 3, 1, 7, 270)])
 def test_stem_direct(case, dt):
     """7x7/2 stem as an implicit GEMM over the padded NHWC4 input (what the engine runs): forward with BatchNorm
     partials and weight gradient against the oracle's direct conv."""
