@@ -503,17 +503,45 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
 // ---- direct stem weight gradient: dw[k][c][r][s] from dy [M][64] and the padded NHWC4 input.
 // GEMM per "tap" t = filter rows 2t, 2t+1: 64 k x 64 columns (2 rows x 8 pixels x 4 channels); the
 // reduce kernel picks the 7x7xCin real entries out of the [64][4][64] tile.
+// Block = 16 consecutive float4 of the [64][4][64] tile x 16 split-lanes (lane l adds slices l, l+16, ..., four loads in
+// flight; a thread per OUTPUT looping over all slices serially took 67 us at 512 slices); the lanes are folded through LDS
+// in a fixed order and the 7x7xCin real entries are scattered to [64][Cin][7][7].
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                                 int nsplit, int Cin) {
-    const int total = 64 * Cin * 49;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int s = i % 7, r = (i / 7) % 7, c = (i / 49) % Cin, k = i / (49 * Cin);
-    const size_t idx = ((size_t)k * 4 + (r >> 1)) * 64 + (r & 1) * 32 + s * 4 + c;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int sp = 0; sp < nsplit; ++sp) acc += partial[(size_t)sp * (64 * 4 * 64) + idx];
-    out[i] = acc;
+    __shared__ float4 red[16][16];
+    constexpr int TILE4 = 64 * 4 * 64 / 4;
+    const int o = threadIdx.x & 15, l = threadIdx.x >> 4;
+    const int idx4 = blockIdx.x * 16 + o;  // < TILE4 (grid = TILE4 / 16)
+    const float4* p = (const float4*)partial + idx4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = l;
+    for (; sp + 48 < nsplit; sp += 64) {
+        const float4 v0 = p[(size_t)sp * TILE4], v1 = p[(size_t)(sp + 16) * TILE4];
+        const float4 v2 = p[(size_t)(sp + 32) * TILE4], v3 = p[(size_t)(sp + 48) * TILE4];
+        s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
+        s.x += v1.x, s.y += v1.y, s.z += v1.z, s.w += v1.w;
+        s.x += v2.x, s.y += v2.y, s.z += v2.z, s.w += v2.w;
+        s.x += v3.x, s.y += v3.y, s.z += v3.z, s.w += v3.w;
+    }
+    for (; sp < nsplit; sp += 16) {
+        const float4 v0 = p[(size_t)sp * TILE4];
+        s.x += v0.x, s.y += v0.y, s.z += v0.z, s.w += v0.w;
+    }
+    red[l][o] = s;
+    __syncthreads();
+    if (l != 0) return;
+#pragma unroll
+    for (int jj = 1; jj < 16; ++jj) {
+        const float4 v = red[jj][o];
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    // float4 idx4 -> (k, tap, c = 4q .. 4q+3) with q = (r & 1) * 8 + s_px: channel = component
+    const int q = idx4 & 15, tap = (idx4 >> 4) & 3, k = idx4 >> 6;
+    const int r = 2 * tap + (q >> 3), px = q & 7;
+    if (r < 7 && px < 7) {
+        const float v[4] = {s.x, s.y, s.z, s.w};
+        for (int c = 0; c < Cin; ++c) out[((k * Cin + c) * 7 + r) * 7 + px] = v[c];
+    }
 }
 
 // ---- bf16 stem weight gradient, row-slab form.  The per-tap kernel above fetches, per 64 output pixels and tap, a
@@ -733,7 +761,7 @@ int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const 
             GDL_CHECK_LAUNCH("stem_wgrad_rows_kernel");
         }
         ProfScope prof("gdl::stem_wgrad_reduce_kernel", PROF_HBM, st, (double)64 * Cin * 49 * 4.0 * (p.nsplit + 1));
-        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(64 * Cin * 49, 256)), dim3(256), 0, st, r.partial, dw, p.nsplit,
+        hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * 4 * 64 / 4 / 16), dim3(256), 0, st, r.partial, dw, p.nsplit,
                            Cin);
         GDL_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
         return GDL_OK;
@@ -772,7 +800,7 @@ int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const 
     int rc = dtype == GDL_BF16 ? launch_wg<bf16, 64, 64>(a, st) : launch_wg<float, 64, 64>(a, st);
     if (rc) return rc;
     ProfScope prof("gdl::stem_wgrad_reduce_kernel", PROF_HBM, st, (double)64 * Cin * 49 * 4.0 * (p.nsplit + 1));
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(ceil_div(64 * Cin * 49, 256)), dim3(256), 0, st, a.partial, dw, p.nsplit,
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * 4 * 64 / 4 / 16), dim3(256), 0, st, a.partial, dw, p.nsplit,
                        Cin);
     GDL_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
     return GDL_OK;
