@@ -22,6 +22,8 @@
 // values (BatchNorm statistics), 16-byte coalesced stores.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gather.h"
 #include "prof.h"
@@ -51,6 +53,9 @@ struct ConvArgs {
     // come from off0 + delta[tap], chunks 4..7 from off0 + delta_hi[tap]
     int split;
     int delta_hi[9];
+    // row-slab stem (conv_stem_rows_kernel): GEMM row g = stage*64 + i, stage = (image row R, segment sg): output pixel
+    // R*seg_Q + ow0 + i with ow0 = min(64*sg, seg_Q - 64); rows i < 64*sg - ow0 repeat the previous stage: not stored
+    int seg_Q, seg_nseg, seg_stages;
     double flops;  // algorithmic work of the launch (measurement tap)
 #ifdef GDL_TIMING
     unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
@@ -173,7 +178,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int m = m0 + er0 + p * RPI;
-        om[p] = m < a.M ? (a.orow ? a.orow[m] : m) : -1;
+        if (a.seg_Q) {
+            const int stg = m >> 6, i = m & 63;
+            const int R = stg / a.seg_nseg, sg = stg - R * a.seg_nseg;
+            const int ow0 = min(64 * sg, a.seg_Q - 64);
+            om[p] = (stg < a.seg_stages && i >= 64 * sg - ow0) ? R * a.seg_Q + ow0 + i : -1;
+        } else {
+            om[p] = m < a.M ? (a.orow ? a.orow[m] : m) : -1;
+        }
     }
     // accumulators -> LDS tile [BM][BN] of T.
     // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
@@ -392,6 +404,99 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     __syncthreads();
 
     conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile);
+}
+
+// =====================================================================================================
+// Row-slab stem forward (bf16): the 7x7 stride-2 convolution over the padded NHWC4 input, 256 GEMM rows per block =
+// four stages of 64 consecutive pixels of one output row each (see stem_wgrad_rows_kernel in conv_wgrad.hip for the
+// geometry).  Wave w owns stage 4*tile + w: its A operand is the stage's 8 padded-input rows (8 contiguous runs of
+// 1 072 B at an LDS pitch of 1 088 B, 9 DMA pieces, loaded and waited for by the wave itself), the B operand the
+// whole 64 x (4 taps x 64) weight matrix (32 KB, loaded once per block).  The flat kernel moved 160 pieces per 256
+// rows through the L2->LDS path, this one 68, with no K-loop barrier; every fragment address is ONE per-lane base
+// plus an instruction offset: A fragment (tap t, half kk = filter row 2t+kk, pixel fragment m) sits at
+// (2t+kk)*1088 + m*256 from  slab + pixel*16 + kgroup*16.
+// =====================================================================================================
+constexpr int SRF_PITCH = 1088, SRF_SLAB = 9 * 1024, SRF_W = 4 * 64 * 128;
+template <int T4, int KK, int M4>
+__device__ __forceinline__ uint4 srf_a(unsigned base) { return lds_read16_asm_off<(2 * T4 + KK) * SRF_PITCH + M4 * 256>(base); }
+__global__ __launch_bounds__(256) void conv_stem_rows_kernel(ConvArgs a, int P, int Hp, int Wp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int mt_per_xcd = (a.mtiles + 7) >> 3;
+    const int mtile = xcd * mt_per_xcd + j;
+    if (mtile >= a.mtiles) return;
+    const unsigned smem_base = lds_addr(smem);
+    unsigned char* Ws = smem;                            // [4 taps][64 oc][128 B]
+    unsigned char* Xs = smem + SRF_W + wave * SRF_SLAB;  // this wave's stage
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    // ---- loads: the wave's slab (9 pieces), then its quarter of the weights (8 pieces: tap = wave)
+    {
+        const int stg = mtile * 4 + wave;
+        const int R = stg / a.seg_nseg, sg = stg - R * a.seg_nseg;
+        const int n = R / P, oh = R - n * P;
+        const int ow0 = min(64 * sg, a.seg_Q - 64);
+        const int x_base = ((n * Hp + 2 * oh) * Wp + 2 * ow0) * 8;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int off = 1024 * p + 16 * lane;
+            const int row = off / SRF_PITCH, col = off - row * SRF_PITCH;
+            const bool ok = stg < a.seg_stages && row < 8 && col < 1072;
+            dma16(rin, Xs + p * 1024, ok ? x_base + row * Wp * 8 + col : (int)0x80000000);
+        }
+        // weight tile of tap `wave`: 64 rows x 128 B, chunk swizzle as in the flat kernel
+        const int prow = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + prow;
+            const int sch = pch ^ ((row >> 1) & 7);
+            dma16(rwt, Ws + wave * 8192 + i * 1024, (row * 4 + wave) * 128 + sch * 16);
+        }
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[nn][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const unsigned abase = lds_addr(Xs) + frow * 16 + fg * 16;
+    const unsigned wb0 = smem_base + frow * 128 + (((0 + fg) ^ fswz) << 4), wb1 = smem_base + frow * 128 + (((4 + fg) ^ fswz) << 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's share of the weights has landed
+    asm volatile("" ::: "memory");
+    auto half = [&](auto T4c, auto KKc) __attribute__((always_inline)) {
+        constexpr int T4 = decltype(T4c)::value, KK = decltype(KKc)::value;
+        uint4 px[4], wf[4];
+        px[0] = srf_a<T4, KK, 0>(abase);
+        px[1] = srf_a<T4, KK, 1>(abase);
+        px[2] = srf_a<T4, KK, 2>(abase);
+        px[3] = srf_a<T4, KK, 3>(abase);
+        const unsigned wb = KK ? wb1 : wb0;
+        wf[0] = lds_read16_asm_off<T4 * 8192 + 0>(wb);
+        wf[1] = lds_read16_asm_off<T4 * 8192 + 2048>(wb);
+        wf[2] = lds_read16_asm_off<T4 * 8192 + 4096>(wb);
+        wf[3] = lds_read16_asm_off<T4 * 8192 + 6144>(wb);
+        lds_wait();
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) Mma<bf16>::run(wf[nn], px[m], acc[nn][m]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    half(I0{}, I0{});
+    half(I0{}, I1{});
+    half(I1{}, I0{});
+    half(I1{}, I1{});
+    half(I2{}, I0{});
+    half(I2{}, I1{});
+    half(I3{}, I0{});
+    half(I3{}, I1{});
+    __syncthreads();
+    conv_epilogue<bf16, 256, 64, 4, 1>(acc, smem, a, mtile * 256, 0, mtile);
 }
 
 // =====================================================================================================
@@ -856,8 +961,18 @@ int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial
 // ---- direct stem forward (layout.hip / gather.h): implicit GEMM over the padded NHWC4 input
 int stem_taps(int dtype);
 int stem_ic(int dtype);
+// the bf16 stem runs on the row-slab kernels when an output row has at least 64 pixels
+static bool stem_rows(int dtype, int W) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_STEM_ROWS_FWD");  // tuning aid: 0 = flat kernel
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0 && dtype == GDL_BF16 && (W - 1) / 2 + 1 >= 64;
+}
 int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
     const int M = n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    if (stem_rows(dtype, W)) return ceil_div(n_img * ((H - 1) / 2 + 1) * ceil_div((W - 1) / 2 + 1, 64), 4);
     return ceil_div(M, pick_cfg(M, 64, dtype).bm);
 }
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
@@ -892,6 +1007,25 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     }
     GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
     a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
+    if (stem_rows(dtype, W)) {
+        a.seg_Q = Q;
+        a.seg_nseg = ceil_div(Q, 64);
+        a.seg_stages = n_img * P * a.seg_nseg;
+        a.mtiles = ceil_div(a.seg_stages, 4);
+        GDL_REQUIRE((size_t)a.seg_stages * 64 < (1UL << 31), "stem: too many rows");
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_stem_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               SRF_W + 4 * SRF_SLAB);
+            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_stem_rows)");
+            attr_set = true;
+        }
+        ProfScope prof("gdl::conv_stem_rows_kernel", PROF_MFMA, st, a.flops, true);
+        hipExtLaunchKernelGGL(conv_stem_rows_kernel, dim3((a.mtiles + 7) / 8 * 8), dim3(256), SRF_W + 4 * SRF_SLAB, st, prof.e0(),
+                              prof.e1(), 0, a, P, Hp, Wp);
+        GDL_CHECK_LAUNCH("conv_stem_rows_kernel");
+        return GDL_OK;
+    }
     const TileCfg c = pick_cfg(a.M, 64, dtype);
     ConvPlan pl{};
     pl.slab = 0;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The stem weight gradient alone at the CREMA-D B=64 shapes (visual 192x224x224x3, audio 64x257x188x1)."""
+"""The stem forward convolution and weight gradient alone at the CREMA-D B=64 shapes (visual 192x224x224x3, audio 64x257x188x1)."""
 import os
 import sys
 
@@ -26,6 +26,24 @@ for name, n_img, H, W, Cin in (("visual", 192, 224, 224, 3), ("audio", 64, 257, 
     def run():
         L.call("gdl_stem_conv_wgrad", dt, L.ptr(dy), L.ptr(xp), L.ptr(dw), L.ptr(tab), n_img, H, W, Cin, L.ptr(ws), nb, st)
 
+    wp = torch.randn(lib.gdl_stem_weight_bytes(dt) // 2, device=dev).bfloat16()
+    y = torch.empty(n_img * P * Q, 64, device=dev, dtype=torch.bfloat16)
+    part = torch.empty(lib.gdl_stem_conv_bn_tiles(dt, n_img, H, W), 64, 2, device=dev)
+
+    def fwd():
+        L.call("gdl_stem_conv_fwd", dt, L.ptr(xp), L.ptr(wp), L.ptr(y), L.ptr(part), L.ptr(tab), n_img, H, W, Cin, st)
+
+    for _ in range(3):
+        fwd()
+    torch.cuda.synchronize()
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    f0.record()
+    for _ in range(20):
+        fwd()
+    f1.record()
+    torch.cuda.synchronize()
+    fus = f0.elapsed_time(f1) / 20 * 1e3
+    print(f"{name}: forward {fus:.1f} us, y {y.numel() * 2 / 1e6:.0f} MB -> {y.numel() * 2 / fus / 1e3:.0f} GB/s written")
     for _ in range(3):
         run()
     torch.cuda.synchronize()
