@@ -33,6 +33,41 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
             sc[4 * q4 + 0] = a.x, sc[4 * q4 + 1] = a.y, sc[4 * q4 + 2] = a.z, sc[4 * q4 + 3] = a.w;
             sf[4 * q4 + 0] = b.x, sf[4 * q4 + 1] = b.y, sf[4 * q4 + 2] = b.z, sf[4 * q4 + 3] = b.w;
         }
+        if constexpr (sizeof(T) == 2) {
+            // bf16: a rounded non-negative value has 16 zero low bits, so (bits | 15 - code) is ONE unsigned key whose
+            // maximum is the largest value and, among equal values, the first window position: a v_max_u32 per
+            // candidate instead of compare + two selects, and the rounding is one v_cvt_pk_bf16_f32 per pair.
+            uint32_t key[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) key[e] = 0u;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int ih = p * 2 - 1 + r;
+                if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int iw = q * 2 - 1 + s;
+                    if ((unsigned)iw >= (unsigned)W) continue;
+                    float f[EPC];
+                    unpack16<T>(*(const uint4*)(y + (((size_t)n * H + ih) * W + iw) * C + vc * EPC), f);
+                    const uint32_t tag = 15u - (uint32_t)(r * 3 + s);
+#pragma unroll
+                    for (int e = 0; e < EPC; e += 2) {
+                        float v0 = f[e] * sc[e] + sf[e], v1 = f[e + 1] * sc[e + 1] + sf[e + 1];
+                        v0 = v0 > 0.f ? v0 : 0.f;  // (+0 also for -0 and NaN: the key compare is unsigned)
+                        v1 = v1 > 0.f ? v1 : 0.f;
+                        const uint32_t u = pack2bf(v0, v1);
+                        key[e] = max(key[e], (u << 16) | tag);
+                        key[e + 1] = max(key[e + 1], (u & 0xffff0000u) | tag);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                best[e] = __uint_as_float(key[e] & 0xffff0000u);
+                bi[e] = 15 - (int)(key[e] & 15u);
+            }
+        } else {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             best[e] = -INFINITY;
@@ -58,6 +93,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                     }
                 }
             }
+        }
         }
         *(uint4*)(out + i * EPC) = pack16<T>(best);
         uint8_t* ip = idx + i * EPC;
