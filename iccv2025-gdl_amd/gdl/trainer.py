@@ -1,9 +1,9 @@
 """Native DGL training step: the whole body of /root/reference/main_dgl.py:97-154 as one
-sequence of gfx950 kernels on three HIP streams, without an autograd tape.
+sequence of gfx950 kernels on two HIP streams (+ a side stream for the visual weight gradients), without an autograd tape.
 
 Per step (all asynchronous, nothing is read back unless `read()` is called):
   audio encoder forward  (stream A)  ||  visual encoder forward (stream V)
-  fusion head forward, 3x cross-entropy, head backward with the DGL truncation   (main stream)
+  fusion head forward, 3x cross-entropy, head backward with the DGL truncation   (stream A)
       - encoders receive only alpha * d(CE(a_out) + CE(v_out))      (main_dgl.py:108-110)
       - fc_out receives only d CE(out) on detached features          (:114-122)
       - fc_auxi never receives a gradient and is skipped by SGD      
@@ -166,7 +166,17 @@ class DGLTrainer:
         """spec [B,F,T'] float, image [B,3,T,H,W] float, label [B] int64 -- all resident on the device."""
         self._prepare(spec, image)
         self._bind()
-        main = torch.cuda.current_stream(self.device)
+        # The head, the losses and the optimizer run on the audio chain's stream rather than on the caller's: one stream
+        # (hardware queue) less in play measured +1 % (tools: 9 660 -> 9 760 samples/s).  The caller's stream is ordered
+        # before the step and behind it, so the call keeps ordinary stream semantics.
+        caller = torch.cuda.current_stream(self.device)
+        main = self.s_a
+        main.wait_stream(caller)
+        with torch.cuda.stream(main):
+            self._step_on(main, spec, image, label)
+        caller.wait_stream(main)
+
+    def _step_on(self, main, spec, image, label):
         audio = spec.unsqueeze(1)  # main_dgl.py:100
         label = label.contiguous()
         B, n = self.B, self.n_classes
