@@ -55,7 +55,7 @@ extern unsigned long long* g_timing_buf;
 #endif
 
 constexpr int W9_BP = 64;        // pixels per stage
-constexpr int W9_RING = 32768;   // bytes of the slab ring (256 rows)
+// (slab ring: 256 rows = 32 KiB for 2W+2 <= 128, 512 rows = 64 KiB for 2W+2 <= 384; template parameter RING = KiB / 32)
 
 __device__ __forceinline__ void w9_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base, int voffset) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -111,7 +111,7 @@ __device__ __forceinline__ int w9_swz(int row) { return ((row >> 1) & 1) | (((ro
 // AND; the second K-step's +4096 instruction offset may run past the ring's end, so rows 0..31 are mirrored behind it
 // (4 extra pieces every fourth stage).  Used where it saves at least 6 pieces per stage (W >= 24); the narrow layers
 // keep the plain double buffer, whose LDS footprint is smaller there.
-template <bool SPEC, bool RING>
+template <bool SPEC, int RING>
 __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,11 +135,12 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
     const int nins = (a.slab_rows + 7) >> 3;        // 1 KiB DMA pieces of the slab
     // plain: [stage 0: dy tile + slab][stage 1][zero row][mask stages]
     // RING:  [ring 32 KiB][mirror of rows 0..31, 4 KiB][dy tile 0][dy tile 1][zero row][mask stages]
+    constexpr int W9_RING = RING * 32768;  // bytes of the ring (0: plain double buffer)
     const int STAGE = RING ? W9_BP * 128 : W9_BP * 128 + nins * 1024;
     const int DY0 = RING ? W9_RING + 4096 : 0;      // byte offset of dy tile 0
     const int ZOFF = RING ? DY0 + 2 * STAGE : 2 * STAGE;
     const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
-    if (RING && (smem_base & (W9_RING - 1)) != 0) __builtin_trap();  // the wrap-by-AND needs the ring at a 32 KiB boundary
+    if (RING && (smem_base & (unsigned)(W9_RING > 0 ? W9_RING - 1 : 0)) != 0) __builtin_trap();  // the wrap-by-AND needs the ring at a 32 KiB boundary
     unsigned char* zero_p = smem + ZOFF;            // 1 KiB zero row
     unsigned char* mask_st = zero_p + 1024;         // two 256-byte mask stages
     const unsigned zrow = smem_base + ZOFF;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
         // RING: stage 0 fills ring rows [0, ringT + 64) with pixels p0 + row, p0 = m_begin - (W+1) - (ringT - 2W - 2);
         // stage s > 0 brings pixels m_s + (W+1) + [0, 64) into block (s + ringT/64) mod 4 (and its first 32 rows
         // into the mirror when that is block 0)
-        const int blk = (ld_s + (ringT >> 6)) & 3;
+        const int blk = (ld_s + (ringT >> 6)) & (RING ? RING * 4 - 1 : 3);  // 64-row blocks of the ring
         const int nx = !RING ? nins : (ld_s == 0 ? (ringT >> 3) + 8 : (blk == 0 ? 12 : 8));
         const int np = 8 + nx + 1;
         for (int p = wave; p < np; p += 4) {
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) baddr[t][h] = RING ? ((baddr[t][h] + 8192u) & (unsigned)(W9_RING - 1)) : baddr[t][h] + dlt;
+            for (int h = 0; h < 2; ++h) baddr[t][h] = RING ? ((baddr[t][h] + 8192u) & (unsigned)(W9_RING > 0 ? W9_RING - 1 : 0)) : baddr[t][h] + dlt;
     }
 #ifdef GDL_TIMING
     unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();
@@ -466,16 +467,24 @@ static bool w9_spec() {
     }
     return v != 0;
 }
-static bool w9_ring(int W) {
+// ring size class of a layer width: 0 = plain double buffer, 1 = 256-row ring, 2 = 512-row ring
+static int w9_ring(int W) {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("GDL_WGRAD9_RING");  // tuning aid: 0 = plain double buffer everywhere
         v = e ? atoi(e) : 1;
     }
-    return v != 0 && W >= 24 && 2 * W + 2 <= 128;
+    if (v == 0 || W < 24) return 0;
+    if (2 * W + 2 <= 128) return 1;
+    // wider layers (the 157-pixel audio layer 1 of the Kinetics-Sounds / VGGSound shapes): the plain double buffer would
+    // not fit at all; the 512-row ring does (85.5 KB: one block per CU)
+    const int rows = W9_BP + 2 * W + 2;
+    const size_t plain = 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024 + 512;
+    return (plain > 80 * 1024 && 2 * W + 2 <= 384) ? 2 : 0;
 }
 static size_t w9_lds_bytes(int W) {
-    if (w9_ring(W)) return (size_t)W9_RING + 4096 + 2 * W9_BP * 128 + 1024 + 512;  // ring + mirror + dy tiles + zero row + masks
+    const int ring = w9_ring(W);
+    if (ring) return (size_t)ring * 32768 + 4096 + 2 * W9_BP * 128 + 1024 + 512;  // ring + mirror + dy tiles + zero row + masks
     const int rows = W9_BP + 2 * W + 2;
     // two stages (dy tile + slab) + zero row + two mask stages
     return 2 * (size_t)(W9_BP * 128 + ((rows + 7) / 8) * 1024) + 1024 + 512;
@@ -484,7 +493,7 @@ static size_t w9_lds_bytes(int W) {
 // true if this geometry runs on the 9-tap kernel
 bool conv_wgrad9_ok(int dtype, int W, int C, int K, int R, int S, int stride, int pad) {
     return conv_wgrad9_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && C % 64 == 0 &&
-           K % 64 == 0 && w9_lds_bytes(W) <= 80 * 1024;
+           K % 64 == 0 && w9_lds_bytes(W) <= 96 * 1024;
 }
 
 int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K, void* ws,
@@ -517,14 +526,17 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     }
     a.partial = (float*)ws;
     const size_t lds = w9_lds_bytes(W);
-    const bool ring = w9_ring(W), spec = w9_spec();
-    auto kern = spec ? (ring ? conv_wgrad9_kernel<true, true> : conv_wgrad9_kernel<true, false>)
-                     : (ring ? conv_wgrad9_kernel<false, true> : conv_wgrad9_kernel<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[spec * 2 + ring]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    const int ring = w9_ring(W);
+    const bool spec = w9_spec();
+    using KernT = void (*)(Wgrad9Args);
+    static const KernT kerns[2][3] = {{conv_wgrad9_kernel<false, 0>, conv_wgrad9_kernel<false, 1>, conv_wgrad9_kernel<false, 2>},
+                                      {conv_wgrad9_kernel<true, 0>, conv_wgrad9_kernel<true, 1>, conv_wgrad9_kernel<true, 2>}};
+    const KernT kern = kerns[spec][ring];
+    static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
+    if (!attr_set[spec][ring]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad9)");
-        attr_set[spec * 2 + ring] = true;
+        attr_set[spec][ring] = true;
     }
     const int per_slice = a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;

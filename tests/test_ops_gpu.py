@@ -97,6 +97,9 @@ WGRAD_SHAPES = [
     (2, 64, 3, 63, 128, 3, 1, 1),    # widest ring geometry (2W+2 = 128)
     (2, 64, 2, 64, 64, 3, 1, 1),     # just past it: plain
     (1, 128, 40, 47, 64, 3, 1, 1),   # audio layer-1 width: the ring wraps several times per slice
+    (1, 64, 9, 157, 64, 3, 1, 1),    # Kinetics-Sounds audio layer-1 width: the 512-row ring
+    (2, 64, 3, 191, 128, 3, 1, 1),   # widest 512-row ring geometry (2W+2 = 384)
+    (1, 64, 3, 192, 64, 3, 1, 1),    # just past it: per-tap kernel
 ]
 
 
