@@ -212,7 +212,7 @@ struct PackDesc {
 };
 // Block = one 32(k) x 32(c) patch of one tensor, all R*S taps: the float32 source rows
 // w[k][c0..c0+31][:] are contiguous runs, the patch is transposed through LDS and both
-// destinations are written in 64-byte runs (krsc: 32 consecutive c; crsk: 32 consecutive k).
+// destinations are written in 64-byte runs (krsc: 32 consecutive c; crsk: 32 consecutive k), 16 bytes per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDesc* __restrict__ desc, int ndesc) {
     __shared__ float tile[32][32 * 9 + 1];
@@ -224,23 +224,41 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackDes
     const int local = (int)blockIdx.x - pd.blk0;
     const int k0 = (local / ctiles) * 32, c0 = (local % ctiles) * 32;
     const int run = 32 * RS;  // contiguous floats per k row of the patch
-    for (int i = threadIdx.x; i < 32 * run; i += 256) {
-        const int kk = i / run, j = i - kk * run;  // j = cc*RS + rs
-        tile[kk][j] = pd.w[((size_t)(k0 + kk) * pd.C + c0) * RS + j];
+    if ((run & 3) == 0) {  // (32*RS is a multiple of 4 and the row starts are 16-byte aligned: C*RS*4 and c0*RS*4 are)
+        const int run4 = run >> 2;
+        for (int i = threadIdx.x; i < 32 * run4; i += 256) {
+            const int kk = i / run4, j4 = i - kk * run4;
+            const float4 v = *(const float4*)(pd.w + ((size_t)(k0 + kk) * pd.C + c0) * RS + 4 * j4);
+            float* t = &tile[kk][4 * j4];
+            t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 32 * run; i += 256) {
+            const int kk = i / run, j = i - kk * run;  // j = cc*RS + rs
+            tile[kk][j] = pd.w[((size_t)(k0 + kk) * pd.C + c0) * RS + j];
+        }
     }
     __syncthreads();
     T* krsc = (T*)pd.krsc;
     T* crsk = (T*)pd.crsk;
-    for (int i = threadIdx.x; i < 32 * run; i += 256) {  // krsc[k][rs][c]: c fastest
-        const int cc = i & 31, t = i >> 5;
+    // 16-byte stores (EPC elements of the fast index per thread; 2-byte stores made this kernel 3x slower than its traffic)
+    constexpr int EPC = TT<T>::EPC, G = 32 / EPC;
+    for (int i = threadIdx.x; i < 32 * RS * G; i += 256) {  // krsc[k][rs][c]: c fastest
+        const int cg = i % G, t = i / G;
         const int rs = t % RS, kk = t / RS;
-        storeT<T>(krsc + ((size_t)(k0 + kk) * RS + rs) * pd.C + c0 + cc, tile[kk][cc * RS + rs]);
+        float v[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = tile[kk][(cg * EPC + e) * RS + rs];
+        *(uint4*)(krsc + ((size_t)(k0 + kk) * RS + rs) * pd.C + c0 + cg * EPC) = pack16<T>(v);
     }
     if (crsk)
-        for (int i = threadIdx.x; i < 32 * run; i += 256) {  // crsk[c][rs][k]: k fastest
-            const int kk = i & 31, t = i >> 5;
+        for (int i = threadIdx.x; i < 32 * RS * G; i += 256) {  // crsk[c][rs][k]: k fastest
+            const int kg = i % G, t = i / G;
             const int rs = t % RS, cc = t / RS;
-            storeT<T>(crsk + ((size_t)(c0 + cc) * RS + rs) * pd.K + k0 + kk, tile[kk][cc * RS + rs]);
+            float v[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = tile[kg * EPC + e][cc * RS + rs];
+            *(uint4*)(crsk + ((size_t)(c0 + cc) * RS + rs) * pd.K + k0 + kg * EPC) = pack16<T>(v);
         }
 }
 int pack_weights_batched(int dtype, const void* desc_dev, int ndesc, int total_blocks, double bytes, hipStream_t st) {
