@@ -181,13 +181,88 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
       }
     }
 }
+// The same gather, one thread per 2x2 patch of input pixels (rows 2p, 2p+1, columns 2q, 2q+1): the patch belongs to the
+// four windows (p,q), (p,q+1), (p+1,q), (p+1,q+1), each of which is loaded and decoded ONCE for the (up to four)
+// positions it may name -- 4 window reads per 4 outputs instead of 9, the compares unchanged:
+//   (2p,2q): (p,q)=4 | (2p,2q+1): (p,q)=5, (p,q+1)=3 | (2p+1,2q): (p,q)=7, (p+1,q)=1 |
+//   (2p+1,2q+1): (p,q)=8, (p,q+1)=6, (p+1,q)=2, (p+1,q+1)=0        (code = r*3 + s of the position inside the window)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_patch_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                T* __restrict__ dx, int N, int H, int W, int C, int P, int Q) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    const int PH = (H + 1) >> 1, QW = (W + 1) >> 1;
+    const int rows = N * PH, per_row = QW * cpr;  // a block walks whole patch rows (n, p)
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / PH, p = row - n * PH;
+        for (int jj = threadIdx.x; jj < per_row; jj += blockDim.x) {
+            const int q = jj / cpr, vc = jj - q * cpr;
+            float a00[EPC], a01[EPC], a10[EPC], a11[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a00[e] = a01[e] = a10[e] = a11[e] = 0.f;
+            auto window = [&](int pp, int qq, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
+                if (pp >= P || qq >= Q) return;
+                const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
+                float d[EPC];
+                unpack16<T>(*(const uint4*)(dout + o), d);
+                uint32_t ix[EPC];
+                if (EPC == 8) {
+                    const uint2 u = *(const uint2*)(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ix[e] = (u.x >> (8 * e)) & 0xff;
+                        ix[(4 + e) % EPC] = (u.y >> (8 * e)) & 0xff;
+                    }
+                } else {
+                    const uint32_t u = *(const uint32_t*)(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ix[e] = (u >> (8 * e)) & 0xff;
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    if (c00 >= 0 && ix[e] == (uint32_t)c00) a00[e] += d[e];
+                    if (c01 >= 0 && ix[e] == (uint32_t)c01) a01[e] += d[e];
+                    if (c10 >= 0 && ix[e] == (uint32_t)c10) a10[e] += d[e];
+                    if (c11 >= 0 && ix[e] == (uint32_t)c11) a11[e] += d[e];
+                }
+            };
+            // (the order of the additions into one position is that of maxpool_bwd_kernel: window rows, then columns)
+            window(p, q, 4, 5, 7, 8);
+            window(p, q + 1, -1, 3, -1, 6);
+            window(p + 1, q, -1, -1, 1, 2);
+            window(p + 1, q + 1, -1, -1, -1, 0);
+            const int h = 2 * p, w = 2 * q;
+            T* o0 = dx + (((size_t)n * H + h) * W + w) * C + vc * EPC;
+            *(uint4*)o0 = pack16<T>(a00);
+            if (w + 1 < W) *(uint4*)(o0 + C) = pack16<T>(a01);
+            if (h + 1 < H) {
+                T* o1 = o0 + (size_t)W * C;
+                *(uint4*)o1 = pack16<T>(a10);
+                if (w + 1 < W) *(uint4*)(o1 + C) = pack16<T>(a11);
+            }
+        }
+    }
+}
 int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, hipStream_t st) {
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     const size_t total = (size_t)N * H * W * (C / epc);
     const int grid = N * H > 16384 ? 16384 : N * H;
     ProfScope prof(dtype == GDL_BF16 ? "gdl::maxpool_bwd_kernel<gdl::bf16>" : "gdl::maxpool_bwd_kernel<float>", PROF_HBM, st, (double)total * 16.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
-    if (dtype == GDL_BF16)
+    static int patch = -1;
+    if (patch < 0) {
+        const char* e = getenv("GDL_POOL_PATCH");  // tuning aid: 0 = one thread per input pixel
+        patch = e ? atoi(e) : 1;
+    }
+    if (patch) {
+        const int prow = N * ((H + 1) / 2), pgrid = prow > 16384 ? 16384 : prow;
+        if (dtype == GDL_BF16)
+            hipLaunchKernelGGL(maxpool_bwd_patch_kernel<bf16>, dim3(pgrid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N,
+                               H, W, C, P, Q);
+        else
+            hipLaunchKernelGGL(maxpool_bwd_patch_kernel<float>, dim3(pgrid), dim3(256), 0, st, (const float*)dout, idx, (float*)dx,
+                               N, H, W, C, P, Q);
+    } else if (dtype == GDL_BF16)
         hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H,
                            W, C, P, Q);
     else
