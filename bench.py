@@ -38,6 +38,12 @@ WORKLOADS = {
            "name": "Kinetics-Sounds DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x129x626 + frames 3x3x224x224, "
                    "34 logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
            "metric": "audio-visual samples/sec, Kinetics-Sounds DGL train step (whole job)"},
+    # configs[4]'s data shapes (VGGSound: the Kinetics-Sounds shapes with 309 logits) on the ResNet18 visual branch -- the
+    # Swin-T branch of that configuration is not reachable from main_dgl.py and is not built
+    "vggsound": {"dataset": "VGGSound", "n_classes": 309, "spec": (129, 626), "alpha": 2.0, "gflop": 50.563,
+                 "name": "VGGSound-shaped DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x129x626 + frames 3x3x224x224, "
+                         "309 logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
+                 "metric": "audio-visual samples/sec, VGGSound-shaped DGL train step (whole job)"},
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
 HBM_PEAK_GBS = 8000.0
@@ -51,7 +57,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="cremad", choices=sorted(WORKLOADS),
-                    help="cremad = BASELINE configs[1] (the metric's configuration); ks = configs[2] shapes")
+                    help="cremad = BASELINE configs[1] (the metric's configuration); ks = configs[2] shapes; vggsound = configs[4] shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="samples in the CPU oracle step (about 10-20 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
