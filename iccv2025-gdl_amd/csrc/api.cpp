@@ -55,6 +55,26 @@ int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* b
     GDL_REQUIRE(x && w_krsc && y, "conv_fwd: null pointer");
     return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
 }
+static FoldWs fold_ws_of(void* ws) {
+    return FoldWs{(unsigned*)ws, (double*)((unsigned char*)ws + align_up(fold_ctr_bytes(), 256))};
+}
+size_t gdl_fold_workspace_bytes(void) { return align_up(fold_ctr_bytes(), 256) + fold_gpart_bytes(); }
+int gdl_fold_workspace_init(void* fold_ws, size_t bytes, void* stream) {
+    GDL_REQUIRE(fold_ws && bytes >= gdl_fold_workspace_bytes() && ((uintptr_t)fold_ws & 15) == 0, "fold_workspace_init: bad workspace");
+    return check_hip(hipMemsetAsync(fold_ws, 0, fold_ctr_bytes(), (hipStream_t)stream), "fold_workspace_init");
+}
+int gdl_conv_fwd_bn(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
+                    int W, int C, int K, int R, int S, int stride, int pad, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_rstd, float* scale,
+                    float* shift, void* fold_ws, void* stream) {
+    GDL_REQUIRE(x && w_krsc && y && bn_partial && gamma && beta && save_mean && save_rstd && scale && shift && fold_ws,
+                "conv_fwd_bn: null pointer");
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    const FoldWs fw = fold_ws_of(fold_ws);
+    const BnFinTrain fin{bn_partial, 0, K, (double)N * P * Q, gamma, beta, running_mean, running_var, nbt, save_mean, save_rstd,
+                         scale, shift};
+    return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, &fw, &fin);
+}
 int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N,
                    int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
     GDL_REQUIRE(dy && w_crsk && dx, "conv_dgrad: null pointer");
@@ -159,6 +179,14 @@ int gdl_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scal
     GDL_REQUIRE(dt_ok(dtype) && g && y && save_mean && save_rstd && partial, "bn_bwd_reduce: bad arguments");
     return bn_bwd_reduce(dtype, g, y, scale, shift, save_mean, save_rstd, relu_mask, partial, M, C, (hipStream_t)stream);
 }
+int gdl_bn_bwd_reduce_fin(int dtype, const void* g, const void* y, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M, int C,
+                          double count, float* dgamma, float* dbeta, float* coef, void* fold_ws, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && g && y && save_mean && save_rstd && partial && dgamma && dbeta && coef && fold_ws,
+                "bn_bwd_reduce_fin: bad arguments");
+    return bn_bwd_reduce_fold(dtype, g, y, scale, shift, save_mean, save_rstd, relu_mask, partial, M, C, count, dgamma, dbeta,
+                              coef, fold_ws_of(fold_ws), (hipStream_t)stream);
+}
 int gdl_bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                         void* stream) {
     GDL_REQUIRE(partial && dgamma && dbeta && coef, "bn_bwd_finalize: null pointer");
@@ -177,9 +205,17 @@ int gdl_relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n,
 }
 
 int gdl_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx,
-                            int N, int H, int W, int C, void* stream) {
+                            void* ymax, int N, int H, int W, int C, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && y && scale && shift && out && idx, "bn_relu_maxpool_fwd: bad arguments");
-    return bn_relu_maxpool_fwd(dtype, y, scale, shift, out, idx, N, H, W, C, (hipStream_t)stream);
+    return bn_relu_maxpool_fwd(dtype, y, scale, shift, out, idx, ymax, N, H, W, C, (hipStream_t)stream);
+}
+int gdl_maxpool_bn_bwd_apply(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* scale,
+                             const float* shift, const float* save_mean, const float* save_rstd, const float* gamma,
+                             const float* coef, void* dy, int N, int H, int W, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dout && idx && y && scale && shift && save_mean && save_rstd && gamma && coef && dy,
+                "maxpool_bn_bwd_apply: bad arguments");
+    return maxpool_bn_bwd_apply(dtype, dout, idx, y, scale, shift, save_mean, save_rstd, gamma, coef, dy, N, H, W, C,
+                                (hipStream_t)stream);
 }
 int gdl_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && dout && idx && dx, "maxpool_bwd: bad arguments");

@@ -25,7 +25,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fold.h"
 #include "gather.h"
+#include "ops.h"
 #include "prof.h"
 
 #include <hip/hip_ext.h>
@@ -57,6 +59,10 @@ struct ConvArgs {
     // R*seg_Q + ow0 + i with ow0 = min(64*sg, seg_Q - 64); rows i < 64*sg - ow0 repeat the previous stage: not stored
     int seg_Q, seg_nseg, seg_stages;
     double flops;  // algorithmic work of the launch (measurement tap)
+    // BatchNorm finalize folded into the launch (fold.h): the block that completes the statistics computes
+    // mean / rstd / scale / shift and the running statistics (fold.ctr == nullptr: the caller launches bn_finalize_train)
+    FoldWs fold;
+    FinTrain fin;
 #ifdef GDL_TIMING
     unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
 #endif
@@ -162,7 +168,7 @@ struct ConvSmem {
 // LDS-DMA in flight.
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], unsigned char* smem,
-                                              const ConvArgs& a, int m0, int n0, int mtile) {
+                                              const ConvArgs& a, int m0, int n0, int mtile, int ntile = 0) {
     using SM = ConvSmem<BM, BN, T>;
     constexpr int EPC = TT<T>::EPC;
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -261,8 +267,9 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             const int c = tid >> 1, w = tid & 1;
             const float s = ((red[(0 * BN + c) * 2 + w] + red[(1 * BN + c) * 2 + w]) + red[(2 * BN + c) * 2 + w]) +
                             red[(3 * BN + c) * 2 + w];
-            a.stats[((size_t)mtile * a.OC + n0 + c) * 2 + w] = s;
+            st_agent(a.stats + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
         }
+        if (a.fold.ctr) fold_finalize(a.stats, a.mtiles, a.OC, n0, BN, mtile, ntile, a.fold, smem, a.fin);
     }
 }
 
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (empty) tail stages before LDS is reused
     __syncthreads();
 
-    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile);
+    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile, ntile);
 }
 
 // =====================================================================================================
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     GDL_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile);
+    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile, ntile);
     GDL_STAMP(5);
 #ifdef GDL_TIMING
     if (a.dbg && threadIdx.x == 0) {
@@ -898,9 +905,15 @@ int conv_dgrad_bm(int dtype, int N, int H, int W, int C, int K, int R, int S, in
     return plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad).bm;
 }
 
+// BatchNorm finalize arguments -> the device functor (fold.h); `count` = GEMM rows
+static FinTrain make_fin(const BnFinTrain& b, float eps, float momentum) {
+    return FinTrain{b.gamma, b.beta, b.running_mean, b.running_var, b.nbt, b.save_mean, b.save_rstd, b.scale, b.shift, b.count,
+                    eps, momentum};
+}
+
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                    hipStream_t st) {
+                    hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -938,6 +951,12 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
     const ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
     a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction
+    if (fold && fold->ctr) {
+        GDL_REQUIRE(stats && bn && mode == GATHER_FWD && fold_fits(ceil_div(a.M, pl.bm), a.OC) && a.OC / pl.bn <= FOLD_NCG,
+                    "conv: bad fold arguments");
+        a.fold = *fold;
+        a.fin = make_fin(*bn, 1e-5f, 0.1f);
+    }
     if (mode == GATHER_DGRAD && stride == 2) {
         a.orow = (const int*)((const GatherEntry*)table + dgrad_perm_cap(N, H, W));
         a.tile_taps = (const unsigned*)(a.orow + dgrad_perm_cap(N, H, W));
@@ -957,8 +976,8 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
 }
 
 int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,
-             int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
-    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st);
+             int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn) {
+    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st, fold, bn);
 }
 
 // ---- direct stem forward (layout.hip / gather.h): implicit GEMM over the padded NHWC4 input
@@ -979,7 +998,7 @@ int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
     return ceil_div(M, pick_cfg(M, 64, dtype).bm);
 }
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
-                  int W, int Cin, hipStream_t st) {
+                  int W, int Cin, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "stem: bad dtype %d", dtype);
     GDL_REQUIRE(xp && wp && y && table, "stem: null pointer");
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
@@ -1010,6 +1029,11 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     }
     GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
     a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
+    if (fold && fold->ctr) {
+        GDL_REQUIRE(bn_partial && bn && fold_fits(conv_stem_tiles_m(dtype, n_img, H, W), 64), "stem: bad fold arguments");
+        a.fold = *fold;
+        a.fin = make_fin(*bn, 1e-5f, 0.1f);
+    }
     if (stem_rows(dtype, W)) {
         a.seg_Q = Q;
         a.seg_nseg = ceil_div(Q, 64);

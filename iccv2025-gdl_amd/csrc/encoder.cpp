@@ -64,7 +64,7 @@ struct gdl_encoder {
     int h0, w0, h1, w1, kp;
     long m0;  // n_img*h0*w0
     BN bn0;
-    void *col = nullptr, *w0p = nullptr, *y0 = nullptr, *x1 = nullptr;
+    void *col = nullptr, *w0p = nullptr, *y0 = nullptr, *x1 = nullptr, *ymax = nullptr;
     uint8_t* idx = nullptr;
     std::vector<Block> blocks;
     int hf, wf;  // final map
@@ -91,6 +91,7 @@ struct gdl_encoder {
     float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr, *dw0p = nullptr;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
+    FoldWs fold{nullptr, nullptr};  // in-launch BatchNorm finalize (fold.h): counters + group rows, used on the caller's stream
     size_t ws_bytes = 0;
     void* ws = nullptr;
     // bound tables
@@ -130,6 +131,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     y0 = b.take((size_t)m0 * 64 * e);
     x1 = b.take((size_t)n_img * h1 * w1 * 64 * e);
     idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
+    ymax = b.take((size_t)n_img * h1 * w1 * 64 * e);  // raw stem output at each pooling window's argmax
     dw0p = (float*)b.take((size_t)64 * kp * sizeof(float));
     pack_dev = b.take(32 * sizeof(PackDescHost));
     auto bn_alloc = [&](BN& n) {
@@ -225,6 +227,8 @@ size_t gdl_encoder::plan(unsigned char* base) {
     bnb_partial2 = (float*)b.take(bnb_partial_floats * sizeof(float));
     wg_ws_bytes = wg;
     wg_ws = b.take(wg);
+    fold.ctr = (unsigned*)b.take(fold_ctr_bytes());
+    fold.gpart = (double*)b.take(fold_gpart_bytes());
     return align_up(b.off, 256);
 }
 
@@ -406,6 +410,28 @@ static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double co
     return bn_finalize_eval(n.c, gamma, beta, 1e-5f, e->rmean[n.bidx], e->rvar[n.bidx], n.scale, n.shift, st);
 }
 
+static bool wgrad_late() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = getenv("GDL_WGRAD_LATE");  // tuning aid (side-stream mode only)
+        v = env ? atoi(env) : 0;
+    }
+    return v != 0;
+}
+
+// In-launch BatchNorm finalize (fold.h), GDL_FOLD=1.  OFF by default: measured on MI355X (B=64 bf16 step, same box,
+// 40 steps) 6.69 ms with it against 6.22 ms with the 80 separate finalize launches -- every block pays the drain +
+// ticket round trip at its tail (bn_bwd_reduce 28 -> 58 us, the 3x3 forward +16 us per launch) and the folding block
+// two dependent trips to the memory side, which is more than the ~9 us a finalize launch costs its chain.
+static bool fold_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = getenv("GDL_FOLD");
+        v = env ? atoi(env) : 0;
+    }
+    return v != 0;
+}
+
 static bool separate_stats() {
     static int sep = -1;
     if (sep < 0) {
@@ -415,19 +441,30 @@ static bool separate_stats() {
     return sep != 0;
 }
 
-static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st) {
+static BnFinTrain fin_train_args(gdl_encoder* e, BN& n, const float* partial, int tiles, double count) {
+    return BnFinTrain{partial, tiles, n.c, count, e->params[n.pidx], e->params[n.pidx + 1], e->rmean[n.bidx], e->rvar[n.bidx],
+                      e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift};
+}
+
+static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int nimg, int training, hipStream_t st,
+                   float* partial = nullptr) {
     const bool sep = separate_stats();
+    if (!partial) partial = e->bn_partial;
+    const int M = nimg * c.p * c.q;
     if (sep && training) {
         RC(conv_fwd(e->dtype, x, c.w_krsc, y, nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st));
-        const int M = nimg * c.p * c.q;
-        RC(bn_stats(e->dtype, y, e->bn_partial, M, c.cout, st));
+        RC(bn_stats(e->dtype, y, partial, M, c.cout, st));
         return bn_finalize(e, n, training, bn_stats_tiles(M), (double)M, st);
     }
-    RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? e->bn_partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout,
-                c.r, c.s, c.stride, c.pad, st));
-    const int M = nimg * c.p * c.q;
-    return bn_finalize(e, n, training, conv_tiles_m(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad),
-                       (double)M, st);
+    const int tiles = conv_tiles_m(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad);
+    if (training && fold_on() && fold_fits(tiles, c.cout)) {  // statistics AND finalize inside the convolution's launch
+        const BnFinTrain fin = fin_train_args(e, n, partial, tiles, (double)M);
+        return conv_fwd(e->dtype, x, c.w_krsc, y, partial, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
+                        &e->fold, &fin);
+    }
+    RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s,
+                c.stride, c.pad, st));
+    return bn_finalize(e, n, training, tiles, (double)M, st);
 }
 
 int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* feat_out, float* fmap_nchw,
@@ -444,6 +481,8 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         RC(build_stem_table(dt, e->n_img, e->H, e->W, stem_taps(dt), (GatherEntry*)e->tab_stem, st));
         for (const gdl_encoder::TabJob& j : e->tab_jobs)
             RC(build_gather_table(j.mode, dt, j.N, j.H, j.W, j.C, j.K, j.R, j.S, j.stride, j.pad, (GatherEntry*)j.dst, st));
+        hipError_t he = hipMemsetAsync(e->fold.ctr, 0, fold_ctr_bytes(), st);  // ticket counters: zero once, self-resetting
+        if (he != hipSuccess) return check_hip(he, "encoder_forward: counter reset");
         e->tabs_dirty = false;
     }
     if (e->pack_dirty) {  // (re)build the descriptor table of the batched packing launch
@@ -479,16 +518,26 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
     // stem: conv1 (7x7/2) as im2col + GEMM, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
-    RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin,
-                     st));
-    RC(bn_finalize(e, e->bn0, training, conv_stem_tiles_m(dt, e->n_img, e->H, e->W), (double)e->m0, st));
-    RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, e->n_img, e->h0, e->w0, 64, st));
+    {
+        const int tiles = conv_stem_tiles_m(dt, e->n_img, e->H, e->W);
+        if (training && fold_on() && fold_fits(tiles, 64)) {
+            const BnFinTrain fin = fin_train_args(e, e->bn0, e->bn_partial, tiles, (double)e->m0);
+            RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, e->bn_partial, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, &e->fold,
+                             &fin));
+        } else {
+            RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, e->n_img, e->H, e->W,
+                             e->cin, st));
+            RC(bn_finalize(e, e->bn0, training, tiles, (double)e->m0, st));
+        }
+    }
+    RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, training ? e->ymax : nullptr, e->n_img,
+                           e->h0, e->w0, 64, st));
     // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
     for (Block& k : e->blocks) {
         const size_t Mo = (size_t)k.n * k.p * k.q;
         RC(conv_bn(e, k.c1, k.b1, k.xin, k.y1, k.n, training, st));
         RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st));
-        if (k.has_ds && training && !separate_stats()) {
+        if (k.has_ds && training && !separate_stats() && !fold_on()) {
             // bn2 and the downsample BatchNorm are independent: both convolutions first, ONE finalize launch for the two
             // (a finalize kernel costs the chain its whole ~6 us; 80 of them were 0.56 ms of the step)
             auto fin = [&](const Conv& c, BN& n, const float* partial) {
@@ -506,7 +555,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         }
         RC(conv_bn(e, k.c2, k.b2, k.a1, k.y2, k.n, training, st));
         if (k.has_ds) {
-            RC(conv_bn(e, k.cd, k.bd, k.xin, k.yd, k.n, training, st));
+            RC(conv_bn(e, k.cd, k.bd, k.xin, k.yd, k.n, training, st, e->bn_partial2));
             RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st));
         } else {
             RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.xin, nullptr, nullptr, 1, k.z, Mo, k.cout, st));
@@ -522,11 +571,20 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     return GDL_OK;
 }
 
+// reductions + finalize of one BatchNorm's backward: gamma / beta gradients and coef.  `count`: elements per channel the
+// BatchNorm normalised over (differs from M only for the stem's pooled form)
+static int bn_backward_reduce(gdl_encoder* e, BN& n, const void* g, const void* y, int relu_mask, size_t M, double count,
+                              float* const* grads, hipStream_t st) {
+    const int blocks = bn_bwd_blocks(M, n.c);
+    if (fold_on() && fold_fits(blocks, n.c))
+        return bn_bwd_reduce_fold(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, count,
+                                  grads[n.pidx], grads[n.pidx + 1], n.coef, e->fold, st);
+    RC(bn_bwd_reduce(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, st));
+    return bn_bwd_finalize(e->bnb_partial, blocks, n.c, count, grads[n.pidx], grads[n.pidx + 1], n.coef, st);
+}
 static int bn_backward(gdl_encoder* e, BN& n, const void* g, const void* y, int relu_mask, void* dy, size_t M,
                        float* const* grads, hipStream_t st) {
-    const int blocks = bn_bwd_blocks(M, n.c);
-    RC(bn_bwd_reduce(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, st));
-    RC(bn_bwd_finalize(e->bnb_partial, blocks, n.c, (double)M, grads[n.pidx], grads[n.pidx + 1], n.coef, st));
+    RC(bn_backward_reduce(e, n, g, y, relu_mask, M, (double)M, grads, st));
     return bn_bwd_apply(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, relu_mask, dy, M, n.c,
                         st);
 }
@@ -590,18 +648,22 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         // fused: do2 = dz * (z > 0) in place (relu of backbone.py:66) + reductions of bn2 (and of the
         // downsample BatchNorm); then finalize + apply per BatchNorm
         void* do2 = dz;
-        RC(block_bwd_reduce(dt, dz, k.z, k.y2, k.has_ds ? k.yd : nullptr, k.b2.mean, k.b2.rstd, k.has_ds ? k.bd.mean : nullptr,
-                            k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st));
         {
             const int blocks = bn_bwd_blocks(Mo, k.cout);
-            if (k.has_ds)  // one finalize launch for bn2 and the downsample BatchNorm
-                RC(bn_bwd_finalize_pair(
-                    BnFinBwd{e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef},
-                    BnFinBwd{e->bnb_partial2, blocks, k.cout, (double)Mo, grads[k.bd.pidx], grads[k.bd.pidx + 1], k.bd.coef},
-                    st));
-            else
-                RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1],
-                                   k.b2.coef, st));
+            const BnFinBwd f2{e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef};
+            const BnFinBwd fd{e->bnb_partial2, blocks, k.cout, (double)Mo, k.has_ds ? grads[k.bd.pidx] : nullptr,
+                              k.has_ds ? grads[k.bd.pidx + 1] : nullptr, k.has_ds ? k.bd.coef : nullptr};
+            const bool fold = fold_on() && fold_fits(blocks, k.cout);
+            RC(block_bwd_reduce(dt, dz, k.z, k.y2, k.has_ds ? k.yd : nullptr, k.b2.mean, k.b2.rstd, k.has_ds ? k.bd.mean : nullptr,
+                                k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st,
+                                fold ? &e->fold : nullptr, &f2, &fd));
+            if (!fold) {
+                if (k.has_ds)  // one finalize launch for bn2 and the downsample BatchNorm
+                    RC(bn_bwd_finalize_pair(f2, fd, st));
+                else
+                    RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1],
+                                       k.b2.coef, st));
+            }
             if (k.has_ds)  // gB = dy2 and gD = dyd from one pass over do2
                 RC(bn_bwd_apply2(dt, do2, k.y2, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, gB, k.yd, k.bd.mean,
                                  k.bd.rstd, e->params[k.bd.pidx], k.bd.coef, gD, Mo, k.cout, st));
@@ -609,24 +671,36 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                 RC(bn_bwd_apply(dt, do2, k.y2, k.b2.scale, k.b2.shift, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef,
                                 0, gB, Mo, k.cout, st));  // gB = dy2
         }
-        RC(fork());  // dy2 (and dyd) exist
-        RC(conv_wgrad(dt, gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
-                      e->wg_ws, e->wg_ws_bytes, sw));
-        if (k.has_ds)
-            RC(conv_wgrad(dt, gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0,
-                          k.cin, e->wg_ws, e->wg_ws_bytes, sw));
+        auto wgrad2 = [&]() -> int {  // weight gradients of conv2 (and of the downsample convolution): need dy2 (dyd)
+            RC(fork());
+            RC(conv_wgrad(dt, gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
+                          e->wg_ws, e->wg_ws_bytes, sw));
+            if (k.has_ds)
+                RC(conv_wgrad(dt, gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0,
+                              k.cin, e->wg_ws, e->wg_ws_bytes, sw));
+            return GDL_OK;
+        };
+        // late: fork AFTER the data gradient that consumes the same dy, so that the (MFMA-bound) weight gradient runs
+        // beside the (HBM-bound) BatchNorm passes that follow rather than beside another MFMA-bound kernel
+        const bool late = e->side && wgrad_late();
+        if (!late) RC(wgrad2());
         RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
                       st));  // gC = da1
+        if (late) RC(wgrad2());
         // relu + bn1 / conv1
         RC(bn_backward(e, k.b1, gC, k.y1, 1, gC, Mo, grads, st));  // gC = dy1 (in place)
-        RC(fork());  // dy1 exists
-        RC(conv_wgrad(dt, gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
-                      k.cin, e->wg_ws, e->wg_ws_bytes, sw));
-        if (e->side) {
-            hipError_t he = hipEventRecord(e->ev_side[par], e->side);
-            if (he != hipSuccess) return check_hip(he, "encoder_backward: side event");
-            e->side_pending[par] = true;
-        }
+        auto wgrad1 = [&]() -> int {  // weight gradient of conv1: needs dy1
+            RC(fork());
+            RC(conv_wgrad(dt, gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
+                          k.cin, e->wg_ws, e->wg_ws_bytes, sw));
+            if (e->side) {
+                hipError_t he = hipEventRecord(e->ev_side[par], e->side);
+                if (he != hipSuccess) return check_hip(he, "encoder_backward: side event");
+                e->side_pending[par] = true;
+            }
+            return GDL_OK;
+        };
+        if (!late) RC(wgrad1());
         void* dxin;
         if (k.has_ds) {
             RC(conv_dgrad(dt, gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
@@ -640,6 +714,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
             dxin = do2;
         }
+        if (late) RC(wgrad1());
         dz = dxin;
     }
     if (phase == 1) {  // hand over to phase 2; the layer4 gradients must be complete on st
@@ -655,9 +730,16 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         return GDL_OK;
     }
     e->bw_serial = -1;
-    // stem: maxpool -> relu -> bn1 -> conv1 weight gradient (the input needs no gradient)
-    RC(maxpool_bwd(dt, dz, e->idx, e->g0, e->n_img, e->h0, e->w0, 64, st));
-    RC(bn_backward(e, e->bn0, e->g0, e->y0, 1, e->g0, (size_t)e->m0, grads, st));
+    // stem: maxpool -> relu -> bn1 -> conv1 weight gradient (the input needs no gradient).  The gathered gradient
+    // g0 = maxpool_bwd(dz) is never stored: bn1's two reductions run over the POOLED pair (dz, ymax) --
+    // sum_pos g0'*xhat(y0[pos]) = sum_windows dz'*xhat(ymax) -- and the gather is fused into the apply pass.
+    {
+        BN& n = e->bn0;
+        const size_t Mp = (size_t)e->n_img * e->h1 * e->w1;
+        RC(bn_backward_reduce(e, n, dz, e->ymax, 1, Mp, (double)e->m0, grads, st));
+        RC(maxpool_bn_bwd_apply(dt, dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->g0,
+                                e->n_img, e->h0, e->w0, 64, st));
+    }
     RC(fork());
     RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
     if (e->side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients

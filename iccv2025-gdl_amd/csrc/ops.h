@@ -2,16 +2,36 @@
 // engine in encoder.cpp are thin layers over these.
 #pragma once
 #include "common.h"
+#include "fold.h"
 #include "gather.h"
 
 namespace gdl {
 
 const char* last_error();
 
+// argument sets of the finalize kernels (the *_pair forms finalize two BatchNorms of equal width in one launch)
+struct BnFinTrain {
+    const float* partial;
+    int tiles, C;
+    double count;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    int64_t* nbt;
+    float *save_mean, *save_rstd, *scale, *shift;
+};
+struct BnFinBwd {
+    const float* partial;
+    int blocks, C;
+    double count;
+    float *dgamma, *dbeta, *coef;
+};
+
 // conv_igemm.hip
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+// (fold != nullptr: the BatchNorm finalize of `bn` runs inside the launch, fold.h; bn->partial / tiles are ignored)
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
-             int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
+             int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold = nullptr,
+             const BnFinTrain* bn = nullptr);
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // direct (implicit-GEMM) stem: layout.hip (padded NHWC4 input, row-wise weights), gather.hip (table),
@@ -23,7 +43,7 @@ int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, 
 int pack_stem_rows(int dtype, const float* w, void* wp, int cin, hipStream_t st);
 int conv_stem_tiles_m(int dtype, int n_img, int H, int W);
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
-                  int W, int Cin, hipStream_t st);
+                  int W, int Cin, hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr);
 size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W);
 int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
                     void* ws, size_t ws_bytes, hipStream_t st);
@@ -48,22 +68,6 @@ int nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, in
 // bn.hip
 int bn_stats_tiles(int M);
 int bn_stats(int dtype, const void* y, float* partial, int M, int C, hipStream_t st);
-// argument sets of the finalize kernels (the *_pair forms finalize two BatchNorms of equal width in one launch)
-struct BnFinTrain {
-    const float* partial;
-    int tiles, C;
-    double count;
-    const float *gamma, *beta;
-    float *running_mean, *running_var;
-    int64_t* nbt;
-    float *save_mean, *save_rstd, *scale, *shift;
-};
-struct BnFinBwd {
-    const float* partial;
-    int blocks, C;
-    double count;
-    float *dgamma, *dbeta, *coef;
-};
 int bn_finalize_train_pair(const BnFinTrain& a, const BnFinTrain& b, float eps, float momentum, hipStream_t st);
 int bn_bwd_apply2(int dtype, const void* g, const void* yA, const float* meanA, const float* rstdA, const float* gammaA,
                   const float* coefA, void* dyA, const void* yB, const float* meanB, const float* rstdB, const float* gammaB,
@@ -79,9 +83,15 @@ int bn_act(int dtype, const void* y, const float* scale, const float* shift, con
 int bn_bwd_blocks(size_t M, int C);
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
+// (fws != nullptr: the finalize of bn2 -- and of the downsample BatchNorm -- is folded into the launch, fold.h; the
+// partial / blocks fields of fin2 / find are ignored)
 int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                      const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
-                     float* partiald, size_t M, int C, hipStream_t st);
+                     float* partiald, size_t M, int C, hipStream_t st, const FoldWs* fws = nullptr,
+                     const BnFinBwd* fin2 = nullptr, const BnFinBwd* find = nullptr);
+int bn_bwd_reduce_fold(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, int relu_mask, float* partial, size_t M, int C, double count, float* dgamma,
+                       float* dbeta, float* coef, const FoldWs& fws, hipStream_t st);
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                     hipStream_t st);
 int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
@@ -89,8 +99,11 @@ int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, co
                  hipStream_t st);
 int relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, hipStream_t st);
 // pool.hip
-int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
-                        int H, int W, int C, hipStream_t st);
+int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ymax,
+                        int N, int H, int W, int C, hipStream_t st);
+int maxpool_bn_bwd_apply(int dtype, const void* dout, const uint8_t* idx, const void* y0, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* gamma, const float* coef, void* dy, int N, int H,
+                         int W, int C, hipStream_t st);
 int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, hipStream_t st);
 int avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int C, hipStream_t st);
 int avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, int C, hipStream_t st);

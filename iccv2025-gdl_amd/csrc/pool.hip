@@ -11,11 +11,14 @@ namespace gdl {
 // out[n,p,q,c] = max_{window} relu(y*scale+shift); idx = first maximum in row-major window
 // order (ATen's CPU kernel updates on strict '>'); windows never are empty (pad 1 < kernel 3).
 // One thread = one 16-byte channel vector of one output pixel.
-template <typename T>
+// YMAX: also store the RAW (pre-BatchNorm) value at the chosen position, ymax[n,p,q,c] = y[argmax]: with it the stem's
+// BatchNorm-backward reduction runs over pooled-size tensors (sum_pos g0*xhat = sum_windows dout*xhat(ymax), see
+// maxpool_bn_bwd_apply_kernel) instead of over the stem output, the largest activation of the network.
+template <typename T, bool YMAX>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, T* __restrict__ out,
-                                                              uint8_t* __restrict__ idx, int N, int H, int W, int C, int P,
-                                                              int Q) {
+                                                              uint8_t* __restrict__ idx, T* __restrict__ ymax, int N, int H,
+                                                              int W, int C, int P, int Q) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
     // a block walks whole output rows (n,p): one 32-bit division per row instead of three 64-bit ones per element
@@ -34,12 +37,17 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
             sf[4 * q4 + 0] = b.x, sf[4 * q4 + 1] = b.y, sf[4 * q4 + 2] = b.z, sf[4 * q4 + 3] = b.w;
         }
         if constexpr (sizeof(T) == 2) {
-            // bf16: a rounded non-negative value has 16 zero low bits, so (bits | 15 - code) is ONE unsigned key whose
-            // maximum is the largest value and, among equal values, the first window position: a v_max_u32 per
-            // candidate instead of compare + two selects, and the rounding is one v_cvt_pk_bf16_f32 per pair.
+            // bf16 storage: the candidates are compared as fp32 (as the reference compares them) through ONE unsigned
+            // key per candidate -- a non-negative float orders like its bit pattern, and its 4 lowest mantissa bits
+            // carry 15 - code, so that among equal values the first window position wins (values closer than 16 fp32
+            // ulps count as equal).  The winner's raw input rides along for YMAX.
             uint32_t key[EPC];
+            float ym[EPC];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) key[e] = 0u;
+            for (int e = 0; e < EPC; ++e) {
+                key[e] = 0u;
+                ym[e] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int ih = p * 2 - 1 + r;
@@ -52,26 +60,29 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                     unpack16<T>(*(const uint4*)(y + (((size_t)n * H + ih) * W + iw) * C + vc * EPC), f);
                     const uint32_t tag = 15u - (uint32_t)(r * 3 + s);
 #pragma unroll
-                    for (int e = 0; e < EPC; e += 2) {
-                        float v0 = f[e] * sc[e] + sf[e], v1 = f[e + 1] * sc[e + 1] + sf[e + 1];
-                        v0 = v0 > 0.f ? v0 : 0.f;  // (+0 also for -0 and NaN: the key compare is unsigned)
-                        v1 = v1 > 0.f ? v1 : 0.f;
-                        const uint32_t u = pack2bf(v0, v1);
-                        key[e] = max(key[e], (u << 16) | tag);
-                        key[e + 1] = max(key[e + 1], (u & 0xffff0000u) | tag);
+                    for (int e = 0; e < EPC; ++e) {
+                        float v = f[e] * sc[e] + sf[e];
+                        v = v > 0.f ? v : 0.f;  // (+0 also for -0 and NaN: the key compare is unsigned)
+                        const uint32_t k = (__float_as_uint(v) & 0xfffffff0u) | tag;
+                        const bool gt = k > key[e];
+                        key[e] = gt ? k : key[e];
+                        if constexpr (YMAX) ym[e] = gt ? f[e] : ym[e];
                     }
                 }
             }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                best[e] = __uint_as_float(key[e] & 0xffff0000u);
+                best[e] = __uint_as_float(key[e] & 0xfffffff0u);
                 bi[e] = 15 - (int)(key[e] & 15u);
             }
+            if constexpr (YMAX) *(uint4*)(ymax + i * EPC) = pack16<T>(ym);
         } else {
+        float ym[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             best[e] = -INFINITY;
             bi[e] = -1;
+            ym[e] = 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -90,10 +101,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                     if (v > best[e] || bi[e] < 0) {
                         best[e] = v;
                         bi[e] = r * 3 + s;
+                        ym[e] = f[e];
                     }
                 }
             }
         }
+        if constexpr (YMAX) *(uint4*)(ymax + i * EPC) = pack16<T>(ym);
         }
         *(uint4*)(out + i * EPC) = pack16<T>(best);
         uint8_t* ip = idx + i * EPC;
@@ -107,21 +120,31 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
       }
     }
 }
-int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int N,
-                        int H, int W, int C, hipStream_t st) {
+int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ymax,
+                        int N, int H, int W, int C, hipStream_t st) {
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     GDL_REQUIRE(C % epc == 0, "maxpool: C=%d", C);
     const size_t total = (size_t)N * P * Q * (C / epc);
     const int grid = N * P > 8192 ? 8192 : N * P;
     // read the stem output once, write pooled values + 1-byte indices
-    ProfScope prof(dtype == GDL_BF16 ? "gdl::bn_relu_maxpool_kernel<gdl::bf16>" : "gdl::bn_relu_maxpool_kernel<float>", PROF_HBM, st, (double)N * H * W * C * (16.0 / epc) + (double)total * (16.0 + epc));
-    if (dtype == GDL_BF16)
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, scale, shift,
-                           (bf16*)out, idx, N, H, W, C, P, Q);
-    else
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, scale, shift,
-                           (float*)out, idx, N, H, W, C, P, Q);
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::bn_relu_maxpool_kernel<gdl::bf16>" : "gdl::bn_relu_maxpool_kernel<float>", PROF_HBM, st,
+                   (double)N * H * W * C * (16.0 / epc) + (double)total * ((ymax ? 32.0 : 16.0) + epc));
+#define GDL_POOL_LAUNCH(TT_, YM)                                                                                         \
+    hipLaunchKernelGGL((bn_relu_maxpool_kernel<TT_, YM>), dim3(grid), dim3(256), 0, st, (const TT_*)y, scale, shift, \
+                       (TT_*)out, idx, (TT_*)ymax, N, H, W, C, P, Q)
+    if (dtype == GDL_BF16) {
+        if (ymax)
+            GDL_POOL_LAUNCH(bf16, true);
+        else
+            GDL_POOL_LAUNCH(bf16, false);
+    } else {
+        if (ymax)
+            GDL_POOL_LAUNCH(float, true);
+        else
+            GDL_POOL_LAUNCH(float, false);
+    }
+#undef GDL_POOL_LAUNCH
     GDL_CHECK_LAUNCH("bn_relu_maxpool_kernel");
     return GDL_OK;
 }
@@ -269,6 +292,132 @@ int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N
         hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, idx, (float*)dx, N,
                            H, W, C, P, Q);
     GDL_CHECK_LAUNCH("maxpool_bwd_kernel");
+    return GDL_OK;
+}
+
+// Stem backward, max-pool gather + ReLU mask + BatchNorm-backward apply in one pass (maxpool_bwd + bn_bwd_apply<MASK>):
+//   g0[pos]  = sum of dout over the windows whose idx names pos            (never stored: the stem output is the largest
+//   dy0[pos] = gamma*rstd*( (bn(y0[pos]) > 0 ? g0[pos] : 0) - coef0 - xhat(y0[pos])*coef1 )           activation)
+// One thread per 2x2 patch of stem-output pixels and 16-byte channel vector, as maxpool_bwd_patch_kernel.  The two
+// reductions behind coef come from the pooled tensors: sum_pos g0' = sum_windows dout',  sum_pos g0'*xhat(y0[pos]) =
+// sum_windows dout'*xhat(ymax)  with  dout' = dout*(bn(ymax) > 0)  -- i.e. bn_bwd_reduce<MASK> over (dout, ymax).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ idx,
+                                                                   const T* __restrict__ y0, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ coef, T* __restrict__ dy, int N,
+                                                                   int H, int W, int C, int P, int Q) {
+    constexpr int EPC = TT<T>::EPC;
+    const int cpr = C / EPC;
+    const int PH = (H + 1) >> 1, QW = (W + 1) >> 1;
+    const int rows = N * PH, per_row = QW * cpr;  // a block walks whole patch rows (n, p)
+    // blockDim % cpr == 0: the thread's channel vector is the same for every patch it visits
+    const int vc = threadIdx.x % cpr;
+    // dy = gamma*rstd*(g' - k1 - (y - mean)*rstd*k2) = A*g' + Bc*y + D   (three constants per channel instead of five)
+    float sc[EPC], sf[EPC], A[EPC], Bc[EPC], D[EPC];
+    {
+        float mu[EPC], rs[EPC], gr[EPC], k1[EPC], k2[EPC];
+#pragma unroll
+        for (int q4 = 0; q4 < EPC / 4; ++q4) {
+            auto ld = [&](const float* p, float* v) {
+                const float4 t = *(const float4*)(p + vc * EPC + 4 * q4);
+                v[4 * q4 + 0] = t.x, v[4 * q4 + 1] = t.y, v[4 * q4 + 2] = t.z, v[4 * q4 + 3] = t.w;
+            };
+            ld(scale, sc), ld(shift, sf), ld(mean, mu), ld(rstd, rs), ld(gamma, gr), ld(coef, k1), ld(coef + C, k2);
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            A[e] = gr[e] * rs[e];
+            Bc[e] = -A[e] * rs[e] * k2[e];
+            D[e] = -A[e] * k1[e] - Bc[e] * mu[e];
+        }
+    }
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / PH, p = row - n * PH;
+        for (int jj = threadIdx.x; jj < per_row; jj += blockDim.x) {
+            const int q = jj / cpr;
+            const int h = 2 * p, w = 2 * q;
+            const bool w1 = w + 1 < W, h1 = h + 1 < H;
+            const size_t o00 = (((size_t)n * H + h) * W + w) * C + vc * EPC;
+            // the four y0 vectors of the patch are requested before the windows are decoded
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            const uint4 y00 = *(const uint4*)(y0 + o00);
+            const uint4 y01 = w1 ? *(const uint4*)(y0 + o00 + C) : z;
+            const uint4 y10 = h1 ? *(const uint4*)(y0 + o00 + (size_t)W * C) : z;
+            const uint4 y11 = (h1 && w1) ? *(const uint4*)(y0 + o00 + (size_t)W * C + C) : z;
+            float a00[EPC], a01[EPC], a10[EPC], a11[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) a00[e] = a01[e] = a10[e] = a11[e] = 0.f;
+            auto window = [&](int pp, int qq, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
+                if (pp >= P || qq >= Q) return;
+                const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
+                float d[EPC];
+                unpack16<T>(*(const uint4*)(dout + o), d);
+                uint32_t ix[EPC];
+                if (EPC == 8) {
+                    const uint2 u = *(const uint2*)(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ix[e] = (u.x >> (8 * e)) & 0xff;
+                        ix[(4 + e) % EPC] = (u.y >> (8 * e)) & 0xff;
+                    }
+                } else {
+                    const uint32_t u = *(const uint32_t*)(idx + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ix[e] = (u >> (8 * e)) & 0xff;
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    if (c00 >= 0 && ix[e] == (uint32_t)c00) a00[e] += d[e];
+                    if (c01 >= 0 && ix[e] == (uint32_t)c01) a01[e] += d[e];
+                    if (c10 >= 0 && ix[e] == (uint32_t)c10) a10[e] += d[e];
+                    if (c11 >= 0 && ix[e] == (uint32_t)c11) a11[e] += d[e];
+                }
+            };
+            window(p, q, 4, 5, 7, 8);
+            window(p, q + 1, -1, 3, -1, 6);
+            window(p + 1, q, -1, -1, 1, 2);
+            window(p + 1, q + 1, -1, -1, -1, 0);
+            auto apply = [&](const uint4& yq, float (&g)[EPC]) __attribute__((always_inline)) {
+                float yv[EPC];
+                unpack16<T>(yq, yv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float gg = (yv[e] * sc[e] + sf[e] > 0.f) ? g[e] : 0.f;
+                    g[e] = A[e] * gg + (Bc[e] * yv[e] + D[e]);
+                }
+                return pack16<T>(g);
+            };
+            T* d0 = dy + o00;
+            *(uint4*)d0 = apply(y00, a00);
+            if (w1) *(uint4*)(d0 + C) = apply(y01, a01);
+            if (h1) {
+                T* d1 = d0 + (size_t)W * C;
+                *(uint4*)d1 = apply(y10, a10);
+                if (w1) *(uint4*)(d1 + C) = apply(y11, a11);
+            }
+        }
+    }
+}
+int maxpool_bn_bwd_apply(int dtype, const void* dout, const uint8_t* idx, const void* y0, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, const float* gamma, const float* coef, void* dy, int N, int H,
+                         int W, int C, hipStream_t st) {
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+    const int epc = dtype == GDL_BF16 ? 8 : 4;
+    GDL_REQUIRE(C % epc == 0 && 256 % (C / epc) == 0, "maxpool_bn_bwd_apply: C=%d", C);
+    const size_t total = (size_t)N * H * W * (C / epc);
+    const int prow = N * ((H + 1) / 2), pgrid = prow > 16384 ? 16384 : prow;
+    // read y0 + the pooled gradient and indices, write dy0
+    ProfScope prof(dtype == GDL_BF16 ? "gdl::maxpool_bn_bwd_apply_kernel<gdl::bf16>" : "gdl::maxpool_bn_bwd_apply_kernel<float>",
+                   PROF_HBM, st, (double)total * 32.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
+    if (dtype == GDL_BF16)
+        hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel<bf16>, dim3(pgrid), dim3(256), 0, st, (const bf16*)dout, idx, (const bf16*)y0,
+                           scale, shift, mean, rstd, gamma, coef, (bf16*)dy, N, H, W, C, P, Q);
+    else
+        hipLaunchKernelGGL(maxpool_bn_bwd_apply_kernel<float>, dim3(pgrid), dim3(256), 0, st, (const float*)dout, idx,
+                           (const float*)y0, scale, shift, mean, rstd, gamma, coef, (float*)dy, N, H, W, C, P, Q);
+    GDL_CHECK_LAUNCH("maxpool_bn_bwd_apply_kernel");
     return GDL_OK;
 }
 

@@ -27,6 +27,10 @@ SIGNATURES = {
     "gdl_conv_build_table": ("i", "ii" + "iiiiiiiii" + "pp"),
     "gdl_conv_fwd": ("i", "ippppp" + "iiiiiiiii" + "p"),
     "gdl_conv_dgrad": ("i", "ippppp" + "iiiiiiiii" + "p"),
+    "gdl_fold_workspace_bytes": ("z", ""),
+    "gdl_fold_workspace_init": ("i", "pzp"),
+    "gdl_conv_fwd_bn": ("i", "ippppp" + "iiiiiiiii" + "ppppp" + "pppp" + "pp"),
+    "gdl_bn_bwd_reduce_fin": ("i", "ipppppp" + "i" + "p" + "zi" + "d" + "ppp" + "pp"),
     "gdl_conv_wgrad_workspace_bytes": ("z", "iiiiiiiiii"),
     "gdl_conv_wgrad": ("i", "ipppp" + "iiiiiiiii" + "pzp"),
     "gdl_pack_weight": ("i", "ippp" + "iiii" + "p"),
@@ -56,7 +60,8 @@ SIGNATURES = {
     "gdl_bn_bwd_finalize": ("i", "pii" + "d" + "ppp" + "p"),
     "gdl_bn_bwd_apply": ("i", "ipppppppp" + "i" + "p" + "zi" + "p"),
     "gdl_relu_bwd": ("i", "ipppzp"),
-    "gdl_bn_relu_maxpool_fwd": ("i", "ippppp" + "iiii" + "p"),
+    "gdl_bn_relu_maxpool_fwd": ("i", "ipppppp" + "iiii" + "p"),
+    "gdl_maxpool_bn_bwd_apply": ("i", "ippppppppp" + "p" + "iiii" + "p"),
     "gdl_maxpool_bwd": ("i", "ippp" + "iiii" + "p"),
     "gdl_avgpool_fwd": ("i", "ipp" + "iiii" + "p"),
     "gdl_avgpool_bwd": ("i", "ipp" + "iiii" + "p"),

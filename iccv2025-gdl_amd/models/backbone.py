@@ -72,10 +72,13 @@ class _ResNetFn(torch.autograd.Function):
         ctx.serial = eng.serial
         ctx.pshapes = [p.shape for p in params]
         ctx.pdev = params[0].device
+        ctx.set_materialize_grads(False)  # an undefined upstream gradient (the fusion head returned None) costs nothing
         return feat if want == "feat" else fmap
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return (None, None, None) + (None,) * len(ctx.pshapes)
         eng = ctx.eng
         if not ctx.training:
             raise RuntimeError("gdl: backward through an eval-mode encoder forward is not supported")

@@ -26,6 +26,10 @@ class _ConcatDGLFn(torch.autograd.Function):
         L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B,
                n, L.cur_stream())
         ctx.save_for_backward(x, y, W)
+        # undefined upstream gradients stay None (not zero tensors): the reference's second backward,
+        # loss_f.backward() (main_dgl.py:122), reaches this node through `output` only, which was computed from
+        # detached features -- returning None for dx / dy then keeps autograd from re-running both encoder backwards
+        ctx.set_materialize_grads(False)
         return x_out, y_out, out
 
     @staticmethod
@@ -35,7 +39,10 @@ class _ConcatDGLFn(torch.autograd.Function):
         gx = _f32c(g_x_out) if g_x_out is not None else None
         gy = _f32c(g_y_out) if g_y_out is not None else None
         go = _f32c(g_out) if g_out is not None else None
-        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        if gx is None and gy is None and go is None:
+            return None, None, None, None
+        to_feat = gx is not None or gy is not None
+        dx, dy = (torch.empty_like(x), torch.empty_like(y)) if to_feat else (None, None)
         dW, db = torch.empty_like(W), torch.empty(n, device=x.device)
         # `output` was computed from cat(x, y).detach() (fusion_modules.py:53-56): it never reaches x / y
         L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 1, L.ptr(dx),
@@ -77,6 +84,7 @@ class _SumDGLFn(torch.autograd.Function):
         L.call("gdl_head_sum_fwd", L.ptr(x), L.ptr(y), L.ptr(Wx), L.ptr(bx), L.ptr(Wy), L.ptr(by), L.ptr(out), L.ptr(x_out),
                L.ptr(y_out), B, n, L.cur_stream())
         ctx.save_for_backward(x, y, Wx, Wy)
+        ctx.set_materialize_grads(False)  # see _ConcatDGLFn
         return x_out, y_out, out
 
     @staticmethod
@@ -86,7 +94,10 @@ class _SumDGLFn(torch.autograd.Function):
         gx = _f32c(g_x_out) if g_x_out is not None else None
         gy = _f32c(g_y_out) if g_y_out is not None else None
         go = _f32c(g_out) if g_out is not None else None
-        dx, dy = torch.empty_like(x), torch.empty_like(y)
+        if gx is None and gy is None and go is None:
+            return None, None, None, None, None, None
+        to_feat = gx is not None or gy is not None
+        dx, dy = (torch.empty_like(x), torch.empty_like(y)) if to_feat else (None, None)
         dWx, dWy = torch.empty_like(Wx), torch.empty_like(Wy)
         dbx, dby = torch.empty(n, device=x.device), torch.empty(n, device=x.device)
         # `output` was computed from x.detach() / y.detach() (fusion_modules.py:27-29): it never reaches x / y
@@ -120,6 +131,7 @@ class _GatedDGLFn(torch.autograd.Function):
         L.call("gdl_head_gated_fwd", L.ptr(x), L.ptr(y), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2), L.ptr(Wo), L.ptr(bo),
                L.ptr(hx), L.ptr(hy), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B, n, L.cur_stream())
         ctx.save_for_backward(x, y, hx, hy, W1, W2, Wo)
+        ctx.set_materialize_grads(False)  # see _ConcatDGLFn
         return x_out, y_out, out
 
     @staticmethod
@@ -129,6 +141,8 @@ class _GatedDGLFn(torch.autograd.Function):
         gx = _f32c(g_x_out) if g_x_out is not None else None
         gy = _f32c(g_y_out) if g_y_out is not None else None
         go = _f32c(g_out) if g_out is not None else None
+        if gx is None and gy is None and go is None:
+            return (None,) * 8
         dx, dy = torch.empty_like(x), torch.empty_like(y)
         dW1, dW2, dWo = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wo)
         db1, db2, dbo = torch.empty(512, device=x.device), torch.empty(512, device=x.device), torch.empty(n, device=x.device)
@@ -178,6 +192,7 @@ class _FiLMDGLFn(torch.autograd.Function):
         L.call("gdl_head_film_fwd", L.ptr(x), L.ptr(y), L.ptr(Wfc), L.ptr(bfc), L.ptr(Wo), L.ptr(bo), L.ptr(hidden), L.ptr(out),
                L.ptr(x_out), L.ptr(y_out), B, n, L.ptr(ws), nb, L.cur_stream())
         ctx.save_for_backward(x, y, Wfc, Wo, hidden, ws)
+        ctx.set_materialize_grads(False)  # see _ConcatDGLFn
         return x_out, y_out, out
 
     @staticmethod
@@ -187,6 +202,8 @@ class _FiLMDGLFn(torch.autograd.Function):
         gx = _f32c(g_x_out) if g_x_out is not None else None
         gy = _f32c(g_y_out) if g_y_out is not None else None
         go = _f32c(g_out) if g_out is not None else None
+        if gx is None and gy is None and go is None:
+            return (None,) * 6
         uni_only_out = gx is None and gy is None  # `output` alone never reaches x / y (detached, fusion_modules.py:150-158)
         dx = None if uni_only_out else torch.empty_like(x)
         dy = None if uni_only_out else torch.empty_like(y)

@@ -69,6 +69,23 @@ GDL_API int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, 
 GDL_API int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
                            const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                            void* stream);
+/* In-launch BatchNorm finalize ("the last block folds"): the kernel that produces the per-block partial sums also
+ * reduces them -- the block that completes them, found by an arrival ticket, folds them in a fixed order and runs
+ * the finalize arithmetic -- so no separate finalize launch sits on the chain (backbone.py:45-48,104: conv -> bn).
+ * `fold_ws`: gdl_fold_workspace_bytes() bytes, prepared ONCE with gdl_fold_workspace_init and then owned by one
+ * stream (the launches that use it must be ordered).  Results are bit-identical from run to run.
+ * gdl_conv_fwd_bn = gdl_conv_fwd(bn_partial) + gdl_bn_finalize_train(count = N*P*Q, eps 1e-5, momentum 0.1);
+ * gdl_bn_bwd_reduce_fin = gdl_bn_bwd_reduce + gdl_bn_bwd_finalize(count). */
+GDL_API size_t gdl_fold_workspace_bytes(void);
+GDL_API int gdl_fold_workspace_init(void* fold_ws, size_t bytes, void* stream);
+GDL_API int gdl_conv_fwd_bn(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table,
+                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            float* save_mean, float* save_rstd, float* scale, float* shift, void* fold_ws, void* stream);
+GDL_API int gdl_bn_bwd_reduce_fin(int dtype, const void* g, const void* y, const float* scale, const float* shift,
+                                  const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M,
+                                  int C, double count, float* dgamma, float* dbeta, float* coef, void* fold_ws,
+                                  void* stream);
 GDL_API size_t gdl_conv_wgrad_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
                                               int pad);
 GDL_API int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw_kcrs, const void* table, int N, int H,
@@ -168,12 +185,23 @@ GDL_API int gdl_relu_bwd(int dtype, const void* dy, const void* out, void* dx, s
  * nn.MaxPool2d(3,2,1): backbone.py:106, fused with the stem's BN+ReLU:
  *   out[n,p,q,c] = max over the window of relu(y*scale+shift); idx (uint8, 0..8)
  *   records the first maximum in row-major window order.
+ *   ymax (optional, may be NULL) receives the RAW y at that position.
  * gdl_maxpool_bwd gathers: dx[n,h,w,c] = sum of dout over windows whose idx
  *   points at (h,w).
+ * gdl_maxpool_bn_bwd_apply: the stem's backward (backbone.py:104-106 reversed) in one
+ *   pass, without storing the gathered gradient g0 = maxpool_bwd(dout):
+ *     dy[pos] = gamma*rstd*( (y*scale+shift > 0 ? g0 : 0) - coef0 - xhat(y)*coef1 );
+ *   coef comes from gdl_bn_bwd_reduce(relu_mask=1) over the POOLED pair (dout, ymax)
+ *   [sum_pos g0'*xhat(y[pos]) == sum_windows dout'*xhat(ymax)] and gdl_bn_bwd_finalize
+ *   with count = N*H*W (the stem-output pixel count).
  * Global average pools of basic_model.py:73-82: x [B*T][HW][C] dtype -> feat
  *   [B][C] float32 (mean over T*HW); backward broadcasts dfeat/(T*HW). */
 GDL_API int gdl_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out,
-                                    uint8_t* idx, int N, int H, int W, int C, void* stream);
+                                    uint8_t* idx, void* ymax, int N, int H, int W, int C, void* stream);
+GDL_API int gdl_maxpool_bn_bwd_apply(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* scale,
+                                     const float* shift, const float* save_mean, const float* save_rstd,
+                                     const float* gamma, const float* coef, void* dy, int N, int H, int W, int C,
+                                     void* stream);
 GDL_API int gdl_maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C,
                             void* stream);
 GDL_API int gdl_avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int C, void* stream);

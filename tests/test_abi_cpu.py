@@ -88,7 +88,7 @@ def test_engine_plans_without_gpu_and_reports_errors():
     L.call("gdl_encoder_create", ctypes.byref(big), L.GDL_VISUAL, L.dtype_code("bf16"), 64, 3, 224, 224)
     small_ws = ws
     try:
-        assert lib.gdl_encoder_workspace_bytes(big) > 16 * small_ws  # sized for the real batch
+        assert lib.gdl_encoder_workspace_bytes(big) > 12 * small_ws  # sized for the real batch (32x the samples; tables and fold rows are fixed)
     finally:
         lib.gdl_encoder_destroy(big)
 

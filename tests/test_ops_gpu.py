@@ -301,10 +301,23 @@ def test_maxpool(N, H, W, dt):
     ix = torch.empty((N, P, Q, C), dtype=torch.uint8, device=DEV)
     st = L.cur_stream()
     scd, shd = dev(sc), dev(sh)  # keep alive: the caching allocator reuses freed temporaries at once
-    L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(out), L.ptr(ix), N, H, W, C, st)
+    ym = empty((N, P, Q, C), dt)
+    L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(out), L.ptr(ix), L.ptr(ym), N, H, W, C, st)
     torch.cuda.synchronize()
     got = from_nhwc(out)
     np.testing.assert_allclose(got, pref, rtol=tol(dt, 1e-5, 1e-2), atol=tol(dt, 1e-6, 1e-2))
+    # ymax = the raw y at the position the DEVICE chose (bit-exact gather)
+    code = ix.cpu().numpy().astype(np.int64)  # [N,P,Q,C], r*3+s
+    pp, qq = np.meshgrid(np.arange(P), np.arange(Q), indexing="ij")
+    ih = np.clip(2 * pp[None, :, :, None] - 1 + code // 3, 0, H - 1)
+    iw = np.clip(2 * qq[None, :, :, None] - 1 + code % 3, 0, W - 1)
+    y_nhwc = np.transpose(y, (0, 2, 3, 1))
+    want = y_nhwc[np.arange(N)[:, None, None, None], ih, iw, np.arange(C)[None, None, None, :]]
+    np.testing.assert_array_equal(np.transpose(from_nhwc(ym), (0, 2, 3, 1)), want)
+    out2, ix2 = empty((N, P, Q, C), dt), torch.empty_like(ix)  # without ymax: same values and indices
+    L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(out2), L.ptr(ix2), None, N, H, W, C, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out) and torch.equal(ix2, ix)
     dout = quant(rng.standard_normal((N, C, P, Q), dtype=np.float32), dt)
     # reference backward with the argmax recomputed from the DEVICE output's own choice is not
     # available; where `a` has no exact ties inside a window both agree, so compare sums per
@@ -322,6 +335,66 @@ def test_maxpool(N, H, W, dt):
     else:  # bf16 ties between positive neighbours may route differently; totals must still agree
         np.testing.assert_allclose(gotb.sum((2, 3)), quant(dref, dt).sum((2, 3)), rtol=5e-2, atol=0.3)
         assert relerr(gotb * mask, dref * mask) < 0.15
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("N,H,W", [(2, 33, 24), (3, 16, 16), (1, 7, 9)])
+def test_stem_pool_bn_backward(N, H, W, dt):
+    """The stem's backward without the gathered gradient: bn_bwd_reduce over the pooled (dout, ymax), finalize with
+    the stem-output count, maxpool_bn_bwd_apply -- against maxpool_bwd -> relu_bwd -> bn_bwd of the oracle
+    (/root/reference/models/backbone.py:104-106 differentiated)."""
+    C = 64
+    y = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    gamma[::7] *= -1
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    rm, rv = np.zeros(C, np.float32), np.ones(C, np.float32)
+    yref, mean, invstd = orc.bn_fwd_train(y, gamma, beta, rm, rv)
+    sc = (gamma * invstd).astype(np.float32)
+    sh = (beta - mean * gamma * invstd).astype(np.float32)
+    a = quant(np.maximum(y * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32), dt)
+    pref, idx = orc.maxpool_fwd(a)
+    P, Q = pref.shape[2], pref.shape[3]
+    dout = quant(rng.standard_normal((N, C, P, Q), dtype=np.float32), dt)
+    d_a = orc.maxpool_bwd(dout, idx, a.shape)
+    dyref, dgref, dbref = orc.bn_bwd(orc.relu_bwd(d_a, a), y, gamma, mean, invstd)
+    lib = L.load()
+    st = L.cur_stream()
+    yd, doutd = to_nhwc(y, dt), to_nhwc(dout, dt)
+    scd, shd, smd, srd, gd = dev(sc), dev(sh), dev(mean.astype(np.float32)), dev(invstd.astype(np.float32)), dev(gamma)
+    out, ym = empty((N, P, Q, C), dt), empty((N, P, Q, C), dt)
+    ix = torch.empty((N, P, Q, C), dtype=torch.uint8, device=DEV)
+    L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(out), L.ptr(ix), L.ptr(ym), N, H, W, C, st)
+    Mp, M = N * P * Q, N * H * W
+    blocks = lib.gdl_bn_bwd_blocks(Mp, C)
+    bpart = torch.empty((blocks, C, 2), device=DEV)
+    dg, db, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)
+    L.call("gdl_bn_bwd_reduce", dt, L.ptr(doutd), L.ptr(ym), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd), 1, L.ptr(bpart),
+           Mp, C, st)
+    L.call("gdl_bn_bwd_finalize", L.ptr(bpart), blocks, C, float(M), L.ptr(dg), L.ptr(db), L.ptr(coef), st)
+    dyd = empty((N, H, W, C), dt)
+    L.call("gdl_maxpool_bn_bwd_apply", dt, L.ptr(doutd), L.ptr(ix), L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd),
+           L.ptr(gd), L.ptr(coef), L.ptr(dyd), N, H, W, C, st)
+    torch.cuda.synchronize()
+    # (bf16: ties between equal rounded neighbours may route to another position than the oracle's first maximum)
+    assert relerr(dg.cpu().numpy(), dgref) < tol(dt, 1e-4, 2e-2)
+    assert relerr(db.cpu().numpy(), dbref) < tol(dt, 1e-4, 2e-2)
+    assert relerr(from_nhwc(dyd), dyref) < tol(dt, 1e-4, 0.15)
+    # and against the unfused device kernels fed by the same device indices: gather -> reduce -> finalize -> apply
+    g0 = empty((N, H, W, C), dt)
+    L.call("gdl_maxpool_bwd", dt, L.ptr(doutd), L.ptr(ix), L.ptr(g0), N, H, W, C, st)
+    b2 = lib.gdl_bn_bwd_blocks(M, C)
+    bp2 = torch.empty((b2, C, 2), device=DEV)
+    dg2, db2, coef2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)
+    L.call("gdl_bn_bwd_reduce", dt, L.ptr(g0), L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd), 1, L.ptr(bp2), M, C, st)
+    L.call("gdl_bn_bwd_finalize", L.ptr(bp2), b2, C, float(M), L.ptr(dg2), L.ptr(db2), L.ptr(coef2), st)
+    dy2 = empty((N, H, W, C), dt)
+    L.call("gdl_bn_bwd_apply", dt, L.ptr(g0), L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd), L.ptr(gd), L.ptr(coef2),
+           1, L.ptr(dy2), M, C, st)
+    torch.cuda.synchronize()
+    assert relerr(dg.cpu().numpy(), dg2.cpu().numpy()) < tol(dt, 1e-5, 5e-3)
+    assert relerr(db.cpu().numpy(), db2.cpu().numpy()) < tol(dt, 1e-5, 5e-3)
+    assert relerr(from_nhwc(dyd), from_nhwc(dy2)) < tol(dt, 1e-5, 6e-3)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -355,6 +428,118 @@ def test_layout_roundtrip():
         torch.cuda.synchronize()
         np.testing.assert_array_equal(back.cpu().numpy(), x)
         np.testing.assert_array_equal(from_nhwc(t), x)
+
+
+def _fold_ws():
+    lib = L.load()
+    nb = lib.gdl_fold_workspace_bytes()
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV).random_()  # garbage everywhere but the counters
+    L.call("gdl_fold_workspace_init", L.ptr(ws), nb, L.cur_stream())
+    return ws
+
+
+FOLD_CONV = [
+    # N, C, H, W, K, R, stride, pad -- rows (M-tiles) x column groups of the fold
+    (2, 64, 17, 13, 64, 3, 1, 1),      # one group, one column group
+    (24, 64, 56, 56, 64, 3, 1, 1),     # 588 rows: 10 groups, ragged last group
+    (16, 128, 28, 28, 256, 3, 1, 1),   # 128-channel tiles: two column groups
+    (16, 64, 65, 47, 128, 3, 2, 1),    # flat kernel, stride 2
+    (48, 512, 7, 7, 512, 3, 1, 1),     # few rows, four column groups
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", FOLD_CONV)
+def test_conv_fwd_bn_fold(shape, dt):
+    """gdl_conv_fwd_bn (statistics + finalize inside the convolution's launch, "the last block folds") against
+    gdl_conv_fwd + gdl_bn_finalize_train: same outputs, statistics to double-rounding, bit-identical from run to run,
+    with the consumer-visible arrays poisoned before every run (a stale or early read shows as NaN / a changed bit)."""
+    N, C, H, W, K, R, stride, pad = shape
+    lib = L.load()
+    st = L.cur_stream()
+    td = L.torch_dtype(dt)
+    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    M = N * P * Q
+    x = torch.randn(N, H, W, C, device=DEV).to(td)
+    wk = (torch.randn(K, R, R, C, device=DEV) * (2.0 / (C * R * R)) ** 0.5).to(td)
+    tab = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
+    tiles = lib.gdl_conv_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
+    gamma, beta = dev((1 + 0.1 * rng.standard_normal(K)).astype(np.float32)), dev((0.1 * rng.standard_normal(K)).astype(np.float32))
+    rm0, rv0 = (0.05 * rng.standard_normal(K)).astype(np.float32), (1 + 0.1 * np.abs(rng.standard_normal(K))).astype(np.float32)
+    # reference: the two separate launches
+    y0 = torch.empty(N, P, Q, K, device=DEV, dtype=td)
+    part0 = torch.empty(tiles, K, 2, device=DEV)
+    rm, rv, nbt = dev(rm0), dev(rv0), torch.zeros((), dtype=torch.int64, device=DEV)
+    ref = [torch.empty(K, device=DEV) for _ in range(4)]
+    L.call("gdl_conv_fwd", dt, L.ptr(x), L.ptr(wk), L.ptr(y0), L.ptr(part0), L.ptr(tab), N, H, W, C, K, R, R, stride, pad, st)
+    L.call("gdl_bn_finalize_train", L.ptr(part0), tiles, K, float(M), L.ptr(gamma), L.ptr(beta), 1e-5, 0.1, L.ptr(rm), L.ptr(rv),
+           L.ptr(nbt), L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]), L.ptr(ref[3]), st)
+    torch.cuda.synchronize()
+    ws = _fold_ws()
+    first = None
+    filler = torch.randn(1 << 22, device=DEV)
+    for rep in range(6):
+        y = torch.full((N, P, Q, K), float("nan"), device=DEV, dtype=td)
+        part = torch.full((tiles, K, 2), float("nan"), device=DEV)
+        rm2, rv2, nbt2 = dev(rm0), dev(rv0), torch.zeros((), dtype=torch.int64, device=DEV)
+        out = [torch.full((K,), float("nan"), device=DEV) for _ in range(4)]
+        filler.mul_(1.0001)  # other work between the runs
+        L.call("gdl_conv_fwd_bn", dt, L.ptr(x), L.ptr(wk), L.ptr(y), L.ptr(part), L.ptr(tab), N, H, W, C, K, R, R, stride, pad,
+               L.ptr(gamma), L.ptr(beta), L.ptr(rm2), L.ptr(rv2), L.ptr(nbt2), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]),
+               L.ptr(out[3]), L.ptr(ws), st)
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16 if dt == L.GDL_BF16 else torch.int32),
+                           y0.view(torch.int16 if dt == L.GDL_BF16 else torch.int32))
+        assert torch.equal(part, part0)
+        assert int(nbt2.item()) == 1
+        for a, b in zip(out + [rm2, rv2], ref + [rm, rv]):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=1e-7)
+        cur = [t.view(torch.int32).clone() for t in out + [rm2, rv2]]
+        if first is None:
+            first = cur
+        else:
+            for a, b in zip(cur, first):
+                assert torch.equal(a, b)
+    # the counters reset themselves: the workspace's counter area is all zero again
+    assert int(ws[: (1 + 256) * 8 * 4].view(torch.int32).abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,C", [(300, 64), (37632, 256), (602112, 64), (9408, 512)])
+def test_bn_bwd_reduce_fold(M, C, dt):
+    """gdl_bn_bwd_reduce_fin against gdl_bn_bwd_reduce + gdl_bn_bwd_finalize (one block ... 2048 blocks, C up to 512)."""
+    lib = L.load()
+    st = L.cur_stream()
+    td = L.torch_dtype(dt)
+    g = torch.randn(M, C, device=DEV).to(td)
+    y = torch.randn(M, C, device=DEV).to(td)
+    sc, sh = dev((1 + 0.1 * rng.standard_normal(C)).astype(np.float32)), dev((0.1 * rng.standard_normal(C)).astype(np.float32))
+    mu, rs = dev((0.1 * rng.standard_normal(C)).astype(np.float32)), dev((1 + 0.1 * np.abs(rng.standard_normal(C))).astype(np.float32))
+    blocks = lib.gdl_bn_bwd_blocks(M, C)
+    part0 = torch.empty(blocks, C, 2, device=DEV)
+    ref = [torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)]
+    L.call("gdl_bn_bwd_reduce", dt, L.ptr(g), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(rs), 1, L.ptr(part0), M, C, st)
+    L.call("gdl_bn_bwd_finalize", L.ptr(part0), blocks, C, float(M), L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]), st)
+    torch.cuda.synchronize()
+    ws = _fold_ws()
+    first = None
+    for rep in range(6):
+        part = torch.full((blocks, C, 2), float("nan"), device=DEV)
+        out = [torch.full((C,), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV),
+               torch.full((2 * C,), float("nan"), device=DEV)]
+        L.call("gdl_bn_bwd_reduce_fin", dt, L.ptr(g), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(rs), 1, L.ptr(part), M, C,
+               float(M), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(ws), st)
+        torch.cuda.synchronize()
+        assert torch.equal(part, part0)
+        for a, b in zip(out, ref):
+            scale = float(b.abs().max().item())
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=2e-6 * scale)
+        cur = [t.view(torch.int32).clone() for t in out]
+        if first is None:
+            first = cur
+        else:
+            for a, b in zip(cur, first):
+                assert torch.equal(a, b)
 
 
 def test_conv_run_to_run_determinism():

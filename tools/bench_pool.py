@@ -37,8 +37,16 @@ for name, N, H, W in (("visual", 192, 112, 112), ("audio", 64, 129, 94)):
     idx = torch.empty(N, P, Q, C, device=dev, dtype=torch.uint8)
     dout = torch.randn(N, P, Q, C, device=dev).bfloat16()
     dx = torch.empty(N, H, W, C, device=dev, dtype=torch.bfloat16)
-    f = timeit(lambda: L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(out), L.ptr(idx), N, H, W, C, st))
+    ym = torch.empty_like(out)
+    mu, rs, ga, coef = torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5, torch.rand(C, device=dev) + 0.5, \
+        torch.randn(2 * C, device=dev) * 0.01
+    f = timeit(lambda: L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(out), L.ptr(idx), None, N, H, W, C, st))
+    f2 = timeit(lambda: L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(out), L.ptr(idx), L.ptr(ym), N, H, W, C, st))
     b = timeit(lambda: L.call("gdl_maxpool_bwd", dt, L.ptr(dout), L.ptr(idx), L.ptr(dx), N, H, W, C, st))
+    b2 = timeit(lambda: L.call("gdl_maxpool_bn_bwd_apply", dt, L.ptr(dout), L.ptr(idx), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mu),
+                               L.ptr(rs), L.ptr(ga), L.ptr(coef), L.ptr(dx), N, H, W, C, st))
     fb = (y.numel() * 2 + out.numel() * 3) / 1e6
     bb = (dx.numel() * 2 + out.numel() * 3) / 1e6
-    print(f"{name}: fwd {f:.1f} us ({fb:.0f} MB, {fb / f * 1e3:.0f} GB/s)   bwd {b:.1f} us ({bb:.0f} MB, {bb / b * 1e3:.0f} GB/s)")
+    print(f"{name}: fwd {f:.1f} us ({fb:.0f} MB, {fb / f * 1e3:.0f} GB/s), +ymax {f2:.1f} us   bwd {b:.1f} us ({bb:.0f} MB, "
+          f"{bb / b * 1e3:.0f} GB/s)   fused bwd+bn apply {b2:.1f} us ({bb + dx.numel() * 2 / 1e6:.0f} MB, "
+          f"{(bb + dx.numel() * 2 / 1e6) / b2 * 1e3:.0f} GB/s)")
