@@ -52,40 +52,76 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="cremad", choices=sorted(WORKLOADS),
                     help="cremad = BASELINE configs[1] (the metric's configuration); ks = configs[2] shapes; vggsound = configs[4] shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="samples in the CPU oracle step (about 10-20 s of CPU work)")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="samples in the C-port CPU step (about 10-20 s of CPU work)")
+    ap.add_argument("--cpu-torch-batch", type=int, default=8, help="samples in the PyTorch-operator CPU step (3 warm-up + 5 timed)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the short exact-f32 run behind the f32_exact field")
+    ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches resident in HBM, fed round robin")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     ap.add_argument("--no-prof", action="store_true", help="do not tap per-kernel HIP events in the timed region")
     ap.add_argument("--phases", action="store_true", help="also report forward / head / backward / optimizer phase times")
     return ap.parse_args()
 
 
-def cpu_baseline(batch, threads, wl):
-    """The CPU oracle's DGL step (kind 'port') on a bounded sample: one warm-up + one timed step."""
+def src_hash():
+    """sha256 over the kernel / engine sources the loaded library was built from: stamps PMC measurements."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "iccv2025-gdl_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "iccv2025-gdl_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "iccv2025-gdl_amd", "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(batch, torch_batch, threads, wl):
+    """The DGL step on this machine's host cores, on a bounded sample, two ways (both `kind: port` -- restatements of
+    the reference's arithmetic, never its files): the PyTorch-operator restatement (oracle/torch_step.py: ATen / oneDNN
+    kernels, what the reference itself runs on a CPU; B=8, 3 warm-up + 5 timed steps) is the
+    reported baseline, the plain-C port (oracle/gdl_oracle.c, the parity oracle; 1 warm-up + 1 timed step) rides along."""
     from oracle import fixtures as fx
     from oracle import oracle as orc
+    from oracle.torch_step import TorchStep
 
     cores = os.cpu_count() or 1
     thr = threads if threads > 0 else min(cores, 64)
-    orc.set_num_threads(thr)
     P, Bf = fx.model_state(wl["n_classes"], "concat_dgl")
+    # ---- PyTorch operators
+    torch.set_num_threads(thr)
+    spec, image, label = fx.make_batch(0, torch_batch, wl["spec"], 3, (224, 224), wl["n_classes"])
+    ts = TorchStep(P, Bf)
+    for _ in range(3):
+        ts.train_step(spec, image, label, wl["alpha"], 2e-3)
+    t0 = time.time()
+    for _ in range(5):
+        ts.train_step(spec, image, label, wl["alpha"], 2e-3)
+    dt_t = (time.time() - t0) / 5
+    del ts
+    # ---- C port
+    orc.set_num_threads(thr)
     model = orc.AVModel(P, Bf, "dgl")
     spec, image, label = fx.make_batch(0, batch, wl["spec"], 3, (224, 224), wl["n_classes"])
     t0 = time.time()
     model.train_step(spec, image, label, wl["alpha"], 2e-3)
     t1 = time.time()
     model.train_step(spec, image, label, wl["alpha"], 2e-3)
-    t2 = time.time()
-    dt = t2 - t1
-    return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": thr, "kind": "port",
-            "sample": f"oracle/ C port, {wl['dataset']} T=3 DGL step, B={batch}, fp32, 1 warm-up ({t1 - t0:.1f} s) + 1 timed "
-                      f"step ({dt:.1f} s) on {thr} of {cores} host threads"}
+    dt_c = time.time() - t1
+    c_port = {"value": round(batch / dt_c, 3), "unit": "samples/s", "cores": thr, "kind": "port",
+              "sample": f"oracle/ C port, {wl['dataset']} T=3 DGL step, B={batch}, fp32, 1 warm-up ({t1 - t0:.1f} s) + 1 timed "
+                        f"step ({dt_c:.1f} s) on {thr} of {cores} host threads"}
+    return {"value": round(torch_batch / dt_t, 3), "unit": "samples/s", "cores": thr, "kind": "port",
+            "sample": f"oracle/torch_step.py (PyTorch {torch.__version__} CPU operators), {wl['dataset']} T=3 DGL step, "
+                      f"B={torch_batch}, fp32, 3 warm-up + 5 timed steps ({dt_t:.2f} s each) on {thr} of {cores} host threads",
+            "c_port": c_port}
 
 
 def main():
@@ -136,9 +172,18 @@ def main():
     # synthetic CREMA-D batch, seed 1234 + rank, resident on the device
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B = a.batch
-    spec = torch.randn(B, *wl["spec"], generator=g).to(dev)
-    image = torch.randn(B, 3, 3, 224, 224, generator=g).to(dev)
-    label = torch.randint(0, wl["n_classes"], (B,), generator=g).to(dev)
+    # `--batches` distinct batches (resident in HBM, fed round robin): a single repeated batch is memorised within a
+    # few dozen steps, after which the losses vanish and the clip is never active
+    data = []
+    for _ in range(max(1, a.batches)):
+        data.append((torch.randn(B, *wl["spec"], generator=g).to(dev), torch.randn(B, 3, 3, 224, 224, generator=g).to(dev),
+                     torch.randint(0, wl["n_classes"], (B,), generator=g).to(dev)))
+    counter = [0]
+
+    def step():
+        spec, image, label = data[counter[0] % len(data)]
+        counter[0] += 1
+        tr.step(spec, image, label)
 
     def barrier():
         if world > 1:
@@ -171,7 +216,7 @@ def main():
         return table
 
     for _ in range(a.warmup):
-        tr.step(spec, image, label)
+        step()
     torch.cuda.synchronize()
     prof = (not a.no_prof) and rank == 0
     kernels, dominant = None, None
@@ -183,7 +228,7 @@ def main():
             lib.gdl_prof_set_filter(None)
             lib.gdl_prof_enable(1)
         for _ in range(3):
-            tr.step(spec, image, label)
+            step()
         if prof:
             lib.gdl_prof_enable(0)
             kernels = collect(3)
@@ -195,7 +240,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.step(spec, image, label)
+        step()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
@@ -212,14 +257,17 @@ def main():
         lib.gdl_prof_enable(0)
         d = [k for k in collect(a.steps) if k["kernel"] == dominant][0]
         lib.gdl_prof_set_filter(None)
-        # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes
-        # (tools/pmc_wgrad9.sh), so the committed measurement is read back here; null if it is not for this kernel
+        # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (tools/pmc_kernels.sh
+        # over this very command), so the committed measurement is read back -- but only if it was taken on the kernel
+        # sources this library was built from (hash stamp), for this workload / dtype / batch; otherwise null
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))).get(d["kernel"])
-            if pm and a.dtype == "bf16" and B == 64 and a.workload == "cremad":
-                traffic = round(pm["bytes_per_launch"])
-        except (OSError, ValueError):
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
+            k = pm.get("kernels", {}).get(d["kernel"])
+            if (k and pm.get("src_hash") == src_hash() and pm.get("dtype") == a.dtype and pm.get("batch") == B and
+                    pm.get("workload") == a.workload):
+                traffic = round(k["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
             pass
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
@@ -228,7 +276,7 @@ def main():
     if a.phases:  # (every rank runs the extra steps: they contain collectives)
         tr.phase_events = []
         for _ in range(5):
-            tr.step(spec, image, label)
+            step()
         torch.cuda.synchronize()
         ev = tr.phase_events
         tr.phase_events = None
@@ -239,6 +287,61 @@ def main():
             for k in range(4):
                 acc.setdefault(names[k] + "->" + names[k + 1], []).append(es[k].elapsed_time(es[k + 1]))
         phases = {k: round(sum(v) / len(v), 3) for k, v in acc.items()}
+    comm = None
+    if world > 1:
+        # What the collectives cost and how much of it the backward hides: each bucket's all-reduce alone, and the
+        # step with the reducer moving no data (same kernels, same events; NOT a valid training step -- timing only).
+        import torch.distributed as dist
+
+        buckets_ms = tr.reducer.time_buckets(torch.cuda.synchronize, barrier)
+        tr.reducer.enabled = False
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        nn_ = max(10, a.steps // 4)
+        for _ in range(nn_):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        t_nc = (time.perf_counter() - t0) / nn_ * 1e3
+        tr.reducer.enabled = True
+        t = torch.tensor([t_nc], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_nc = float(t.item())
+        tot = sum(buckets_ms.values())
+        exposed = max(0.0, elapsed / a.steps * 1e3 - t_nc)
+        comm = {"allreduce_alone_ms": buckets_ms, "allreduce_alone_sum_ms": round(tot, 4), "step_ms_without_comm": round(t_nc, 3),
+                "exposed_ms": round(exposed, 3), "overlapped_frac": round(1.0 - min(1.0, exposed / tot), 4) if tot > 0 else None,
+                "bucket_mbytes": {k: round((hi - lo) * 4 / 1e6, 3) for k, (lo, hi) in tr.bucket.items()}}
+    f32_exact = None
+    if a.dtype == "bf16" and not a.no_f32:
+        # the exact-parity mode (f32 storage, f32-input MFMA == an fmaf chain) on the same workload: a short run
+        del tr
+        torch.cuda.empty_cache()
+        setup_seed(0)
+        model32 = AVClassifier_DGL(args)
+        model32.apply(weight_init)
+        model32.to(dev)
+        model32.train()
+        tr32 = DGLTrainer(model32, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype="f32",
+                          process_group=pg)
+        for i in range(3):
+            tr32.step(*data[i % len(data)])
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        n32 = 10
+        for i in range(n32):
+            tr32.step(*data[i % len(data)])
+        torch.cuda.synchronize()
+        barrier()
+        dt32 = time.perf_counter() - t0
+        f32_exact = {"value": round(world * B * n32 / dt32, 2), "unit": "samples/s", "ms_per_step": round(dt32 / n32 * 1e3, 3),
+                     "steps": n32, "note": "f32 storage + f32-input MFMA (bit-for-bit an fp32 fmaf chain): the parity mode, "
+                                           "not the benchmark configuration"}
+        del tr32
     if world > 1:
         import torch.distributed as dist
 
@@ -261,10 +364,12 @@ def main():
         "mfma_frac_end_to_end": round(value / world * wl["gflop"] / 1e3 / MFMA_PEAK_TFLOPS[a.dtype], 4),
         "loss_f": round(res["loss_f"], 5), "loss_a": round(res["loss_a"], 5), "loss_v": round(res["loss_v"], 5),
         "total_norm": round(res["total_norm"], 4),
-        "roofline": roof, "kernels": kernels, "phases_ms": phases,
+        "clip_coef": round(res["clip_coef"], 4),
+        "roofline": roof, "kernels": kernels, "phases_ms": phases, "f32_exact": f32_exact, "comm": comm,
+        "batches": len(data), "src_hash": src_hash(),
     }
     if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_threads, wl)
+        out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_torch_batch, a.cpu_threads, wl)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

@@ -47,6 +47,7 @@ struct ConvArgs {
     int delta[9];
     // slab kernel only (3x3, stride 1): image width, per-tap pixel shift, source pixel count, slab rows
     int W, in_pixels, slab_rows;
+    int single_slab;  // 1: one slab buffer (the next channel chunk's slab is loaded at the chunk boundary, exposed)
     int pshift[9];
     // permuted stride-2 data gradient (gather.h): output pixel of each GEMM row (-1: padding row)
     const int* orow;
@@ -159,7 +160,7 @@ struct ConvSmem {
     static constexpr int MAIN = NSTAGE * STAGE;
     static constexpr int PITCH = BN * (int)sizeof(T) + 16;
     static constexpr int CS = BM * PITCH;
-    static constexpr int RED = 4 * BN * 2 * 4;
+    static constexpr int RED = 8 * BN * 2 * 4;  // up to 8 waves
     static constexpr int BYTES = (MAIN > CS + RED) ? MAIN : (CS + RED);
 };
 
@@ -169,6 +170,7 @@ struct ConvSmem {
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], unsigned char* smem,
                                               const ConvArgs& a, int m0, int n0, int mtile, int ntile = 0) {
+    constexpr int NT = WM * WN * 64;  // threads of the block (256 or 512)
     using SM = ConvSmem<BM, BN, T>;
     constexpr int EPC = TT<T>::EPC;
     constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -177,7 +179,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     // output row of every pass of the store loop below, fetched now so that the (permuted data
     // gradient's) row-index loads overlap the staging through LDS; -1 = nothing to store
     constexpr int CH = BN * (int)sizeof(T) / 16;  // 16-byte chunks per tile row
-    constexpr int RPI = 256 / CH;                  // rows per pass
+    constexpr int RPI = NT / CH;                   // rows per pass
     constexpr int NPASS = BM / RPI;
     const int ec = tid % CH, er0 = tid / CH;
     int om[NPASS];
@@ -252,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
                 ssq[e] += __shfl_xor(ssq[e], msk);
             }
         }
-        float* red = (float*)(smem + SM::CS);  // [4 waves][BN][2]
+        float* red = (float*)(smem + SM::CS);  // [waves][BN][2]
         if (CH >= 64 || lane < CH) {
             // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
             const int c = (lane % CH) * EPC;
@@ -265,11 +267,15 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
         __syncthreads();
         if (tid < BN * 2) {
             const int c = tid >> 1, w = tid & 1;
-            const float s = ((red[(0 * BN + c) * 2 + w] + red[(1 * BN + c) * 2 + w]) + red[(2 * BN + c) * 2 + w]) +
-                            red[(3 * BN + c) * 2 + w];
+            float s = ((red[(0 * BN + c) * 2 + w] + red[(1 * BN + c) * 2 + w]) + red[(2 * BN + c) * 2 + w]) +
+                      red[(3 * BN + c) * 2 + w];
+            if constexpr (NT == 512)
+                s += ((red[(4 * BN + c) * 2 + w] + red[(5 * BN + c) * 2 + w]) + red[(6 * BN + c) * 2 + w]) +
+                     red[(7 * BN + c) * 2 + w];
             st_agent(a.stats + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
         }
-        if (a.fold.ctr) fold_finalize(a.stats, a.mtiles, a.OC, n0, BN, mtile, ntile, a.fold, smem, a.fin);
+        if constexpr (NT == 256)  // (the fold's thread mapping is written for 256-thread blocks)
+            if (a.fold.ctr) fold_finalize(a.stats, a.mtiles, a.OC, n0, BN, mtile, ntile, a.fold, smem, a.fin);
     }
 }
 
@@ -387,7 +393,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (NST > 2 || kt + 1 < nk) load_tile(ldbuf);  // deeper rings need the constant DMA count per K-step
         const unsigned As = smem_base + buf * SM::STAGE + (wm * WTM) * 128;
         const unsigned Bs = smem_base + buf * SM::STAGE + BM * 128 + (wn * WTN) * 128;
 #pragma unroll
@@ -398,6 +403,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int m = 0; m < MI; ++m) px[m] = lds_read16_asm(As + m * 16 * 128 + off);
 #pragma unroll
             for (int n = 0; n < NI; ++n) wf[n] = lds_read16_asm(Bs + n * 16 * 128 + off);
+            if (kk == 0) {
+                // the next stage's DMA is issued while the first half's fragment reads are in flight (issuing it
+                // blocks the wave for about as long as the reads take; see the slab kernel)
+                asm volatile("" ::: "memory");
+                if (NST > 2 || kt + 1 < nk) load_tile(ldbuf);  // deeper rings need the constant DMA count per K-step
+                asm volatile("" ::: "memory");
+            }
             lds_wait();
 #pragma unroll
             for (int n = 0; n < NI; ++n)
@@ -525,14 +537,12 @@ __global__ __launch_bounds__(256) void conv_stem_rows_kernel(ConvArgs a, int P, 
 // fragments (wb + 2048*n), all through instruction offsets
 template <int MI, int NI>
 __device__ __forceinline__ void slab_reads(uint4 (&px)[MI], uint4 (&wf)[NI], const unsigned (&pb)[MI], unsigned wb) {
-    static_assert(MI == 2 || MI == 4, "MI");
+    static_assert(MI >= 2 && MI <= 4, "MI");
     static_assert(NI == 4 || NI == 8, "NI");
     px[0] = lds_read16_asm_off<0>(pb[0]);
     px[1] = lds_read16_asm_off<2048>(pb[1]);
-    if constexpr (MI == 4) {
-        px[2] = lds_read16_asm_off<4096>(pb[2]);
-        px[3] = lds_read16_asm_off<6144>(pb[3]);
-    }
+    if constexpr (MI >= 3) px[2] = lds_read16_asm_off<4096>(pb[2]);
+    if constexpr (MI == 4) px[3] = lds_read16_asm_off<6144>(pb[3]);
     wf[0] = lds_read16_asm_off<0>(wb);
     wf[1] = lds_read16_asm_off<2048>(wb);
     wf[2] = lds_read16_asm_off<4096>(wb);
@@ -545,18 +555,21 @@ __device__ __forceinline__ void slab_reads(uint4 (&px)[MI], uint4 (&wf)[NI], con
     }
 }
 
-template <typename T, int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
+// (NWV = 8 -- the same tile on 512 threads, 4 x 2 waves, four waves per SIMD with two blocks per CU -- was built and
+// measured: no faster than four waves (128 x 128 at 128 / 256 channels: 53 / 57 us forward either way; the step 6.45
+// against 6.48 ms).  Occupancy is not what bounds this kernel; the parameter stays for the record, only 4 is launched.)
+template <typename T, int BM, int BN, int MODE, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128) ? 2 : 1)) void conv3x3_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WM = 4, WN = 1;
+    constexpr int WM = 4, WN = NWV / 4;
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
-    constexpr int BROWS = BN / 32;
-    constexpr int WTM = BM / WM, MI = WTM / 16, NI = BN / 16;
+    constexpr int BROWS = BN / (8 * NWV);  // weight-tile DMA instructions per wave and K-step
+    constexpr int WTM = BM / WM, MI = WTM / 16, WTN = BN / WN, NI = WTN / 16;
     constexpr int WSTAGE = BN * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave;
+    const int wm = wave & 3, wn = wave >> 2;
     const int ntn = a.OC / BN;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int mt_per_xcd = (a.mtiles + 7) >> 3;
@@ -577,7 +590,8 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
     // zero row for masked (padding) taps: the rows of slab 0 past slab_rows (its last DMA piece is only partly
     // used; the out-of-range lanes deposit zeros) when there are any, else 1 KiB after the slabs
     const bool spare_row = (a.slab_rows & 7) != 0;
-    const unsigned zrow = spare_row ? slab_base + a.slab_rows * 128 : slab_base + (kpt > 1 ? 2 : 1) * slab_bytes;
+    const int nslab = (kpt > 1 && !a.single_slab) ? 2 : 1;
+    const unsigned zrow = spare_row ? slab_base + a.slab_rows * 128 : slab_base + nslab * slab_bytes;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
@@ -593,21 +607,21 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
         const int mm = m0 + wm * WTM + m * 16 + frow;
         fmask[m] = mm < a.M ? a.table[mm].mask : 0u;
     }
-    // weight tile DMA: lane -> row (tid>>3) + 32*i, physical chunk tid&7 (source chunk swizzled)
+    // weight tile DMA: lane -> row (tid>>3) + 8*NWV*i, physical chunk tid&7 (source chunk swizzled)
     const int row0 = tid >> 3, schunk = (tid & 7) ^ ((row0 >> 1) & 7);
     int b_off[BROWS];
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + schunk * 16;
+    for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 8 * NWV * i) * a.ntaps * a.IC * esz + schunk * 16;
     const int wrow = wave * 8;
     auto load_w = [&](int buf, int kc, int tap) {
         const int ub = (tap * a.IC) * esz + kc * 128;
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) dma16(rwt, smem + buf * WSTAGE + (wrow + 32 * i) * 128, b_off[i] + ub);
+        for (int i = 0; i < BROWS; ++i) dma16(rwt, smem + buf * WSTAGE + (wrow + 8 * NWV * i) * 128, b_off[i] + ub);
     };
-    // slab DMA: instruction jj covers slab rows 8*jj .. 8*jj+7; waves take jj = wave, wave+4, ...
+    // slab DMA: instruction jj covers slab rows 8*jj .. 8*jj+7; waves take jj = wave, wave+NWV, ...
     auto load_slab = [&](int sbuf, int kc) {
         unsigned char* dst = smem + 2 * WSTAGE + sbuf * slab_bytes;
-        for (int jj = wave; jj < nins; jj += 4) {
+        for (int jj = wave; jj < nins; jj += NWV) {
             const int sr = jj * 8 + (lane >> 3);
             const int pix = m0 - (a.W + 1) + sr;
             const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.in_pixels;
@@ -622,7 +636,8 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
 #pragma unroll
         for (int m = 0; m < MI; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int fswz = (frow >> 1) & 7;
-    const int woff0 = frow * 128 + (((0 + fg) ^ fswz) << 4), woff1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
+    // (this wave's weight fragments start WTN rows into the tile: 64 rows keep the swizzle term)
+    const int woff0 = (wn * WTN + frow) * 128 + (((0 + fg) ^ fswz) << 4), woff1 = (wn * WTN + frow) * 128 + (((4 + fg) ^ fswz) << 4);
     int prow[MI];
     unsigned zb[MI];  // zero-row address of fragment m, pre-biased by the instruction offset 2048*m
 #pragma unroll
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
 #define TSEG(accv)
 #endif
     for (int kc = 0; kc < kpt; ++kc) {
-        const unsigned slab = slab_base + (kc & 1) * slab_bytes;
+        const unsigned slab = slab_base + (nslab == 2 ? (kc & 1) * slab_bytes : 0);
         int sh = sh0, scol = 0;
         for (int tap = 0; tap < a.ntaps; ++tap) {
 #ifdef GDL_TIMING
@@ -657,23 +672,19 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (nslab == 1 && tap == 0 && kc > 0) {
+                // single slab buffer: every wave is past its last read of the previous chunk's slab (barrier above);
+                // fetch this chunk's slab now -- the wait is exposed once per chunk (9 K-steps), the other block of
+                // the CU works meanwhile, and the LDS it saves is what lets two 256-row blocks share a CU
+                load_slab(0, kc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
             TSEG(acc_wait)
             if (kc == 0 && tap == 0) GDL_STAMP(2);
             if (kc == 0 && tap == 1) GDL_STAMP(3);
-            {  // prefetch: the weight tile of the next K-step; at tap 0 also the next chunk's slab
-                int ntap = tap + 1, nkc = kc;
-                if (ntap == a.ntaps) {
-                    ntap = 0;
-                    ++nkc;
-                }
-                if (nkc < kpt) load_w(wbuf ^ 1, nkc, ntap);
-                if (tap == 0 && kc + 1 < kpt) load_slab((kc + 1) & 1, kc + 1);
-            }
-            TSEG(acc_issue)
             const unsigned Bs = smem_base + wbuf * WSTAGE;
-            // both 32-channel halves' fragments are requested up front; the second half's LDS latency
-            // hides behind the first half's MFMAs
-            uint4 px[2][MI], wf[2][NI];
             // Pixel fragment m sits 16 rows (2048 bytes) below fragment 0 and 16 rows do not change the
             // swizzle term, so ONE address is computed per tap; the per-fragment part is an instruction
             // offset.  A masked (padding) tap reads the zero row: its base is pre-biased by -2048*m.
@@ -684,24 +695,70 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MI; ++m) pb[m] = ((fmask[m] >> tap) & 1u) ? ad0 : zb[m];
             const unsigned wb0 = Bs + woff0, wb1 = Bs + woff1;
-            slab_reads<MI, NI>(px[0], wf[0], pb, wb0);
+            // Prefetch AFTER fragment reads have been requested: issuing LDS-DMA blocks the wave for ~150 clk per
+            // 1 KiB piece (tools/timing_probe.py: 490-610 clk per K-step), about the time the fragment reads need to
+            // come back (~460 clk) -- issued in front of the reads the two latencies added up.  The weight tile of the
+            // next K-step goes to the OTHER ring slot, at tap 0 the next chunk's slab to the other slab buffer:
+            // nothing the pending reads touch.
+            auto prefetch = [&]() __attribute__((always_inline)) {
+                asm volatile("" ::: "memory");
+                int ntap = tap + 1, nkc = kc;
+                if (ntap == a.ntaps) {
+                    ntap = 0;
+                    ++nkc;
+                }
+                if (nkc < kpt) load_w(wbuf ^ 1, nkc, ntap);
+                if (nslab == 2 && tap == 0 && kc + 1 < kpt) load_slab((kc + 1) & 1, kc + 1);
+                asm volatile("" ::: "memory");
+            };
+            if constexpr ((MI + NI) * 8 > 80) {
+                // big tile (MI = 4, NI = 8): 128 accumulator registers leave room for ONE half's fragments (48) if two
+                // waves are to share a SIMD: the halves are read one after the other
+                uint4 px[MI], wf[NI];
+                slab_reads<MI, NI>(px, wf, pb, wb0);
+                TSEG(acc_rd)
+                prefetch();
+                TSEG(acc_issue)
+                lds_wait();
 #pragma unroll
-            for (int m = 0; m < MI; ++m) pb[m] ^= 64u;
-            slab_reads<MI, NI>(px[1], wf[1], pb, wb1);
-            // (lgkmcnt counts at most 15: with 8 weight fragments the second half's 10 reads are all that may remain)
-            lds_wait_n<MI + NI>();
-            TSEG(acc_rd)
+                for (int n = 0; n < NI; ++n)
 #pragma unroll
-            for (int n = 0; n < NI; ++n)
+                    for (int m = 0; m < MI; ++m) Mma<T>::run(wf[n], px[m], acc[n][m]);
+                TSEG(acc_m0)
 #pragma unroll
-                for (int m = 0; m < MI; ++m) Mma<T>::run(wf[0][n], px[0][m], acc[n][m]);
-            lds_wait();
-            TSEG(acc_m0)
+                for (int m = 0; m < MI; ++m) pb[m] ^= 64u;
+                slab_reads<MI, NI>(px, wf, pb, wb1);
+                lds_wait();
 #pragma unroll
-            for (int n = 0; n < NI; ++n)
+                for (int n = 0; n < NI; ++n)
 #pragma unroll
-                for (int m = 0; m < MI; ++m) Mma<T>::run(wf[1][n], px[1][m], acc[n][m]);
-            TSEG(acc_m1)
+                    for (int m = 0; m < MI; ++m) Mma<T>::run(wf[n], px[m], acc[n][m]);
+                TSEG(acc_m1)
+            } else {
+                // both 32-channel halves' fragments are requested up front; the second half's LDS latency
+                // hides behind the first half's MFMAs
+                uint4 px[2][MI], wf[2][NI];
+                slab_reads<MI, NI>(px[0], wf[0], pb, wb0);
+#pragma unroll
+                for (int m = 0; m < MI; ++m) pb[m] ^= 64u;
+                slab_reads<MI, NI>(px[1], wf[1], pb, wb1);
+                TSEG(acc_rd)
+                prefetch();
+                TSEG(acc_issue)
+                // (lgkmcnt counts at most 15: with 8 weight fragments the second half's 10 reads are all that may remain)
+                lds_wait_n<MI + NI>();
+#pragma unroll
+                for (int n = 0; n < NI; ++n)
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) Mma<T>::run(wf[0][n], px[0][m], acc[n][m]);
+                lds_wait();
+                TSEG(acc_m0)
+#pragma unroll
+                for (int n = 0; n < NI; ++n)
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) Mma<T>::run(wf[1][n], px[1][m], acc[n][m]);
+                TSEG(acc_m1)
+            }
             wbuf ^= 1;
             if (++scol == 3) {
                 scol = 0;
@@ -729,12 +786,12 @@ __global__ __launch_bounds__(256) void conv3x3_slab_kernel(ConvArgs a) {
 #endif
 }
 
-static size_t slab_lds_bytes(int BM, int BN, int W, int IC, int dtype) {
+static size_t slab_lds_bytes(int BM, int BN, int W, int IC, int dtype, bool single = false) {
     const int bke = dtype == GDL_BF16 ? 64 : 32, esz = dtype == GDL_BF16 ? 2 : 4;
     const int rows = BM + 2 * W + 2;
     const size_t slab = (size_t)((rows + 7) / 8) * 1024;
-    const size_t main = 2 * (size_t)BN * 128 + (IC / bke > 1 ? 2 : 1) * slab + ((rows & 7) ? 0 : 1024);
-    const size_t epi = (size_t)BM * (BN * esz + 16) + 4 * (size_t)BN * 2 * 4;
+    const size_t main = 2 * (size_t)BN * 128 + ((IC / bke > 1 && !single) ? 2 : 1) * slab + ((rows & 7) ? 0 : 1024);
+    const size_t epi = (size_t)BM * (BN * esz + 16) + 8 * (size_t)BN * 2 * 4;
     return main > epi ? main : epi;
 }
 
@@ -792,21 +849,23 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     return GDL_OK;
 }
 
-template <typename T, int BM, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE, int NWV = 4>
 static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, BM);
-    auto kfn = conv3x3_slab_kernel<T, BM, BN, MODE>;
+    auto kfn = conv3x3_slab_kernel<T, BM, BN, MODE, NWV>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_slab)");
         attr_set = true;
     }
+    if (NWV != 4) GDL_REQUIRE(!a.fold.ctr, "conv: the in-launch BatchNorm finalize needs a 256-thread tile configuration");
     const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / BN);
     static char pname[96] = "";
-    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d, %d>", prof_tname<T>(), BM, BN, MODE);
+    if (!pname[0])
+        snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, MODE, NWV);
     ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
-    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
+    hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
     return GDL_OK;
 }
@@ -816,7 +875,24 @@ struct ConvPlan {
     int slab;  // 1: conv3x3_slab_kernel
     int bm, bn;
     size_t lds;
+    int single;  // slab kernel: one slab buffer
 };
+static int slab_cfg() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_SLAB_CFG");  // tuning aid, bits: 1 = allow the 256 x 128 single-slab tile, 2 = the 192 x 128 one
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+static long slab_big_min() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("GDL_SLAB_BIG_MIN");  // tuning aid: fewest blocks for which the 192 / 256 x 128 tiles are used
+        v = e ? atol(e) : 128;
+    }
+    return v;
+}
 static long slab_bn128_min() {
     static long v = -1;
     if (v < 0) {
@@ -850,6 +926,40 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
         }
         // 128 x 128 tile when the layer is wide enough and still yields a block per CU: the slab is fetched
         // once per 128 output channels and a K-step carries twice the MFMAs for the same barrier / DMA issue
+        // 128-channel tiles of 192 / 256 rows with ONE slab buffer (bf16): more MFMAs per barrier / weight-tile DMA /
+        // address arithmetic than the 128 x 128 tile and fewer fragment bytes per MFMA (PMC of the 128 x 128 kernel:
+        // MFMA 24 % of a wave's cycles, the rest waits, LDS issue stalls and scalar / vector address work); two blocks
+        // per CU still fit because the next chunk's slab is not double buffered.  Which M-tile wins is mostly a matter
+        // of how the tile count divides by the 512 block slots: measured block times fit T(BM) ~ 130 + BM (256 x 128:
+        // 26.5 us against 17.7 us for 128 x 128 at 128 channels), so pick the smallest rounds(BM) * (130 + BM).
+        if (slab_cfg() != 0 && !slab_bm && dtype == GDL_BF16 && OC % 128 == 0 && slab_cap == (size_t)80 * 1024) {
+            int best_bm = 0;
+            double best = 0.0;
+            for (int bm : {128, 192, 256}) {
+                if (bm == 192 && !(slab_cfg() & 2)) continue;
+                if (bm == 256 && !(slab_cfg() & 1)) continue;
+                const bool single = bm != 128;
+                const size_t lds = slab_lds_bytes(bm, 128, W, IC, dtype, single);
+                if (lds > slab_cap) continue;
+                const long blocks = (long)((M + bm - 1) / bm) * (OC / 128);
+                if (bm != 128 && blocks < slab_big_min()) continue;
+                if (bm == 128 && blocks < slab_bn128_min()) continue;
+                const double rounds = (double)((blocks + 511) / 512);
+                const double cost = rounds * (130.0 + bm);
+                if (!best_bm || cost < best) {
+                    best = cost;
+                    best_bm = bm;
+                }
+            }
+            if (best_bm) {
+                p.slab = 1;
+                p.bm = best_bm;
+                p.bn = 128;
+                p.single = best_bm != 128;
+                p.lds = slab_lds_bytes(best_bm, 128, W, IC, dtype, p.single != 0);
+                return p;
+            }
+        }
         if (!slab_bm && slab_bn != 64 && OC % 128 == 0) {
             const size_t lds = slab_lds_bytes(128, 128, W, IC, dtype);
             const long blocks = (long)((M + 127) / 128) * (OC / 128);
@@ -884,6 +994,10 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
 template <typename T, int MODE>
 static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
     if (pl.slab) {
+        if constexpr (std::is_same<T, bf16>::value)
+            if (pl.bn == 128 && pl.bm == 256) return launch_slab<T, 256, 128, MODE>(a, pl.lds, st);
+        if constexpr (std::is_same<T, bf16>::value)
+            if (pl.bn == 128 && pl.bm == 192) return launch_slab<T, 192, 128, MODE>(a, pl.lds, st);
         if (pl.bn == 128) return launch_slab<T, 128, 128, MODE>(a, pl.lds, st);
         if (pl.bm == 256) return launch_slab<T, 256, 64, MODE>(a, pl.lds, st);
         return launch_slab<T, 128, 64, MODE>(a, pl.lds, st);
@@ -964,6 +1078,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     }
     if (pl.slab) {
         a.W = W;
+        a.single_slab = pl.single;
         a.in_pixels = N * H * W;
         a.slab_rows = pl.bm + 2 * W + 2;
         for (int r = 0; r < 3; ++r)

@@ -193,8 +193,12 @@ __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logit
         float se = 0.f;
         for (int j = 0; j < n; ++j) se += expf(l[j] - mx);
         const float lse = mx + logf(se);
-        const int lab = (int)labels[b];
-        acc += lse - l[lab];
+        // a class index outside [0, n) (a device assert in the reference's CrossEntropyLoss) must not become an
+        // out-of-bounds read: the sample contributes NaN to the loss (visible in DGLTrainer.read()) and no one-hot term
+        const long lab64 = (long)labels[b];
+        const bool lab_ok = lab64 >= 0 && lab64 < n;
+        const int lab = lab_ok ? (int)lab64 : -1;
+        acc += lab_ok ? lse - l[lab] : __builtin_nanf("");
         if (dlogits)
             for (int j = 0; j < n; ++j)
                 dlogits[(size_t)b * n + j] = scale * (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)B;

@@ -30,6 +30,8 @@ class BucketReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.pending = {}
+        self.enabled = True  # False: launch() / wait_all() keep their bookkeeping but move no data (bench.py times the
+        #                      step without its collectives to report how much of them the backward hides)
         spans = sorted(self.buckets.values())
         for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
             if b0 < a1:
@@ -45,7 +47,7 @@ class BucketReducer:
         if name in self.pending:
             raise RuntimeError(f"BucketReducer: bucket {name!r} reduced twice in one step")
         lo, hi = self.buckets[name]
-        if self.world == 1:
+        if self.world == 1 or not self.enabled:
             self.pending[name] = None
             return
         self.pending[name] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -62,8 +64,37 @@ class BucketReducer:
         self.pending = {}
 
     def broadcast_buffers(self, tensors, src=0):
-        """Mirror 'replica 0 persists' for BatchNorm running statistics before eval / checkpoint."""
+        """Mirror 'replica 0 persists' for BatchNorm running statistics before eval / checkpoint
+        (the reference's nn.DataParallel keeps replica 0's buffers, main_dgl.py:244)."""
         if self.world == 1:
             return
         for t in tensors:
             dist.broadcast(t, src=src, group=self.pg)
+
+    def sync_state(self, tensors, src=0):
+        """Make every rank's replica state (flat parameter / momentum arenas, BatchNorm buffers) equal to rank
+        `src`'s: one broadcast per tensor.  Called once when the trainer is built and after a checkpoint load, so a
+        rank-0-only load or a seed that differs between ranks cannot diverge silently."""
+        self.broadcast_buffers(tensors, src)
+
+    def time_buckets(self, sync, barrier=None, reps=5):
+        """Stand-alone duration of each bucket's all-reduce (ms, best of `reps`; nothing else on the device):
+        what the step would pay if none of it were overlapped.  `sync()` must drain the device."""
+        import time
+
+        out = {}
+        for name, (lo, hi) in self.buckets.items():
+            if self.world == 1:
+                out[name] = 0.0
+                continue
+            scratch = torch.zeros_like(self.flat[lo:hi])
+            best = float("inf")
+            for _ in range(reps + 1):
+                (barrier or (lambda: dist.barrier(group=self.pg)))()
+                sync()
+                t0 = time.perf_counter()
+                dist.all_reduce(scratch, op=dist.ReduceOp.SUM, group=self.pg)
+                sync()
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+            out[name] = round(best, 4)
+        return out

@@ -97,6 +97,10 @@ class DGLTrainer:
 
             self.reducer = BucketReducer(self.grads, self.bucket, process_group)
             self.world = self.reducer.world
+            # Replica state follows rank 0 (parameters, momentum, BatchNorm running statistics / counters): a seed
+            # that differs between ranks or a rank-0-only checkpoint load must not diverge silently.  fc_auxi (and the
+            # gated head's fc_x / fc_y) live outside the arena: they are never updated but still part of the state.
+            self.reducer.sync_state([self.params, self.momentum] + self._replica_buffers())
         h = ctypes.c_void_p()
         so = (ctypes.c_int64 * len(offs))(*offs)
         sg = (ctypes.c_int32 * len(group))(*group)
@@ -111,6 +115,36 @@ class DGLTrainer:
         self.eng_a = self.eng_v = None
         self.steps = 0
         self.phase_events = None  # set to [] to record (name, event) marks on the main stream per step
+
+    def _replica_buffers(self):
+        """Every tensor of the replica that is not in the flat arenas: BatchNorm running statistics and counters of
+        both encoders, and the fusion-head parameters the step never trains."""
+        m = self.model
+        in_arena = {v.data_ptr() for v in getattr(self, "pviews", [])}
+        extra = [p.data for p in m.fusion_module.parameters() if p.data.data_ptr() not in in_arena]
+        return [b for net in (m.audio_net, m.visual_net) for b in net.buffers()] + extra
+
+    def sync_replicas(self):
+        """Broadcast rank 0's BatchNorm buffers (before eval / checkpoint: 'replica 0 persists', main_dgl.py:244 --
+        BatchNorm statistics are per rank during training, as with the reference's nn.DataParallel replicas)."""
+        if self.reducer is not None:
+            self.reducer.broadcast_buffers(self._replica_buffers())
+
+    def state_dict(self):
+        """Optimizer-side state a reference checkpoint keeps besides model.state_dict() (optimizer.state_dict() /
+        scheduler, main_dgl.py:372): momentum arena, learning rate, step count.  In data-parallel mode the BatchNorm
+        buffers are first made rank 0's, so model.state_dict() taken next is the reference's replica-0 state."""
+        self.sync_replicas()
+        return {"momentum": self.momentum.detach().clone(), "lr": self.lr, "steps": self.steps, "names": list(self.names),
+                "offsets": list(self.offsets), "mu": self.mu, "weight_decay": self.wd}
+
+    def load_state_dict(self, sd):
+        if list(sd["offsets"]) != list(self.offsets) or list(sd["names"]) != list(self.names):
+            raise L.GdlError("DGLTrainer.load_state_dict: the checkpoint's parameter layout differs from this model's")
+        self.momentum.copy_(sd["momentum"].to(self.device))
+        self.lr, self.steps = float(sd["lr"]), int(sd["steps"])
+        if self.reducer is not None:  # the model's parameters alias the arena: whatever rank 0 loaded is the truth
+            self.reducer.sync_state([self.params, self.momentum] + self._replica_buffers())
 
     def __del__(self):
         try:
@@ -161,10 +195,18 @@ class DGLTrainer:
             eng.set_params([p.data for p in net.parameters()], [b.running_mean for b in bns],
                            [b.running_var for b in bns], [b.num_batches_tracked for b in bns])
 
+    def _check_label(self, label):
+        """The loss kernels index logits by label: require the reference's dtype and shape (a class index outside
+        [0, n) raises a device assert in the reference; here the loss kernel skips the sample and poisons the loss)."""
+        if label.dtype != torch.int64 or label.dim() != 1 or label.shape[0] != self.B or label.device != self.device:
+            raise L.GdlError(f"DGLTrainer: label must be an int64 [B={self.B}] tensor on {self.device}, got "
+                             f"{label.dtype} {tuple(label.shape)} on {label.device}")
+
     # ------------------------------------------------------------------ the step
     def step(self, spec, image, label):
         """spec [B,F,T'] float, image [B,3,T,H,W] float, label [B] int64 -- all resident on the device."""
         self._prepare(spec, image)
+        self._check_label(label)
         self._bind()
         # The head, the losses and the optimizer run on the audio chain's stream rather than on the caller's: one stream
         # (hardware queue) less in play measured +1 % (tools: 9 660 -> 9 760 samples/s).  The caller's stream is ordered
@@ -305,8 +347,10 @@ class DGLTrainer:
         n = self.n_classes
         cnt = torch.zeros((4, n), dtype=torch.int64, device=self.device)
         main = torch.cuda.current_stream(self.device)
+        self.sync_replicas()  # data-parallel: evaluate with rank 0's running statistics (SURVEY 8(e) "Buffers")
         for spec, image, label in batches:
             self._prepare(spec, image)
+            self._check_label(label)
             self._bind()
             audio = spec.unsqueeze(1)
             label = label.contiguous()

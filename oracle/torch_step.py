@@ -1,0 +1,93 @@
+"""TEST INFRASTRUCTURE -- the DGL training step restated with PyTorch CPU operators.
+
+Written from scratch on torch.nn.functional (none of the reference's files): it is the "PyTorch-op restatement" of
+BASELINE.md section 3 / SURVEY 8(d), timed by bench.py's `cpu_baseline` beside the C port (oracle/gdl_oracle.c) so that
+the reported CPU baseline is the arithmetic the reference actually runs on a CPU (ATen / oneDNN kernels), not only a
+naive port.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+What it follows: ResNet18 without pool / fc (/root/reference/models/backbone.py:75-201: 7x7/2 stem, BN, ReLU,
+MaxPool 3/2/1, four layers of two BasicBlocks with a 1x1/2 conv + BN shortcut on the first block of layers 2-4), the
+pooling glue and ConcatFusion_DGL head of models/basic_model.py:65-86 and models/fusion_modules.py:45-59, and the step
+body of main_dgl.py:97-154 (three cross-entropies, two backward passes with the fusion-head gradients dropped in between,
+clip_grad_norm_(40), SGD with momentum 0.9 and weight decay 1e-4).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, P, Bf, name, training):
+    return F.batch_norm(x, Bf[name + ".running_mean"], Bf[name + ".running_var"], P[name + ".weight"], P[name + ".bias"],
+                        training=training, momentum=0.1, eps=1e-5)
+
+
+def _block(x, P, Bf, pre, stride, has_ds, training):
+    out = F.relu(_bn(F.conv2d(x, P[pre + ".conv1.weight"], stride=stride, padding=1), P, Bf, pre + ".bn1", training))
+    out = _bn(F.conv2d(out, P[pre + ".conv2.weight"], stride=1, padding=1), P, Bf, pre + ".bn2", training)
+    if has_ds:
+        x = _bn(F.conv2d(x, P[pre + ".downsample.0.weight"], stride=stride), P, Bf, pre + ".downsample.1", training)
+    return F.relu(out + x)
+
+
+def encoder(x, P, Bf, pre, training):
+    """x [N, Cin, H, W] -> [N, 512, h, w]   (ResNet.forward without the permute, backbone.py:166-201)"""
+    x = F.relu(_bn(F.conv2d(x, P[pre + ".conv1.weight"], stride=2, padding=3), P, Bf, pre + ".bn1", training))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li in range(1, 5):
+        for bi in range(2):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            x = _block(x, P, Bf, f"{pre}.layer{li}.{bi}", stride, li > 1 and bi == 0, training)
+    return x
+
+
+class TorchStep:
+    def __init__(self, params, buffers, threads=None):
+        """params / buffers: name -> numpy array (oracle.fixtures.model_state)."""
+        if threads:
+            torch.set_num_threads(int(threads))
+        self.P = {k: torch.from_numpy(np.array(v)).clone().requires_grad_(True) for k, v in params.items()}
+        self.Bf = {k: torch.from_numpy(np.array(v)).clone() for k, v in buffers.items()}
+        self.mom = {}
+
+    def forward(self, spec, image, training=True):
+        P, Bf = self.P, self.Bf
+        B, _, T, H, W = image.shape
+        a = encoder(spec.unsqueeze(1), P, Bf, "audio_net", training)
+        v = encoder(image.permute(0, 2, 1, 3, 4).reshape(B * T, 3, H, W), P, Bf, "visual_net", training)
+        v = v.view(B, T, 512, v.shape[-2], v.shape[-1]).permute(0, 2, 1, 3, 4)
+        fa = torch.flatten(F.adaptive_avg_pool2d(a, 1), 1)
+        fv = torch.flatten(F.adaptive_avg_pool3d(v, 1), 1)
+        W_, b_ = P["fusion_module.fc_out.weight"], P["fusion_module.fc_out.bias"]
+        z = torch.zeros_like(fa)
+        out = F.linear(torch.cat((fa, fv), 1).detach(), W_, b_)
+        out_a = F.linear(torch.cat((fa, z), 1), W_, b_)
+        out_v = F.linear(torch.cat((z, fv), 1), W_, b_)
+        return out, out_a, out_v
+
+    def train_step(self, spec, image, label, alpha, lr, momentum=0.9, wd=1e-4, max_norm=40.0):
+        spec, image = torch.as_tensor(spec), torch.as_tensor(image)
+        label = torch.as_tensor(label).long()
+        P = self.P
+        for p in P.values():
+            p.grad = None
+        out, out_a, out_v = self.forward(spec, image, True)
+        loss_v, loss_a, loss_f = F.cross_entropy(out_v, label), F.cross_entropy(out_a, label), F.cross_entropy(out, label)
+        ((loss_a + loss_v) * alpha).backward(retain_graph=True)
+        for k, p in P.items():
+            if k.startswith("fusion_module."):
+                p.grad = None
+        loss_f.backward()
+        with_grad = [p for p in P.values() if p.grad is not None]
+        total = float(torch.nn.utils.clip_grad_norm_(with_grad, max_norm))
+        with torch.no_grad():
+            for k, p in P.items():
+                if p.grad is None:
+                    continue
+                g = p.grad + wd * p
+                if k not in self.mom:
+                    self.mom[k] = g.clone()
+                else:
+                    self.mom[k].mul_(momentum).add_(g)
+                p.add_(self.mom[k], alpha=-lr)
+        return {"out": out.detach().numpy(), "out_a": out_a.detach().numpy(), "out_v": out_v.detach().numpy(),
+                "loss_f": loss_f.item(), "loss_a": loss_a.item(), "loss_v": loss_v.item(), "total_norm": total}

@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -80,3 +81,69 @@ def test_bucket_allreduce_world2():
     assert all(ok for _, ok, _ in res), res
     sums = [s for _, _, s in res]
     np.testing.assert_allclose(sums[0], sums[1], rtol=1e-9)  # both ranks hold identical reduced grads
+
+
+def _worker5(rank, world, port, q):
+    """The five buckets of DGLTrainer in the issue order of its data-parallel step (trainer.py: fusion, audio_l4,
+    visual_l4, audio_rest, visual_rest), ranks seeded differently, replica state synchronised from rank 0 first."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gdl.ddp import BucketReducer
+
+    sizes = {"fusion": 615, "audio_rest": 2780, "audio_l4": 8390, "visual_rest": 2790, "visual_l4": 8390}  # real sizes / 1000
+    layout = ["fusion", "audio_rest", "audio_l4", "visual_rest", "visual_l4"]  # arena order: head | audio (rest, l4) | visual
+    offs, o = {}, 0
+    for n in layout:
+        offs[n] = (o, o + sizes[n])
+        o += sizes[n]
+    g = torch.Generator().manual_seed(7 + 13 * rank)  # every rank its own "initialisation" and gradients
+    params, momentum, bn = torch.randn(o, generator=g), torch.randn(o, generator=g), torch.randn(40, generator=g)
+    flat = torch.randn(o, generator=g)
+    mine = flat.clone()
+    red = BucketReducer(flat, offs)
+    ok = True
+    red.sync_state([params, momentum, bn])
+    ref = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(ref, params)
+    ok = ok and all(torch.equal(r, ref[0]) for r in ref)  # every replica starts from rank 0's parameters
+    g0 = torch.Generator().manual_seed(7)
+    ok = ok and torch.equal(params, torch.randn(o, generator=g0))
+    for step in range(2):
+        for n in ("fusion", "audio_l4", "visual_l4", "audio_rest", "visual_rest"):
+            red.launch(n)
+        red.wait_all()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        expect = sum(gathered)
+        ok = ok and torch.allclose(flat, expect, rtol=1e-5, atol=1e-5)
+        mine = flat.clone()  # next step reduces the reduced values again: sums grow by `world`
+    # timing helper runs (gloo): one number per bucket
+    t = red.time_buckets(lambda: None, reps=1)
+    ok = ok and set(t) == set(layout) and all(v >= 0 for v in t.values())
+    # a disabled reducer keeps the bookkeeping and moves nothing
+    red.enabled = False
+    before = flat.clone()
+    for n in layout:
+        red.launch(n)
+    red.wait_all()
+    ok = ok and torch.equal(before, flat)
+    q.put((rank, ok, float(flat.double().sum())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_five_buckets_world(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker5, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    sums = [s for _, _, s in res]
+    np.testing.assert_allclose(sums, sums[0], rtol=1e-9)

@@ -266,3 +266,23 @@ def test_normalize_frames_golden(golden_dir):
     u8 = g["frames.u8"]
     got = orc.normalize_frames(u8.reshape(-1, *u8.shape[2:])).reshape(g["frames.norm"].shape)
     np.testing.assert_array_equal(got, g["frames.norm"])
+
+
+def test_torch_restatement_matches_oracle():
+    """oracle/torch_step.py (the PyTorch-operator restatement bench.py times as the second CPU baseline) against the
+    C/numpy oracle on the tiny DGL fixture: same logits, losses and pre-clip gradient norm."""
+    from oracle import fixtures as fx
+    from oracle import oracle as orc
+    from oracle.torch_step import TorchStep
+
+    B, spec_hw, T, img_hw, ncls = 4, (65, 47), 2, (64, 64), 6
+    spec, image, label = fx.make_batch(0, B, spec_hw, T, img_hw, ncls)
+    P, Bf = fx.model_state(ncls, "concat_dgl")
+    ref = orc.AVModel({k: v.copy() for k, v in P.items()}, {k: np.array(v) for k, v in Bf.items()}, "dgl")
+    r = ref.train_step(spec, image, label, 4.0, 2e-3)
+    t = TorchStep(P, Bf).train_step(spec, image, label, 4.0, 2e-3)
+    for k in ("out", "out_a", "out_v"):
+        np.testing.assert_allclose(t[k], r[k], rtol=0, atol=1e-4, err_msg=k)
+    for k in ("loss_f", "loss_a", "loss_v"):
+        np.testing.assert_allclose(t[k], r[k], rtol=1e-5, err_msg=k)
+    np.testing.assert_allclose(t["total_norm"], r["total_norm"], rtol=1e-3)

