@@ -33,6 +33,8 @@ CONV_SHAPES = [
     (3, 64, 120, 115, 64, 3, 1, 1),   # 256x64, ragged tail
     (4, 64, 112, 112, 128, 3, 1, 1),  # 256x64, two N-tiles
     (2, 256, 14, 14, 512, 3, 2, 1),   # stride 2, C=256
+    (4, 64, 56, 56, 64, 3, 1, 1),     # 64 -> 64 channels: the weights-stationary persistent kernel (bf16), 98 tiles
+    (3, 64, 65, 47, 64, 3, 1, 1),     # the same with odd spatial dims and a ragged last tile (M = 9165)
 ]
 
 

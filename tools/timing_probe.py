@@ -79,12 +79,23 @@ def main():
     live = d[:, 0] != 0
     d = d[live]
     print(f"{a.op} {a.shape}: {e0.elapsed_time(e1) * 1e3:.1f} us, {len(d)} blocks stamped")
-    t0 = d[:, 0].min()
-    span = d[:, ns - 1].max() - t0
-    print(f"kernel span {span} ticks (shader cycles)" )
+    # s_memtime counters are per XCD (block b runs on XCD b % 8) and not synchronised with each other: spans per XCD
+    bid = np.nonzero(live)[0]
     life = d[:, ns - 1] - d[:, 0]
-    print(f"block life: mean {life.mean():.0f} p10 {np.percentile(life, 10):.0f} p90 {np.percentile(life, 90):.0f}; "
-          f"sum(life)/span = {life.sum() / span:.1f} blocks resident")
+    spans, resid = [], []
+    for x in range(8):
+        sel = (bid & 7) == x
+        if not sel.any():
+            continue
+        sp = d[sel, ns - 1].max() - d[sel, 0].min()
+        spans.append(sp)
+        resid.append(life[sel].sum() / sp)
+    span = float(np.mean(spans))
+    wall_us = e0.elapsed_time(e1) * 1e3
+    print(f"kernel span per XCD: mean {span:.0f} ticks (min {min(spans)}, max {max(spans)}) for {wall_us:.1f} us of wall time "
+          f"-> {span / wall_us / 1e3:.2f} ticks/ns; blocks resident per XCD: {np.mean(resid):.1f} (= {np.mean(resid) / 32:.2f} per CU)")
+    t0 = d[:, 0].min()
+    print(f"block life: mean {life.mean():.0f} p10 {np.percentile(life, 10):.0f} p90 {np.percentile(life, 90):.0f}")
     for i in range(ns - 1):
         seg = d[:, i + 1] - d[:, i]
         print(f"  {names[i]:>10s} -> {names[i + 1]:<10s} mean {seg.mean():8.0f}  p10 {np.percentile(seg, 10):8.0f}  p90 "
