@@ -94,21 +94,6 @@ int gdl_pack_weight(int dtype, const float* w, void* w_krsc, void* w_crsk, int K
     GDL_REQUIRE(dt_ok(dtype) && w, "pack_weight: bad arguments");
     return pack_weight(dtype, w, w_krsc, w_crsk, K, C, R, S, (hipStream_t)stream);
 }
-int gdl_stem_kp(int cin, int dtype) { return stem_kp(cin, dtype); }
-int gdl_stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && x && col, "stem_im2col: bad arguments");
-    return stem_im2col(dtype, x, col, B, Cin, T, H, W, (hipStream_t)stream);
-}
-int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && w && wp, "pack_stem_weight: bad arguments");
-    return pack_stem_weight(dtype, w, wp, Cin, (hipStream_t)stream);
-}
-int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, const void* table, int M, int Cin, void* ws,
-                   size_t ws_bytes, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && dy && col && dw, "stem_wgrad: bad arguments");
-    return conv_wgrad(dtype, dy, col, dw, table, M, 1, 1, stem_kp(Cin, dtype), 64, 1, 1, 1, 0, Cin * 49, ws, ws_bytes,
-                      (hipStream_t)stream);
-}
 // direct stem
 size_t gdl_stem_pad_bytes(int dtype, int n_img, int H, int W) { return dt_ok(dtype) ? stem_pad_bytes(dtype, n_img, H, W) : 0; }
 size_t gdl_stem_weight_bytes(int dtype) {

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
 static bool ew_v4() {  // tuning aid: GDL_EW_V4=1 -> 4 instead of 8 vectors per thread on small tensors
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_EW_V4");
+        const char* e = tune_env("GDL_EW_V4");
         v = e ? atoi(e) : 0;
     }
     return v != 0;

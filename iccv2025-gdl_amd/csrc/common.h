@@ -127,6 +127,10 @@ int check_hip(hipError_t e, const char* what);
         }                                 \
     } while (0)
 
+// Tuning aids: the GDL_* environment knobs of the kernels' planners are read only when GDL_TUNING=1 is set (tools/ and
+// the A/B runs behind DESIGN.md's numbers); a production process never consults the environment.
+const char* tune_env(const char* name);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

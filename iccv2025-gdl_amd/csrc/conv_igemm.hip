@@ -1,8 +1,8 @@
 // conv_igemm.hip -- implicit-GEMM convolution forward / data-gradient on MFMA (gfx950).
 //
 // Replaces nn.Conv2d forward and its input-gradient for the shapes the reference
-// encoder uses (/root/reference/models/backbone.py:20-28 conv3x3 / conv1x1, and
-// the stem after im2col).  GEMM view: M = N*OH*OW output pixels, Ngemm = OC
+// encoder uses (/root/reference/models/backbone.py:20-28 conv3x3 / conv1x1, and the
+// 7x7/2 stem of :96-101 as a direct implicit GEMM over a zero-padded NHWC4 copy of the input).  GEMM view: M = N*OH*OW output pixels, Ngemm = OC
 // output channels, Kgemm = R*S*IC; NHWC activations make every K-step a
 // contiguous 128-byte slice of one input pixel (fixed tap, 64 bf16 / 32 f32
 // channels) and the [OC][R][S][IC] weight layout makes the matching weight slice
@@ -803,7 +803,7 @@ struct TileCfg {
 static int forced_cfg() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_CONV_CFG");  // tuning aid: 1 = 256x64, 3 = 64x64, 4 = 128x64
+        const char* e = tune_env("GDL_CONV_CFG");  // tuning aid: 1 = 256x64, 3 = 64x64, 4 = 128x64
         v = e ? atoi(e) : 0;
     }
     return v;
@@ -880,7 +880,7 @@ struct ConvPlan {
 static int slab_cfg() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_SLAB_CFG");  // tuning aid, bits: 1 = allow the 256 x 128 single-slab tile, 2 = the 192 x 128 one
+        const char* e = tune_env("GDL_SLAB_CFG");  // tuning aid, bits: 1 = allow the 256 x 128 single-slab tile, 2 = the 192 x 128 one
         v = e ? atoi(e) : 1;
     }
     return v;
@@ -888,7 +888,7 @@ static int slab_cfg() {
 static long slab_big_min() {
     static long v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_SLAB_BIG_MIN");  // tuning aid: fewest blocks for which the 192 / 256 x 128 tiles are used
+        const char* e = tune_env("GDL_SLAB_BIG_MIN");  // tuning aid: fewest blocks for which the 192 / 256 x 128 tiles are used
         v = e ? atol(e) : 128;
     }
     return v;
@@ -896,7 +896,7 @@ static long slab_big_min() {
 static long slab_bn128_min() {
     static long v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_SLAB_BN128_MIN");  // tuning aid: fewest blocks for which the 128-channel tile is used
+        const char* e = tune_env("GDL_SLAB_BN128_MIN");  // tuning aid: fewest blocks for which the 128-channel tile is used
         v = e ? atol(e) : 100;
     }
     return v;
@@ -905,12 +905,12 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     ConvPlan p{};
     static int noslab = -1;
     if (noslab < 0) {
-        const char* e = getenv("GDL_CONV_NOSLAB");  // tuning aid
+        const char* e = tune_env("GDL_CONV_NOSLAB");  // tuning aid
         noslab = e ? atoi(e) : 0;
     }
     static int slab_bm = -1;
     if (slab_bm < 0) {
-        const char* e = getenv("GDL_SLAB_BM");  // tuning aid: force the slab kernel's M-tile (128 / 256)
+        const char* e = tune_env("GDL_SLAB_BM");  // tuning aid: force the slab kernel's M-tile (128 / 256)
         slab_bm = e ? atoi(e) : 0;
     }
     // LDS budget of the slab kernel: 80 KB (two blocks per CU); a layer too wide for that (the 79-pixel audio layer 2 of the
@@ -921,7 +921,7 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
         // blocks per CU) beats the 256-row one (64 KB, two) by ~1 %, although they tie when run alone.
         static int slab_bn = -1;
         if (slab_bn < 0) {
-            const char* e = getenv("GDL_SLAB_BN");  // tuning aid: 64 = never use the 128-channel tile
+            const char* e = tune_env("GDL_SLAB_BN");  // tuning aid: 64 = never use the 128-channel tile
             slab_bn = e ? atoi(e) : 0;
         }
         // 128 x 128 tile when the layer is wide enough and still yields a block per CU: the slab is fetched
@@ -1102,7 +1102,7 @@ int stem_ic(int dtype);
 static bool stem_rows(int dtype, int W) {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_STEM_ROWS_FWD");  // tuning aid: 0 = flat kernel
+        const char* e = tune_env("GDL_STEM_ROWS_FWD");  // tuning aid: 0 = flat kernel
         v = e ? atoi(e) : 1;
     }
     return v != 0 && dtype == GDL_BF16 && (W - 1) / 2 + 1 >= 64;

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #endif
 }
 
-// out[k][c][r][s] = sum_split partial[split][k][rs][c], c < Cout (Cout <= C drops im2col padding)
+// out[k][c][r][s] = sum_split partial[split][k][rs][c], c < Cout (Cout <= C drops padding channels)
 // Block = 256 threads = (256/LANES) consecutive outputs x LANES split-lanes; lane l sums splits
 // l, l+LANES, ... and the lanes are folded through LDS in a fixed order (deterministic).
 template <int LANES>
@@ -380,7 +380,7 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS) {
     // multiple of 8 (XCD mapping).  GDL_WGRAD_BLOCKS overrides the target (tuning aid).
     static int target = -1;
     if (target < 0) {
-        const char* e = getenv("GDL_WGRAD_BLOCKS");
+        const char* e = tune_env("GDL_WGRAD_BLOCKS");
         target = e ? atoi(e) : 384;
     }
     int ns = (target + tiles - 1) / tiles;
@@ -425,7 +425,7 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
     return GDL_OK;
 }
 
-// Cout: number of leading input channels kept in dw (== C except for the padded stem im2col)
+// Cout: number of leading input channels kept in dw (== C unless the channel axis is padded)
 int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K,
                int R, int S, int stride, int pad, int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "wgrad: bad dtype %d", dtype);
@@ -703,7 +703,7 @@ struct StemRowsPlan {
 static bool stem_rows_ok(int dtype, int W) {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_STEM_ROWS");  // tuning aid: 0 = per-tap kernel
+        const char* e = tune_env("GDL_STEM_ROWS");  // tuning aid: 0 = per-tap kernel
         v = e ? atoi(e) : 1;
     }
     return v != 0 && dtype == GDL_BF16 && (W - 1) / 2 + 1 >= 64;
@@ -715,7 +715,7 @@ static StemRowsPlan plan_stem_rows(int n_img, int H, int W) {
     p.stages = n_img * P * p.nseg;
     static int target = -1;
     if (target < 0) {
-        const char* e = getenv("GDL_STEM_ROWS_BLOCKS");  // tuning aid
+        const char* e = tune_env("GDL_STEM_ROWS_BLOCKS");  // tuning aid
         target = e ? atoi(e) : 512;
     }
     int ns = target;

@@ -451,7 +451,7 @@ static W9Plan plan_w9(int M, int C, int K) {
     const int tiles = (K / 64) * (C / 64);
     static int target = -1;
     if (target < 0) {
-        const char* e = getenv("GDL_WGRAD9_BLOCKS");  // tuning aid
+        const char* e = tune_env("GDL_WGRAD9_BLOCKS");  // tuning aid
         // 512 blocks win when the kernel runs alone (tools/bench_conv.py); inside the step, where four
         // streams share the CUs and every block leaves 144 KB of partials, 256 do (bench.py: -2 % step time)
         target = e ? atoi(e) : 256;
@@ -459,7 +459,7 @@ static W9Plan plan_w9(int M, int C, int K) {
     // every block leaves 144 KB of partials: at least W9_MIN_STAGES stages of work per block
     static int min_st = -1;
     if (min_st < 0) {
-        const char* e = getenv("GDL_WGRAD9_MINST");  // tuning aid
+        const char* e = tune_env("GDL_WGRAD9_MINST");  // tuning aid
         min_st = e ? atoi(e) : 8;
     }
     int ns = (target + tiles - 1) / tiles;
@@ -477,7 +477,7 @@ static W9Plan plan_w9(int M, int C, int K) {
 bool conv_wgrad9_enabled() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_WGRAD9");  // tuning aid: 0 = per-tap kernel everywhere
+        const char* e = tune_env("GDL_WGRAD9");  // tuning aid: 0 = per-tap kernel everywhere
         v = e ? atoi(e) : 1;
     }
     return v != 0;
@@ -495,7 +495,7 @@ static bool w9_spec() {
         // (tools/bench_conv.py: 0.069 vs 0.086 ms at 64x56x56) but the step is 4 % SLOWER with it (bench.py, same box:
         // 8 900 vs 9 280 samples/s) -- 8 waves x 220 VGPRs fill the CU's register file, so the blocks of the kernels
         // on the other streams no longer fit beside it.  Default: four waves that load and multiply.
-        const char* e = getenv("GDL_WGRAD9_SPEC");  // tuning aid: 1 = 4 worker + 4 loader waves
+        const char* e = tune_env("GDL_WGRAD9_SPEC");  // tuning aid: 1 = 4 worker + 4 loader waves
         v = e ? atoi(e) : 0;
     }
     return v != 0;
@@ -504,7 +504,7 @@ static bool w9_spec() {
 static int w9_ring(int W) {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("GDL_WGRAD9_RING");  // tuning aid: 0 = plain double buffer everywhere
+        const char* e = tune_env("GDL_WGRAD9_RING");  // tuning aid: 0 = plain double buffer everywhere
         v = e ? atoi(e) : 1;
     }
     if (v == 0 || W < 24) return 0;

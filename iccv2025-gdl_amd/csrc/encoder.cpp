@@ -4,7 +4,7 @@
 // (:75-156 topology, :158-201 forward, BasicBlock.forward :52-68) plus the pooling glue of
 // AVClassifier_DGL.forward (/root/reference/models/basic_model.py:73-82).  No autograd tape:
 // the engine keeps exactly the tensors its own backward needs in a caller-provided workspace
-// (sized for 288 GB HBM: nothing is recomputed, the stem im2col matrix is kept for wgrad).
+// (sized for 288 GB HBM: nothing is recomputed; the stem keeps its zero-padded NHWC4 input copy for the weight gradient).
 //
 // Per BasicBlock forward:   y1 = conv1(x) [+BN stats in the conv epilogue]; a1 = relu(bn1(y1));
 //                           y2 = conv2(a1); [yd = convd(x)]; z = relu(bn2(y2) + (bnd(yd) | x)).
@@ -61,7 +61,7 @@ struct gdl_encoder {
     int modality, dtype, B, T, H, W, cin, n_img;
     int esz;  // bytes per activation element
     // stem
-    int h0, w0, h1, w1, kp;
+    int h0, w0, h1, w1;
     long m0;  // n_img*h0*w0
     BN bn0;
     void *col = nullptr, *w0p = nullptr, *y0 = nullptr, *x1 = nullptr, *ymax = nullptr;
@@ -88,7 +88,7 @@ struct gdl_encoder {
             if (ev_side[p]) (void)hipEventDestroy(ev_side[p]);
         if (side) (void)hipStreamDestroy(side);
     }
-    float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr, *dw0p = nullptr;
+    float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
     FoldWs fold{nullptr, nullptr};  // in-launch BatchNorm finalize (fold.h): counters + group rows, used on the caller's stream
@@ -132,7 +132,6 @@ size_t gdl_encoder::plan(unsigned char* base) {
     x1 = b.take((size_t)n_img * h1 * w1 * 64 * e);
     idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
     ymax = b.take((size_t)n_img * h1 * w1 * 64 * e);  // raw stem output at each pooling window's argmax
-    dw0p = (float*)b.take((size_t)64 * kp * sizeof(float));
     pack_dev = b.take(32 * sizeof(PackDescHost));
     auto bn_alloc = [&](BN& n) {
         n.scale = (float*)b.take(sizeof(float) * n.c);
@@ -254,7 +253,6 @@ int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int 
     e->w0 = (W + 6 - 7) / 2 + 1;
     e->h1 = (e->h0 - 1) / 2 + 1;  // MaxPool2d(3,2,1)
     e->w1 = (e->w0 - 1) / 2 + 1;
-    e->kp = stem_kp(e->cin, dtype);
     e->m0 = (long)e->n_img * e->h0 * e->w0;
     if (e->m0 >= (1L << 24)) {
         set_error("encoder_create: stem output has %ld pixels (limit 2^24); lower the batch", e->m0);
@@ -413,7 +411,7 @@ static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double co
 static bool wgrad_late() {
     static int v = -1;
     if (v < 0) {
-        const char* env = getenv("GDL_WGRAD_LATE");  // tuning aid (side-stream mode only)
+        const char* env = tune_env("GDL_WGRAD_LATE");  // tuning aid (side-stream mode only)
         v = env ? atoi(env) : 0;
     }
     return v != 0;
@@ -426,7 +424,7 @@ static bool wgrad_late() {
 static bool fold_on() {
     static int v = -1;
     if (v < 0) {
-        const char* env = getenv("GDL_FOLD");
+        const char* env = tune_env("GDL_FOLD");
         v = env ? atoi(env) : 0;
     }
     return v != 0;
@@ -435,7 +433,7 @@ static bool fold_on() {
 static bool separate_stats() {
     static int sep = -1;
     if (sep < 0) {
-        const char* env = getenv("GDL_SEPARATE_STATS");  // tuning aid: statistics by a separate pass over y
+        const char* env = tune_env("GDL_SEPARATE_STATS");  // tuning aid: statistics by a separate pass over y
         sep = env ? atoi(env) : 0;
     }
     return sep != 0;
@@ -516,7 +514,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         e->pack_dirty = false;
     }
     RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
-    // stem: conv1 (7x7/2) as im2col + GEMM, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
+    // stem: conv1 (7x7/2) as a direct implicit GEMM over the padded input, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
     {
         const int tiles = conv_stem_tiles_m(dt, e->n_img, e->H, e->W);

@@ -1,4 +1,5 @@
 // errors.cpp -- thread-local error state of libgdl_hip.
+#include <stdlib.h>
 #include <stdarg.h>
 
 #include "common.h"
@@ -18,4 +19,12 @@ int check_hip(hipError_t e, const char* what) {
     return GDL_ERR_HIP;
 }
 const char* last_error() { return g_err; }
+const char* tune_env(const char* name) {
+    static int on = -1;
+    if (on < 0) {
+        const char* t = getenv("GDL_TUNING");
+        on = (t && atoi(t) != 0) ? 1 : 0;
+    }
+    return on ? getenv(name) : nullptr;
+}
 }  // namespace gdl

@@ -1,4 +1,4 @@
-// layout.hip -- weight packing, stem im2col and NHWC<->NCHW conversion (HBM-bound helpers).
+// layout.hip -- weight packing, the stem's padded NHWC4 input copy and NHWC<->NCHW conversion (HBM-bound helpers).
 //
 // The reference keeps conv weights as float32 [K][C][R][S] (nn.Conv2d, backbone.py:20-28,
 // 96-101) and activations NCHW.  Inside the library activations are NHWC `dtype`, weights
@@ -42,92 +42,6 @@ int pack_weight(int dtype, const float* w, void* krsc, void* crsk, int K, int C,
 }
 
 // ---------------------------------------------------------------- stem
-int stem_kp(int cin, int dtype) {
-    const int bke = (dtype == GDL_BF16) ? 64 : 32;
-    int kp = (cin * 49 + bke - 1) / bke * bke;
-    if (kp % 64) kp = (kp + 63) / 64 * 64;  // wgrad tiles are 64 wide
-    return kp;
-}
-
-// float32 [64][Cin*49] -> T [64][Kp], zero padded
-template <typename T>
-__global__ void pack_stem_weight_kernel(const float* __restrict__ w, T* __restrict__ wp, int kin, int kp) {
-    const int total = 64 * kp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int k = i / kp, j = i - k * kp;
-        storeT<T>(wp + i, j < kin ? w[k * kin + j] : 0.f);
-    }
-}
-int pack_stem_weight(int dtype, const float* w, void* wp, int cin, hipStream_t st) {
-    const int kp = stem_kp(cin, dtype);
-    if (dtype == GDL_BF16)
-        hipLaunchKernelGGL(pack_stem_weight_kernel<bf16>, dim3(48), dim3(256), 0, st, w, (bf16*)wp, cin * 49, kp);
-    else
-        hipLaunchKernelGGL(pack_stem_weight_kernel<float>, dim3(48), dim3(256), 0, st, w, (float*)wp, cin * 49, kp);
-    GDL_CHECK_LAUNCH("pack_stem_weight_kernel");
-    return GDL_OK;
-}
-
-// im2col of the 7x7 / stride 2 / pad 3 stem.  x float32 [B][Cin][T][H][W] (the reference's own
-// input tensor; image n = b*T + t, backbone.py:162-164).  col [M][Kp], M = B*T*P*Q,
-// column j = (c*7 + r)*7 + s.  One block = one output row (n, p): the 7 input rows it needs are
-// staged once in LDS (zero padded, coalesced float loads), then every thread assembles 16-byte
-// chunks from LDS through a j -> patch-offset table.  HBM sees the input ~once (7/2 re-reads of a
-// row by neighbouring blocks are L2 hits) and the im2col matrix once.
-template <typename T>
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int Cin, int Tn,
-                                                          int H, int W, int P, int Q, int kp) {
-    constexpr int EPC = TT<T>::EPC;
-    extern __shared__ float patch[];  // [Cin*7][Wp] then int offtab[kp]
-    const int Wp = W + 6;
-    const int npatch = Cin * 7 * Wp;
-    int* offtab = (int*)(patch + npatch);
-    const int n = blockIdx.x / P, p = blockIdx.x - n * P;
-    const int b = n / Tn, t = n - b * Tn;
-    for (int idx = threadIdx.x; idx < npatch; idx += 256) {
-        const int cr = idx / Wp, xw = idx - cr * Wp;
-        const int c = cr / 7, r = cr - c * 7;
-        const int ih = 2 * p - 3 + r, iw = xw - 3;
-        float v = 0.f;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-            v = x[((((size_t)b * Cin + c) * Tn + t) * H + ih) * W + iw];
-        patch[idx] = v;
-    }
-    for (int j = threadIdx.x; j < kp; j += 256) offtab[j] = j < Cin * 49 ? (j / 7) * Wp + (j % 7) : -1;
-    __syncthreads();
-    const int cpr = kp / EPC;
-    T* dst = col + (size_t)blockIdx.x * Q * kp;
-    for (int i = threadIdx.x; i < Q * cpr; i += 256) {
-        const int q = i / cpr, ch = i - q * cpr;
-        float f[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const int o = offtab[ch * EPC + e];
-            f[e] = o >= 0 ? patch[o + 2 * q] : 0.f;
-        }
-        *(uint4*)(dst + (size_t)i * EPC) = pack16<T>(f);
-    }
-}
-int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, hipStream_t st) {
-    const int P = (H + 6 - 7) / 2 + 1, Q = (W + 6 - 7) / 2 + 1;
-    const int kp = stem_kp(Cin, dtype);
-    const size_t total = (size_t)B * T * P * Q * (kp / (dtype == GDL_BF16 ? 8 : 4));
-    const size_t sh = (size_t)Cin * 7 * (W + 6) * sizeof(float) + (size_t)kp * sizeof(int);
-    GDL_REQUIRE(sh <= 64 * 1024, "stem_im2col: input rows of %d floats do not fit the LDS patch", W);
-    // algorithmic bytes: read the float32 input once, write the im2col matrix once
-    ProfScope prof(dtype == GDL_BF16 ? "gdl::stem_im2col_kernel<gdl::bf16>" : "gdl::stem_im2col_kernel<float>", PROF_HBM, st,
-                   (double)B * Cin * T * H * W * 4.0 + (double)total * 16.0);
-    if (dtype == GDL_BF16)
-        hipLaunchKernelGGL(stem_im2col_kernel<bf16>, dim3(B * T * P), dim3(256), sh, st, x, (bf16*)col, Cin, T, H, W, P, Q,
-                           kp);
-    else
-        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(B * T * P), dim3(256), sh, st, x, (float*)col, Cin, T, H, W, P,
-                           Q, kp);
-    GDL_CHECK_LAUNCH("stem_im2col_kernel");
-    return GDL_OK;
-}
-
-// ---------------------------------------------------------------- direct (implicit-GEMM) stem
 // The 7x7/2 pad-3 stem as an implicit GEMM needs no im2col matrix if the network input is first copied
 // ONCE into a zero-padded channels-last image with 4 channels per pixel:
 //     xp [n_img][H+6][W+8][4] of T   (3 rows / columns of zeros before, >= 3 rows / 5 columns after)

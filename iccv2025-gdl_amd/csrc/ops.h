@@ -60,9 +60,6 @@ struct PackDescHost {  // mirrors layout.hip::PackDesc
     int K, C, RS, blk0;
 };
 int pack_weights_batched(int dtype, const void* desc_dev, int ndesc, int total_blocks, double bytes, hipStream_t st);
-int stem_kp(int cin, int dtype);
-int pack_stem_weight(int dtype, const float* w, void* wp, int cin, hipStream_t st);
-int stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, hipStream_t st);
 int nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, hipStream_t st);
 int nchw_f32_to_nhwc(int dtype, const float* x, void* y, int N, int H, int W, int C, hipStream_t st);
 // bn.hip

@@ -274,7 +274,7 @@ int maxpool_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N
     ProfScope prof(dtype == GDL_BF16 ? "gdl::maxpool_bwd_kernel<gdl::bf16>" : "gdl::maxpool_bwd_kernel<float>", PROF_HBM, st, (double)total * 16.0 + (double)N * P * Q * C * (16.0 / epc + 1.0));
     static int patch = -1;
     if (patch < 0) {
-        const char* e = getenv("GDL_POOL_PATCH");  // tuning aid: 0 = one thread per input pixel
+        const char* e = tune_env("GDL_POOL_PATCH");  // tuning aid: 0 = one thread per input pixel
         patch = e ? atoi(e) : 1;
     }
     if (patch) {

@@ -34,10 +34,6 @@ SIGNATURES = {
     "gdl_conv_wgrad_workspace_bytes": ("z", "iiiiiiiiii"),
     "gdl_conv_wgrad": ("i", "ipppp" + "iiiiiiiii" + "pzp"),
     "gdl_pack_weight": ("i", "ippp" + "iiii" + "p"),
-    "gdl_stem_kp": ("i", "ii"),
-    "gdl_stem_im2col": ("i", "ipp" + "iiiii" + "p"),
-    "gdl_pack_stem_weight": ("i", "ippip"),
-    "gdl_stem_wgrad": ("i", "ipppp" + "ii" + "pzp"),
     "gdl_stem_pad_bytes": ("z", "iiii"),
     "gdl_stem_weight_bytes": ("z", "i"),
     "gdl_stem_table_bytes": ("z", "iii"),

@@ -168,7 +168,8 @@ class DGLTrainer:
         self.eng_v = EncoderEngine("visual", self.dtype, B, T, H, W, self.device)
         # A fourth stream for the visual (critical-path) encoder's weight gradients -- but never a fifth:
         # with a process group the collective's stream is the fourth (see gdl_encoder_side_stream).
-        side = os.environ.get("GDL_SIDE_STREAM")  # tuning aid: 0 = off, 1 = both engines
+        # (tuning aid, honoured only with GDL_TUNING=1: GDL_SIDE_STREAM 0 = off, 1 = both engines)
+        side = os.environ.get("GDL_SIDE_STREAM") if os.environ.get("GDL_TUNING") == "1" else None
         if side == "1":
             self.eng_a.side_stream(True)
         if side == "1" or (side is None and self.reducer is None):

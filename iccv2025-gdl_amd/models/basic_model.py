@@ -3,8 +3,10 @@
 Same constructor (reads args.fusion_method / dataset / modality), same attribute and parameter
 names in the same registration order (fusion head, audio_net, visual_net), same forward
 signature and return order `(out, a_out, v_out)`.  The two encoders run concurrently on two
-HIP streams.  Only the full-modality concat path of the DGL scripts is implemented; the other
-fusion methods raise NotImplementedError naming what is missing.
+HIP streams.  All four DGL fusion heads of the reference are built (`concat`, `sum`, `gated` with
+x_gate=True, `film`; fusion_modules.py:16-30,45-59,126-178,213-250) for the full-modality setting of the
+DGL scripts; `modality != 'full'` raises NotImplementedError.  FiLM_DGL handles at most 64 samples per
+call (its kernels put one sample per lane of a wavefront; the reference scripts train with batch 64).
 """
 import torch
 import torch.nn as nn

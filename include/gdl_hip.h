@@ -95,21 +95,6 @@ GDL_API int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw_k
 GDL_API int gdl_pack_weight(int dtype, const float* w_kcrs, void* w_krsc, void* w_crsk, int K, int C, int R, int S,
                             void* stream);
 
-/* Stem 7x7/2 pad 3 (backbone.py:96-101) runs as im2col + the same GEMM kernels.
- * x is the reference's own input tensor: float32 [B][Cin][T][H][W] (T = 1 and
- * Cin = 1 for audio `spec.unsqueeze(1)`; the visual permute/view of
- * backbone.py:162-164 is folded into the indexing).  col: [B*T*P*Q][Kp] dtype,
- * Kp = gdl_stem_kp(Cin, dtype) >= Cin*49, zero padded.
- * gdl_pack_stem_weight: float32 [64][Cin][7][7] -> dtype [64][Kp]. */
-GDL_API int gdl_stem_kp(int cin, int dtype);
-GDL_API int gdl_stem_im2col(int dtype, const float* x, void* col, int B, int Cin, int T, int H, int W, void* stream);
-GDL_API int gdl_pack_stem_weight(int dtype, const float* w, void* wp, int Cin, void* stream);
-/* The GEMM on the im2col matrix is gdl_conv_fwd with N = M, H = W = 1, C = Kp, K = 64, R = S = 1 and a
- * GDL_GATHER_FWD table of that geometry; the same table serves gdl_stem_wgrad:
- * dw [64][Cin][7][7] float32 from dy [M][64] and the im2col matrix; ws sized by
- * gdl_conv_wgrad_workspace_bytes(dtype, M, 1, 1, Kp, 64, 1, 1, 1, 0) */
-GDL_API int gdl_stem_wgrad(int dtype, const void* dy, const void* col, float* dw, const void* table, int M, int Cin,
-                           void* ws, size_t ws_bytes, void* stream);
 
 /* Direct (implicit-GEMM) stem -- what the encoder engine runs; the im2col entry points above remain for
  * callers that want the matrix.  The reference's input tensor (same as gdl_stem_im2col) is copied once

@@ -44,8 +44,6 @@ def test_host_queries_need_no_gpu():
     lib = L.load()
     bf16, f32 = L.dtype_code("bf16"), L.dtype_code("f32")
     # stem K padding: 147 -> 192 (bf16, 64-element K-steps), 49 -> 64
-    assert lib.gdl_stem_kp(3, bf16) == 192 and lib.gdl_stem_kp(1, bf16) == 64
-    assert lib.gdl_stem_kp(3, f32) >= 147 and lib.gdl_stem_kp(3, f32) % 32 == 0 and lib.gdl_stem_kp(1, f32) == 64
     # gather tables: 8 bytes per GEMM row; the permuted stride-2 data-gradient table carries row indices too
     N, H, W = 4, 56, 56
     assert lib.gdl_conv_table_bytes(L.GDL_GATHER_FWD if hasattr(L, "GDL_GATHER_FWD") else 0, N, H, W, 3, 3, 1, 1) == N * H * W * 8

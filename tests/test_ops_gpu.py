@@ -126,43 +126,6 @@ def test_conv_wgrad(shape, dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("case", [("audio", 2, 1, 1, 65, 47), ("visual", 2, 3, 2, 40, 36)])
-def test_stem(case, dt):
-    """7x7/2 stem as im2col + GEMM (forward and weight gradient) against the oracle's direct conv."""
-    _, B, Cin, T, H, W = case
-    x = rng.standard_normal((B, Cin, T, H, W), dtype=np.float32)
-    w = (rng.standard_normal((64, Cin, 7, 7), dtype=np.float32) * 0.1).astype(np.float32)
-    xq = quant(x, dt)  # im2col rounds the input to the storage type
-    wq = quant(w, dt)
-    x4 = np.ascontiguousarray(xq.transpose(0, 2, 1, 3, 4)).reshape(B * T, Cin, H, W)
-    ref = orc.conv2d_fwd(x4, wq, 2, 3)
-    P, Q = ref.shape[2], ref.shape[3]
-    M = B * T * P * Q
-    kp = L.load().gdl_stem_kp(Cin, dt)
-    col = empty((M, kp), dt)
-    wp = empty((64, kp), dt)
-    y = empty((B * T, P, Q, 64), dt)
-    xd, wd = dev(x), dev(w)
-    st = L.cur_stream()
-    L.call("gdl_stem_im2col", dt, L.ptr(xd), L.ptr(col), B, Cin, T, H, W, st)
-    L.call("gdl_pack_stem_weight", dt, L.ptr(wd), L.ptr(wp), Cin, st)
-    tab = gather_table(L.GATHER_FWD, dt, M, 1, 1, kp, 64, 1, 1, 1, 0)
-    L.call("gdl_conv_fwd", dt, L.ptr(col), L.ptr(wp), L.ptr(y), None, L.ptr(tab), M, 1, 1, kp, 64, 1, 1, 1, 0, st)
-    torch.cuda.synchronize()
-    got = from_nhwc(y)
-    assert relerr(got, ref) < tol(dt, 2e-6, 3e-3), relerr(got, ref)
-    dy = quant(rng.standard_normal((B * T, 64, P, Q), dtype=np.float32), dt)
-    refw = orc.conv2d_bwd_weight(dy, x4, (64, Cin, 7, 7), 2, 3)
-    dyd = to_nhwc(dy, dt)
-    nbytes = L.load().gdl_conv_wgrad_workspace_bytes(dt, M, 1, 1, kp, 64, 1, 1, 1, 0)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    dw = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
-    L.call("gdl_stem_wgrad", dt, L.ptr(dyd), L.ptr(col), L.ptr(dw), L.ptr(tab), M, Cin, L.ptr(ws), nbytes, st)
-    torch.cuda.synchronize()
-    assert relerr(dw.cpu().numpy(), refw) < 2e-5, relerr(dw.cpu().numpy(), refw)
-
-
-@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("case", [("audio", 2, 1, 1, 65, 47), ("visual", 2, 3, 2, 40, 36), ("visual_odd", 1, 3, 3, 33, 29),
                                   # output rows of >= 64 pixels: the bf16 weight gradient runs on the row-slab kernel
                                   ("row64", 1, 3, 2, 12, 128), ("row95_odd_h", 2, 1, 1, 9, 190), ("row135", 2, 3, 1, 7, 270)])

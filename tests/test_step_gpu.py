@@ -519,17 +519,39 @@ def test_dropin_autograd_step_golden(name):
     model.train()
     spec, image, label = _batch(cfg, 0)
     optimizer.zero_grad()
-    out, out_a, out_v = model(spec.unsqueeze(1).float(), image.float())
-    loss_v = criterion(out_v, label)
-    loss_a = criterion(out_a, label)
-    loss_f = criterion(out, label)
-    loss_unimodal = (loss_a + loss_v) * cfg["alpha"]
-    loss_unimodal.backward(retain_graph=True)
-    for nme, parms in model.named_parameters():
-        layer = str(nme).split('.')[1]
-        if 'fusion' in layer:
-            parms.grad = None
-    loss_f.backward()
+    # count the encoder-engine backward passes: the second backward (loss_f, detached features) must not reach them
+    from gdl.encoder import EncoderEngine
+
+    calls = []
+    orig_bwd = EncoderEngine.backward
+
+    def counting_bwd(self, *a, **k):
+        calls.append(self)
+        return orig_bwd(self, *a, **k)
+
+    EncoderEngine.backward = counting_bwd
+    try:
+        out, out_a, out_v = model(spec.unsqueeze(1).float(), image.float())
+        loss_v = criterion(out_v, label)
+        loss_a = criterion(out_a, label)
+        loss_f = criterion(out, label)
+        loss_unimodal = (loss_a + loss_v) * cfg["alpha"]
+        loss_unimodal.backward(retain_graph=True)
+        assert len(calls) == 2  # one per encoder
+        for nme, parms in model.named_parameters():
+            layer = str(nme).split('.')[1]
+            if 'fusion' in layer:
+                parms.grad = None
+        loss_f.backward()
+        assert len(calls) == 2, "loss_f.backward() re-ran an encoder backward (undefined gradients were materialised)"
+    finally:
+        EncoderEngine.backward = orig_bwd
+    _dropin_checks(model, optimizer, g, cfg, out, loss_f, loss_a)
+
+
+def _dropin_checks(model, optimizer, g, cfg, out, loss_f, loss_a):
+    import torch.nn as nn
+
     total = nn.utils.clip_grad_norm_(model.parameters(), max_norm=40, norm_type=2)
     audio_grad_sum = sum(torch.abs(p.grad).mean().item() for p in model.module.audio_net.parameters())
     visual_grad_sum = sum(torch.abs(p.grad).mean().item() for p in model.module.visual_net.parameters())
@@ -547,6 +569,52 @@ def test_dropin_autograd_step_golden(name):
     sd = model.module.state_dict()
     for i, n in enumerate(names):
         np.testing.assert_allclose(sd[n].double().abs().sum().item(), ps[i][1], rtol=2e-5, err_msg=n)
+
+
+def test_trainer_checkpoint_and_label_checks():
+    """DGLTrainer.state_dict / load_state_dict (momentum arena, lr, step count -- what a reference checkpoint keeps in
+    optimizer.state_dict(), main_dgl.py:372): a run resumed from a checkpoint continues bit-identically; labels of the
+    wrong dtype / shape are refused, an out-of-range class index poisons the loss instead of reading out of bounds."""
+    from gdl.trainer import DGLTrainer
+
+    g = _gold("dgl_tiny_b4")
+    cfg = json.loads(str(g["config"]))
+
+    def fresh():
+        m = _make_model(cfg, "f32")
+        m.train()
+        return m, DGLTrainer(m, lr=cfg["lr"], alpha=cfg["alpha"], mode=cfg["mode"])
+
+    m0, t0 = fresh()
+    b0, b1 = _batch(cfg, 0), _batch(cfg, 1)
+    t0.step(*b0)
+    ck_model = {k: v.clone() for k, v in m0.state_dict().items()}
+    ck_opt = t0.state_dict()
+    assert ck_opt["steps"] == 1 and ck_opt["momentum"].abs().sum().item() > 0
+    t0.step(*b1)
+    want = t0.read()
+    m1, t1 = fresh()
+    m1.load_state_dict(ck_model)
+    t1 = DGLTrainer(m1, lr=cfg["lr"], alpha=cfg["alpha"], mode=cfg["mode"])  # (re-alias the arena to the loaded weights)
+    t1.load_state_dict(ck_opt)
+    assert t1.steps == 1
+    t1.step(*b1)
+    got = t1.read()
+    np.testing.assert_array_equal(got["out"], want["out"])
+    assert got["total_norm"] == want["total_norm"]
+    for k, v in m0.state_dict().items():
+        assert torch.equal(v, m1.state_dict()[k]), k
+    with pytest.raises(L.GdlError):
+        t1.load_state_dict({**ck_opt, "offsets": ck_opt["offsets"][:-1]})
+    spec, image, label = b0
+    with pytest.raises(L.GdlError):
+        t1.step(spec, image, label.to(torch.int32))
+    with pytest.raises(L.GdlError):
+        t1.step(spec, image, label[:-1])
+    bad = label.clone()
+    bad[0] = cfg["n_classes"] + 3
+    t1.step(spec, image, bad)
+    assert np.isnan(t1.read()["loss_f"])
 
 
 def test_full_size_properties():
