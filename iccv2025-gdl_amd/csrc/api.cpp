@@ -55,6 +55,16 @@ int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* b
     GDL_REQUIRE(x && w_krsc && y, "conv_fwd: null pointer");
     return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
 }
+int gdl_bn_act_bits(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* res_scale,
+                    const float* res_shift, void* out, uint8_t* relu_bits, size_t M, int C, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && y && scale && shift && out && relu_bits, "bn_act_bits: bad arguments");
+    return bn_act(dtype, y, scale, shift, res, res_scale, res_shift, 1, out, M, C, (hipStream_t)stream, relu_bits);
+}
+int gdl_conv_dgrad_relu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const uint8_t* relu_bits,
+                        const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
+    GDL_REQUIRE(dy && w_crsk && dx && relu_bits, "conv_dgrad_relu: null pointer");
+    return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits);
+}
 static FoldWs fold_ws_of(void* ws) {
     return FoldWs{(unsigned*)ws, (double*)((unsigned char*)ws + align_up(fold_ctr_bytes(), 256))};
 }

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
                                                             const float* __restrict__ shift, const T* __restrict__ res,
                                                             const float* __restrict__ rscale,
                                                             const float* __restrict__ rshift, T* __restrict__ out,
-                                                            size_t nvec, int C, size_t stride_vec) {
+                                                            uint8_t* __restrict__ bits, size_t nvec, int C,
+                                                            size_t stride_vec) {
     constexpr int EPC = TT<T>::EPC;
     size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
     if (i >= nvec) return;
@@ -244,6 +245,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
             f[e] = v;
         }
         *(uint4*)(out + j * EPC) = pack16<T>(f);
+        if (RELU && bits) {  // sign bits of the output (one byte per 16-byte vector): the backward's ReLU mask
+            unsigned mk = 0u;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) mk |= (f[e] > 0.f ? 1u : 0u) << e;
+            bits[j] = (uint8_t)mk;
+        }
     };
     // two vectors per trip: both loads are in flight before either is consumed
     for (; i + stride_vec < nvec; i += 2 * stride_vec) {
@@ -295,7 +302,7 @@ static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec
 
 template <typename T>
 static int bn_act_t(const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                    const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st) {
+                    const float* rshift, int relu, void* out, uint8_t* bits, size_t M, int C, hipStream_t st) {
     constexpr int EPC = TT<T>::EPC;
     GDL_REQUIRE(C % EPC == 0, "bn_act: C=%d not a multiple of %d", C, EPC);
     const size_t nvec = M * (size_t)C / EPC;
@@ -309,7 +316,7 @@ static int bn_act_t(const void* y, const float* scale, const float* shift, const
     ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * (resmode ? 3 : 2));
 #define BN_ACT_LAUNCH(RM, RL)                                                                                        \
     hipLaunchKernelGGL((bn_act_kernel<T, RM, RL>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale, shift, \
-                       (const T*)res, rscale, rshift, (T*)out, nvec, C, stride)
+                       (const T*)res, rscale, rshift, (T*)out, bits, nvec, C, stride)
     if (resmode == 0 && relu) BN_ACT_LAUNCH(0, true);
     if (resmode == 0 && !relu) BN_ACT_LAUNCH(0, false);
     if (resmode == 1 && relu) BN_ACT_LAUNCH(1, true);
@@ -321,9 +328,10 @@ static int bn_act_t(const void* y, const float* scale, const float* shift, const
     return GDL_OK;
 }
 int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st) {
-    if (dtype == GDL_BF16) return bn_act_t<bf16>(y, scale, shift, res, rscale, rshift, relu, out, M, C, st);
-    return bn_act_t<float>(y, scale, shift, res, rscale, rshift, relu, out, M, C, st);
+           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st, uint8_t* relu_bits) {
+    GDL_REQUIRE(!relu_bits || relu, "bn_act: relu_bits without relu");
+    if (dtype == GDL_BF16) return bn_act_t<bf16>(y, scale, shift, res, rscale, rshift, relu, out, relu_bits, M, C, st);
+    return bn_act_t<float>(y, scale, shift, res, rscale, rshift, relu, out, relu_bits, M, C, st);
 }
 
 // ---------------------------------------------------------------- backward
@@ -443,7 +451,9 @@ int bn_bwd_reduce_fold(int dtype, const void* g, const void* y, const float* sca
 // path and both BN applies read it) together with the reductions of bn2 and, when the block has a
 // downsample branch, of its BatchNorm -- one pass over dz, z, y2 (, yd) instead of relu_bwd +
 // two reduce kernels.  partial2 / partiald: [blocks][C][2].
-template <typename T, bool DS>
+// PRE: dz already carries the ReLU mask (the data gradient that produced it applied the block output's sign bits in its
+// epilogue, conv_igemm.hip): z is not read and do2 (== dz) not written -- two tensor passes instead of four.
+template <typename T, bool DS, bool PRE>
 __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                       const T* __restrict__ y2, const T* __restrict__ yd,
                                                                       const float* __restrict__ mean2,
@@ -470,23 +480,27 @@ __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* _
     auto one = [&](size_t j, const uint4& gq, const uint4& zq, const uint4& yq, const uint4& dq) {
         float gv[EPC], zv[EPC], yv[EPC], dv[EPC];
         unpack16<T>(gq, gv);
-        unpack16<T>(zq, zv);
+        if (!PRE) unpack16<T>(zq, zv);
         unpack16<T>(yq, yv);
         if (DS) unpack16<T>(dq, dv);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float gg = zv[e] > 0.f ? gv[e] : 0.f;
+            const float gg = PRE ? gv[e] : (zv[e] > 0.f ? gv[e] : 0.f);
             gv[e] = gg;
             a1[e] += gg;
             a2[e] += gg * ((yv[e] - mu2[e]) * rs2[e]);
             if (DS) b2[e] += gg * ((dv[e] - mud[e]) * rsd[e]);
         }
-        *(uint4*)(do2 + j * EPC) = pack16<T>(gv);
+        if (!PRE) *(uint4*)(do2 + j * EPC) = pack16<T>(gv);
     };
     for (; i + stride_vec < nvec; i += 2 * stride_vec) {
         const size_t j = i + stride_vec;
         const uint4 g0 = *(const uint4*)(dz + i * EPC), g1 = *(const uint4*)(dz + j * EPC);
-        const uint4 z0 = *(const uint4*)(z + i * EPC), z1 = *(const uint4*)(z + j * EPC);
+        uint4 z0 = g0, z1 = g1;
+        if (!PRE) {
+            z0 = *(const uint4*)(z + i * EPC);
+            z1 = *(const uint4*)(z + j * EPC);
+        }
         const uint4 y0 = *(const uint4*)(y2 + i * EPC), y1 = *(const uint4*)(y2 + j * EPC);
         uint4 d0 = y0, d1 = y1;
         if (DS) {
@@ -500,7 +514,8 @@ __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* _
         const uint4 y0 = *(const uint4*)(y2 + i * EPC);
         uint4 d0 = y0;
         if (DS) d0 = *(const uint4*)(yd + i * EPC);
-        one(i, *(const uint4*)(dz + i * EPC), *(const uint4*)(z + i * EPC), y0, d0);
+        const uint4 g0 = *(const uint4*)(dz + i * EPC);
+        one(i, g0, PRE ? g0 : *(const uint4*)(z + i * EPC), y0, d0);
     }
     const int rpp = BN_THREADS / cpr, vr = threadIdx.x / cpr;
     float* redd = red + (size_t)rpp * C * 2;
@@ -538,7 +553,7 @@ template <typename T>
 static int block_bwd_reduce_t(const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                               const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
                               float* partiald, size_t M, int C, const FoldWs& fws, const FinBwd& fin2, const FinBwd& find,
-                              hipStream_t st) {
+                              hipStream_t st, bool pre) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
     GDL_REQUIRE(C % EPC == 0 && cpr <= BN_THREADS && BN_THREADS % cpr == 0, "block_bwd_reduce: C=%d unsupported", C);
@@ -546,25 +561,28 @@ static int block_bwd_reduce_t(const void* dz, const void* z, const void* y2, con
     const int blocks = bn_bwd_blocks(M, C);
     const size_t stride = (size_t)blocks * BN_THREADS;
     const size_t sh = (size_t)(BN_THREADS / cpr) * C * 2 * sizeof(float) * (yd ? 2 : 1);
-    static char pname[2][96];
-    char* pn = pname[yd ? 1 : 0];
-    if (!pn[0]) snprintf(pn, 96, "gdl::block_bwd_reduce_kernel<%s, %s>", prof_tname<T>(), yd ? "true" : "false");
-    ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * (yd ? 5 : 4));
-    if (yd)
-        hipLaunchKernelGGL((block_bwd_reduce_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)dz,
-                           (const T*)z, (const T*)y2, (const T*)yd, mean2, rstd2, meand, rstdd, (T*)do2, partial2, partiald,
-                           nvec, C, stride, fws, fin2, find);
-    else
-        hipLaunchKernelGGL((block_bwd_reduce_kernel<T, false>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)dz,
-                           (const T*)z, (const T*)y2, (const T*)nullptr, mean2, rstd2, meand, rstdd, (T*)do2, partial2,
-                           partiald, nvec, C, stride, fws, fin2, find);
+    static char pname[4][96];
+    char* pn = pname[(yd ? 1 : 0) + (pre ? 2 : 0)];
+    if (!pn[0])
+        snprintf(pn, 96, "gdl::block_bwd_reduce_kernel<%s, %s, %s>", prof_tname<T>(), yd ? "true" : "false", pre ? "true" : "false");
+    ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * ((yd ? 5 : 4) - (pre ? 2 : 0)));
+#define GDL_BBR(DSV, PREV)                                                                                                  \
+    hipLaunchKernelGGL((block_bwd_reduce_kernel<T, DSV, PREV>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)dz,        \
+                       (const T*)z, (const T*)y2, (const T*)yd, mean2, rstd2, meand, rstdd, (T*)do2, partial2, partiald, nvec, \
+                       C, stride, fws, fin2, find)
+    if (yd && pre) GDL_BBR(true, true);
+    if (yd && !pre) GDL_BBR(true, false);
+    if (!yd && pre) GDL_BBR(false, true);
+    if (!yd && !pre) GDL_BBR(false, false);
+#undef GDL_BBR
     GDL_CHECK_LAUNCH("block_bwd_reduce_kernel");
     return GDL_OK;
 }
 int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                      const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
                      float* partiald, size_t M, int C, hipStream_t st, const FoldWs* fws, const BnFinBwd* fin2,
-                     const BnFinBwd* find) {
+                     const BnFinBwd* find, bool premasked) {
+    GDL_REQUIRE(premasked || (z && do2), "block_bwd_reduce: z / do2 missing");
     FoldWs w{nullptr, nullptr};
     FinBwd f2{}, fd{};
     if (fws && fws->ctr) {
@@ -574,8 +592,10 @@ int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, c
         if (yd) fd = FinBwd{find->dgamma, find->dbeta, find->coef, C, find->count};
     }
     if (dtype == GDL_BF16)
-        return block_bwd_reduce_t<bf16>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, w, f2, fd, st);
-    return block_bwd_reduce_t<float>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, w, f2, fd, st);
+        return block_bwd_reduce_t<bf16>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, w, f2, fd, st,
+                                        premasked);
+    return block_bwd_reduce_t<float>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, w, f2, fd, st,
+                                     premasked);
 }
 
 // dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M

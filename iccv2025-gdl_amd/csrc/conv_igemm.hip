@@ -39,6 +39,7 @@ struct ConvArgs {
     const void* wt;            // [OC][ntaps][IC]
     void* out;                 // NHWC rows of OC channels, row m = GEMM row m
     const void* addend;        // optional, like out
+    const uint8_t* relu_bits;  // optional: one byte per 16-byte vector of out; the stored value is zeroed where its bit is 0
     float* stats;              // optional [mtiles][OC][2]
     const GatherEntry* table;  // [M]
     int M, OC, IC, ntaps;
@@ -232,6 +233,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             unpack16<T>(w, g);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            v = pack16<T>(f);
+        }
+        if (a.relu_bits) {  // ReLU backward of the tensor this is the gradient of, folded into the store
+            const unsigned mk = a.relu_bits[goff / EPC];
+            float f[EPC];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
             v = pack16<T>(f);
         }
         if (a.stats) {
@@ -1027,7 +1036,8 @@ static FinTrain make_fin(const BnFinTrain& b, float eps, float momentum) {
 
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                    hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr) {
+                    hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
+                    const uint8_t* relu_bits = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1044,6 +1054,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     a.wt = wt;
     a.out = out;
     a.addend = addend;
+    a.relu_bits = relu_bits;
     a.stats = stats;
     a.table = (const GatherEntry*)table;
     a.M = g.rows;
@@ -1178,8 +1189,9 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
 }
 
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
-               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
-    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st);
+               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits) {
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
+                    nullptr, relu_bits);
 }
 
 }  // namespace gdl

@@ -41,6 +41,8 @@ struct Block {
     bool has_ds = false;
     int n, h, w, p, q, cin, cout;
     void *y1 = nullptr, *a1 = nullptr, *y2 = nullptr, *yd = nullptr, *z = nullptr;
+    uint8_t* zbits = nullptr;  // sign bits of z (one byte per 16-byte vector): the backward's ReLU mask, applied by the
+                               // data gradient that produces the gradient of z (conv_dgrad's relu_bits)
     const void* xin = nullptr;
 };
 
@@ -80,6 +82,7 @@ struct gdl_encoder {
     bool side_pending[2] = {false, false};
     // gdl_encoder_backward_phase: state carried from phase 1 (layer4) to phase 2 (the rest)
     void *bw_dz = nullptr, *bw_spare = nullptr;
+    bool bw_premasked = false;  // bw_dz already carries the ReLU mask of its block's output
     long bw_serial = -1;  // serial of the forward whose phase 1 ran
     ~gdl_encoder() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -175,6 +178,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
         k.a1 = b.take(out_el * e);
         k.y2 = b.take(out_el * e);
         k.z = b.take(out_el * e);
+        k.zbits = (uint8_t*)b.take(out_el * e / 16);
         conv_alloc(k.c1);
         conv_alloc(k.c2);
         for (Conv* c : {&k.c1, &k.c2}) {
@@ -430,6 +434,16 @@ static bool fold_on() {
     return v != 0;
 }
 
+// ReLU mask of a block output applied by the producing data gradient (default on; GDL_PREMASK=0: the block masks itself)
+static bool premask_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = tune_env("GDL_PREMASK");
+        v = env ? atoi(env) : 1;
+    }
+    return v != 0;
+}
+
 static bool separate_stats() {
     static int sep = -1;
     if (sep < 0) {
@@ -548,15 +562,18 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
             RC(conv_fwd(dt, k.xin, k.cd.w_krsc, k.yd, e->bn_partial2, k.cd.tab_fwd, k.n, k.cd.h, k.cd.w, k.cd.cin, k.cd.cout,
                         k.cd.r, k.cd.s, k.cd.stride, k.cd.pad, st));
             RC(bn_finalize_train_pair(fin(k.c2, k.b2, e->bn_partial), fin(k.cd, k.bd, e->bn_partial2), 1e-5f, 0.1f, st));
-            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st));
+            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st,
+                      training ? k.zbits : nullptr));
             continue;
         }
         RC(conv_bn(e, k.c2, k.b2, k.a1, k.y2, k.n, training, st));
         if (k.has_ds) {
             RC(conv_bn(e, k.cd, k.bd, k.xin, k.yd, k.n, training, st, e->bn_partial2));
-            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st));
+            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st,
+                      training ? k.zbits : nullptr));
         } else {
-            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.xin, nullptr, nullptr, 1, k.z, Mo, k.cout, st));
+            RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.xin, nullptr, nullptr, 1, k.z, Mo, k.cout, st,
+                      training ? k.zbits : nullptr));
         }
     }
     const Block& last = e->blocks.back();
@@ -625,6 +642,10 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         dz = e->bw_dz;
         spare = e->bw_spare;
     }
+    // The gradient of a block's output reaches the block already multiplied by the output's ReLU mask when the data
+    // gradient that produced it applied the saved sign bits in its epilogue (every block but the last one): the block
+    // then skips one read of z and one write of the masked gradient (two of its four tensor passes).
+    bool premasked = phase == 2 ? e->bw_premasked : false;
     // weight gradients: forked onto the side stream (sw) once their dy exists on st
     hipStream_t sw = e->side ? e->side : st;
     auto fork = [&]() -> int {  // sw waits for everything enqueued on st so far
@@ -654,7 +675,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             const bool fold = fold_on() && fold_fits(blocks, k.cout);
             RC(block_bwd_reduce(dt, dz, k.z, k.y2, k.has_ds ? k.yd : nullptr, k.b2.mean, k.b2.rstd, k.has_ds ? k.bd.mean : nullptr,
                                 k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st,
-                                fold ? &e->fold : nullptr, &f2, &fd));
+                                fold ? &e->fold : nullptr, &f2, &fd, premasked));
             if (!fold) {
                 if (k.has_ds)  // one finalize launch for bn2 and the downsample BatchNorm
                     RC(bn_bwd_finalize_pair(f2, fd, st));
@@ -700,24 +721,30 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         };
         if (!late) RC(wgrad1());
         void* dxin;
+        // the block's input is the previous block's output z (for block 0: the pooled stem output, whose mask the
+        // stem's own backward applies): its sign bits turn dx into the masked gradient the previous block wants
+        const uint8_t* inbits = (bi > 0 && premask_on()) ? e->blocks[bi - 1].zbits : nullptr;
         if (k.has_ds) {
             RC(conv_dgrad(dt, gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
                           k.cd.stride, 0, st));
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, spare, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3,
-                          k.c1.stride, 1, st));
+                          k.c1.stride, 1, st, inbits));
             dxin = spare;
             spare = dz;  // the old dz buffer is free now
         } else {
             // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
-            RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st));
+            RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st,
+                          inbits));
             dxin = do2;
         }
+        premasked = inbits != nullptr;
         if (late) RC(wgrad1());
         dz = dxin;
     }
     if (phase == 1) {  // hand over to phase 2; the layer4 gradients must be complete on st
         e->bw_dz = dz;
         e->bw_spare = spare;
+        e->bw_premasked = premasked;
         e->bw_serial = (long)e->serial;
         if (e->side) {
             hipError_t he = hipEventRecord(e->ev_join, e->side);

@@ -32,8 +32,9 @@ int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
              int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold = nullptr,
              const BnFinTrain* bn = nullptr);
+// relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
-               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
+               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr);
 // direct (implicit-GEMM) stem: layout.hip (padded NHWC4 input, row-wise weights), gather.hip (table),
 // conv_igemm.hip (forward), conv_wgrad.hip (weight gradient)
 size_t stem_pad_bytes(int dtype, int n_img, int H, int W);
@@ -75,8 +76,9 @@ int bn_finalize_train(const float* partial, int tiles, int C, double count, cons
                       float* scale, float* shift, hipStream_t st);
 int bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, const float* rm, const float* rv,
                      float* scale, float* shift, hipStream_t st);
+// relu_bits (optional, with relu): one byte per 16-byte vector of `out`, bit e = (out element e > 0)
 int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st);
+           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st, uint8_t* relu_bits = nullptr);
 int bn_bwd_blocks(size_t M, int C);
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
@@ -85,7 +87,7 @@ int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, c
 int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                      const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
                      float* partiald, size_t M, int C, hipStream_t st, const FoldWs* fws = nullptr,
-                     const BnFinBwd* fin2 = nullptr, const BnFinBwd* find = nullptr);
+                     const BnFinBwd* fin2 = nullptr, const BnFinBwd* find = nullptr, bool premasked = false);
 int bn_bwd_reduce_fold(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                        const float* rstd, int relu_mask, float* partial, size_t M, int C, double count, float* dgamma,
                        float* dbeta, float* coef, const FoldWs& fws, hipStream_t st);

@@ -69,6 +69,17 @@ GDL_API int gdl_conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, 
 GDL_API int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
                            const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                            void* stream);
+/* ReLU backward folded into the data gradient (BasicBlock: out = relu(bn2(conv2(..)) + identity), backbone.py:62-66).
+ * gdl_bn_act_bits = gdl_bn_act(relu = 1) that also stores the sign bits of its output, one byte per 16-byte vector
+ * (bit e = element e > 0); gdl_conv_dgrad_relu = gdl_conv_dgrad whose stored result (dx + addend) is zeroed where the
+ * bit of the tensor it is the gradient of is 0 -- the next block's backward then needs neither that tensor nor a
+ * separate masking pass. */
+GDL_API int gdl_bn_act_bits(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                            const float* res_scale, const float* res_shift, void* out, uint8_t* relu_bits, size_t M, int C,
+                            void* stream);
+GDL_API int gdl_conv_dgrad_relu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
+                                const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
+                                int stride, int pad, void* stream);
 /* In-launch BatchNorm finalize ("the last block folds"): the kernel that produces the per-block partial sums also
  * reduces them -- the block that completes them, found by an arrival ticket, folds them in a fixed order and runs
  * the finalize arithmetic -- so no separate finalize launch sits on the chain (backbone.py:45-48,104: conv -> bn).

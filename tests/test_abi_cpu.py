@@ -148,3 +148,28 @@ def test_seeded_init_matches_reference():
         assert list(sd.keys()) == [str(k) for k in g[fusion + ".keys"]]
         got = np.stack([[v.double().sum().item(), v.double().abs().sum().item()] for v in sd.values()])
         np.testing.assert_allclose(got, g[fusion + ".sums"], rtol=1e-12, atol=1e-12)
+
+
+def test_reference_script_starts_on_the_dropin_modules():
+    """The UNMODIFIED /root/reference/main_dgl.py starts on the mirror (SURVEY 8(b) "Who calls"): gdl.run_reference puts the
+    package first on sys.path -- models.basic_model / utils.utils / dataset.* resolve to the mirror and the synthetic
+    dataset stand-ins -- and supplies a no-op SummaryWriter when the tensorboard package is absent.  Only the import +
+    argument-parsing phase can run here (the script hard-codes cuda:0); skipped where the reference checkout is absent."""
+    import subprocess
+    import sys
+
+    script = "/root/reference/main_dgl.py"
+    if not os.path.exists(script):
+        pytest.skip("reference checkout not present")
+    pkg = os.path.join(ROOT, "iccv2025-gdl_amd")
+    r = subprocess.run([sys.executable, "-m", "gdl.run_reference", script, "--help"], cwd=pkg, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "--fusion_method" in r.stdout and "--alpha" in r.stdout
+    probe = ("import sys; sys.path.insert(0, %r); import dataset.CramedDataset as d, models.basic_model as m, utils.utils as u;"
+             "from dataset.KSDataset import KSDataset; ds = KSDataset(None, mode='test'); s, i, l = ds[0];"
+             "assert tuple(s.shape) == (129, 626) and tuple(i.shape) == (3, 3, 224, 224) and 0 <= l < 34;"
+             "print(d.__file__, m.__file__, u.__file__)") % pkg
+    r = subprocess.run([sys.executable, "-c", probe], cwd="/tmp", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count(pkg) == 3

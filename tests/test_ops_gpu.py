@@ -395,6 +395,52 @@ def test_layout_roundtrip():
         np.testing.assert_array_equal(from_nhwc(t), x)
 
 
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", [(2, 64, 17, 13, 64, 3, 1, 1), (3, 64, 20, 18, 128, 3, 2, 1), (4, 64, 56, 56, 64, 3, 1, 1),
+                                   (2, 64, 9, 6, 128, 1, 2, 0)])
+def test_relu_bits_and_masked_dgrad(shape, dt):
+    """gdl_bn_act_bits stores the sign bits of relu(bn(y) + res); gdl_conv_dgrad_relu zeroes the data gradient where
+    they are 0: together the ReLU backward of a BasicBlock output (backbone.py:65-66) without a separate masking pass --
+    against dgrad + relu_bwd of the oracle."""
+    N, C, H, W, K, R, stride, pad = shape
+    st = L.cur_stream()
+    # the tensor whose gradient the dgrad produces: z = relu(y*sc + sh + res), NHWC [N,H,W,C]
+    y = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    r = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    sc, sh = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    bc = lambda v: v[None, :, None, None]
+    zref = np.maximum(y * bc(sc) + bc(sh) + r, 0)
+    M = N * H * W
+    epc = 8 if dt == L.GDL_BF16 else 4
+    z = empty((N, H, W, C), dt)
+    bits = torch.zeros(M * C // epc, dtype=torch.uint8, device=DEV)
+    yd, rd, scd, shd = to_nhwc(y, dt), to_nhwc(r, dt), dev(sc), dev(sh)
+    L.call("gdl_bn_act_bits", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(rd), None, None, L.ptr(z), L.ptr(bits), M, C, st)
+    torch.cuda.synchronize()
+    zg = from_nhwc(z)
+    assert relerr(zg, zref) < tol(dt, 2e-6, 3e-3)
+    want_bits = (np.transpose(zg, (0, 2, 3, 1)).reshape(-1, epc) > 0)
+    got_bits = ((bits.cpu().numpy()[:, None] >> np.arange(epc)[None, :]) & 1).astype(bool)
+    np.testing.assert_array_equal(got_bits, want_bits)
+    # masked data gradient (+ addend) against the oracle
+    w = quant((rng.standard_normal((K, C, R, R), dtype=np.float32) * np.sqrt(2.0 / (C * R * R))).astype(np.float32), dt)
+    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = quant(rng.standard_normal((N, K, P, Q), dtype=np.float32), dt)
+    add = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    ref = orc.conv2d_bwd_data(dy, w, (N, C, H, W), stride, pad) + add
+    ref = np.where(zg > 0, ref, 0).astype(np.float32)
+    _, crsk = pack_weight(w, dt)
+    dyd = to_nhwc(dy, dt)
+    dx = to_nhwc(add, dt)
+    tab = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, R, R, stride, pad)
+    L.call("gdl_conv_dgrad_relu", dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), L.ptr(dx), L.ptr(bits), L.ptr(tab), N, H, W, C, K, R, R,
+           stride, pad, st)
+    torch.cuda.synchronize()
+    got = from_nhwc(dx)
+    assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
+    assert np.all(got[zg <= 0] == 0)
+
+
 def _fold_ws():
     lib = L.load()
     nb = lib.gdl_fold_workspace_bytes()
