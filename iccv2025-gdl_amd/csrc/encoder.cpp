@@ -73,9 +73,10 @@ struct gdl_encoder {
     // scratch
     void *gA = nullptr, *gE = nullptr, *g0 = nullptr;
     void *gB[2] = {nullptr, nullptr}, *gC[2] = {nullptr, nullptr}, *gD[2] = {nullptr, nullptr};  // by block parity
-    // Weight gradients run on an engine-owned low-priority side stream, forked from / joined into the
-    // caller's stream with events: they are off the dy -> dx dependency chain, so they fill the CUs
-    // the (often small) kernels of that chain leave idle.  The gradient buffers they read alternate
+    // Weight gradients run on an engine-owned side stream, forked from / joined into the caller's
+    // stream with events: they are off the dy -> dx dependency chain, so they fill the CUs the
+    // (often small) kernels of that chain leave idle.  (Stream priorities were measured and do
+    // nothing here: the range is {0, -1} and the step time is the same with any assignment.)  The gradient buffers they read alternate
     // with the block parity; ev_side[p] = "the side stream is done with parity p's buffers".
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side[2] = {nullptr, nullptr};
