@@ -263,10 +263,12 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
-            k = pm.get("kernels", {}).get(d["kernel"])
-            if (k and pm.get("src_hash") == src_hash() and pm.get("dtype") == a.dtype and pm.get("batch") == B and
+            # the tap names a kernel without its template arguments: launch-weighted mean over its instantiations
+            ks = [v for n, v in pm.get("kernels", {}).items() if n == d["kernel"] or n.startswith(d["kernel"] + "<")]
+            if (ks and pm.get("src_hash") == src_hash() and pm.get("dtype") == a.dtype and pm.get("batch") == B and
                     pm.get("workload") == a.workload):
-                traffic = round(k["hbm_bytes_per_launch"])
+                nl = sum(v["launches_per_step"] for v in ks)
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in ks) / nl)
         except (OSError, ValueError, KeyError):
             pass
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"

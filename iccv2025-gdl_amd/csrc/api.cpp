@@ -65,6 +65,11 @@ int gdl_conv_dgrad_relu(int dtype, const void* dy, const void* w_crsk, void* dx,
     GDL_REQUIRE(dy && w_crsk && dx && relu_bits, "conv_dgrad_relu: null pointer");
     return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits);
 }
+int gdl_conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
+                      const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, void* stream) {
+    GDL_REQUIRE(dy && w_crsk && dy_ds && w_ds_ck && dx, "conv_dgrad_ds: null pointer");
+    return conv_dgrad_ds(dtype, dy, w_crsk, dy_ds, w_ds_ck, dx, table, N, H, W, C, K, (hipStream_t)stream, relu_bits);
+}
 static FoldWs fold_ws_of(void* ws) {
     return FoldWs{(unsigned*)ws, (double*)((unsigned char*)ws + align_up(fold_ctr_bytes(), 256))};
 }

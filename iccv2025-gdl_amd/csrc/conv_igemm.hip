@@ -53,6 +53,12 @@ struct ConvArgs {
     // permuted stride-2 data gradient (gather.h): output pixel of each GEMM row (-1: padding row)
     const int* orow;
     const unsigned* tile_taps;  // per M-tile: OR of its rows' tap masks
+    // ... with the 1x1 stride-2 data gradient of the block's downsample branch folded in (flat kernel): the (even, even)
+    // input pixels -- the class whose tiles carry the centre tap -- get one more "tap" that gathers the SAME dy pixel as
+    // the centre tap from a second gradient tensor (in2, [.][IC]) and multiplies it with a second matrix (wt2, [OC][IC])
+    const void* in2;
+    const void* wt2;
+    unsigned in2_bytes, wt2_bytes;
     // direct bf16 stem (layout.hip): a 128-byte K-step is TWO 64-byte filter rows -- chunks 0..3 of a tile row
     // come from off0 + delta[tap], chunks 4..7 from off0 + delta_hi[tap]
     int split;
@@ -336,42 +342,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     int b_off[BROWS];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 32 * i) * a.ntaps * a.IC * esz + schunk * 16;
+    int b_off2[BROWS];  // rows of the folded downsample matrix [OC][IC]
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) b_off2[i] = (n0 + row0 + 32 * i) * a.IC * esz + schunk * 16;
     const int kpt = a.IC / BKE;  // K-steps per tap
     // taps this tile multiplies: all of them, or (class-pure tiles of a permuted stride-2 data gradient)
     // only those that are valid for at least one of its rows
-    const unsigned tapset = a.tile_taps ? a.tile_taps[mtile] : (1u << a.ntaps) - 1u;
+    unsigned tapset = a.tile_taps ? a.tile_taps[mtile] : (1u << a.ntaps) - 1u;
+    // folded downsample branch: pseudo-tap number ntaps (= 9) wherever the centre tap (4) is present
+    const bool ds = MODE == MODE_DGRAD && a.in2 != nullptr;
+    const int ntaps_all = ds ? a.ntaps + 1 : a.ntaps;
+    if (ds && (tapset & 16u)) tapset |= 1u << a.ntaps;
     const int nk = __popc(tapset) * kpt;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin2 = __builtin_amdgcn_make_buffer_rsrc((void*)(ds ? a.in2 : a.in), 0, ds ? a.in2_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwt2 = __builtin_amdgcn_make_buffer_rsrc((void*)(ds ? a.wt2 : a.wt), 0, ds ? a.wt2_bytes : 0u, 0x00020000);
     const int wrow = (tid >> 6) * 8;  // first tile row this wave's DMA instruction covers (plus 32*i)
 
-    int ld_tap = tapset ? __builtin_ctz(tapset) : a.ntaps, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
+    int ld_tap = tapset ? __builtin_ctz(tapset) : ntaps_all, ld_kc = 0;  // (tap, channel chunk) of the NEXT tile to load
     // Pixel shift of that tap, fetched (scalar loads from the kernel arguments) when ld_tap changes, i.e. one tile
     // ahead of its use.  Indexing a.delta[] / a.delta_hi[] by lane inside load_tile made it a VECTOR load whose
     // latency sat between the barrier and the DMA issue of every K-step.
-    int d_lo = a.delta[ld_tap < a.ntaps ? ld_tap : 0], d_hi = a.split ? a.delta_hi[ld_tap < a.ntaps ? ld_tap : 0] : 0;
+    // (the folded downsample tap gathers where the centre tap does)
+    auto tap_src = [&](int t) { return t < a.ntaps ? t : (t == a.ntaps && ds ? 4 : 0); };
+    int d_lo = a.delta[tap_src(ld_tap)], d_hi = a.split ? a.delta_hi[tap_src(ld_tap)] : 0;
     // Every call issues exactly AROWS+BROWS DMA instructions per wave (the counted s_waitcnt below
     // relies on it); past the last K-step they are all out of range: no memory traffic, zeros into
     // a ring slot nobody reads.
     auto load_tile = [&](int buf) {
-        const bool live = ld_tap < a.ntaps;
-        const int tap = live ? ld_tap : 0;
+        const bool live = ld_tap < ntaps_all;
+        const bool x2 = ds && ld_tap == a.ntaps;  // the folded downsample tap (uniform)
+        const int tap = live ? tap_src(ld_tap) : 0;
         const int ua = (a_hi ? d_hi : d_lo) + ld_kc * 128;  // uniform unless split
-        const int ub = (tap * a.IC) * esz + ld_kc * 128;  // uniform
+        const int ub = x2 ? ld_kc * 128 : (tap * a.IC) * esz + ld_kc * 128;  // uniform
         unsigned char* As = smem + buf * SM::STAGE;
         unsigned char* Bs = As + BM * 128;
+        const __amdgpu_buffer_rsrc_t ra = x2 ? rin2 : rin, rb = x2 ? rwt2 : rwt;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const int v = (live && ((a_mask[i] >> tap) & 1u)) ? a_off[i] + ua : (int)0x80000000;
-            dma16(rin, As + (wrow + 32 * i) * 128, v);
+            dma16(ra, As + (wrow + 32 * i) * 128, v);
         }
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) dma16(rwt, Bs + (wrow + 32 * i) * 128, live ? b_off[i] + ub : (int)0x80000000);
+        for (int i = 0; i < BROWS; ++i)
+            dma16(rb, Bs + (wrow + 32 * i) * 128, live ? (x2 ? b_off2[i] : b_off[i]) + ub : (int)0x80000000);
         if (++ld_kc == kpt) {
             ld_kc = 0;
             const unsigned rest = ld_tap + 1 < 32 ? tapset >> (ld_tap + 1) : 0u;
-            ld_tap = rest ? ld_tap + 1 + __builtin_ctz(rest) : a.ntaps;  // next tap of the set
-            const int nt = ld_tap < a.ntaps ? ld_tap : 0;
+            ld_tap = rest ? ld_tap + 1 + __builtin_ctz(rest) : ntaps_all;  // next tap of the set
+            const int nt = tap_src(ld_tap);
             d_lo = a.delta[nt];
             if (a.split) d_hi = a.delta_hi[nt];
         }
@@ -1037,7 +1057,7 @@ static FinTrain make_fin(const BnFinTrain& b, float eps, float momentum) {
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
-                    const uint8_t* relu_bits = nullptr) {
+                    const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1081,6 +1101,15 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
                     "conv: bad fold arguments");
         a.fold = *fold;
         a.fin = make_fin(*bn, 1e-5f, 0.1f);
+    }
+    if (dy_ds) {
+        GDL_REQUIRE(mode == GATHER_DGRAD && stride == 2 && R == 3 && S == 3 && pad == 1 && w_ds && !pl.slab,
+                    "conv: the folded downsample branch needs the 3x3 stride-2 pad-1 data gradient");
+        a.in2 = dy_ds;
+        a.wt2 = w_ds;
+        a.in2_bytes = a.in_bytes;  // same [N][P][Q][K] shape as dy
+        a.wt2_bytes = (unsigned)((size_t)K * C * esz);
+        a.flops += 2.0 * (double)N * P * Q * K * C;
     }
     if (mode == GATHER_DGRAD && stride == 2) {
         a.orow = (const int*)((const GatherEntry*)table + dgrad_perm_cap(N, H, W));
@@ -1192,6 +1221,13 @@ int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const vo
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits) {
     return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
                     nullptr, relu_bits);
+}
+
+int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
+                  const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits) {
+    GDL_REQUIRE(dy_ds && w_ds_ck, "conv_dgrad_ds: null pointer");
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, 3, 3, 2, 1, st, nullptr, nullptr,
+                    relu_bits, dy_ds, w_ds_ck);
 }
 
 }  // namespace gdl

@@ -436,6 +436,14 @@ static bool fold_on() {
 }
 
 // ReLU mask of a block output applied by the producing data gradient (default on; GDL_PREMASK=0: the block masks itself)
+static bool ds_fold_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = tune_env("GDL_DS_FOLD");  // tuning aid: 0 = separate 1x1 data gradient + addend
+        v = env ? atoi(env) : 1;
+    }
+    return v != 0;
+}
 static bool premask_on() {
     static int v = -1;
     if (v < 0) {
@@ -725,7 +733,14 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         // the block's input is the previous block's output z (for block 0: the pooled stem output, whose mask the
         // stem's own backward applies): its sign bits turn dx into the masked gradient the previous block wants
         const uint8_t* inbits = (bi > 0 && premask_on()) ? e->blocks[bi - 1].zbits : nullptr;
-        if (k.has_ds) {
+        if (k.has_ds && ds_fold_on() && k.c1.stride == 2) {
+            // the shortcut's 1x1 stride-2 data gradient rides in the 3x3 one as a tenth tap of the (even, even) pixels:
+            // one launch and one tensor write instead of two launches, two writes and a read
+            RC(conv_dgrad_ds(dt, gC, k.c1.w_crsk, gD, k.cd.w_crsk, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, st,
+                             inbits));
+            dxin = spare;
+            spare = dz;
+        } else if (k.has_ds) {
             RC(conv_dgrad(dt, gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
                           k.cd.stride, 0, st));
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, spare, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3,

@@ -35,6 +35,10 @@ int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_pa
 // relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr);
+// the 3x3 stride-2 pad-1 data gradient of a downsample block's conv1 with the 1x1 stride-2 data gradient of its shortcut
+// convolution folded in: dx = dgrad(dy, w_crsk) + dgrad_1x1s2(dy_ds, w_ds_ck) (+ relu_bits), one launch, no addend pass
+int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
+                  const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits = nullptr);
 // direct (implicit-GEMM) stem: layout.hip (padded NHWC4 input, row-wise weights), gather.hip (table),
 // conv_igemm.hip (forward), conv_wgrad.hip (weight gradient)
 size_t stem_pad_bytes(int dtype, int n_img, int H, int W);

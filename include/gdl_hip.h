@@ -80,6 +80,13 @@ GDL_API int gdl_bn_act_bits(int dtype, const void* y, const float* scale, const 
 GDL_API int gdl_conv_dgrad_relu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
                                 const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
                                 int stride, int pad, void* stream);
+/* First block of layers 2-4 (backbone.py:119-124, 141-146: conv1 is 3x3 stride 2, the shortcut a 1x1 stride-2 conv +
+ * BatchNorm): the gradient of the block input is the sum of two data gradients,
+ *   dx = conv1^T(dy [N][P][Q][K], w_crsk [C][3][3][K]) + downsample^T(dy_ds [N][P][Q][K], w_ds_ck [C][K]),
+ * computed in ONE launch (the shortcut is one more tap of the (even, even) input pixels); relu_bits optional as in
+ * gdl_conv_dgrad_relu.  `table` = the GDL_GATHER_DGRAD table of the 3x3 stride-2 pad-1 geometry. */
+GDL_API int gdl_conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
+                              const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, void* stream);
 /* In-launch BatchNorm finalize ("the last block folds"): the kernel that produces the per-block partial sums also
  * reduces them -- the block that completes them, found by an arrival ticket, folds them in a fixed order and runs
  * the finalize arithmetic -- so no separate finalize launch sits on the chain (backbone.py:45-48,104: conv -> bn).

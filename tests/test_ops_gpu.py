@@ -87,6 +87,46 @@ def test_conv_dgrad(shape, dt, with_addend):
     assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
 
 
+DS_SHAPES = [
+    # N, C (block input), H, W, K (block output): conv1 3x3/2 pad 1 and the 1x1/2 shortcut of a downsample block
+    (3, 64, 20, 18, 128),   # even dims
+    (2, 64, 65, 47, 128),   # odd dims (the audio layer-2 geometry): the four parity classes differ in size
+    (2, 256, 14, 14, 512),  # four K-steps per tap
+    (5, 128, 7, 9, 256),    # tiny planes, ragged classes
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", DS_SHAPES)
+@pytest.mark.parametrize("with_bits", [False, True])
+def test_conv_dgrad_ds(shape, dt, with_bits):
+    """dx = conv1^T(dy) + downsample^T(dy_ds) in one launch == the two data gradients of the oracle, summed."""
+    N, C, H, W, K = shape
+    _, w = _conv_case(N, C, H, W, K, 3, 2, 1, dt)
+    wds = quant(rng.standard_normal((K, C, 1, 1), dtype=np.float32) * 0.2, dt)
+    P, Q = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = quant(rng.standard_normal((N, K, P, Q), dtype=np.float32), dt)
+    dyd = quant(rng.standard_normal((N, K, P, Q), dtype=np.float32), dt)
+    ref = orc.conv2d_bwd_data(dy, w, (N, C, H, W), 2, 1) + orc.conv2d_bwd_data(dyd, wds, (N, C, H, W), 2, 0)
+    _, crsk = pack_weight(w, dt)
+    _, ck = pack_weight(wds, dt)
+    dx = empty((N, H, W, C), dt)
+    bits = None
+    if with_bits:  # sign bits of a random "block input" (one byte per 16-byte vector)
+        z = rng.standard_normal((N, C, H, W), dtype=np.float32)
+        ref = ref * (z > 0)
+        per = 16 // dx.element_size()
+        zb = (torch.from_numpy(np.ascontiguousarray(z.transpose(0, 2, 3, 1))).reshape(-1, per) > 0).to(torch.int32)
+        bits = (zb << torch.arange(per, dtype=torch.int32)).sum(1).to(torch.uint8).to(DEV)
+    tab = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, 3, 3, 2, 1)
+    dy_d, dyd_d = to_nhwc(dy, dt), to_nhwc(dyd, dt)
+    L.call("gdl_conv_dgrad_ds", dt, L.ptr(dy_d), L.ptr(crsk), L.ptr(dyd_d), L.ptr(ck), L.ptr(dx),
+           L.ptr(bits) if with_bits else None, L.ptr(tab), N, H, W, C, K, L.cur_stream())
+    torch.cuda.synchronize()
+    got = from_nhwc(dx)
+    assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
+
+
 WGRAD_SHAPES = [
     (2, 64, 17, 13, 64, 3, 1, 1),    # 64x64 tiles
     (3, 64, 20, 18, 128, 3, 2, 1),   # TK=128, TC=64
