@@ -849,6 +849,16 @@ static TileCfg pick_cfg(int M, int OC, int dtype) {
     // Measured on MI355X (tools/bench_conv.py, CREMA-D B=64 shapes): 256x64 wins whenever it still
     // yields >= ~160 blocks, also for wide layers (the A panel re-read per N-tile is served by L2);
     // below that the smaller M-tiles fill the chip better.
+    // 128x128 (wide layers): 8 DMA pieces per wave and K-step instead of 256x64's 10 for the same 32 MFMAs, each A row
+    // gathered for half as many N-tiles.  Measured: the stride-2 convolutions are 10 % faster ALONE (visual forward
+    // 44 / 44 / 41 -> 40 / 39 / 36 us, data gradients 58 / 64 -> 52 / 58 us) and the step is 0.4 % slower with it (two
+    // A/B pairs, 6.05 vs 6.075 ms): off by default
+    static int bn128 = -1;
+    if (bn128 < 0) {
+        const char* e = tune_env("GDL_FLAT_BN128");  // tuning aid: the minimum block count for 128x128 tiles (0 = never)
+        bn128 = e ? atoi(e) : 0;
+    }
+    if (bn128 > 0 && OC % 128 == 0 && (long)((M + 127) / 128) * (OC / 128) >= bn128) return {128, 128};
     const long b256 = (long)((M + 255) / 256) * (OC / 64);
     if (b256 >= 160) return {256, 64};
     const long b128 = (long)((M + 127) / 128) * (OC / 64);
@@ -1031,6 +1041,7 @@ static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
         if (pl.bm == 256) return launch_slab<T, 256, 64, MODE>(a, pl.lds, st);
         return launch_slab<T, 128, 64, MODE>(a, pl.lds, st);
     }
+    if (pl.bn == 128) return launch_one<T, 128, 128, 2, 2, MODE>(a, st);
     if (pl.bm == 256) return launch_one<T, 256, 64, 4, 1, MODE>(a, st);
     if (pl.bm == 128) return launch_one<T, 128, 64, 2, 2, MODE>(a, st);
     return launch_one<T, 64, 64, 2, 2, MODE>(a, st);
