@@ -274,6 +274,32 @@ def main():
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
                 "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
+    if prof and world == 1 and kernels:
+        # The same kernels WITHOUT contention: each encoder's forward + backward on its own, weight gradients on the
+        # chain's stream -- every launch has the device to itself.  The step's table says what a launch costs beside the
+        # other streams (what the job pays); this one says what the kernel itself does (`roofline.alone`).
+        tr.eng_v.side_stream(False)
+        spec, image, _ = data[0]
+        nf = tr.nf
+        lib.gdl_prof_set_filter(None)
+        lib.gdl_prof_enable(1)
+        for eng, x, gv, df, feat in ((tr.eng_v, image, tr.gviews[nf + 60:nf + 120], tr.dfv, tr.fv),
+                                     (tr.eng_a, spec.unsqueeze(1), tr.gviews[nf:nf + 60], tr.dfa, tr.fa)):
+            for _ in range(3):
+                eng.forward(x, True, feat_out=feat)
+                eng.backward(gv, dfeat=df)
+        torch.cuda.synchronize()
+        lib.gdl_prof_enable(0)
+        alone = {k["kernel"]: k for k in collect(3)}
+        tr.eng_v.side_stream(True)
+        for k in kernels:
+            if k["kernel"] in alone:
+                k["alone_avg_us"], k["alone_frac"] = alone[k["kernel"]]["avg_us"], alone[k["kernel"]]["frac"]
+        if roof and roof["kernel"] in alone:
+            al = alone[roof["kernel"]]
+            roof["alone"] = {"avg_launch_us": al["avg_us"], "achieved": al["achieved"], "frac": al["frac"],
+                             "note": "same launches with nothing else on the device (encoders run one after the other, "
+                                     "no side stream)"}
     phases = None
     if a.phases:  # (every rank runs the extra steps: they contain collectives)
         tr.phase_events = []
