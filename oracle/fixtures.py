@@ -42,8 +42,8 @@ def named_tensor(name, shape):
     if len(shape) == 2:  # linear weight [out, in]; xavier_normal_
         std = np.sqrt(2.0 / (shape[0] + shape[1]))
         return (std * r.standard_normal(shape)).astype(np.float32)
-    # 1-D: BN gamma / beta, or a linear bias
-    is_bn = ("bn" in name) or ("downsample.1" in name)
+    # 1-D: BN / LayerNorm gamma / beta, or a linear bias
+    is_bn = ("bn" in name) or ("downsample.1" in name) or ("norm" in name)
     if leaf == "weight" and is_bn:
         return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
     if leaf == "bias" and is_bn:
@@ -163,3 +163,51 @@ def model_state(n_classes, fusion="concat_dgl"):
     ps = make_state(model_param_shapes(n_classes, fusion))
     bs = make_state(model_buffer_shapes())
     return ps, bs
+
+
+# ---------------------------------------------------------------- Swin topology ("next" row N4)
+# /root/reference/models/swin_transformer.py:486-560: constructor arguments of the two configurations the tests use.
+# The reference's defaults are Swin-B; Swin-T's settings are passed explicitly.
+SWIN_T = dict(img=224, patch=4, embed=96, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), window=7, mlp=4)
+SWIN_TINY2 = dict(img=56, patch=4, embed=96, depths=(2, 2), heads=(3, 6), window=7, mlp=4)  # 14x14 -> 7x7 tokens
+
+
+def swin_param_shapes(cfg, prefix=""):
+    """Ordered {name: shape} of SwinTransformer.named_parameters() (args.pe = 0, ape = False, patch_norm = True):
+    swin_transformer.py:463-478 (patch embed), :98-122 (attention), :205-215 (block), :321-323 (merging), :556."""
+    E, p = cfg["embed"], cfg["patch"]
+    res = cfg["img"] // p
+    sh = {prefix + "patch_embed.proj.weight": (E, 3, p, p), prefix + "patch_embed.proj.bias": (E,),
+          prefix + "patch_embed.norm.weight": (E,), prefix + "patch_embed.norm.bias": (E,)}
+    nl = len(cfg["depths"])
+    for i, (depth, nh) in enumerate(zip(cfg["depths"], cfg["heads"])):
+        dim, r = E << i, res >> i
+        ws = min(cfg["window"], r)
+        for j in range(depth):
+            b = f"{prefix}layers.{i}.blocks.{j}."
+            sh[b + "norm1.weight"] = (dim,)
+            sh[b + "norm1.bias"] = (dim,)
+            sh[b + "attn.relative_position_bias_table"] = ((2 * ws - 1) ** 2, nh)
+            sh[b + "attn.qkv.weight"] = (3 * dim, dim)
+            sh[b + "attn.qkv.bias"] = (3 * dim,)
+            sh[b + "attn.proj.weight"] = (dim, dim)
+            sh[b + "attn.proj.bias"] = (dim,)
+            sh[b + "norm2.weight"] = (dim,)
+            sh[b + "norm2.bias"] = (dim,)
+            sh[b + "mlp.fc1.weight"] = (cfg["mlp"] * dim, dim)
+            sh[b + "mlp.fc1.bias"] = (cfg["mlp"] * dim,)
+            sh[b + "mlp.fc2.weight"] = (dim, cfg["mlp"] * dim)
+            sh[b + "mlp.fc2.bias"] = (dim,)
+        if i < nl - 1:
+            d = f"{prefix}layers.{i}.downsample."
+            sh[d + "reduction.weight"] = (2 * dim, 4 * dim)
+            sh[d + "norm.weight"] = (4 * dim,)
+            sh[d + "norm.bias"] = (4 * dim,)
+    sh[prefix + "norm.weight"] = (E << (nl - 1),)
+    sh[prefix + "norm.bias"] = (E << (nl - 1),)
+    return sh
+
+
+def swin_input(cfg, batch, frames, seed=0):
+    """[B, 3, T, img, img] float32 frames (the 'visual' modality layout, swin_transformer.py:598-601)."""
+    return np.random.default_rng([4321, seed]).standard_normal((batch, 3, frames, cfg["img"], cfg["img"]), dtype=np.float32)

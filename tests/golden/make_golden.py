@@ -238,6 +238,36 @@ def run_encoder_case(name, bb, modality, in_shape, seed=0):
     print(name, d["y"].shape, float(np.abs(d["y"]).mean()))
 
 
+def run_swin_case(name, cfg, batch, frames, seed=0):
+    """Pooled features + parameter gradients of the imported `SwinTransformer` (swin_transformer.py:486-674, through the
+    3-symbol timm stub above; drop_path_rate = 0 makes the identity DropPath exact) for a fixed upstream gradient."""
+    import models.swin_transformer as sw
+
+    args = argparse.Namespace(pe=0)
+    net = sw.SwinTransformer(args, "visual", img_size=cfg["img"], patch_size=cfg["patch"], in_chans=3, embed_dim=cfg["embed"],
+                             depths=list(cfg["depths"]), num_heads=list(cfg["heads"]), window_size=cfg["window"],
+                             mlp_ratio=float(cfg["mlp"]), drop_path_rate=0.0)
+    ps = fx.make_state(fx.swin_param_shapes(cfg))
+    assert [n for n, _ in net.named_parameters()] == list(ps), "parameter order differs from the reference's"
+    missing = net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in ps.items()}, strict=False)
+    assert not missing.unexpected_keys and all("relative_position_index" in k or "attn_mask" in k for k in missing.missing_keys)
+    x = fx.swin_input(cfg, batch, frames, seed)
+    net.train()
+    y = net(torch.from_numpy(x))
+    dy = np.random.default_rng([79, seed]).standard_normal(tuple(y.shape), dtype=np.float32)
+    y.backward(torch.from_numpy(dy))
+    d = {"config": np.array(json.dumps(dict(cfg, batch=batch, frames=frames, seed=seed))), "y": y.detach().numpy(), "dy": dy}
+    for n, p in net.named_parameters():
+        g = p.grad.numpy()
+        d["gradstat." + n] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum()), np.abs(g).mean()])
+        if g.size <= 10000:
+            d["grad." + n] = g.copy()
+        else:
+            d["gradsample." + n] = g.reshape(-1)[::997].copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, d["y"].shape, float(np.abs(d["y"]).mean()))
+
+
 def run_head_case(name, fm, cls, n_classes, batch=4):
     """Isolated fusion head (fusion_modules.py:33-59) forward + both backward
     phases of main_dgl.py:110-122."""
@@ -456,6 +486,8 @@ def main():
         "head_gated_dgl_c6": lambda: run_gated_head_case("head_gated_dgl_c6", fm, 6),
         "dgl_gated_tiny_b4": lambda: run_step_case("dgl_gated_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                    fusion="gated"),
+        "swin_tiny2_b2": lambda: run_swin_case("swin_tiny2_b2", fx.SWIN_TINY2, 2, 2),
+        "swin_t_b1": lambda: run_swin_case("swin_t_b1", fx.SWIN_T, 1, 2),
         "concat_cremad_b2": lambda: run_step_case("concat_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224),
                                                   2, 0.0, 1, mode="concat"),
     }

@@ -286,3 +286,28 @@ def test_torch_restatement_matches_oracle():
     for k in ("loss_f", "loss_a", "loss_v"):
         np.testing.assert_allclose(t[k], r[k], rtol=1e-5, err_msg=k)
     np.testing.assert_allclose(t["total_norm"], r["total_norm"], rtol=1e-3)
+
+
+@pytest.mark.parametrize("name,cfg_name", [("swin_tiny2_b2", "SWIN_TINY2"), ("swin_t_b1", "SWIN_T")])
+def test_swin_oracle_matches_reference_golden(golden_dir, name, cfg_name):
+    """oracle/swin_oracle.py (index-list windows, region-id masks; autograd) against features and parameter gradients of
+    the imported reference SwinTransformer (swin_transformer.py:486-674; Swin-T settings and a two-stage 56x56 variant)."""
+    import json
+
+    from oracle import swin_oracle as so
+
+    cfg = getattr(fx, cfg_name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    c = json.loads(str(g["config"]))
+    P = fx.make_state(fx.swin_param_shapes(cfg))
+    y, grads = so.forward_backward(fx.swin_input(cfg, c["batch"], c["frames"], c["seed"]), P, cfg, g["dy"])
+    assert np.abs(y - g["y"]).max() <= 2e-6 * np.abs(g["y"]).max()
+    assert set(grads) == {k[len("gradstat."):] for k in g.files if k.startswith("gradstat.")}
+    for k, v in grads.items():
+        want_norm = g["gradstat." + k][0]
+        assert abs(np.sqrt((v.astype(np.float64) ** 2).sum()) - want_norm) <= 2e-5 * want_norm, k
+        if "grad." + k in g.files:
+            np.testing.assert_allclose(v, g["grad." + k], rtol=0, atol=2e-5 * np.abs(g["grad." + k]).max(), err_msg=k)
+        else:
+            w = g["gradsample." + k]
+            np.testing.assert_allclose(v.reshape(-1)[::997], w, rtol=0, atol=2e-5 * np.abs(w).max(), err_msg=k)
