@@ -333,4 +333,61 @@ int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, floa
     return softmax_ce(logits, labels, scale, loss, dlogits, B, n_classes, (hipStream_t)stream);
 }
 
+// ---- Swin visual encoder: non-GEMM operators; the Linears are gdl_conv_fwd / _dgrad / _wgrad (1x1)
+int gdl_swin_patch_gather(int dtype, const float* x, void* a, int B, int T, int H, int W, int patch, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && a, "swin_patch_gather: bad arguments");
+    return swin_patch_gather(dtype, x, a, B, T, H, W, patch, (hipStream_t)stream);
+}
+int gdl_swin_bias_act(int dtype, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && y && bias, "swin_bias_act: bad arguments");
+    return swin_bias_act(dtype, y, bias, u, res, M, ld, mode, (hipStream_t)stream);
+}
+int gdl_swin_ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
+                    void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && gamma && beta && y && stats, "swin_ln_fwd: bad arguments");
+    return swin_ln_fwd(dtype, x, gamma, beta, y, stats, M, C, ld, (hipStream_t)stream);
+}
+size_t gdl_swin_partial_bytes(int ld) { return swin_partial_bytes(ld); }
+int gdl_swin_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
+                    float* dgamma_dbeta, void* partial, size_t M, int C, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx && dgamma_dbeta, "swin_ln_bwd: bad arguments");
+    return swin_ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma_dbeta, (float*)partial, M, C, ld, (hipStream_t)stream);
+}
+int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && g && db, "swin_colsum: bad arguments");
+    return swin_colsum(dtype, g, u, db, (float*)partial, M, ld, (hipStream_t)stream);
+}
+int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out, int n_img, int H, int W, int window, int shift,
+                      int heads, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && qkv && table && out, "swin_attn_fwd: bad arguments");
+    return swin_attn_fwd(dtype, qkv, table, out, n_img, H, W, window, shift, heads, ld, (hipStream_t)stream);
+}
+size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int window, int heads) { return swin_attn_bwd_ws_bytes(n_img, window, heads); }
+int gdl_swin_attn_bwd(int dtype, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, void* ws, int n_img,
+                      int H, int W, int window, int shift, int heads, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && qkv && table && dout && dqkv, "swin_attn_bwd: bad arguments");
+    return swin_attn_bwd(dtype, qkv, table, dout, dqkv, dtable, (float*)ws, n_img, H, W, window, shift, heads, ld, (hipStream_t)stream);
+}
+int gdl_swin_merge(int dtype, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && src && dst, "swin_merge: bad arguments");
+    return swin_merge(dtype, src, dst, N, H, W, C, ldx, scatter, (hipStream_t)stream);
+}
+int gdl_swin_token_mean(int dtype, const void* x, float* y, int N, int L, int C, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && y, "swin_token_mean: bad arguments");
+    return swin_token_mean(dtype, x, y, N, L, C, ld, (hipStream_t)stream);
+}
+int gdl_swin_token_mean_bwd(int dtype, const float* dy, void* dx, int N, int L, int C, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && dx, "swin_token_mean_bwd: bad arguments");
+    return swin_token_mean_bwd(dtype, dy, dx, N, L, C, ld, (hipStream_t)stream);
+}
+int gdl_swin_pack_matrix(int dtype, const float* src, void* dst, void* dstT, int n, int k, int nseg, int nseg_pad, int kseg,
+                         int kseg_pad, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && src && dst, "swin_pack_matrix: bad arguments");
+    return swin_pack_matrix(dtype, src, dst, dstT, n, k, nseg, nseg_pad, kseg, kseg_pad, (hipStream_t)stream);
+}
+int gdl_swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad, void* stream) {
+    GDL_REQUIRE(src && dst, "swin_unpack_matrix: null pointer");
+    return swin_unpack_matrix(src, dst, n, k, nseg, nseg_pad, kseg, kseg_pad, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -147,4 +147,25 @@ int softmax_ce_multi(int nsets, const float* const* logits, const int64_t* label
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
                hipStream_t st);
 
+// ---- Swin visual encoder, non-GEMM operators (swin.hip; the Linears run on conv_fwd / conv_dgrad / conv_wgrad as 1x1)
+int swin_patch_gather(int dt, const float* x, void* a, int B, int T, int H, int W, int p, hipStream_t st);
+int swin_bias_act(int dt, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode, hipStream_t st);
+int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
+                hipStream_t st);
+size_t swin_partial_bytes(int ld);
+int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
+                float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st);
+int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st);
+int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_img, int H, int W, int ws, int shift, int nh, int ld,
+                  hipStream_t st);
+size_t swin_attn_bwd_ws_bytes(int n_img, int ws, int nh);
+int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* tpart, int n_img,
+                  int H, int W, int ws, int shift, int nh, int ld, hipStream_t st);
+int swin_merge(int dt, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, hipStream_t st);
+int swin_token_mean(int dt, const void* x, float* y, int N, int L, int C, int ld, hipStream_t st);
+int swin_token_mean_bwd(int dt, const float* dy, void* dx, int N, int L, int C, int ld, hipStream_t st);
+int swin_pack_matrix(int dt, const float* src, void* dst, void* dstT, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad,
+                     hipStream_t st);
+int swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad, hipStream_t st);
+
 }  // namespace gdl

@@ -1,0 +1,762 @@
+// swin.hip -- the non-GEMM operators of the Swin visual encoder (the reference's
+// /root/reference/models/swin_transformer.py, which its DGL script never reaches: SURVEY G5 -- a new composition).
+//
+// Tokens live as rows [N*L][ld] of the activation type T (bf16 / f32), ld = the channel count rounded up to a multiple
+// of 64 (96 -> 128 in stage 1 of Swin-T; every other width already is one), padding columns always zero.  Every Linear is
+// a 1x1 convolution of this library (conv_igemm.hip / conv_wgrad.hip: forward, data gradient, weight gradient on MFMA),
+// whose weights are zero-padded copies made by `swin_pack_matrix`; a QKV row is three ld-wide segments [q | k | v], so a
+// head's 32 channels sit at h*32 of each segment.  What this file adds:
+//
+//   patch_gather       4x4 patches of the [B,3,T,H,W] float32 frames -> GEMM rows [N*Hp*Wp][64] (48 real columns,
+//                      order (c, kh, kw) = the flattened Conv2d weight, swin_transformer.py:463,480)
+//   bias_act           y += b  |  u = y + b, y = gelu(u)  |  y = y + b + residual           (Mlp :26-42, block :287-290)
+//   layernorm fwd/bwd  one wave per token, two-pass statistics over the real channels, rows kept in registers;
+//                      backward adds the residual gradient and leaves per-block partials of d(gamma), d(beta)
+//   colsum / gelu_bwd  bias gradients (column sums, fixed order), fused with the GELU derivative where one precedes it
+//   window attention   (S)W-MSA without materialising rolled / partitioned copies (:124-157, :256-285): a window slot is
+//                      mapped to its token of the un-rolled grid on the fly, the shift mask comes from the slots' region
+//                      ids (:222-240), the relative-position bias from the (2ws-1)^2 table (:103-113).  One wave per
+//                      (window, head): 49 x 49 x 32 products are plain FMAs (0.2 % of the model's arithmetic).  The
+//                      backward recomputes the probabilities, and sums d(bias table) per (image, head) in fixed order.
+//   merge gather / scatter   PatchMerging's 2x2 concatenation (:336-344) and its adjoint
+//   token mean fwd / bwd     the final AdaptiveAvgPool2d over the 7x7 tokens (:629-631)
+//   pack / unpack            float32 parameters [n][k] <-> zero-padded (and transposed) kernel layouts, segment-wise
+//
+// All reductions are fixed-order (partials + a second kernel): two runs are bit-identical.
+#include "common.h"
+#include "ops.h"
+#include "prof.h"
+
+namespace gdl {
+
+constexpr int SW_HD = 32;      // head dimension of every Swin-T / -S / -B stage (dim / heads)
+constexpr int SW_MAXT = 49;    // tokens per window (7 x 7)
+constexpr int SW_MAXV = 24;    // row elements per lane in the LayerNorm kernels: ld <= 1536
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float u) {
+    return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
+
+// ------------------------------------------------------------------------------------------------ patch embedding rows
+template <typename T>
+__global__ __launch_bounds__(256) void swin_patch_gather_kernel(const float* __restrict__ x, T* __restrict__ a, int B, int Tt,
+                                                                int H, int W, int p) {
+    const int Hp = H / p, Wp = W / p;
+    const size_t total = (size_t)B * Tt * Hp * Wp * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int col = (int)(i & 63);
+        size_t r = i >> 6;
+        const int wp = (int)(r % Wp);
+        r /= Wp;
+        const int hp = (int)(r % Hp);
+        r /= Hp;
+        const int t = (int)(r % Tt), b = (int)(r / Tt);
+        float v = 0.f;
+        if (col < 3 * p * p) {
+            const int c = col / (p * p), kh = (col / p) % p, kw = col % p;
+            v = x[((((size_t)b * 3 + c) * Tt + t) * H + hp * p + kh) * W + wp * p + kw];
+        }
+        storeT(a + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bias / GELU / residual
+// mode 0: y = y + b;  mode 1: u = y + b (stored), y = gelu(u);  mode 2: y = y + b + res
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, const float* __restrict__ bias, T* __restrict__ u,
+                                                            const T* __restrict__ res, size_t M, int ld) {
+    constexpr int EPC = TT<T>::EPC;
+    const int vpr = ld / EPC;
+    const size_t total = M * vpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c0 = (int)(i % vpr) * EPC;
+        float f[EPC], r[EPC];
+        unpack16<T>(((const uint4*)y)[i], f);
+        if (MODE == 2) unpack16<T>(((const uint4*)res)[i], r);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            f[e] += bias[c0 + e];
+            if (MODE == 2) f[e] += r[e];
+        }
+        if (MODE == 1) {
+            ((uint4*)u)[i] = pack16<T>(f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = gelu_f(roundT<T>(f[e]));
+        }
+        ((uint4*)y)[i] = pack16<T>(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; lane l holds columns l + 64 i.  stats[row] = (mean, rstd).
+template <typename T>
+__global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ y,
+                                                          float2* __restrict__ stats, size_t M, int C, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int nv = ld >> 6;
+    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (size_t)gridDim.x * 4) {
+        const T* xr = x + row * ld;
+        float v[SW_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SW_MAXV; ++i)
+            if (i < nv) {
+                v[i] = loadT(xr + lane + 64 * i);
+                s += v[i];  // padding columns are zero
+            }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < SW_MAXV; ++i)
+            if (i < nv && lane + 64 * i < C) q += (v[i] - mu) * (v[i] - mu);
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+        if (lane == 0) stats[row] = make_float2(mu, rstd);
+        T* yr = y + row * ld;
+#pragma unroll
+        for (int i = 0; i < SW_MAXV; ++i)
+            if (i < nv) {
+                const int c = lane + 64 * i;
+                storeT(yr + c, c < C ? (v[i] - mu) * rstd * gamma[c] + beta[c] : 0.f);
+            }
+    }
+}
+
+// dx = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial[blk][0][c] = sum dy*xhat,
+// partial[blk][1][c] = sum dy over the rows of the block (fixed order: rows ascending per wave, then waves 0..3)
+template <typename T>
+__global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float2* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const T* __restrict__ add, T* __restrict__ dx,
+                                                          float* __restrict__ partial, size_t M, int C, int ld) {
+    __shared__ float red[4][2][64 * SW_MAXV / 4];  // reused in two halves below (ld <= 1536 -> at most 24 per lane)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = ld >> 6;
+    float ag[SW_MAXV], ab[SW_MAXV];
+#pragma unroll
+    for (int i = 0; i < SW_MAXV; ++i) ag[i] = ab[i] = 0.f;
+    for (size_t row = (size_t)blockIdx.x * 4 + wave; row < M; row += (size_t)gridDim.x * 4) {
+        const float2 st = stats[row];
+        float xh[SW_MAXV], g[SW_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < SW_MAXV; ++i)
+            if (i < nv) {
+                const int c = lane + 64 * i;
+                const float d = loadT(dy + row * ld + c);
+                xh[i] = c < C ? (loadT(x + row * ld + c) - st.x) * st.y : 0.f;
+                g[i] = c < C ? d * gamma[c] : 0.f;
+                s1 += g[i];
+                s2 += g[i] * xh[i];
+                ag[i] += d * xh[i];
+                ab[i] += c < C ? d : 0.f;
+            }
+        const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < SW_MAXV; ++i)
+            if (i < nv) {
+                const int c = lane + 64 * i;
+                float o = c < C ? st.y * (g[i] - m1 - xh[i] * m2) : 0.f;
+                if (add) o += loadT(add + row * ld + c);
+                storeT(dx + row * ld + c, o);
+            }
+    }
+    // block partials: waves 0..3 in order, 6 columns-per-lane at a time through LDS
+    float* outp = partial + (size_t)blockIdx.x * 2 * ld;
+    for (int i0 = 0; i0 < nv; i0 += 6) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i0 + i < nv) {
+                red[wave][0][i * 64 + lane] = ag[i0 + i];
+                red[wave][1][i * 64 + lane] = ab[i0 + i];
+            }
+        __syncthreads();
+        if (wave == 0)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i0 + i < nv) {
+                    const int c = lane + 64 * (i0 + i);
+                    outp[c] = ((red[0][0][i * 64 + lane] + red[1][0][i * 64 + lane]) + red[2][0][i * 64 + lane]) + red[3][0][i * 64 + lane];
+                    outp[ld + c] = ((red[0][1][i * 64 + lane] + red[1][1][i * 64 + lane]) + red[2][1][i * 64 + lane]) + red[3][1][i * 64 + lane];
+                }
+    }
+}
+
+// out[j] = sum_b partial[b][j], b ascending (j < width)
+__global__ __launch_bounds__(256) void swin_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                  int nblk, int width) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= width) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * width + j];
+    out[j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums (+ GELU')
+// GELU = 1: g <- g * gelu'(u) in place first.  partial[blk][c] = sum over the block's rows (rows ascending, fixed).
+// Block = 256 threads = 4 row groups x 64 column lanes of 16-byte vectors... kept simple: thread = one column vector,
+// the block walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; ld / EPC <= 256 vector columns per pass.
+template <typename T, int GELU>
+__global__ __launch_bounds__(256) void swin_colsum_kernel(T* __restrict__ g, const T* __restrict__ u, float* __restrict__ partial,
+                                                          size_t M, int ld) {
+    constexpr int EPC = TT<T>::EPC;
+    const int vpr = ld / EPC;
+    for (int v0 = 0; v0 < vpr; v0 += 256) {
+        const int vc = v0 + threadIdx.x;
+        if (vc >= vpr) continue;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (size_t row = blockIdx.x; row < M; row += gridDim.x) {
+            float f[EPC];
+            unpack16<T>(((const uint4*)g)[row * vpr + vc], f);
+            if (GELU) {
+                float uu[EPC];
+                unpack16<T>(((const uint4*)u)[row * vpr + vc], uu);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_df(uu[e]));
+                ((uint4*)g)[row * vpr + vc] = pack16<T>(f);
+            }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) partial[(size_t)blockIdx.x * ld + vc * EPC + e] = acc[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ window attention
+struct SwinAttnGeom {
+    int H, W, ws, shift, nh, ld;  // token grid, window, roll, heads, row stride of one q / k / v segment and of `out`
+    int nwin;                     // windows per image
+};
+// token row (within the image) of slot i of window w, and its mask region
+__device__ __forceinline__ int sw_token(const SwinAttnGeom& g, int w, int i, int* region) {
+    const int wpr = g.W / g.ws;
+    const int R = (w / wpr) * g.ws + i / g.ws, Cc = (w % wpr) * g.ws + i % g.ws;  // rolled coordinates
+    if (region) {
+        const int rh = R < g.H - g.ws ? 0 : (R < g.H - g.shift ? 1 : 2), rw = Cc < g.W - g.ws ? 0 : (Cc < g.W - g.shift ? 1 : 2);
+        *region = rh * 3 + rw;
+    }
+    int h = R + g.shift, c = Cc + g.shift;
+    if (h >= g.H) h -= g.H;
+    if (c >= g.W) c -= g.W;
+    return h * g.W + c;
+}
+
+// forward: one wave per (image, window, head); lane i < T owns query i.  K, V of the window in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
+                                                            T* __restrict__ out, SwinAttnGeom g, int n_img) {
+    __shared__ float Ks[4][SW_MAXT][SW_HD + 1], Vs[4][SW_MAXT][SW_HD + 1];
+    __shared__ int regs[4][SW_MAXT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Tn = g.ws * g.ws, L = g.H * g.W;
+    const long unit = (long)blockIdx.x * 4 + wave, nunits = (long)n_img * g.nwin * g.nh;
+    const bool live = unit < nunits;
+    const int h = live ? (int)(unit % g.nh) : 0;
+    const int w = live ? (int)((unit / g.nh) % g.nwin) : 0;
+    const int n = live ? (int)(unit / ((long)g.nh * g.nwin)) : 0;
+    int reg = 0;
+    const bool act = live && lane < Tn;
+    const int tok = act ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : 0;
+    const size_t row = (size_t)n * L + tok;
+    float q[SW_HD];
+    if (act) {
+        const T* base = qkv + row * 3 * g.ld + h * SW_HD;
+        const float scale = 0.17677669529663687f;  // 32^-0.5
+#pragma unroll
+        for (int d = 0; d < SW_HD; ++d) {
+            q[d] = loadT(base + d) * scale;
+            Ks[wave][lane][d] = loadT(base + g.ld + d);
+            Vs[wave][lane][d] = loadT(base + 2 * g.ld + d);
+        }
+        regs[wave][lane] = reg;
+    }
+    __syncthreads();
+    if (!act) return;
+    const int ri = lane / g.ws, ci = lane % g.ws, tw = 2 * g.ws - 1;
+    float s[SW_MAXT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < SW_MAXT; ++j)
+        if (j < Tn) {
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) a += q[d] * Ks[wave][j][d];
+            const int rj = j / g.ws, cj = j % g.ws;
+            a += table[((ri - rj + g.ws - 1) * tw + (ci - cj + g.ws - 1)) * g.nh + h];
+            if (g.shift && regs[wave][j] != reg) a -= 100.f;
+            s[j] = a;
+            mx = fmaxf(mx, a);
+        }
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < SW_MAXT; ++j)
+        if (j < Tn) {
+            s[j] = __expf(s[j] - mx);
+            den += s[j];
+        }
+    const float inv = 1.f / den;
+    float o[SW_HD];
+#pragma unroll
+    for (int d = 0; d < SW_HD; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < SW_MAXT; ++j)
+        if (j < Tn) {
+            const float p = s[j] * inv;
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) o[d] += p * Vs[wave][j][d];
+        }
+    T* ob = out + row * g.ld + h * SW_HD;
+#pragma unroll
+    for (int d = 0; d < SW_HD; ++d) storeT(ob + d, o[d]);
+    if (h == 0)  // the row's padding columns (nh*32 .. ld) belong to nobody: keep them zero
+        for (int c = g.nh * SW_HD; c < g.ld; ++c) storeT(out + row * g.ld + c, 0.f);
+}
+
+// backward: one wave (block of 64) per (image, head), looping over the image's windows.  Recomputes P; writes dq, dk, dv
+// into dqkv (same layout as qkv) and the (image, head) partial of d(table): tpart[(n*nh + h)*tw*tw + r].
+template <typename T>
+__global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
+                                                           const T* __restrict__ dout, T* __restrict__ dqkv,
+                                                           float* __restrict__ tpart, SwinAttnGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
+    constexpr int PD = SW_HD + 1, PT = SW_MAXT + 1;
+    float(*Qs)[PD] = (float(*)[PD])sw_smem;
+    float(*Ks)[PD] = Qs + SW_MAXT;
+    float(*Vs)[PD] = Ks + SW_MAXT;
+    float(*Os)[PD] = Vs + SW_MAXT;
+    float(*Ps)[PT] = (float(*)[PT])(Os + SW_MAXT);
+    float(*Ds)[PT] = Ps + SW_MAXT;
+    float(*Da)[PT] = Ds + SW_MAXT;
+    int* regs = (int*)(Da + SW_MAXT);
+    const int lane = threadIdx.x;
+    const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
+    const int h = blockIdx.x % g.nh, n = blockIdx.x / g.nh;
+    const float scale = 0.17677669529663687f;
+    const bool act = lane < Tn;
+    const int ri = lane / g.ws, ci = lane % g.ws;
+    if (act)
+        for (int j = 0; j < Tn; ++j) Da[lane][j] = 0.f;
+    for (int w = 0; w < g.nwin; ++w) {
+        int reg = 0;
+        const int tok = act ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : 0;
+        const size_t row = (size_t)n * L + tok;
+        __syncthreads();
+        if (act) {
+            const T* base = qkv + row * 3 * g.ld + h * SW_HD;
+            const T* db = dout + row * g.ld + h * SW_HD;
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) {
+                Qs[lane][d] = loadT(base + d) * scale;
+                Ks[lane][d] = loadT(base + g.ld + d);
+                Vs[lane][d] = loadT(base + 2 * g.ld + d);
+                Os[lane][d] = loadT(db + d);
+            }
+            regs[lane] = reg;
+        }
+        __syncthreads();
+        if (act) {
+            float s[SW_MAXT];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < SW_MAXT; ++j)
+                if (j < Tn) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int d = 0; d < SW_HD; ++d) a += Qs[lane][d] * Ks[j][d];
+                    const int rj = j / g.ws, cj = j % g.ws;
+                    a += table[((ri - rj + g.ws - 1) * tw + (ci - cj + g.ws - 1)) * g.nh + h];
+                    if (g.shift && regs[j] != reg) a -= 100.f;
+                    s[j] = a;
+                    mx = fmaxf(mx, a);
+                }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < SW_MAXT; ++j)
+                if (j < Tn) {
+                    s[j] = __expf(s[j] - mx);
+                    den += s[j];
+                }
+            const float inv = 1.f / den;
+            float pd = 0.f;
+            float dp[SW_MAXT];
+#pragma unroll
+            for (int j = 0; j < SW_MAXT; ++j)
+                if (j < Tn) {
+                    s[j] *= inv;
+                    float a = 0.f;
+#pragma unroll
+                    for (int d = 0; d < SW_HD; ++d) a += Os[lane][d] * Vs[j][d];
+                    dp[j] = a;
+                    pd += s[j] * a;
+                }
+            float dq[SW_HD];
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) dq[d] = 0.f;
+#pragma unroll
+            for (int j = 0; j < SW_MAXT; ++j)
+                if (j < Tn) {
+                    const float ds = s[j] * (dp[j] - pd);
+                    Ps[lane][j] = s[j];
+                    Ds[lane][j] = ds;
+                    Da[lane][j] += ds;
+#pragma unroll
+                    for (int d = 0; d < SW_HD; ++d) dq[d] += ds * Ks[j][d];
+                }
+            T* ob = dqkv + row * 3 * g.ld + h * SW_HD;
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) storeT(ob + d, dq[d] * scale);
+        }
+        __syncthreads();
+        if (act) {  // lane = key / value index j: column sums over the queries i (ascending)
+            float dk[SW_HD], dv[SW_HD];
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) dk[d] = dv[d] = 0.f;
+            for (int i = 0; i < Tn; ++i) {
+                const float p = Ps[i][lane], ds = Ds[i][lane];
+#pragma unroll
+                for (int d = 0; d < SW_HD; ++d) {
+                    dv[d] += p * Os[i][d];
+                    dk[d] += ds * Qs[i][d];  // Qs already carries the scale
+                }
+            }
+            T* ob = dqkv + row * 3 * g.ld + h * SW_HD;
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) {
+                storeT(ob + g.ld + d, dk[d]);
+                storeT(ob + 2 * g.ld + d, dv[d]);
+            }
+            if (h == 0)  // padding columns of the three segments stay zero
+                for (int sgm = 0; sgm < 3; ++sgm)
+                    for (int c = g.nh * SW_HD; c < g.ld; ++c) storeT(dqkv + row * 3 * g.ld + sgm * g.ld + c, 0.f);
+        }
+    }
+    __syncthreads();
+    // d(table)[r] of this (image, head): the pairs (i, j) with i - j = (dh, dw), j ascending
+    float* tp = tpart + (size_t)blockIdx.x * tw * tw;
+    for (int r = lane; r < tw * tw; r += 64) {
+        const int dh = r / tw - (g.ws - 1), dw = r % tw - (g.ws - 1);
+        float a = 0.f;
+        for (int rj = 0; rj < g.ws; ++rj) {
+            const int rr = rj + dh;
+            if (rr < 0 || rr >= g.ws) continue;
+            for (int cj = 0; cj < g.ws; ++cj) {
+                const int cc = cj + dw;
+                if (cc < 0 || cc >= g.ws) continue;
+                a += Da[rr * g.ws + cc][rj * g.ws + cj];
+            }
+        }
+        tp[r] = a;
+    }
+}
+
+// dtable[r][h] = sum_n tpart[n][h][r]
+__global__ __launch_bounds__(256) void swin_table_reduce_kernel(const float* __restrict__ tpart, float* __restrict__ dtable,
+                                                                int n_img, int nh, int tt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nh * tt) return;
+    const int h = i / tt, r = i % tt;
+    float s = 0.f;
+    for (int n = 0; n < n_img; ++n) s += tpart[((size_t)n * nh + h) * tt + r];
+    dtable[r * nh + h] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ patch merging
+// fwd: cat[n][h2][w2][q*C + c] = x[n][2 h2 + (q & 1)][2 w2 + (q >> 1)][c]   (q = 0..3: (0,0), (1,0), (0,1), (1,1));
+// bwd (SCATTER = 1): the adjoint, padding columns of dx zeroed
+template <typename T, int SCATTER>
+__global__ __launch_bounds__(256) void swin_merge_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W,
+                                                         int C, int ldx) {
+    const int H2 = H / 2, W2 = W / 2;
+    const size_t total = (size_t)N * H * W * ldx;  // iterate over the un-merged tensor's elements (padding included)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % ldx);
+        size_t r = i / ldx;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H), n = (int)(r / H);
+        if (c >= C) {
+            if (SCATTER) storeT(dst + i, 0.f);
+            continue;
+        }
+        const int q = (h & 1) + 2 * (w & 1);
+        const size_t m = (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * (4 * C) + q * C + c;
+        if (SCATTER)
+            dst[i] = src[m];
+        else
+            dst[m] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ token mean
+template <typename T>
+__global__ __launch_bounds__(256) void swin_token_mean_kernel(const T* __restrict__ x, float* __restrict__ y, int L, int C, int ld) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += loadT(x + ((size_t)n * L + l) * ld + c);
+        y[(size_t)n * C + c] = s / (float)L;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void swin_token_mean_bwd_kernel(const float* __restrict__ dy, T* __restrict__ dx, int N, int L,
+                                                                  int C, int ld) {
+    const size_t total = (size_t)N * L * ld;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % ld);
+        const size_t n = i / ((size_t)L * ld);
+        storeT(dx + i, c < C ? dy[n * C + c] / (float)L : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ parameter layouts
+// A matrix [n][k] whose rows come in segments of nseg real rows stored at a pitch of nseg_pad (QKV: 96 -> 128 per
+// segment), columns likewise (kseg / kseg_pad).  PACK: src float32 real [n][k] -> dst T padded [np][kp] (+ dstT T
+// [kp][np] when given).  UNPACK (T = float): src padded float32 -> dst real float32.
+struct SwinSeg {
+    int n, k, nseg, nseg_pad, kseg, kseg_pad, np, kp;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void swin_pack_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dstT,
+                                                        SwinSeg s) {
+    const size_t total = (size_t)s.np * s.kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int pk = (int)(i % s.kp), pn = (int)(i / s.kp);
+        const int sn = pn / s.nseg_pad, on = pn % s.nseg_pad, sk = pk / s.kseg_pad, ok = pk % s.kseg_pad;
+        const int rn = sn * s.nseg + on, rk = sk * s.kseg + ok;
+        const float v = (on < s.nseg && ok < s.kseg && rn < s.n && rk < s.k) ? src[(size_t)rn * s.k + rk] : 0.f;
+        storeT(dst + i, v);
+        if (dstT) storeT(dstT + (size_t)pk * s.np + pn, v);
+    }
+}
+__global__ __launch_bounds__(256) void swin_unpack_kernel(const float* __restrict__ src, float* __restrict__ dst, SwinSeg s) {
+    const size_t total = (size_t)s.n * s.k;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int rk = (int)(i % s.k), rn = (int)(i / s.k);
+        const int pn = (rn / s.nseg) * s.nseg_pad + rn % s.nseg, pk = (rk / s.kseg) * s.kseg_pad + rk % s.kseg;
+        dst[i] = src[(size_t)pn * s.kp + pk];
+    }
+}
+
+// ================================================================================================ host side
+static int sw_grid(size_t work, int per_block = 256, int cap = 256 * 16) {
+    const size_t b = (work + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > (size_t)cap ? (size_t)cap : b));
+}
+#define SW_DISPATCH(dt, CALL_F32, CALL_BF16) \
+    do {                                      \
+        if ((dt) == GDL_F32) {                \
+            CALL_F32;                         \
+        } else {                              \
+            CALL_BF16;                        \
+        }                                     \
+    } while (0)
+
+int swin_patch_gather(int dt, const float* x, void* a, int B, int T, int H, int W, int p, hipStream_t st) {
+    GDL_REQUIRE(3 * p * p <= 64 && H % p == 0 && W % p == 0, "swin_patch_gather: patch %d on %dx%d", p, H, W);
+    const size_t total = (size_t)B * T * (H / p) * (W / p) * 64;
+    ProfScope prof("gdl::swin_patch_gather_kernel", PROF_HBM, st, (double)total * (dt == GDL_F32 ? 4 : 2) + (double)B * T * 3 * H * W * 4);
+    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_patch_gather_kernel<float>, dim3(sw_grid(total)), dim3(256), 0, st, x, (float*)a, B, T, H, W, p),
+                hipLaunchKernelGGL(swin_patch_gather_kernel<bf16>, dim3(sw_grid(total)), dim3(256), 0, st, x, (bf16*)a, B, T, H, W, p));
+    GDL_CHECK_LAUNCH("swin_patch_gather_kernel");
+    return GDL_OK;
+}
+
+template <typename T>
+static int bias_act_t(T* y, const float* bias, T* u, const T* res, size_t M, int ld, int mode, hipStream_t st) {
+    const int g = sw_grid(M * (ld / TT<T>::EPC));
+    if (mode == 0)
+        hipLaunchKernelGGL((swin_bias_act_kernel<T, 0>), dim3(g), dim3(256), 0, st, y, bias, u, res, M, ld);
+    else if (mode == 1)
+        hipLaunchKernelGGL((swin_bias_act_kernel<T, 1>), dim3(g), dim3(256), 0, st, y, bias, u, res, M, ld);
+    else
+        hipLaunchKernelGGL((swin_bias_act_kernel<T, 2>), dim3(g), dim3(256), 0, st, y, bias, u, res, M, ld);
+    GDL_CHECK_LAUNCH("swin_bias_act_kernel");
+    return GDL_OK;
+}
+int swin_bias_act(int dt, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode, hipStream_t st) {
+    GDL_REQUIRE(ld % 64 == 0 && mode >= 0 && mode <= 2 && (mode != 1 || u) && (mode != 2 || res), "swin_bias_act: bad arguments");
+    const double esz = dt == GDL_F32 ? 4 : 2;
+    ProfScope prof("gdl::swin_bias_act_kernel", PROF_HBM, st, (double)M * ld * esz * (mode == 0 ? 2 : 3));
+    if (dt == GDL_F32) return bias_act_t<float>((float*)y, bias, (float*)u, (const float*)res, M, ld, mode, st);
+    return bias_act_t<bf16>((bf16*)y, bias, (bf16*)u, (const bf16*)res, M, ld, mode, st);
+}
+
+int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
+                hipStream_t st) {
+    GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld, "swin_ln_fwd: width %d / %d", C, ld);
+    const int g = sw_grid(M, 4, 256 * 32);
+    ProfScope prof("gdl::swin_ln_fwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 8 : 4));
+    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, (float2*)stats, M, C, ld),
+                hipLaunchKernelGGL(swin_ln_fwd_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, (float2*)stats, M, C, ld));
+    GDL_CHECK_LAUNCH("swin_ln_fwd_kernel");
+    return GDL_OK;
+}
+
+constexpr int SW_PARTIAL_BLOCKS = 512;  // blocks (= partial rows) of the LayerNorm backward and column-sum kernels
+size_t swin_partial_bytes(int ld) { return (size_t)SW_PARTIAL_BLOCKS * 2 * ld * sizeof(float); }
+
+static int partial_reduce(const float* partial, float* out, int nblk, int width, hipStream_t st) {
+    hipLaunchKernelGGL(swin_partial_reduce_kernel, dim3((width + 255) / 256), dim3(256), 0, st, partial, out, nblk, width);
+    GDL_CHECK_LAUNCH("swin_partial_reduce_kernel");
+    return GDL_OK;
+}
+
+// dgamma_dbeta: [2][ld] (padded layout)
+int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
+                float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st) {
+    GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld && partial, "swin_ln_bwd: width %d / %d", C, ld);
+    int g = (int)((M + 3) / 4);
+    if (g > SW_PARTIAL_BLOCKS) g = SW_PARTIAL_BLOCKS;
+    {
+        ProfScope prof("gdl::swin_ln_bwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (add ? 4 : 3));
+        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_bwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float2*)stats, gamma, (const float*)add, (float*)dx, partial, M, C, ld),
+                    hipLaunchKernelGGL(swin_ln_bwd_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const float2*)stats, gamma, (const bf16*)add, (bf16*)dx, partial, M, C, ld));
+        GDL_CHECK_LAUNCH("swin_ln_bwd_kernel");
+    }
+    return partial_reduce(partial, dgamma_dbeta, g, 2 * ld, st);
+}
+
+// db[ld] = column sums of g; gelu != 0: g <- g * gelu'(u) first
+int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st) {
+    GDL_REQUIRE(ld % 64 == 0 && partial, "swin_colsum: bad arguments");
+    int nb = (int)(M < (size_t)SW_PARTIAL_BLOCKS ? M : (size_t)SW_PARTIAL_BLOCKS);
+    {
+        ProfScope prof("gdl::swin_colsum_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (u ? 3 : 1));
+        if (dt == GDL_F32) {
+            if (u)
+                hipLaunchKernelGGL((swin_colsum_kernel<float, 1>), dim3(nb), dim3(256), 0, st, (float*)g, (const float*)u, partial, M, ld);
+            else
+                hipLaunchKernelGGL((swin_colsum_kernel<float, 0>), dim3(nb), dim3(256), 0, st, (float*)g, (const float*)u, partial, M, ld);
+        } else {
+            if (u)
+                hipLaunchKernelGGL((swin_colsum_kernel<bf16, 1>), dim3(nb), dim3(256), 0, st, (bf16*)g, (const bf16*)u, partial, M, ld);
+            else
+                hipLaunchKernelGGL((swin_colsum_kernel<bf16, 0>), dim3(nb), dim3(256), 0, st, (bf16*)g, (const bf16*)u, partial, M, ld);
+        }
+        GDL_CHECK_LAUNCH("swin_colsum_kernel");
+    }
+    return partial_reduce(partial, db, nb, ld, st);
+}
+
+static int attn_geom(SwinAttnGeom* g, int H, int W, int ws, int shift, int nh, int ld) {
+    GDL_REQUIRE(ws >= 1 && ws * ws <= SW_MAXT && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws && nh * SW_HD <= ld,
+                "swin_attn: window %d (shift %d) on %dx%d tokens, %d heads in %d channels", ws, shift, H, W, nh, ld);
+    g->H = H, g->W = W, g->ws = ws, g->shift = shift, g->nh = nh, g->ld = ld;
+    g->nwin = (H / ws) * (W / ws);
+    return GDL_OK;
+}
+int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_img, int H, int W, int ws, int shift, int nh, int ld,
+                  hipStream_t st) {
+    SwinAttnGeom g;
+    int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
+    if (rc) return rc;
+    const long units = (long)n_img * g.nwin * nh;
+    ProfScope prof("gdl::swin_attn_fwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 4);
+    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_fwd_kernel<float>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const float*)qkv, table, (float*)out, g, n_img),
+                hipLaunchKernelGGL(swin_attn_fwd_kernel<bf16>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const bf16*)qkv, table, (bf16*)out, g, n_img));
+    GDL_CHECK_LAUNCH("swin_attn_fwd_kernel");
+    return GDL_OK;
+}
+size_t swin_attn_bwd_ws_bytes(int n_img, int ws, int nh) { return (size_t)n_img * nh * (2 * ws - 1) * (2 * ws - 1) * sizeof(float); }
+int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* tpart, int n_img,
+                  int H, int W, int ws, int shift, int nh, int ld, hipStream_t st) {
+    SwinAttnGeom g;
+    int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
+    if (rc) return rc;
+    GDL_REQUIRE(tpart && dtable, "swin_attn_bwd: null workspace");
+    const size_t lds = (size_t)4 * SW_MAXT * (SW_HD + 1) * 4 + (size_t)3 * SW_MAXT * (SW_MAXT + 1) * 4 + SW_MAXT * 4;
+    static bool attr[2] = {false, false};
+    const int di = dt == GDL_F32 ? 0 : 1;
+    if (!attr[di]) {
+        hipError_t e = dt == GDL_F32 ? hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                     : hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_bwd)");
+        attr[di] = true;
+    }
+    {
+        ProfScope prof("gdl::swin_attn_bwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 7);
+        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_bwd_kernel<float>, dim3(n_img * nh), dim3(64), lds, st, (const float*)qkv, table, (const float*)dout, (float*)dqkv, tpart, g),
+                    hipLaunchKernelGGL(swin_attn_bwd_kernel<bf16>, dim3(n_img * nh), dim3(64), lds, st, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, tpart, g));
+        GDL_CHECK_LAUNCH("swin_attn_bwd_kernel");
+    }
+    const int tt = (2 * ws - 1) * (2 * ws - 1);
+    hipLaunchKernelGGL(swin_table_reduce_kernel, dim3((nh * tt + 255) / 256), dim3(256), 0, st, tpart, dtable, n_img, nh, tt);
+    GDL_CHECK_LAUNCH("swin_table_reduce_kernel");
+    return GDL_OK;
+}
+
+int swin_merge(int dt, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, hipStream_t st) {
+    GDL_REQUIRE(H % 2 == 0 && W % 2 == 0 && C <= ldx, "swin_merge: %dx%d tokens, %d / %d channels", H, W, C, ldx);
+    const size_t total = (size_t)N * H * W * ldx;
+    ProfScope prof("gdl::swin_merge_kernel", PROF_HBM, st, (double)total * (dt == GDL_F32 ? 8 : 4));
+    if (dt == GDL_F32) {
+        if (scatter)
+            hipLaunchKernelGGL((swin_merge_kernel<float, 1>), dim3(sw_grid(total)), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, ldx);
+        else
+            hipLaunchKernelGGL((swin_merge_kernel<float, 0>), dim3(sw_grid(total)), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, ldx);
+    } else {
+        if (scatter)
+            hipLaunchKernelGGL((swin_merge_kernel<bf16, 1>), dim3(sw_grid(total)), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, N, H, W, C, ldx);
+        else
+            hipLaunchKernelGGL((swin_merge_kernel<bf16, 0>), dim3(sw_grid(total)), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, N, H, W, C, ldx);
+    }
+    GDL_CHECK_LAUNCH("swin_merge_kernel");
+    return GDL_OK;
+}
+
+int swin_token_mean(int dt, const void* x, float* y, int N, int L, int C, int ld, hipStream_t st) {
+    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_token_mean_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)x, y, L, C, ld),
+                hipLaunchKernelGGL(swin_token_mean_kernel<bf16>, dim3(N), dim3(256), 0, st, (const bf16*)x, y, L, C, ld));
+    GDL_CHECK_LAUNCH("swin_token_mean_kernel");
+    return GDL_OK;
+}
+int swin_token_mean_bwd(int dt, const float* dy, void* dx, int N, int L, int C, int ld, hipStream_t st) {
+    const size_t total = (size_t)N * L * ld;
+    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_token_mean_bwd_kernel<float>, dim3(sw_grid(total)), dim3(256), 0, st, dy, (float*)dx, N, L, C, ld),
+                hipLaunchKernelGGL(swin_token_mean_bwd_kernel<bf16>, dim3(sw_grid(total)), dim3(256), 0, st, dy, (bf16*)dx, N, L, C, ld));
+    GDL_CHECK_LAUNCH("swin_token_mean_bwd_kernel");
+    return GDL_OK;
+}
+
+static int seg_of(SwinSeg* s, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad) {
+    GDL_REQUIRE(n > 0 && k > 0 && nseg > 0 && kseg > 0 && n % nseg == 0 && k % kseg == 0 && nseg_pad >= nseg && kseg_pad >= kseg,
+                "swin_pack: bad segmentation");
+    s->n = n, s->k = k, s->nseg = nseg, s->nseg_pad = nseg_pad, s->kseg = kseg, s->kseg_pad = kseg_pad;
+    s->np = (n / nseg) * nseg_pad, s->kp = (k / kseg) * kseg_pad;
+    return GDL_OK;
+}
+int swin_pack_matrix(int dt, const float* src, void* dst, void* dstT, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad,
+                     hipStream_t st) {
+    SwinSeg s;
+    int rc = seg_of(&s, n, k, nseg, nseg_pad, kseg, kseg_pad);
+    if (rc) return rc;
+    const size_t total = (size_t)s.np * s.kp;
+    if (dt == GDL_F32)
+        hipLaunchKernelGGL(swin_pack_kernel<float>, dim3(sw_grid(total)), dim3(256), 0, st, src, (float*)dst, (float*)dstT, s);
+    else if (dt == GDL_BF16)
+        hipLaunchKernelGGL(swin_pack_kernel<bf16>, dim3(sw_grid(total)), dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, s);
+    else
+        GDL_REQUIRE(false, "swin_pack_matrix: dtype %d", dt);
+    GDL_CHECK_LAUNCH("swin_pack_kernel");
+    return GDL_OK;
+}
+int swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad, hipStream_t st) {
+    SwinSeg s;
+    int rc = seg_of(&s, n, k, nseg, nseg_pad, kseg, kseg_pad);
+    if (rc) return rc;
+    hipLaunchKernelGGL(swin_unpack_kernel, dim3(sw_grid((size_t)n * k)), dim3(256), 0, st, src, dst, s);
+    GDL_CHECK_LAUNCH("swin_unpack_kernel");
+    return GDL_OK;
+}
+
+}  // namespace gdl

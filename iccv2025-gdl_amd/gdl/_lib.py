@@ -30,6 +30,20 @@ SIGNATURES = {
     "gdl_bn_act_bits": ("i", "ippp" + "ppp" + "pp" + "zi" + "p"),
     "gdl_conv_dgrad_relu": ("i", "ipppppp" + "iiiiiiiii" + "p"),
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
+    "gdl_swin_patch_gather": ("i", "ipp" + "iiiii" + "p"),
+    "gdl_swin_bias_act": ("i", "ipppp" + "zii" + "p"),
+    "gdl_swin_ln_fwd": ("i", "ippppp" + "zii" + "p"),
+    "gdl_swin_partial_bytes": ("z", "i"),
+    "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),
+    "gdl_swin_colsum": ("i", "ipppp" + "zi" + "p"),
+    "gdl_swin_attn_fwd": ("i", "ippp" + "iiiiiii" + "p"),
+    "gdl_swin_attn_bwd_workspace_bytes": ("z", "iii"),
+    "gdl_swin_attn_bwd": ("i", "ipppppp" + "iiiiiii" + "p"),
+    "gdl_swin_merge": ("i", "ipp" + "iiiiii" + "p"),
+    "gdl_swin_token_mean": ("i", "ipp" + "iiii" + "p"),
+    "gdl_swin_token_mean_bwd": ("i", "ipp" + "iiii" + "p"),
+    "gdl_swin_pack_matrix": ("i", "ippp" + "iiiiii" + "p"),
+    "gdl_swin_unpack_matrix": ("i", "pp" + "iiiiii" + "p"),
     "gdl_fold_workspace_bytes": ("z", ""),
     "gdl_fold_workspace_init": ("i", "pzp"),
     "gdl_conv_fwd_bn": ("i", "ippppp" + "iiiiiiiii" + "ppppp" + "pppp" + "pp"),

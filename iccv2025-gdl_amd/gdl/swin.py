@@ -1,0 +1,347 @@
+"""Swin visual encoder on libgdl_hip: forward + backward of the function the reference's
+`SwinTransformer.forward` computes with `args.pe = 0`, `ape = False`, `patch_norm = True` and every dropout / the
+stochastic depth at 0 (/root/reference/models/swin_transformer.py:596-634; block :256-295; window attention :124-157;
+patch merging :330-353; patch embedding :478-486).
+
+The host side here only plans buffers and enqueues kernels (PyTorch = device allocator + streams):
+  * every nn.Linear and the 4x4/4 patch convolution is a 1x1 convolution of the library -- `gdl_conv_fwd`, `gdl_conv_dgrad`,
+    `gdl_conv_wgrad` (MFMA implicit GEMM; weights zero-padded so that every width is a multiple of 64: 96 -> 128 in stage 1,
+    a QKV row is three such segments);
+  * LayerNorm, bias / GELU / residual, window attention (shift, mask, relative-position bias), patch merging and the final
+    token mean are the `gdl_swin_*` kernels of csrc/swin.hip.
+Everything saved for the backward is kept (nothing recomputed except the attention probabilities).
+"""
+import torch
+
+from . import _lib as L
+
+
+def _ld(c):
+    return (c + 63) // 64 * 64
+
+
+class _Linear:
+    """One nn.Linear (weight [n][k], optional bias) in the kernels' padded layouts."""
+
+    def __init__(self, eng, w_idx, b_idx, n, k, nseg=None, kseg=None):
+        self.eng, self.w_idx, self.b_idx, self.n, self.k = eng, w_idx, b_idx, n, k
+        self.nseg, self.kseg = nseg or n, kseg or k
+        self.nseg_pad, self.kseg_pad = _ld(self.nseg), _ld(self.kseg)
+        self.np, self.kp = n // self.nseg * self.nseg_pad, k // self.kseg * self.kseg_pad
+        dev, td = eng.device, eng.tdtype
+        self.w = torch.empty((self.np, self.kp), dtype=td, device=dev)   # [out][in]  (forward, weight gradient)
+        self.wT = torch.empty((self.kp, self.np), dtype=td, device=dev)  # [in][out]  (data gradient)
+        self.b = torch.zeros(self.np, dtype=torch.float32, device=dev) if b_idx is not None else None
+        self.dw = torch.empty((self.np, self.kp), dtype=torch.float32, device=dev)
+        self.db = torch.empty(self.np, dtype=torch.float32, device=dev) if b_idx is not None else None
+
+    def pack(self, params, st):
+        e = self.eng
+        L.call("gdl_swin_pack_matrix", e.dt, L.ptr(params[self.w_idx]), L.ptr(self.w), L.ptr(self.wT), self.n, self.k, self.nseg,
+               self.nseg_pad, self.kseg, self.kseg_pad, st)
+        if self.b is not None:
+            L.call("gdl_swin_pack_matrix", L.GDL_F32, L.ptr(params[self.b_idx]), L.ptr(self.b), None, self.n, 1, self.nseg,
+                   self.nseg_pad, 1, 1, st)
+
+    def unpack(self, grads, st):
+        L.call("gdl_swin_unpack_matrix", L.ptr(self.dw), L.ptr(grads[self.w_idx]), self.n, self.k, self.nseg, self.nseg_pad,
+               self.kseg, self.kseg_pad, st)
+        if self.b is not None:
+            L.call("gdl_swin_unpack_matrix", L.ptr(self.db), L.ptr(grads[self.b_idx]), self.n, 1, self.nseg, self.nseg_pad, 1, 1, st)
+
+    # y[M][np] = x[M][kp] . w^T
+    def fwd(self, x, y, M, st):
+        e = self.eng
+        L.call("gdl_conv_fwd", e.dt, L.ptr(x), L.ptr(self.w), L.ptr(y), None, L.ptr(e.table(L.GATHER_FWD, M, self.kp, self.np)), M, 1,
+               1, self.kp, self.np, 1, 1, 1, 0, st)
+
+    # dx[M][kp] = dy[M][np] . w
+    def dgrad(self, dy, dx, M, st):
+        e = self.eng
+        L.call("gdl_conv_dgrad", e.dt, L.ptr(dy), L.ptr(self.wT), L.ptr(dx), None, L.ptr(e.table(L.GATHER_DGRAD, M, self.kp, self.np)),
+               M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
+
+    # dw[np][kp] = dy^T . x
+    def wgrad(self, dy, x, M, st):
+        e = self.eng
+        ws = e.wgrad_ws(M, self.kp, self.np)
+        L.call("gdl_conv_wgrad", e.dt, L.ptr(dy), L.ptr(x), L.ptr(self.dw), L.ptr(e.table(L.GATHER_FWD, M, self.kp, self.np)), M, 1, 1,
+               self.kp, self.np, 1, 1, 1, 0, L.ptr(ws), ws.numel(), st)
+
+
+class _Norm:
+    def __init__(self, eng, w_idx, b_idx, c):
+        self.eng, self.w_idx, self.b_idx, self.c, self.ld = eng, w_idx, b_idx, c, _ld(c)
+        dev = eng.device
+        self.g = torch.zeros(self.ld, dtype=torch.float32, device=dev)
+        self.b = torch.zeros(self.ld, dtype=torch.float32, device=dev)
+        self.dgb = torch.empty((2, self.ld), dtype=torch.float32, device=dev)
+
+    def pack(self, params, st):
+        for src, dst in ((self.w_idx, self.g), (self.b_idx, self.b)):
+            L.call("gdl_swin_pack_matrix", L.GDL_F32, L.ptr(params[src]), L.ptr(dst), None, self.c, 1, self.c, self.ld, 1, 1, st)
+
+    def unpack(self, grads, st):
+        for row, dst in ((0, self.w_idx), (1, self.b_idx)):
+            L.call("gdl_swin_unpack_matrix", L.ptr(self.dgb[row]), L.ptr(grads[dst]), self.c, 1, self.c, self.ld, 1, 1, st)
+
+    def fwd(self, x, y, stats, M, st):
+        L.call("gdl_swin_ln_fwd", self.eng.dt, L.ptr(x), L.ptr(self.g), L.ptr(self.b), L.ptr(y), L.ptr(stats), M, self.c, self.ld, st)
+
+    def bwd(self, dy, x, stats, add, dx, M, st):
+        e = self.eng
+        L.call("gdl_swin_ln_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(self.g), L.ptr(add) if add is not None else None,
+               L.ptr(dx), L.ptr(self.dgb), L.ptr(e.partial), M, self.c, self.ld, st)
+
+
+class SwinEngine:
+    """A planned Swin encoder for fixed (cfg, dtype, B, T).  `cfg`: dict(img, patch, embed, depths, heads, window, mlp).
+    Parameters / gradients are lists of float32 CUDA tensors in the reference's named_parameters() order
+    (`param_shapes()`); forward(x [B,3,T,img,img] f32) -> float32 [B*T, C_last]; backward(dfeat, grads)."""
+
+    def __init__(self, cfg, dtype, B, T, device):
+        self.lib = L.load()
+        self.cfg, self.B, self.T = dict(cfg), B, T
+        self.N = B * T
+        self.dt = L.dtype_code(dtype)
+        self.tdtype = L.torch_dtype(self.dt)
+        self.device = torch.device(device)
+        self._tables, self._wg = {}, None
+        E, p = cfg["embed"], cfg["patch"]
+        assert cfg["img"] % p == 0 and 3 * p * p <= 64
+        res = cfg["img"] // p
+        names = []
+        idx = {}
+
+        def reg(name, shape):
+            idx[name] = len(names)
+            names.append((name, tuple(shape)))
+            return idx[name]
+
+        dev, td, N = self.device, self.tdtype, self.N
+
+        def buf(rows, cols, dtype=None):
+            return torch.empty((rows, cols), dtype=dtype or td, device=dev)
+
+        # ---- patch embedding
+        self.pe = _Linear(self, reg("patch_embed.proj.weight", (E, 3, p, p)), reg("patch_embed.proj.bias", (E,)), E, 3 * p * p)
+        self.pe_norm = _Norm(self, reg("patch_embed.norm.weight", (E,)), reg("patch_embed.norm.bias", (E,)), E)
+        M0 = N * res * res
+        self.pe_rows = buf(M0, 64)
+        self.pe_out = buf(M0, _ld(E))
+        self.pe_stats = buf(M0, 2, torch.float32)
+        self.x0 = buf(M0, _ld(E))
+        # ---- stages
+        self.stages = []
+        nl = len(cfg["depths"])
+        maxw, maxld = 0, 64
+        x_prev = None
+        for i, (depth, nh) in enumerate(zip(cfg["depths"], cfg["heads"])):
+            C, r = E << i, res >> i
+            assert C == nh * 32, "head dimension must be 32"
+            ws = min(cfg["window"], r)
+            M, ld, hid = N * r * r, _ld(C), cfg["mlp"] * C
+            blocks = []
+            for j in range(depth):
+                pre = f"layers.{i}.blocks.{j}."
+                b = {"shift": 0 if (j % 2 == 0 or r <= cfg["window"]) else cfg["window"] // 2}
+                b["norm1"] = _Norm(self, reg(pre + "norm1.weight", (C,)), reg(pre + "norm1.bias", (C,)), C)
+                b["table_idx"] = reg(pre + "attn.relative_position_bias_table", ((2 * ws - 1) ** 2, nh))
+                b["qkv"] = _Linear(self, reg(pre + "attn.qkv.weight", (3 * C, C)), reg(pre + "attn.qkv.bias", (3 * C,)), 3 * C, C, nseg=C)
+                b["proj"] = _Linear(self, reg(pre + "attn.proj.weight", (C, C)), reg(pre + "attn.proj.bias", (C,)), C, C)
+                b["norm2"] = _Norm(self, reg(pre + "norm2.weight", (C,)), reg(pre + "norm2.bias", (C,)), C)
+                b["fc1"] = _Linear(self, reg(pre + "mlp.fc1.weight", (hid, C)), reg(pre + "mlp.fc1.bias", (hid,)), hid, C)
+                b["fc2"] = _Linear(self, reg(pre + "mlp.fc2.weight", (C, hid)), reg(pre + "mlp.fc2.bias", (C,)), C, hid)
+                # saved for the backward
+                b["x_in"] = None  # set below (the previous block's output)
+                b["stats1"], b["h"], b["qkv_a"], b["attn"] = buf(M, 2, torch.float32), buf(M, ld), buf(M, 3 * ld), buf(M, ld)
+                b["x_mid"], b["stats2"], b["m"] = buf(M, ld), buf(M, 2, torch.float32), buf(M, ld)
+                b["u"], b["a"], b["x_out"] = buf(M, _ld(hid)), buf(M, _ld(hid)), buf(M, ld)
+                blocks.append(b)
+                maxld = max(maxld, 3 * ld, _ld(hid))
+            st = {"C": C, "r": r, "ws": ws, "nh": nh, "M": M, "ld": ld, "hid": hid, "blocks": blocks}
+            if i < nl - 1:
+                pre = f"layers.{i}.downsample."
+                st["red"] = _Linear(self, reg(pre + "reduction.weight", (2 * C, 4 * C)), None, 2 * C, 4 * C)
+                st["mnorm"] = _Norm(self, reg(pre + "norm.weight", (4 * C,)), reg(pre + "norm.bias", (4 * C,)), 4 * C)
+                st["cat"], st["catn"], st["mstats"] = buf(M // 4, 4 * C), buf(M // 4, 4 * C), buf(M // 4, 2, torch.float32)
+                st["merged"] = buf(M // 4, _ld(2 * C))
+                maxld = max(maxld, 4 * C)
+            self.stages.append(st)
+            maxw = max(maxw, N * nh * (2 * ws - 1) ** 2)
+        Cl = E << (nl - 1)
+        self.out_norm = _Norm(self, reg("norm.weight", (Cl,)), reg("norm.bias", (Cl,)), Cl)
+        last = self.stages[-1]
+        self.out_stats, self.out_ln = buf(last["M"], 2, torch.float32), buf(last["M"], last["ld"])
+        self.feat = torch.empty((N, Cl), dtype=torch.float32, device=dev)
+        self.C_out, self.L_out = Cl, last["r"] * last["r"]
+        self.names = names
+        # scratch: LayerNorm / column-sum partials, attention table partials, gradient buffers
+        self.partial = torch.empty(self.lib.gdl_swin_partial_bytes(maxld), dtype=torch.uint8, device=dev)
+        self.tpart = torch.empty(max(maxw, 1), dtype=torch.float32, device=dev)
+        M1, ld1 = self.stages[0]["M"], self.stages[0]["ld"]
+        wide = max(max(3 * s["ld"], _ld(s["hid"])) * s["M"] for s in self.stages)
+        self.g_a = torch.empty(M1 * ld1, dtype=td, device=dev)   # gradient of the residual stream (ping)
+        self.g_b = torch.empty(M1 * ld1, dtype=td, device=dev)   # (pong)
+        self.g_c = torch.empty(M1 * ld1, dtype=td, device=dev)   # branch gradient at token width
+        self.g_w = torch.empty(wide, dtype=td, device=dev)       # branch gradient at QKV / hidden width
+        self.g_cat = torch.empty(max([s["M"] // 4 * 4 * s["C"] for s in self.stages[:-1]] + [1]), dtype=td, device=dev)
+        self.g_cat2 = torch.empty_like(self.g_cat)
+        self._params = None
+        self.have_fwd = False
+
+    # ------------------------------------------------------------------ plumbing
+    def param_shapes(self):
+        return list(self.names)
+
+    def table(self, mode, M, C, K):
+        key = (mode, M, C if mode == L.GATHER_FWD else K)
+        t = self._tables.get(key)
+        if t is None:
+            nb = self.lib.gdl_conv_table_bytes(mode, M, 1, 1, 1, 1, 1, 0)
+            t = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            L.call("gdl_conv_build_table", mode, self.dt, M, 1, 1, C, K, 1, 1, 1, 0, L.ptr(t), L.cur_stream())
+            self._tables[key] = t
+        return t
+
+    def wgrad_ws(self, M, C, K):
+        nb = self.lib.gdl_conv_wgrad_workspace_bytes(self.dt, M, 1, 1, C, K, 1, 1, 1, 0)
+        if self._wg is None or self._wg.numel() < nb:
+            self._wg = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        return self._wg
+
+    def set_params(self, params):
+        if len(params) != len(self.names):
+            raise L.GdlError(f"SwinEngine.set_params: {len(params)} tensors, expected {len(self.names)}")
+        for p, (n, shape) in zip(params, self.names):
+            if p.dtype != torch.float32 or not p.is_contiguous() or tuple(p.shape) != shape or p.device != self.device:
+                raise L.GdlError(f"SwinEngine.set_params: {n} must be a contiguous float32 tensor of shape {shape} on {self.device}")
+        self._params = list(params)
+
+    def _linears_norms(self):
+        yield self.pe
+        yield self.pe_norm
+        for s in self.stages:
+            for b in s["blocks"]:
+                for k in ("norm1", "qkv", "proj", "norm2", "fc1", "fc2"):
+                    yield b[k]
+            if "red" in s:
+                yield s["red"]
+                yield s["mnorm"]
+        yield self.out_norm
+
+    def _v(self, flat, rows, cols):
+        return flat[:rows * cols].view(rows, cols)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if self._params is None:
+            raise L.GdlError("SwinEngine.forward: parameters not set")
+        cfg, dt, N, st = self.cfg, self.dt, self.N, L.cur_stream()
+        B, T = self.B, self.T
+        if tuple(x.shape) != (B, 3, T, cfg["img"], cfg["img"]) or x.dtype != torch.float32 or not x.is_contiguous() or \
+                x.device != self.device:
+            raise L.GdlError("SwinEngine.forward: x must be a contiguous float32 [B, 3, T, img, img] tensor on the engine's device")
+        P = self._params
+        for o in self._linears_norms():  # float32 masters -> kernel layouts (once per step, like the encoder's weight pack)
+            o.pack(P, st)
+        L.call("gdl_swin_patch_gather", dt, L.ptr(x), L.ptr(self.pe_rows), B, T, cfg["img"], cfg["img"], cfg["patch"], st)
+        M0 = self.pe_rows.shape[0]
+        self.pe.fwd(self.pe_rows, self.pe_out, M0, st)
+        L.call("gdl_swin_bias_act", dt, L.ptr(self.pe_out), L.ptr(self.pe.b), None, None, M0, self.pe.np, 0, st)
+        xcur = self.x0
+        self.pe_norm.fwd(self.pe_out, xcur, self.pe_stats, M0, st)
+        for s in self.stages:
+            M, ld, r = s["M"], s["ld"], s["r"]
+            for b in s["blocks"]:
+                b["x_in"] = xcur
+                b["norm1"].fwd(xcur, b["h"], b["stats1"], M, st)
+                b["qkv"].fwd(b["h"], b["qkv_a"], M, st)
+                L.call("gdl_swin_bias_act", dt, L.ptr(b["qkv_a"]), L.ptr(b["qkv"].b), None, None, M, 3 * ld, 0, st)
+                L.call("gdl_swin_attn_fwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(b["attn"]), N, r, r, s["ws"],
+                       b["shift"], s["nh"], ld, st)
+                b["proj"].fwd(b["attn"], b["x_mid"], M, st)
+                L.call("gdl_swin_bias_act", dt, L.ptr(b["x_mid"]), L.ptr(b["proj"].b), None, L.ptr(xcur), M, ld, 2, st)
+                b["norm2"].fwd(b["x_mid"], b["m"], b["stats2"], M, st)
+                b["fc1"].fwd(b["m"], b["a"], M, st)
+                L.call("gdl_swin_bias_act", dt, L.ptr(b["a"]), L.ptr(b["fc1"].b), L.ptr(b["u"]), None, M, b["fc1"].np, 1, st)
+                b["fc2"].fwd(b["a"], b["x_out"], M, st)
+                L.call("gdl_swin_bias_act", dt, L.ptr(b["x_out"]), L.ptr(b["fc2"].b), None, L.ptr(b["x_mid"]), M, ld, 2, st)
+                xcur = b["x_out"]
+            if "red" in s:
+                L.call("gdl_swin_merge", dt, L.ptr(xcur), L.ptr(s["cat"]), N, r, r, s["C"], ld, 0, st)
+                s["mnorm"].fwd(s["cat"], s["catn"], s["mstats"], M // 4, st)
+                s["red"].fwd(s["catn"], s["merged"], M // 4, st)
+                xcur = s["merged"]
+        last = self.stages[-1]
+        self.x_last = xcur
+        self.out_norm.fwd(xcur, self.out_ln, self.out_stats, last["M"], st)
+        L.call("gdl_swin_token_mean", dt, L.ptr(self.out_ln), L.ptr(self.feat), N, self.L_out, self.C_out, last["ld"], st)
+        self.have_fwd = True
+        return self.feat
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dfeat, grads):
+        """dfeat float32 [B*T, C_last]; grads: float32 tensors of the parameter shapes (overwritten)."""
+        if not self.have_fwd:
+            raise L.GdlError("SwinEngine.backward: no forward to differentiate")
+        if len(grads) != len(self.names):
+            raise L.GdlError("SwinEngine.backward: wrong number of gradient tensors")
+        dt, N, st = self.dt, self.N, L.cur_stream()
+        P = self._params
+        last = self.stages[-1]
+        M, ld = last["M"], last["ld"]
+        ga, gb = self._v(self.g_a, M, ld), self._v(self.g_b, M, ld)
+        L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), N, self.L_out, self.C_out, ld, st)
+        self.out_norm.bwd(ga, self.x_last, self.out_stats, None, gb, M, st)
+        self.out_norm.unpack(grads, st)
+        dx, spare = gb, ga  # dx: gradient of the current stage's output tokens
+        for si in range(len(self.stages) - 1, -1, -1):
+            s = self.stages[si]
+            M, ld, r = s["M"], s["ld"], s["r"]
+            if "red" in s:  # dx is the gradient of the merged tokens [M/4][ld(2C)]
+                M4, C4 = M // 4, 4 * s["C"]
+                gc, gc2 = self._v(self.g_cat, M4, C4), self._v(self.g_cat2, M4, C4)
+                s["red"].wgrad(dx, s["catn"], M4, st)
+                s["red"].dgrad(dx, gc, M4, st)
+                s["mnorm"].bwd(gc, s["cat"], s["mstats"], None, gc2, M4, st)
+                s["red"].unpack(grads, st)
+                s["mnorm"].unpack(grads, st)
+                dx = self._v(self.g_a, M, ld)
+                spare = self._v(self.g_b, M, ld)
+                L.call("gdl_swin_merge", dt, L.ptr(gc2), L.ptr(dx), N, r, r, s["C"], ld, 1, st)
+            else:
+                dx, spare = self._v(dx.reshape(-1), M, ld), self._v(spare.reshape(-1), M, ld)
+            gtok = self._v(self.g_c, M, ld)
+            for b in reversed(s["blocks"]):
+                hid_ld = b["fc1"].np
+                gw = self._v(self.g_w, M, hid_ld)
+                # x_out = x_mid + fc2(gelu(fc1(norm2(x_mid)))) ; dx = d x_out
+                L.call("gdl_swin_colsum", dt, L.ptr(dx), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
+                b["fc2"].wgrad(dx, b["a"], M, st)
+                b["fc2"].dgrad(dx, gw, M, st)                                     # d a
+                L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
+                b["fc1"].wgrad(gw, b["m"], M, st)
+                b["fc1"].dgrad(gw, gtok, M, st)                                   # d m
+                b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st)   # spare = d x_mid
+                # x_mid = x_in + proj(attn(qkv(norm1(x_in))))
+                L.call("gdl_swin_colsum", dt, L.ptr(spare), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
+                b["proj"].wgrad(spare, b["attn"], M, st)
+                b["proj"].dgrad(spare, gtok, M, st)                               # d attention output
+                gq = self._v(self.g_w, M, 3 * ld)
+                L.call("gdl_swin_attn_bwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(gtok), L.ptr(gq),
+                       L.ptr(grads[b["table_idx"]]), L.ptr(self.tpart), N, r, r, s["ws"], b["shift"], s["nh"], ld, st)
+                L.call("gdl_swin_colsum", dt, L.ptr(gq), None, L.ptr(b["qkv"].db), L.ptr(self.partial), M, 3 * ld, st)
+                b["qkv"].wgrad(gq, b["h"], M, st)
+                b["qkv"].dgrad(gq, gtok, M, st)                                   # d h
+                b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st)    # dx = d x_in
+                for k in ("norm1", "qkv", "proj", "norm2", "fc1", "fc2"):
+                    b[k].unpack(grads, st)
+        # patch embedding: x0 = norm(conv(x) + b); no input gradient
+        M0 = self.pe_rows.shape[0]
+        g0 = self._v(spare.reshape(-1), M0, self.pe.np)
+        self.pe_norm.bwd(dx, self.pe_out, self.pe_stats, None, g0, M0, st)
+        L.call("gdl_swin_colsum", dt, L.ptr(g0), None, L.ptr(self.pe.db), L.ptr(self.partial), M0, self.pe.np, st)
+        self.pe.wgrad(g0, self.pe_rows, M0, st)
+        self.pe.unpack(grads, st)
+        self.pe_norm.unpack(grads, st)

@@ -384,6 +384,49 @@ GDL_API const char* gdl_prof_slot_name(int slot);
 GDL_API int gdl_prof_slot_bound(int slot);
 GDL_API int gdl_prof_collect(int64_t* launches, double* ms, double* work);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Swin visual encoder (/root/reference/models/swin_transformer.py, which the DGL script does not
+ * reach -- main_dgl.py:236-240 -- so the Swin + DGL-head model is a new composition).  Tokens are rows [N*L][ld] of
+ * `dtype`, ld = channels rounded up to a multiple of 64, padding columns zero.  Every nn.Linear (qkv, proj, fc1, fc2,
+ * PatchMerging.reduction) and the 4x4/4 PatchEmbed convolution is a 1x1 gdl_conv_fwd / gdl_conv_dgrad / gdl_conv_wgrad on
+ * zero-padded weights (gdl_swin_pack_matrix); the entry points below are everything else.  Vectors (bias, gamma, beta)
+ * are float32 in the padded layout.
+ *   gdl_swin_patch_gather   frames [B,3,T,H,W] f32 -> GEMM rows [B*T*(H/p)*(W/p)][64], columns (c,kh,kw)  (:463,:480)
+ *   gdl_swin_bias_act       mode 0: y += b;  1: u = y + b, y = gelu(u);  2: y = y + b + res               (:26-42,:287-290)
+ *   gdl_swin_ln_fwd / _bwd  nn.LayerNorm(eps 1e-5) over the C real channels; stats [M][2] = (mean, rstd); the backward
+ *                           adds `add` (the residual branch's gradient) and returns [2][ld] = (d gamma, d beta)
+ *   gdl_swin_colsum         db[ld] = column sums of g; with u != NULL first g <- g * gelu'(u) (in place)
+ *   gdl_swin_attn_fwd/_bwd  WindowAttention incl. cyclic shift, mask and relative-position bias (:124-157,:222-285) on
+ *                           QKV rows [q | k | v] (three ld-wide segments, head h at h*32); the backward returns dqkv and
+ *                           d(relative_position_bias_table) [(2w-1)^2][heads]
+ *   gdl_swin_merge          PatchMerging's 2x2 concatenation [N,H,W,C] -> [N,H/2,W/2,4C] (:336-344) / its adjoint
+ *   gdl_swin_token_mean     AdaptiveAvgPool2d((1,1)) over the L tokens (:629-631) -> float32 [N][C], and its backward
+ *   gdl_swin_pack_matrix    float32 [n][k] -> `dtype` [np][kp] (+ transposed [kp][np]), rows / columns in segments of
+ *                           nseg / kseg stored at pitch nseg_pad / kseg_pad (QKV rows: 3 x 96 -> 3 x 128)
+ *   gdl_swin_unpack_matrix  float32 padded [np][kp] -> float32 real [n][k] (weight gradients back to parameter shape)
+ * ------------------------------------------------------------------------------------------------------------------- */
+GDL_API int gdl_swin_patch_gather(int dtype, const float* x, void* a, int B, int T, int H, int W, int patch, void* stream);
+GDL_API int gdl_swin_bias_act(int dtype, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode,
+                              void* stream);
+GDL_API int gdl_swin_ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M,
+                            int C, int ld, void* stream);
+GDL_API size_t gdl_swin_partial_bytes(int ld);
+GDL_API int gdl_swin_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
+                            void* dx, float* dgamma_dbeta, void* partial, size_t M, int C, int ld, void* stream);
+GDL_API int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream);
+GDL_API int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out, int n_img, int H, int W, int window,
+                              int shift, int heads, int ld, void* stream);
+GDL_API size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int window, int heads);
+GDL_API int gdl_swin_attn_bwd(int dtype, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
+                              void* ws, int n_img, int H, int W, int window, int shift, int heads, int ld, void* stream);
+GDL_API int gdl_swin_merge(int dtype, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, void* stream);
+GDL_API int gdl_swin_token_mean(int dtype, const void* x, float* y, int N, int L, int C, int ld, void* stream);
+GDL_API int gdl_swin_token_mean_bwd(int dtype, const float* dy, void* dx, int N, int L, int C, int ld, void* stream);
+GDL_API int gdl_swin_pack_matrix(int dtype, const float* src, void* dst, void* dstT, int n, int k, int nseg, int nseg_pad,
+                                 int kseg, int kseg_pad, void* stream);
+GDL_API int gdl_swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
