@@ -333,6 +333,19 @@ int gdl_softmax_ce(const float* logits, const int64_t* labels, float scale, floa
     return softmax_ce(logits, labels, scale, loss, dlogits, B, n_classes, (hipStream_t)stream);
 }
 
+int gdl_head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out,
+                           int B, int n_classes, int x_dim, int y_dim, void* stream) {
+    GDL_REQUIRE(x && y && W && b && out && B > 0 && n_classes > 0 && x_dim > 0 && y_dim > 0, "head_concat_xy_fwd: bad arguments");
+    return head_concat_xy_fwd(x, y, W, b, out, x_out, y_out, B, n_classes, x_dim, y_dim, (hipStream_t)stream);
+}
+int gdl_head_concat_xy_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
+                           const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db, int B,
+                           int n_classes, int x_dim, int y_dim, void* stream) {
+    GDL_REQUIRE(x && y && W && B > 0 && n_classes > 0 && x_dim > 0 && y_dim > 0, "head_concat_xy_bwd: bad arguments");
+    GDL_REQUIRE((dx != nullptr) == (dy != nullptr) && (dW != nullptr) == (db != nullptr), "head_concat_xy_bwd: dx/dy and dW/db come in pairs");
+    return head_concat_xy_bwd(x, y, W, g_x_out, g_y_out, g_out, out_reaches_xy, uni_in_dw, dx, dy, dW, db, B, n_classes, x_dim, y_dim,
+                              (hipStream_t)stream);
+}
 // ---- Swin visual encoder: non-GEMM operators; the Linears are gdl_conv_fwd / _dgrad / _wgrad (1x1)
 int gdl_swin_patch_gather(int dtype, const float* x, void* a, int B, int T, int H, int W, int patch, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && x && a, "swin_patch_gather: bad arguments");

@@ -163,6 +163,100 @@ int head_concat_bwd(const float* x, const float* y, const float* W, const float*
     }
     return GDL_OK;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Concat head with unequal feature widths (the Swin composition: 512 audio + 768 visual; cf. ConcatFusion_Swin,
+// fusion_modules.py:79-88, and ConcatFusion_DGL, :45-59): W [n][dxw + dyw].  Same contract as head_concat_fwd / _bwd.
+// Tiny problems (B x 1280 x n): plain FMA, fixed summation order.
+__global__ __launch_bounds__(256) void head_xy_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          float* __restrict__ out, float* __restrict__ x_out,
+                                                          float* __restrict__ y_out, int n, int dxw, int dyw) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < n; j += 4) {
+        const float* w = W + (size_t)j * (dxw + dyw);
+        float pa = 0.f, pv = 0.f;
+        for (int i = lane; i < dxw; i += 64) pa += w[i] * x[(size_t)b * dxw + i];
+        for (int i = lane; i < dyw; i += 64) pv += w[dxw + i] * y[(size_t)b * dyw + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pa += __shfl_xor(pa, o);
+            pv += __shfl_xor(pv, o);
+        }
+        if (lane == 0) {
+            out[(size_t)b * n + j] = pa + pv + bias[j];
+            if (x_out) x_out[(size_t)b * n + j] = pa + bias[j];
+            if (y_out) y_out[(size_t)b * n + j] = pv + bias[j];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void head_xy_bwd_feat_kernel(const float* __restrict__ W, const float* __restrict__ g_x_out,
+                                                               const float* __restrict__ g_y_out, const float* __restrict__ g_out,
+                                                               int out_reaches_xy, float* __restrict__ dx, float* __restrict__ dy,
+                                                               int n, int dxw, int dyw) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < dxw + dyw; i += 256) {
+        const bool is_y = i >= dxw;
+        const float* gu = is_y ? g_y_out : g_x_out;
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float g = gu ? gu[(size_t)b * n + j] : 0.f;
+            if (out_reaches_xy && g_out) g += g_out[(size_t)b * n + j];
+            s += g * W[(size_t)j * (dxw + dyw) + i];
+        }
+        if (is_y)
+            dy[(size_t)b * dyw + i - dxw] = s;
+        else
+            dx[(size_t)b * dxw + i] = s;
+    }
+}
+// grid = (n, ceil((dxw + dyw) / 256)); db by the first block row
+__global__ __launch_bounds__(256) void head_xy_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ g_x_out, const float* __restrict__ g_y_out,
+                                                            const float* __restrict__ g_out, int uni_in_dw, float* __restrict__ dW,
+                                                            float* __restrict__ db, int B, int n, int dxw, int dyw) {
+    const int j = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+    if (i < dxw + dyw) {
+        const bool is_y = i >= dxw;
+        const float* gu = is_y ? g_y_out : g_x_out;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float g = g_out ? g_out[(size_t)b * n + j] : 0.f;
+            if (uni_in_dw && gu) g += gu[(size_t)b * n + j];
+            s += g * (is_y ? y[(size_t)b * dyw + i - dxw] : x[(size_t)b * dxw + i]);
+        }
+        dW[(size_t)j * (dxw + dyw) + i] = s;
+    }
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            s += g_out ? g_out[(size_t)b * n + j] : 0.f;
+            if (uni_in_dw) s += (g_x_out ? g_x_out[(size_t)b * n + j] : 0.f) + (g_y_out ? g_y_out[(size_t)b * n + j] : 0.f);
+        }
+        db[j] = s;
+    }
+}
+int head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out, int B,
+                       int n, int dxw, int dyw, hipStream_t st) {
+    hipLaunchKernelGGL(head_xy_fwd_kernel, dim3(B), dim3(256), 0, st, x, y, W, b, out, x_out, y_out, n, dxw, dyw);
+    GDL_CHECK_LAUNCH("head_xy_fwd_kernel");
+    return GDL_OK;
+}
+int head_concat_xy_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out, const float* g_out,
+                       int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db, int B, int n, int dxw, int dyw,
+                       hipStream_t st) {
+    if (dx && dy) {
+        hipLaunchKernelGGL(head_xy_bwd_feat_kernel, dim3(B), dim3(256), 0, st, W, g_x_out, g_y_out, g_out, out_reaches_xy, dx, dy, n, dxw,
+                           dyw);
+        GDL_CHECK_LAUNCH("head_xy_bwd_feat_kernel");
+    }
+    if (dW && db) {
+        hipLaunchKernelGGL(head_xy_bwd_w_kernel, dim3(n, (dxw + dyw + 255) / 256), dim3(256), 0, st, x, y, g_x_out, g_y_out, g_out,
+                           uni_in_dw, dW, db, B, n, dxw, dyw);
+        GDL_CHECK_LAUNCH("head_xy_bwd_w_kernel");
+    }
+    return GDL_OK;
+}
+
 int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* Wy, const float* g_x_out, const float* g_y_out,
                  const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dWx, float* dbx,
                  float* dWy, float* dby, int B, int n, hipStream_t st) {

@@ -147,6 +147,12 @@ int softmax_ce_multi(int nsets, const float* const* logits, const int64_t* label
 int softmax_ce(const float* logits, const int64_t* labels, float scale, float* loss, float* dlogits, int B, int n,
                hipStream_t st);
 
+int head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out, int B,
+                       int n, int dxw, int dyw, hipStream_t st);
+int head_concat_xy_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out, const float* g_out,
+                       int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db, int B, int n, int dxw, int dyw,
+                       hipStream_t st);
+
 // ---- Swin visual encoder, non-GEMM operators (swin.hip; the Linears run on conv_fwd / conv_dgrad / conv_wgrad as 1x1)
 int swin_patch_gather(int dt, const float* x, void* a, int B, int T, int H, int W, int p, hipStream_t st);
 int swin_bias_act(int dt, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode, hipStream_t st);

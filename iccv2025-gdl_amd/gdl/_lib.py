@@ -30,6 +30,8 @@ SIGNATURES = {
     "gdl_bn_act_bits": ("i", "ippp" + "ppp" + "pp" + "zi" + "p"),
     "gdl_conv_dgrad_relu": ("i", "ipppppp" + "iiiiiiiii" + "p"),
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
+    "gdl_head_concat_xy_fwd": ("i", "ppppppp" + "iiii" + "p"),
+    "gdl_head_concat_xy_bwd": ("i", "pppppp" + "ii" + "pppp" + "iiii" + "p"),
     "gdl_swin_patch_gather": ("i", "ipp" + "iiiii" + "p"),
     "gdl_swin_bias_act": ("i", "ipppp" + "zii" + "p"),
     "gdl_swin_ln_fwd": ("i", "ippppp" + "zii" + "p"),

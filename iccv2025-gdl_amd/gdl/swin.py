@@ -174,6 +174,7 @@ class SwinEngine:
         last = self.stages[-1]
         self.out_stats, self.out_ln = buf(last["M"], 2, torch.float32), buf(last["M"], last["ld"])
         self.feat = torch.empty((N, Cl), dtype=torch.float32, device=dev)
+        self.feat_b = torch.empty((B, Cl), dtype=torch.float32, device=dev)  # averaged over the T frames of a sample
         self.C_out, self.L_out = Cl, last["r"] * last["r"]
         self.names = names
         # scratch: LayerNorm / column-sum partials, attention table partials, gradient buffers
@@ -234,7 +235,9 @@ class SwinEngine:
         return flat[:rows * cols].view(rows, cols)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x):
+    def forward(self, x, pool_frames=False):
+        """-> float32 [B*T, C_last] (the reference's contract), or [B, C_last] averaged over the frames of a sample
+        (pool_frames: what basic_model.py:77-80 does for the ResNet branch -- the samples' frames are consecutive rows)."""
         if self._params is None:
             raise L.GdlError("SwinEngine.forward: parameters not set")
         cfg, dt, N, st = self.cfg, self.dt, self.N, L.cur_stream()
@@ -276,13 +279,16 @@ class SwinEngine:
         last = self.stages[-1]
         self.x_last = xcur
         self.out_norm.fwd(xcur, self.out_ln, self.out_stats, last["M"], st)
-        L.call("gdl_swin_token_mean", dt, L.ptr(self.out_ln), L.ptr(self.feat), N, self.L_out, self.C_out, last["ld"], st)
+        out = self.feat_b if pool_frames else self.feat
+        L.call("gdl_swin_token_mean", dt, L.ptr(self.out_ln), L.ptr(out), B if pool_frames else N,
+               self.L_out * (T if pool_frames else 1), self.C_out, last["ld"], st)
         self.have_fwd = True
-        return self.feat
+        return out
 
     # ------------------------------------------------------------------ backward
     def backward(self, dfeat, grads):
-        """dfeat float32 [B*T, C_last]; grads: float32 tensors of the parameter shapes (overwritten)."""
+        """dfeat float32 [B*T, C_last] (or [B, C_last] for a pool_frames forward); grads: float32 tensors of the
+        parameter shapes (overwritten)."""
         if not self.have_fwd:
             raise L.GdlError("SwinEngine.backward: no forward to differentiate")
         if len(grads) != len(self.names):
@@ -292,7 +298,11 @@ class SwinEngine:
         last = self.stages[-1]
         M, ld = last["M"], last["ld"]
         ga, gb = self._v(self.g_a, M, ld), self._v(self.g_b, M, ld)
-        L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), N, self.L_out, self.C_out, ld, st)
+        pooled = dfeat.shape[0] == self.B and self.T > 1
+        if tuple(dfeat.shape) != ((self.B if pooled else N), self.C_out) or dfeat.dtype != torch.float32 or not dfeat.is_contiguous():
+            raise L.GdlError("SwinEngine.backward: dfeat must be a contiguous float32 [B*T or B, C_last] tensor")
+        L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), self.B if pooled else N,
+               self.L_out * (self.T if pooled else 1), self.C_out, ld, st)
         self.out_norm.bwd(ga, self.x_last, self.out_stats, None, gb, M, st)
         self.out_norm.unpack(grads, st)
         dx, spare = gb, ga  # dx: gradient of the current stage's output tokens

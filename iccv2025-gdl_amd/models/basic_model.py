@@ -57,6 +57,40 @@ class AVClassifier_DGL(nn.Module):
         return out, a_out, v_out
 
 
+class AVClassifier_DGL_Swin(nn.Module):
+    """BASELINE config 5: DGL with a Swin visual branch.  NOT a class of the reference -- its `main_dgl.py:236-240`
+    refuses every backbone but `resnet`, and `models/basic_model.py:7` only imports `SwinTransformer` -- but
+    the composition SURVEY row N4 defines from the reference's own parts: the ResNet18 audio encoder and its pooling
+    (basic_model.py:65-75), `SwinTransformer` with Swin-T's settings on the frames (swin_transformer.py:486-674, pooled
+    [B*T, 768] features, averaged over the T frames of a sample as `adaptive_avg_pool3d` does for the ResNet branch,
+    basic_model.py:77-80), and `ConcatFusion_DGL` over the 512 + 768 features (fusion_modules.py:45-59; the width of
+    `ConcatFusion_Swin`, :79-88, with the audio branch at 512).  Returns (out, a_out, v_out) like `AVClassifier_DGL`."""
+
+    SWIN_T = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7, drop_path_rate=0.)
+
+    def __init__(self, args, swin_kwargs=None):
+        super(AVClassifier_DGL_Swin, self).__init__()
+        from .swin_transformer import SwinTransformer
+
+        if args.dataset not in N_CLASSES:
+            raise NotImplementedError('Incorrect dataset name {}'.format(args.dataset))
+        if args.fusion_method != 'concat':
+            raise NotImplementedError('gdl: the Swin composition is built with the concat DGL head only')
+        kw = dict(self.SWIN_T if swin_kwargs is None else swin_kwargs)
+        feat = kw["embed_dim"] * 2 ** (len(kw["depths"]) - 1)
+        self.fusion_module = ConcatFusion_DGL(input_dim=512 + feat, output_dim=N_CLASSES[args.dataset])
+        self.audio_net = resnet18(modality='audio', args=args)
+        self.visual_net = SwinTransformer(args, 'visual', **kw)
+        self.modality = 'full'
+        self.args = args
+
+    def forward(self, audio, visual):
+        a = self.audio_net.forward_pooled(audio)  # [B, 512]
+        v = self.visual_net.forward_pooled(visual)  # [B, 768]
+        a_out, v_out, out = self.fusion_module(a, v)
+        return out, a_out, v_out
+
+
 class AVClassifier(nn.Module):
     """BASELINE config 1: the non-DGL concat model of main.py.  The reference class of this name
     no longer exists in models/basic_model.py (main.py:19 cannot be imported); this

@@ -20,11 +20,16 @@ class _ConcatDGLFn(torch.autograd.Function):
     def forward(ctx, x, y, W, b):
         x, y, W, b = _f32c(x), _f32c(y), _f32c(W), _f32c(b)
         B, n = x.shape[0], W.shape[0]
-        if x.shape[1] != 512 or y.shape[1] != 512 or W.shape[1] != 1024:
-            raise RuntimeError("gdl: ConcatFusion_DGL expects 512-d audio and visual features and a 1024-wide fc_out")
+        if W.shape[1] != x.shape[1] + y.shape[1]:
+            raise RuntimeError("gdl: ConcatFusion_DGL: fc_out must be as wide as the two feature vectors together")
         out, x_out, y_out = (torch.empty((B, n), device=x.device) for _ in range(3))
-        L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B,
-               n, L.cur_stream())
+        ctx.xy = None if (x.shape[1] == 512 and y.shape[1] == 512) else (x.shape[1], y.shape[1])
+        if ctx.xy is None:
+            L.call("gdl_head_concat_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B,
+                   n, L.cur_stream())
+        else:  # unequal widths (the Swin composition, 512 + 768)
+            L.call("gdl_head_concat_xy_fwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(b), L.ptr(out), L.ptr(x_out), L.ptr(y_out), B,
+                   n, ctx.xy[0], ctx.xy[1], L.cur_stream())
         ctx.save_for_backward(x, y, W)
         # undefined upstream gradients stay None (not zero tensors): the reference's second backward,
         # loss_f.backward() (main_dgl.py:122), reaches this node through `output` only, which was computed from
@@ -45,8 +50,12 @@ class _ConcatDGLFn(torch.autograd.Function):
         dx, dy = (torch.empty_like(x), torch.empty_like(y)) if to_feat else (None, None)
         dW, db = torch.empty_like(W), torch.empty(n, device=x.device)
         # `output` was computed from cat(x, y).detach() (fusion_modules.py:53-56): it never reaches x / y
-        L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 1, L.ptr(dx),
-               L.ptr(dy), L.ptr(dW), L.ptr(db), B, n, L.cur_stream())
+        if ctx.xy is None:
+            L.call("gdl_head_concat_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 1, L.ptr(dx),
+                   L.ptr(dy), L.ptr(dW), L.ptr(db), B, n, L.cur_stream())
+        else:
+            L.call("gdl_head_concat_xy_bwd", L.ptr(x), L.ptr(y), L.ptr(W), L.ptr(gx), L.ptr(gy), L.ptr(go), 0, 1, L.ptr(dx),
+                   L.ptr(dy), L.ptr(dW), L.ptr(db), B, n, ctx.xy[0], ctx.xy[1], L.cur_stream())
         return dx, dy, dW, db
 
 

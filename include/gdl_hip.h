@@ -229,6 +229,13 @@ GDL_API int gdl_head_concat_fwd(const float* x, const float* y, const float* W, 
 GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out,
                                 const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
                                 float* dy, float* dW, float* db, int B, int n_classes, void* stream);
+/* The same head with unequal feature widths, W [n][x_dim + y_dim] (512 audio + 768 Swin features; the reference's
+ * ConcatFusion_Swin, fusion_modules.py:79-88, in its DGL form :45-59): same contract as the two calls above. */
+GDL_API int gdl_head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out,
+                                   float* y_out, int B, int n_classes, int x_dim, int y_dim, void* stream);
+GDL_API int gdl_head_concat_xy_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,
+                                   const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW,
+                                   float* db, int B, int n_classes, int x_dim, int y_dim, void* stream);
 /* FiLM_DGL (fusion_modules.py:126-178; SURVEY next row N2): fc: Linear(512*512, 512) -- a 134 M-parameter bilinear
  * form per output, h[b][k] = u_b^T W_k v_b + bias_k -- and fc_out: Linear(512, n):
  *   out = fc_out(fc(x.detach() (x) y.detach())),  x_out = fc_out(fc(x (x) x)),  y_out = fc_out(fc(y (x) y)).

@@ -211,3 +211,14 @@ def swin_param_shapes(cfg, prefix=""):
 def swin_input(cfg, batch, frames, seed=0):
     """[B, 3, T, img, img] float32 frames (the 'visual' modality layout, swin_transformer.py:598-601)."""
     return np.random.default_rng([4321, seed]).standard_normal((batch, 3, frames, cfg["img"], cfg["img"]), dtype=np.float32)
+
+
+def swin_dgl_state(n_classes, cfg):
+    """Parameters and buffers of the Swin composition (ResNet18 audio + Swin visual + ConcatFusion_DGL over 512 + C):
+    ({name: array}, {name: array}) in named_parameters() / buffer order."""
+    feat = cfg["embed"] << (len(cfg["depths"]) - 1)
+    sh = {"fusion_module.fc_out.weight": (n_classes, 512 + feat), "fusion_module.fc_out.bias": (n_classes,),
+          "fusion_module.fc_auxi.weight": (n_classes, 512 + feat), "fusion_module.fc_auxi.bias": (n_classes,)}
+    sh.update(resnet18_param_shapes("audio_net.", 1))
+    sh.update(swin_param_shapes(cfg, "visual_net."))
+    return make_state(sh), make_state(resnet18_buffer_shapes("audio_net."))

@@ -94,17 +94,51 @@ class _ConcatAV(nn.Module):
         return out, a, v
 
 
+class _SwinDGL(nn.Module):
+    """BASELINE config 5 (a composition the reference never instantiates) from the reference's own parts:
+    imported `resnet18('audio')` + pooling of basic_model.py:73-75, imported `SwinTransformer` (pooled [B*T, C] features,
+    averaged over the T frames of a sample like basic_model.py:77-80 does for the ResNet branch) and imported
+    `ConcatFusion_DGL` at input_dim = 512 + C."""
+
+    def __init__(self, bb, fm, n_classes, cfg):
+        super().__init__()
+        import models.swin_transformer as sw
+
+        feat = cfg["embed"] << (len(cfg["depths"]) - 1)
+        self.fusion_module = fm.ConcatFusion_DGL(input_dim=512 + feat, output_dim=n_classes)
+        self.audio_net = bb.resnet18(modality="audio", args=None)
+        self.visual_net = sw.SwinTransformer(argparse.Namespace(pe=0), "visual", img_size=cfg["img"], patch_size=cfg["patch"],
+                                             in_chans=3, embed_dim=cfg["embed"], depths=list(cfg["depths"]),
+                                             num_heads=list(cfg["heads"]), window_size=cfg["window"],
+                                             mlp_ratio=float(cfg["mlp"]), drop_path_rate=0.0)
+
+    def forward(self, audio, visual):
+        import torch.nn.functional as F
+
+        a = torch.flatten(F.adaptive_avg_pool2d(self.audio_net(audio), 1), 1)
+        B, T = visual.shape[0], visual.shape[2]
+        v = self.visual_net(visual).view(B, T, -1).mean(1)
+        a_out, v_out, out = self.fusion_module(a, v)
+        return out, a_out, v_out
+
+
 def _summ(t):
     a = t.detach().double().flatten()
     return np.array([a.sum().item(), a.abs().sum().item()], dtype=np.float64)
 
 
 def run_step_case(name, bm, bb, fm, dataset, spec_hw, frames, image_hw, batch, alpha, steps, mode="dgl", seed=0,
-                  lr=2e-3, fusion="concat"):
+                  lr=2e-3, fusion="concat", swin_cfg=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     n_classes = fx.N_CLASSES[dataset]
-    if mode == "dgl":
+    if swin_cfg is not None:
+        model = _SwinDGL(bb, fm, n_classes, swin_cfg)
+        ps, bs = fx.swin_dgl_state(n_classes, swin_cfg)
+        assert [n for n, _ in model.named_parameters()] == list(ps)
+        res = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in {**ps, **bs}.items()}, strict=False)
+        assert not res.unexpected_keys and all("relative_position_index" in k or "attn_mask" in k for k in res.missing_keys)
+    elif mode == "dgl":
         args = argparse.Namespace(fusion_method=fusion, dataset=dataset, modality="full", batch_size=batch)
         model = bm.AVClassifier_DGL(args)
         _load(model, n_classes, fusion + "_dgl")
@@ -120,6 +154,8 @@ def run_step_case(name, bm, bb, fm, dataset, spec_hw, frames, image_hw, batch, a
     cfg = dict(name=name, dataset=dataset, n_classes=n_classes, spec_hw=list(spec_hw), frames=frames,
                image_hw=list(image_hw), batch=batch, alpha=alpha, steps=steps, mode=mode, seed=seed, lr=lr,
                momentum=0.9, weight_decay=1e-4, max_norm=40.0, torch=torch.__version__, fusion=fusion)
+    if swin_cfg is not None:
+        cfg["swin"] = dict(swin_cfg)
     out_d["config"] = np.array(json.dumps(cfg))
     model.train()
     for st in range(steps):
@@ -486,6 +522,8 @@ def main():
         "head_gated_dgl_c6": lambda: run_gated_head_case("head_gated_dgl_c6", fm, 6),
         "dgl_gated_tiny_b4": lambda: run_step_case("dgl_gated_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (64, 64), 4, 4.0, 2,
                                                    fusion="gated"),
+        "dgl_swin_tiny_b4": lambda: run_step_case("dgl_swin_tiny_b4", bm, bb, fm, "CREMAD", (65, 47), 2, (56, 56), 4, 4.0, 2,
+                                                  swin_cfg=fx.SWIN_TINY2),
         "swin_tiny2_b2": lambda: run_swin_case("swin_tiny2_b2", fx.SWIN_TINY2, 2, 2),
         "swin_t_b1": lambda: run_swin_case("swin_t_b1", fx.SWIN_T, 1, 2),
         "concat_cremad_b2": lambda: run_step_case("concat_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224),

@@ -59,8 +59,9 @@ def test_swin_engine_golden(golden_dir, name, cfg_name, dtype):
     print(f"swin {name} {dtype}: features {ey:.2e}, worst gradient {worst:.2e} ({worst_k})")
     # f32: exact-f32 MFMA + fp32 elementwise against the fp32 reference; bf16: storage rounding through 4 / 24 LayerNorm'd
     # residual blocks (element-wise relative error of whole tensors, as for the ResNet encoders)
-    assert ey < (2e-5 if f32 else 3e-2), ey
-    assert worst < (2e-4 if f32 else 8e-2), (worst_k, worst)
+    # measured: f32 4e-7 / 2.7e-6, bf16 6.7e-3 / 2.4e-2 (Swin-T, 224 x 224), both worst on a relative-position bias table
+    assert ey < (5e-6 if f32 else 2e-2), ey
+    assert worst < (3e-5 if f32 else 6e-2), (worst_k, worst)
 
 
 def test_swin_engine_deterministic_and_rebindable():
@@ -73,3 +74,44 @@ def test_swin_engine_deterministic_and_rebindable():
         np.testing.assert_array_equal(g1[k], g2[k], err_msg=k)
     with pytest.raises(L.GdlError):
         eng.set_params([torch.zeros(1, device=DEV)])
+
+
+def test_swin_dgl_dropin_step_golden(golden_dir):
+    """BASELINE config 5's composition (ResNet18 audio + Swin visual + ConcatFusion_DGL over 512 + C) -- built in the golden
+    generator from the reference's own classes -- with the reference's step body (main_dgl.py:97-154) run unchanged on the
+    drop-in modules: forward, three CE losses, two-phase backward with the head-gradient drop, clip, SGD."""
+    import argparse
+
+    import torch.nn as nn
+    from models.basic_model import AVClassifier_DGL_Swin
+    from test_step_gpu import _batch, _dropin_checks
+
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+    sc = cfg["swin"]
+    args = argparse.Namespace(fusion_method="concat", dataset=cfg["dataset"], modality="full", batch_size=cfg["batch"], pe=0)
+    model = AVClassifier_DGL_Swin(args, swin_kwargs=dict(img_size=sc["img"], patch_size=sc["patch"], embed_dim=sc["embed"],
+                                                         depths=list(sc["depths"]), num_heads=list(sc["heads"]),
+                                                         window_size=sc["window"], mlp_ratio=float(sc["mlp"]),
+                                                         drop_path_rate=0.))
+    P, Bf = fx.swin_dgl_state(cfg["n_classes"], sc)
+    assert [n for n, _ in model.named_parameters()] == list(P)
+    res = model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in {**P, **Bf}.items()}, strict=False)
+    assert not res.unexpected_keys and all("relative_position_index" in k or "attn_mask" in k for k in res.missing_keys)
+    model = model.to(DEV)
+    model.audio_net.gdl_dtype = model.visual_net.gdl_dtype = "f32"
+    model = nn.DataParallel(model, device_ids=[0])  # main_dgl.py:244
+    optimizer = torch.optim.SGD(model.parameters(), lr=cfg["lr"], momentum=0.9, weight_decay=1e-4)
+    criterion = nn.CrossEntropyLoss()
+    model.train()
+    spec, image, label = _batch(cfg, 0)
+    optimizer.zero_grad()
+    out, out_a, out_v = model(spec.unsqueeze(1).float(), image.float())
+    loss_v, loss_a, loss_f = criterion(out_v, label), criterion(out_a, label), criterion(out, label)
+    ((loss_a + loss_v) * cfg["alpha"]).backward(retain_graph=True)
+    for nme, parms in model.named_parameters():
+        if 'fusion' in str(nme).split('.')[1]:
+            parms.grad = None
+    loss_f.backward()
+    np.testing.assert_allclose(out_v.detach().cpu().numpy(), g["s0.out_v"], rtol=5e-4, atol=5e-4)
+    _dropin_checks(model, optimizer, g, cfg, out, loss_f, loss_a)
