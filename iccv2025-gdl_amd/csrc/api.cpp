@@ -375,7 +375,9 @@ int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out,
     GDL_REQUIRE(dt_ok(dtype) && qkv && table && out, "swin_attn_fwd: bad arguments");
     return swin_attn_fwd(dtype, qkv, table, out, n_img, H, W, window, shift, heads, ld, (hipStream_t)stream);
 }
-size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int window, int heads) { return swin_attn_bwd_ws_bytes(n_img, window, heads); }
+size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int H, int W, int window, int heads) {
+    return window > 0 ? swin_attn_bwd_ws_bytes(n_img, (H / window) * (W / window), window, heads) : 0;
+}
 int gdl_swin_attn_bwd(int dtype, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, void* ws, int n_img,
                       int H, int W, int window, int shift, int heads, int ld, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && qkv && table && dout && dqkv, "swin_attn_bwd: bad arguments");

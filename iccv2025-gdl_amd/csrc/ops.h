@@ -164,7 +164,7 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
 int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st);
 int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_img, int H, int W, int ws, int shift, int nh, int ld,
                   hipStream_t st);
-size_t swin_attn_bwd_ws_bytes(int n_img, int ws, int nh);
+size_t swin_attn_bwd_ws_bytes(int n_img, int nwin, int ws, int nh);
 int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* tpart, int n_img,
                   int H, int W, int ws, int shift, int nh, int ld, hipStream_t st);
 int swin_merge(int dt, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, hipStream_t st);

@@ -322,62 +322,103 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict_
         for (int c = g.nh * SW_HD; c < g.ld; ++c) storeT(out + row * g.ld + c, 0.f);
 }
 
-// backward: one wave (block of 64) per (image, head), looping over the image's windows.  Recomputes P; writes dq, dk, dv
-// into dqkv (same layout as qkv) and the (image, head) partial of d(table): tpart[(n*nh + h)*tw*tw + r].
+// 32 consecutive channels of a token row -> LDS row (float)
+template <typename T>
+__device__ __forceinline__ void sw_row_to_lds(const T* __restrict__ src, float* dst) {
+    constexpr int EPC = TT<T>::EPC;
+#pragma unroll
+    for (int v = 0; v < SW_HD / EPC; ++v) {
+        float f[EPC];
+        unpack16<T>(((const uint4*)src)[v], f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dst[v * EPC + e] = f[e];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void sw_row_store(T* dst, const float* f, float mul) {
+    constexpr int EPC = TT<T>::EPC;
+#pragma unroll
+    for (int v = 0; v < SW_HD / EPC; ++v) {
+        float t[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) t[e] = f[v * EPC + e] * mul;
+        ((uint4*)dst)[v] = pack16<T>(t);
+    }
+}
+
+// backward: one wave (block of 64) per (image, group of G windows, head).  Two passes per window, nothing of size T x T in
+// LDS but the accumulated d(bias): pass 1, lane = query i: the probabilities of row i are recomputed in registers, dP_ij =
+// dO_i . V_j, pd_i = sum_j P_ij dP_ij, dQ_i; the row's softmax statistics and pd_i go to LDS.  Pass 2, lane = key j:
+// column j is recomputed from the statistics -- P_ij, dS_ij -- giving dV_j, dK_j, and dS_ij is added to the block's
+// [T][T] accumulator (column j is this lane's).  At the end the accumulator is folded into the (2ws-1)^2 entries of the
+// block's partial of d(table): tpart[block][r].
 template <typename T>
 __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
                                                            const T* __restrict__ dout, T* __restrict__ dqkv,
-                                                           float* __restrict__ tpart, SwinAttnGeom g) {
+                                                           float* __restrict__ tpart, SwinAttnGeom g, int G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
     constexpr int PD = SW_HD + 1, PT = SW_MAXT + 1;
-    float(*Qs)[PD] = (float(*)[PD])sw_smem;
+    float(*Qs)[PD] = (float(*)[PD])sw_smem;  // scaled queries
     float(*Ks)[PD] = Qs + SW_MAXT;
     float(*Vs)[PD] = Ks + SW_MAXT;
-    float(*Os)[PD] = Vs + SW_MAXT;
-    float(*Ps)[PT] = (float(*)[PT])(Os + SW_MAXT);
-    float(*Ds)[PT] = Ps + SW_MAXT;
-    float(*Da)[PT] = Ds + SW_MAXT;
-    int* regs = (int*)(Da + SW_MAXT);
+    float(*Os)[PD] = Vs + SW_MAXT;  // d(out)
+    float(*Da)[PT] = (float(*)[PT])(Os + SW_MAXT);
+    float* rmax = (float*)(Da + SW_MAXT);
+    float* rinv = rmax + SW_MAXT;
+    float* rpd = rinv + SW_MAXT;
+    float* tab = rpd + SW_MAXT;  // this head's column of the bias table, (2ws-1)^2 entries
+    int* regs = (int*)(tab + (2 * 7 - 1) * (2 * 7 - 1));
     const int lane = threadIdx.x;
     const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
-    const int h = blockIdx.x % g.nh, n = blockIdx.x / g.nh;
+    const int ngrp = (g.nwin + G - 1) / G;
+    const int h = blockIdx.x % g.nh, grp = (blockIdx.x / g.nh) % ngrp, n = blockIdx.x / (g.nh * ngrp);
     const float scale = 0.17677669529663687f;
     const bool act = lane < Tn;
     const int ri = lane / g.ws, ci = lane % g.ws;
+    for (int r = lane; r < tw * tw; r += 64) tab[r] = table[r * g.nh + h];
     if (act)
-        for (int j = 0; j < Tn; ++j) Da[lane][j] = 0.f;
-    for (int w = 0; w < g.nwin; ++w) {
+        for (int j = 0; j < Tn; ++j) Da[j][lane] = 0.f;
+    for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
         int reg = 0;
         const int tok = act ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : 0;
         const size_t row = (size_t)n * L + tok;
-        __syncthreads();
+        __syncthreads();  // (everybody is done with the previous window's rows)
         if (act) {
             const T* base = qkv + row * 3 * g.ld + h * SW_HD;
-            const T* db = dout + row * g.ld + h * SW_HD;
+            sw_row_to_lds<T>(base, Qs[lane]);
+            sw_row_to_lds<T>(base + g.ld, Ks[lane]);
+            sw_row_to_lds<T>(base + 2 * g.ld, Vs[lane]);
+            sw_row_to_lds<T>(dout + row * g.ld + h * SW_HD, Os[lane]);
 #pragma unroll
-            for (int d = 0; d < SW_HD; ++d) {
-                Qs[lane][d] = loadT(base + d) * scale;
-                Ks[lane][d] = loadT(base + g.ld + d);
-                Vs[lane][d] = loadT(base + 2 * g.ld + d);
-                Os[lane][d] = loadT(db + d);
-            }
+            for (int d = 0; d < SW_HD; ++d) Qs[lane][d] *= scale;
             regs[lane] = reg;
         }
         __syncthreads();
-        if (act) {
-            float s[SW_MAXT];
+        if (act) {  // ---- pass 1: lane = query i
+            float q[SW_HD], go[SW_HD];
+#pragma unroll
+            for (int d = 0; d < SW_HD; ++d) {
+                q[d] = Qs[lane][d];
+                go[d] = Os[lane][d];
+            }
+            float s[SW_MAXT], dp[SW_MAXT];
             float mx = -3.0e38f;
+            int rj = 0, cj = 0;
 #pragma unroll
             for (int j = 0; j < SW_MAXT; ++j)
                 if (j < Tn) {
-                    float a = 0.f;
+                    float a = 0.f, b = 0.f;
 #pragma unroll
-                    for (int d = 0; d < SW_HD; ++d) a += Qs[lane][d] * Ks[j][d];
-                    const int rj = j / g.ws, cj = j % g.ws;
-                    a += table[((ri - rj + g.ws - 1) * tw + (ci - cj + g.ws - 1)) * g.nh + h];
+                    for (int d = 0; d < SW_HD; ++d) {
+                        a += q[d] * Ks[j][d];
+                        b += go[d] * Vs[j][d];
+                    }
+                    a += tab[(ri - rj + g.ws - 1) * tw + (ci - cj + g.ws - 1)];
                     if (g.shift && regs[j] != reg) a -= 100.f;
                     s[j] = a;
+                    dp[j] = b;
                     mx = fmaxf(mx, a);
+                    if (++cj == g.ws) cj = 0, ++rj;
                 }
             float den = 0.f;
 #pragma unroll
@@ -388,60 +429,63 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
                 }
             const float inv = 1.f / den;
             float pd = 0.f;
-            float dp[SW_MAXT];
 #pragma unroll
             for (int j = 0; j < SW_MAXT; ++j)
-                if (j < Tn) {
-                    s[j] *= inv;
-                    float a = 0.f;
-#pragma unroll
-                    for (int d = 0; d < SW_HD; ++d) a += Os[lane][d] * Vs[j][d];
-                    dp[j] = a;
-                    pd += s[j] * a;
-                }
+                if (j < Tn) pd += s[j] * inv * dp[j];
             float dq[SW_HD];
 #pragma unroll
             for (int d = 0; d < SW_HD; ++d) dq[d] = 0.f;
 #pragma unroll
             for (int j = 0; j < SW_MAXT; ++j)
                 if (j < Tn) {
-                    const float ds = s[j] * (dp[j] - pd);
-                    Ps[lane][j] = s[j];
-                    Ds[lane][j] = ds;
-                    Da[lane][j] += ds;
+                    const float ds = s[j] * inv * (dp[j] - pd);
 #pragma unroll
                     for (int d = 0; d < SW_HD; ++d) dq[d] += ds * Ks[j][d];
                 }
-            T* ob = dqkv + row * 3 * g.ld + h * SW_HD;
-#pragma unroll
-            for (int d = 0; d < SW_HD; ++d) storeT(ob + d, dq[d] * scale);
+            rmax[lane] = mx;
+            rinv[lane] = inv;
+            rpd[lane] = pd;
+            sw_row_store<T>(dqkv + row * 3 * g.ld + h * SW_HD, dq, scale);
         }
         __syncthreads();
-        if (act) {  // lane = key / value index j: column sums over the queries i (ascending)
-            float dk[SW_HD], dv[SW_HD];
+        if (act) {  // ---- pass 2: lane = key / value j; queries i ascending
+            float k[SW_HD], v[SW_HD], dk[SW_HD], dv[SW_HD];
 #pragma unroll
-            for (int d = 0; d < SW_HD; ++d) dk[d] = dv[d] = 0.f;
+            for (int d = 0; d < SW_HD; ++d) {
+                k[d] = Ks[lane][d];
+                v[d] = Vs[lane][d];
+                dk[d] = dv[d] = 0.f;
+            }
+            int rq = 0, cq = 0;
             for (int i = 0; i < Tn; ++i) {
-                const float p = Ps[i][lane], ds = Ds[i][lane];
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int d = 0; d < SW_HD; ++d) {
+                    a += Qs[i][d] * k[d];
+                    b += Os[i][d] * v[d];
+                }
+                a += tab[(rq - ri + g.ws - 1) * tw + (cq - ci + g.ws - 1)];
+                if (g.shift && regs[i] != reg) a -= 100.f;
+                const float p = __expf(a - rmax[i]) * rinv[i];
+                const float ds = p * (b - rpd[i]);
+                Da[i][lane] += ds;
 #pragma unroll
                 for (int d = 0; d < SW_HD; ++d) {
                     dv[d] += p * Os[i][d];
-                    dk[d] += ds * Qs[i][d];  // Qs already carries the scale
+                    dk[d] += ds * Qs[i][d];  // Qs carries the scale
                 }
+                if (++cq == g.ws) cq = 0, ++rq;
             }
             T* ob = dqkv + row * 3 * g.ld + h * SW_HD;
-#pragma unroll
-            for (int d = 0; d < SW_HD; ++d) {
-                storeT(ob + g.ld + d, dk[d]);
-                storeT(ob + 2 * g.ld + d, dv[d]);
-            }
+            sw_row_store<T>(ob + g.ld, dk, 1.f);
+            sw_row_store<T>(ob + 2 * g.ld, dv, 1.f);
             if (h == 0)  // padding columns of the three segments stay zero
                 for (int sgm = 0; sgm < 3; ++sgm)
                     for (int c = g.nh * SW_HD; c < g.ld; ++c) storeT(dqkv + row * 3 * g.ld + sgm * g.ld + c, 0.f);
         }
     }
     __syncthreads();
-    // d(table)[r] of this (image, head): the pairs (i, j) with i - j = (dh, dw), j ascending
+    // d(table)[r] of this block: the pairs (i, j) with i - j = (dh, dw), j ascending
     float* tp = tpart + (size_t)blockIdx.x * tw * tw;
     for (int r = lane; r < tw * tw; r += 64) {
         const int dh = r / tw - (g.ws - 1), dw = r % tw - (g.ws - 1);
@@ -459,15 +503,17 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
     }
 }
 
-// dtable[r][h] = sum_n tpart[n][h][r]
+// dtable[r][h] = sum_u tpart[u][h][r], u = (image, window group) ascending: one wave per entry, 64 partial sums in
+// lane order + a fixed butterfly
 __global__ __launch_bounds__(256) void swin_table_reduce_kernel(const float* __restrict__ tpart, float* __restrict__ dtable,
-                                                                int n_img, int nh, int tt) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                                int nu, int nh, int tt) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= nh * tt) return;
     const int h = i / tt, r = i % tt;
     float s = 0.f;
-    for (int n = 0; n < n_img; ++n) s += tpart[((size_t)n * nh + h) * tt + r];
-    dtable[r * nh + h] = s;
+    for (int u = lane; u < nu; u += 64) s += tpart[((size_t)u * nh + h) * tt + r];
+    s = wave_sum(s);
+    if (lane == 0) dtable[r * nh + h] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ patch merging
@@ -667,14 +713,20 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
     GDL_CHECK_LAUNCH("swin_attn_fwd_kernel");
     return GDL_OK;
 }
-size_t swin_attn_bwd_ws_bytes(int n_img, int ws, int nh) { return (size_t)n_img * nh * (2 * ws - 1) * (2 * ws - 1) * sizeof(float); }
+// windows per block of the backward: enough blocks to fill the chip, few enough partials
+static int attn_bwd_group(int nwin) { return nwin >= 64 ? 4 : 1; }
+size_t swin_attn_bwd_ws_bytes(int n_img, int nwin, int ws, int nh) {
+    const int G = attn_bwd_group(nwin);
+    return (size_t)n_img * ((nwin + G - 1) / G) * nh * (2 * ws - 1) * (2 * ws - 1) * sizeof(float);
+}
 int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* tpart, int n_img,
                   int H, int W, int ws, int shift, int nh, int ld, hipStream_t st) {
     SwinAttnGeom g;
     int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
     if (rc) return rc;
     GDL_REQUIRE(tpart && dtable, "swin_attn_bwd: null workspace");
-    const size_t lds = (size_t)4 * SW_MAXT * (SW_HD + 1) * 4 + (size_t)3 * SW_MAXT * (SW_MAXT + 1) * 4 + SW_MAXT * 4;
+    const size_t lds = (size_t)4 * SW_MAXT * (SW_HD + 1) * 4 + (size_t)SW_MAXT * (SW_MAXT + 1) * 4 + 3 * SW_MAXT * 4 + 169 * 4 + SW_MAXT * 4;
+    const int G = attn_bwd_group(g.nwin), ngrp = (g.nwin + G - 1) / G;
     static bool attr[2] = {false, false};
     const int di = dt == GDL_F32 ? 0 : 1;
     if (!attr[di]) {
@@ -685,12 +737,12 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
     }
     {
         ProfScope prof("gdl::swin_attn_bwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 7);
-        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_bwd_kernel<float>, dim3(n_img * nh), dim3(64), lds, st, (const float*)qkv, table, (const float*)dout, (float*)dqkv, tpart, g),
-                    hipLaunchKernelGGL(swin_attn_bwd_kernel<bf16>, dim3(n_img * nh), dim3(64), lds, st, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, tpart, g));
+        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_bwd_kernel<float>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const float*)qkv, table, (const float*)dout, (float*)dqkv, tpart, g, G),
+                    hipLaunchKernelGGL(swin_attn_bwd_kernel<bf16>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, tpart, g, G));
         GDL_CHECK_LAUNCH("swin_attn_bwd_kernel");
     }
     const int tt = (2 * ws - 1) * (2 * ws - 1);
-    hipLaunchKernelGGL(swin_table_reduce_kernel, dim3((nh * tt + 255) / 256), dim3(256), 0, st, tpart, dtable, n_img, nh, tt);
+    hipLaunchKernelGGL(swin_table_reduce_kernel, dim3((nh * tt + 3) / 4), dim3(256), 0, st, tpart, dtable, n_img * ngrp, nh, tt);
     GDL_CHECK_LAUNCH("swin_table_reduce_kernel");
     return GDL_OK;
 }

@@ -39,7 +39,7 @@ SIGNATURES = {
     "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),
     "gdl_swin_colsum": ("i", "ipppp" + "zi" + "p"),
     "gdl_swin_attn_fwd": ("i", "ippp" + "iiiiiii" + "p"),
-    "gdl_swin_attn_bwd_workspace_bytes": ("z", "iii"),
+    "gdl_swin_attn_bwd_workspace_bytes": ("z", "iiiii"),
     "gdl_swin_attn_bwd": ("i", "ipppppp" + "iiiiiii" + "p"),
     "gdl_swin_merge": ("i", "ipp" + "iiiiii" + "p"),
     "gdl_swin_token_mean": ("i", "ipp" + "iiii" + "p"),

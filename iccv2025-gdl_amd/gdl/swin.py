@@ -168,7 +168,7 @@ class SwinEngine:
                 st["merged"] = buf(M // 4, _ld(2 * C))
                 maxld = max(maxld, 4 * C)
             self.stages.append(st)
-            maxw = max(maxw, N * nh * (2 * ws - 1) ** 2)
+            maxw = max(maxw, self.lib.gdl_swin_attn_bwd_workspace_bytes(N, r, r, ws, nh))
         Cl = E << (nl - 1)
         self.out_norm = _Norm(self, reg("norm.weight", (Cl,)), reg("norm.bias", (Cl,)), Cl)
         last = self.stages[-1]
@@ -179,7 +179,7 @@ class SwinEngine:
         self.names = names
         # scratch: LayerNorm / column-sum partials, attention table partials, gradient buffers
         self.partial = torch.empty(self.lib.gdl_swin_partial_bytes(maxld), dtype=torch.uint8, device=dev)
-        self.tpart = torch.empty(max(maxw, 1), dtype=torch.float32, device=dev)
+        self.tpart = torch.empty(max(maxw, 4), dtype=torch.uint8, device=dev)
         M1, ld1 = self.stages[0]["M"], self.stages[0]["ld"]
         wide = max(max(3 * s["ld"], _ld(s["hid"])) * s["M"] for s in self.stages)
         self.g_a = torch.empty(M1 * ld1, dtype=td, device=dev)   # gradient of the residual stream (ping)
@@ -235,7 +235,7 @@ class SwinEngine:
         return flat[:rows * cols].view(rows, cols)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, pool_frames=False):
+    def forward(self, x, pool_frames=False, out=None):
         """-> float32 [B*T, C_last] (the reference's contract), or [B, C_last] averaged over the frames of a sample
         (pool_frames: what basic_model.py:77-80 does for the ResNet branch -- the samples' frames are consecutive rows)."""
         if self._params is None:
@@ -279,7 +279,10 @@ class SwinEngine:
         last = self.stages[-1]
         self.x_last = xcur
         self.out_norm.fwd(xcur, self.out_ln, self.out_stats, last["M"], st)
-        out = self.feat_b if pool_frames else self.feat
+        if out is None:
+            out = self.feat_b if pool_frames else self.feat
+        elif tuple(out.shape) != ((B if pool_frames else N), self.C_out) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise L.GdlError("SwinEngine.forward: `out` must be a contiguous float32 [B*T or B, C_last] tensor")
         L.call("gdl_swin_token_mean", dt, L.ptr(self.out_ln), L.ptr(out), B if pool_frames else N,
                self.L_out * (T if pool_frames else 1), self.C_out, last["ld"], st)
         self.have_fwd = True

@@ -25,6 +25,28 @@ from . import _lib as L
 from .encoder import EncoderEngine
 
 
+class _SwinAdapter:
+    """gdl.swin.SwinEngine behind the EncoderEngine calls the trainer makes (features averaged over the T frames of a
+    sample; no BatchNorm state, no phases: phase 1 is the whole backward, phase 2 nothing)."""
+
+    def __init__(self, cfg, dtype, B, T, device):
+        from .swin import SwinEngine
+
+        self.eng = SwinEngine(cfg, dtype, B, T, device)
+
+    def set_params(self, params):
+        self.eng.set_params(params)
+
+    def forward(self, x, training, feat_out=None):
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            raise L.GdlError("DGLTrainer: frames must be a contiguous float32 [B, 3, T, H, W] tensor")
+        return self.eng.forward(x, pool_frames=True, out=feat_out)
+
+    def backward(self, grads, dfeat=None, phase=0):
+        if phase != 2:
+            self.eng.backward(dfeat, list(grads))
+
+
 class DGLTrainer:
     def __init__(self, model, lr, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, mode="dgl", dtype=None,
                  process_group=None):
@@ -65,6 +87,15 @@ class DGLTrainer:
         nf = self.nf = len(named)
         named += [("audio_net." + n, p) for n, p in model.audio_net.named_parameters()]
         named += [("visual_net." + n, p) for n, p in model.visual_net.named_parameters()]
+        # the visual branch: ResNet18 (60 tensors, 512 features) or the Swin composition of SURVEY row N4
+        # (models.basic_model.AVClassifier_DGL_Swin: gdl.swin.SwinEngine, num_features wide)
+        self.vis_swin = hasattr(model.visual_net, "cfg") and hasattr(model.visual_net, "num_features")
+        self.nv = len(named) - nf - 60
+        self.dv = int(model.visual_net.num_features) if self.vis_swin else 512
+        if self.vis_swin and (self.head != "concat" or mode != "dgl"):
+            raise L.GdlError("DGLTrainer: the Swin visual branch is built for the concat DGL head")
+        if not self.vis_swin and self.nv != 60:
+            raise L.GdlError("DGLTrainer: visual_net must be the ResNet18 mirror or the SwinTransformer mirror")
         self.names = [n for n, _ in named]
         offs, o = [0], 0
         for _, p in named:
@@ -72,7 +103,7 @@ class DGLTrainer:
             offs.append(o)
         self.offsets = offs
         self.total = o
-        group = [0] * nf + [1] * 60 + [2] * 60
+        group = [0] * nf + [1] * 60 + [2] * self.nv
         self.params = torch.empty(o, device=self.device)
         self.grads = torch.zeros(o, device=self.device)
         self.momentum = torch.zeros(o, device=self.device)
@@ -87,9 +118,13 @@ class DGLTrainer:
         # of its 11.2 M parameters, is final right after the first two blocks of the backward: its own bucket lets
         # three quarters of the exchange overlap the rest of the backward.
         a0, v0 = nf, nf + 60
+        # (Swin: the last stage + final norm -- the tensors whose gradients the backward finishes first -- play layer4's
+        # part; its engine has no phases yet, so both visual buckets are launched behind the whole backward)
+        vsplit = v0 + 45 if not self.vis_swin else \
+            v0 + next(i for i, (n, _) in enumerate(named[v0:]) if n.startswith("visual_net.layers.%d." % (model.visual_net.num_layers - 1)))
         self.bucket = {"fusion": (0, offs[nf]),
                        "audio_l4": (offs[a0 + 45], offs[a0 + 60]), "audio_rest": (offs[a0], offs[a0 + 45]),
-                       "visual_l4": (offs[v0 + 45], offs[v0 + 60]), "visual_rest": (offs[v0], offs[v0 + 45])}
+                       "visual_l4": (offs[vsplit], offs[v0 + self.nv]), "visual_rest": (offs[v0], offs[vsplit])}
         self.reducer = None
         self.world = 1
         if process_group is not None:
@@ -165,18 +200,24 @@ class DGLTrainer:
             return
         self._key = key
         self.eng_a = EncoderEngine("audio", self.dtype, B, 1, F_, T_, self.device)
-        self.eng_v = EncoderEngine("visual", self.dtype, B, T, H, W, self.device)
+        if self.vis_swin:
+            cfg = self.model.visual_net.cfg
+            if H != cfg["img"] or W != cfg["img"]:
+                raise L.GdlError(f"DGLTrainer.step: the Swin branch was built for {cfg['img']} x {cfg['img']} frames")
+            self.eng_v = _SwinAdapter(cfg, self.dtype, B, T, self.device)
+        else:
+            self.eng_v = EncoderEngine("visual", self.dtype, B, T, H, W, self.device)
         # A fourth stream for the visual (critical-path) encoder's weight gradients -- but never a fifth:
         # with a process group the collective's stream is the fourth (see gdl_encoder_side_stream).
         # (tuning aid, honoured only with GDL_TUNING=1: GDL_SIDE_STREAM 0 = off, 1 = both engines)
         side = os.environ.get("GDL_SIDE_STREAM") if os.environ.get("GDL_TUNING") == "1" else None
         if side == "1":
             self.eng_a.side_stream(True)
-        if side == "1" or (side is None and self.reducer is None):
+        if (side == "1" or (side is None and self.reducer is None)) and not self.vis_swin:
             self.eng_v.side_stream(True)
         n, d = self.n_classes, self.device
-        self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
-        self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, 512), device=d)
+        self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
+        self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
         if self.head == "film":
             if B > 64:
                 raise L.GdlError("DGLTrainer: the FiLM head handles at most 64 samples per step")
@@ -191,7 +232,9 @@ class DGLTrainer:
 
     def _bind(self):
         m = self.model
-        for eng, net in ((self.eng_a, m.audio_net), (self.eng_v, m.visual_net)):
+        if self.vis_swin:
+            self.eng_v.set_params([p.data for p in m.visual_net.parameters()])
+        for eng, net in ((self.eng_a, m.audio_net),) + (() if self.vis_swin else ((self.eng_v, m.visual_net),)):
             bns = net._bn_layers()
             eng.set_params([p.data for p in net.parameters()], [b.running_mean for b in bns],
                            [b.running_var for b in bns], [b.num_batches_tracked for b in bns])
@@ -265,6 +308,10 @@ class DGLTrainer:
                 L.call("gdl_head_sum_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[2]), L.ptr(self.g_a),
                        L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(gv[0]), L.ptr(gv[1]),
                        L.ptr(gv[2]), L.ptr(gv[3]), B, n, st)
+            elif self.dv != 512:  # 512 + num_features wide fc_out (the Swin composition)
+                L.call("gdl_head_concat_xy_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.pviews[0]), L.ptr(self.g_a),
+                       L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]),
+                       L.ptr(self.gviews[1]), B, n, 512, self.dv, st)
             else:
                 L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(self.pviews[0]), L.ptr(self.g_a),
                        L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dfa), L.ptr(self.dfv), L.ptr(self.gviews[0]),
@@ -279,7 +326,7 @@ class DGLTrainer:
         ev2 = main.record_event()
         self.s_a.wait_event(ev2)
         self.s_v.wait_event(ev2)
-        gv, ga = self.gviews[nf + 60:nf + 120], self.gviews[nf:nf + 60]
+        gv, ga = self.gviews[nf + 60:nf + 60 + self.nv], self.gviews[nf:nf + 60]
         if red is None:
             with torch.cuda.stream(self.s_v):
                 self.eng_v.backward(gv, dfeat=self.dfv)
@@ -330,6 +377,9 @@ class DGLTrainer:
         elif self.head == "sum":  # fusion_modules.py:22-30
             L.call("gdl_head_sum_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(pv[2]), L.ptr(pv[3]),
                    L.ptr(self.out), oa, ov, B, n, st)
+        elif self.dv != 512:
+            L.call("gdl_head_concat_xy_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(self.out), oa, ov,
+                   B, n, 512, self.dv, st)
         else:  # fusion_modules.py:38-42 / 51-59
             L.call("gdl_head_concat_fwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[1]), L.ptr(self.out), oa, ov,
                    B, n, st)

@@ -423,7 +423,7 @@ GDL_API int gdl_swin_ln_bwd(int dtype, const void* dy, const void* x, const floa
 GDL_API int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream);
 GDL_API int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out, int n_img, int H, int W, int window,
                               int shift, int heads, int ld, void* stream);
-GDL_API size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int window, int heads);
+GDL_API size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int H, int W, int window, int heads);
 GDL_API int gdl_swin_attn_bwd(int dtype, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable,
                               void* ws, int n_img, int H, int W, int window, int shift, int heads, int ld, void* stream);
 GDL_API int gdl_swin_merge(int dtype, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, void* stream);

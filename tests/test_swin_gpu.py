@@ -115,3 +115,68 @@ def test_swin_dgl_dropin_step_golden(golden_dir):
     loss_f.backward()
     np.testing.assert_allclose(out_v.detach().cpu().numpy(), g["s0.out_v"], rtol=5e-4, atol=5e-4)
     _dropin_checks(model, optimizer, g, cfg, out, loss_f, loss_a)
+
+
+def _swin_dgl_model(cfg, dtype):
+    import argparse
+
+    from models.basic_model import AVClassifier_DGL_Swin
+
+    sc = cfg["swin"]
+    args = argparse.Namespace(fusion_method="concat", dataset=cfg["dataset"], modality="full", batch_size=cfg["batch"], pe=0)
+    model = AVClassifier_DGL_Swin(args, swin_kwargs=dict(img_size=sc["img"], patch_size=sc["patch"], embed_dim=sc["embed"],
+                                                         depths=list(sc["depths"]), num_heads=list(sc["heads"]),
+                                                         window_size=sc["window"], mlp_ratio=float(sc["mlp"]),
+                                                         drop_path_rate=0.))
+    P, Bf = fx.swin_dgl_state(cfg["n_classes"], sc)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in {**P, **Bf}.items()}, strict=False)
+    model = model.to(DEV)
+    model.audio_net.gdl_dtype = model.visual_net.gdl_dtype = dtype
+    return model
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_swin_dgl_native_step_golden(golden_dir, dtype):
+    """DGLTrainer (flat arenas, fused head / losses / optimizer, two chain streams) with the Swin visual branch, two steps,
+    against the golden of the composed reference parts."""
+    from gdl.trainer import DGLTrainer
+    from test_step_gpu import _batch
+
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+    model = _swin_dgl_model(cfg, dtype)
+    model.train()
+    tr = DGLTrainer(model, lr=cfg["lr"], alpha=cfg["alpha"], mode="dgl", dtype=dtype)
+    f32 = dtype == "f32"
+    for st in range(cfg["steps"]):
+        spec, image, label = _batch(cfg, st)
+        tr.step(spec, image, label)
+        r = tr.read()
+        pre = f"s{st}."
+        if st > 0 and not f32:  # (second bf16 step of a B=4 BatchNorm fixture: finiteness only, as for the ResNet fixtures)
+            assert np.isfinite(r["out"]).all() and np.isfinite(r["total_norm"])
+            continue
+        lt = (1e-2 if st else 5e-4) if f32 else 0.2
+        for k in ("out", "out_a", "out_v"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=lt, atol=lt, err_msg=k)
+        for k in ("loss_f", "loss_a", "loss_v"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=lt if f32 else 5e-2, atol=lt if f32 else 5e-2, err_msg=k)
+        nt = (2e-2 if st else 3e-3) if f32 else 4e-2
+        np.testing.assert_allclose(r["total_norm"], g[pre + "total_norm"], rtol=nt)
+        np.testing.assert_allclose(r["visual_grad_sum"], g[pre + "visual_grad_sum"], rtol=2 * nt)
+        names = [str(n) for n in g[pre + "grad_names"]]
+        gn, isnone = g[pre + "grad_norm"], g[pre + "grad_is_none"]
+        gt = (6e-2 if st else 1e-2) if f32 else 0.3
+        tn = float(g[pre + "total_norm"])
+        for i, n in enumerate(names):
+            if isnone[i]:
+                assert n not in r["grad_norm"]
+                continue
+            assert abs(r["grad_norm"][n] - gn[i]) <= gt * gn[i] + 1e-5 * min(1.0, 40.0 / tn) * tn, (n, r["grad_norm"][n], gn[i])
+    if f32:
+        last = f"s{cfg['steps'] - 1}."
+        ps, sd = g[last + "param_sums"], model.state_dict()
+        for i, n in enumerate(str(x) for x in g[last + "grad_names"]):
+            np.testing.assert_allclose(sd[n].double().abs().sum().item(), ps[i][1], rtol=1e-3, err_msg=n)
+    acc = tr.valid([_batch(cfg, 1000)])
+    assert all(0.0 <= a <= 1.0 for a in acc)
