@@ -44,6 +44,14 @@ WORKLOADS = {
                  "name": "VGGSound-shaped DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x129x626 + frames 3x3x224x224, "
                          "309 logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
                  "metric": "audio-visual samples/sec, VGGSound-shaped DGL train step (whole job)"},
+    # configs[4] proper: the VGGSound shapes with the Swin-T visual branch (SURVEY row N4 -- a composition the reference's
+    # main_dgl.py cannot build, models.basic_model.AVClassifier_DGL_Swin).  Arithmetic per sample: audio ResNet18 at
+    # 129 x 626 13.66 GFLOP (the ks figure minus its 36.9 GFLOP visual ResNet) + 3 frames x 3 x 4.51 GFLOP of Swin-T
+    "vggsound_swin": {"dataset": "VGGSound", "n_classes": 309, "spec": (129, 626), "alpha": 2.0, "gflop": 54.25, "swin": True,
+                      "name": "VGGSound-shaped DGL, ResNet18 audio + Swin-T visual (embed 96, depths 2-2-6-2, heads 3-6-12-24, "
+                              "window 7, drop_path 0) + ConcatFusion_DGL over 512+768, spec 1x129x626 + frames 3x3x224x224, 309 "
+                              "logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
+                      "metric": "audio-visual samples/sec, VGGSound-shaped DGL train step with a Swin-T visual branch (whole job)"},
 }
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md (dense)
 HBM_PEAK_GBS = 8000.0
@@ -162,9 +170,17 @@ def main():
     # model exactly as main_dgl.py:230-246 builds it (random init; identical on every rank via the seed)
     setup_seed(0)
     wl = WORKLOADS[a.workload]
-    args = argparse.Namespace(fusion_method="concat", dataset=wl["dataset"], modality="full", batch_size=a.batch)
-    model = AVClassifier_DGL(args)
-    model.apply(weight_init)
+    args = argparse.Namespace(fusion_method="concat", dataset=wl["dataset"], modality="full", batch_size=a.batch, pe=0)
+    if wl.get("swin"):
+        from models.basic_model import AVClassifier_DGL_Swin
+
+        model = AVClassifier_DGL_Swin(args)  # (the Swin branch keeps its own initialisation, swin_transformer.py:568-576:
+        model.audio_net.apply(weight_init)   #  utils.weight_init would trip over PatchMerging's bias-free Linear)
+        model.fusion_module.apply(weight_init)
+        a.no_f32 = a.no_cpu_baseline = True  # (both legs are written for the ResNet18 pair)
+    else:
+        model = AVClassifier_DGL(args)
+        model.apply(weight_init)
     model.to(dev)
     model.train()
     tr = DGLTrainer(model, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype,
@@ -274,7 +290,7 @@ def main():
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
                 "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
-    if prof and world == 1 and kernels:
+    if prof and world == 1 and kernels and not wl.get("swin"):
         # The same kernels WITHOUT contention: each encoder's forward + backward on its own, weight gradients on the
         # chain's stream -- every launch has the device to itself.  The step's table says what a launch costs beside the
         # other streams (what the job pays); this one says what the kernel itself does (`roofline.alone`).

@@ -31,6 +31,7 @@ namespace gdl {
 
 constexpr int SW_HD = 32;      // head dimension of every Swin-T / -S / -B stage (dim / heads)
 constexpr int SW_MAXT = 49;    // tokens per window (7 x 7)
+constexpr int SW_PD = SW_HD + 4;  // LDS pitch of a 32-float row: 16-byte aligned (float4 broadcast reads)
 constexpr int SW_MAXV = 24;    // row elements per lane in the LayerNorm kernels: ld <= 1536
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -94,98 +95,141 @@ __global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, c
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
-// one wave per row; lane l holds columns l + 64 i.  stats[row] = (mean, rstd).
+// A row is ld / EPC 16-byte vectors; `lpr` lanes (a power of two <= 64, host-chosen: the next one >= the vector count)
+// share a row, 64 / lpr rows per wave, each lane up to SW_MAXVPL vectors (vector sub + lpr*i).  A 128-channel bf16 row is
+// 16 vectors: four rows per wave and one 16-byte load per lane instead of 2-byte loads.  stats[row] = (mean, rstd),
+// two-pass over the C real channels (padding columns hold zeros and are written as zeros).
+constexpr int SW_MAXVPL = 6;
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y,
-                                                          float2* __restrict__ stats, size_t M, int C, int ld) {
-    const int lane = threadIdx.x & 63;
-    const int nv = ld >> 6;
-    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (size_t)gridDim.x * 4) {
-        const T* xr = x + row * ld;
-        float v[SW_MAXV];
+                                                          float2* __restrict__ stats, size_t M, int C, int ld, int lpr) {
+    constexpr int EPC = TT<T>::EPC;
+    const int lane = threadIdx.x & 63, sub = lane & (lpr - 1), rpw = 64 / lpr;
+    const int vpr = ld / EPC;
+    const float invC = 1.f / (float)C;
+    for (size_t row = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr; row < M; row += (size_t)gridDim.x * 4 * rpw) {
+        const uint4* xr = (const uint4*)(x + row * ld);
+        float v[SW_MAXVPL][EPC];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < SW_MAXV; ++i)
-            if (i < nv) {
-                v[i] = loadT(xr + lane + 64 * i);
-                s += v[i];  // padding columns are zero
+        for (int i = 0; i < SW_MAXVPL; ++i)
+            if (sub + lpr * i < vpr) {
+                unpack16<T>(xr[sub + lpr * i], v[i]);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) s += v[i][e];  // padding columns are zero
             }
-        const float mu = wave_sum(s) / (float)C;
+        const float mu = group_sum(s, lpr) * invC;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < SW_MAXV; ++i)
-            if (i < nv && lane + 64 * i < C) q += (v[i] - mu) * (v[i] - mu);
-        const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
-        if (lane == 0) stats[row] = make_float2(mu, rstd);
-        T* yr = y + row * ld;
+        for (int i = 0; i < SW_MAXVPL; ++i)
+            if (sub + lpr * i < vpr) {
+                const int c0 = (sub + lpr * i) * EPC;
 #pragma unroll
-        for (int i = 0; i < SW_MAXV; ++i)
-            if (i < nv) {
-                const int c = lane + 64 * i;
-                storeT(yr + c, c < C ? (v[i] - mu) * rstd * gamma[c] + beta[c] : 0.f);
+                for (int e = 0; e < EPC; ++e)
+                    if (c0 + e < C) q += (v[i][e] - mu) * (v[i][e] - mu);
+            }
+        const float rstd = rsqrtf(group_sum(q, lpr) * invC + 1e-5f);
+        if (sub == 0) stats[row] = make_float2(mu, rstd);
+        uint4* yr = (uint4*)(y + row * ld);
+#pragma unroll
+        for (int i = 0; i < SW_MAXVPL; ++i)
+            if (sub + lpr * i < vpr) {
+                const int c0 = (sub + lpr * i) * EPC;
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[i][e] - mu) * rstd * gamma[c0 + e] + beta[c0 + e] : 0.f;
+                yr[sub + lpr * i] = pack16<T>(o);
             }
     }
 }
 
 // dx = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial[blk][0][c] = sum dy*xhat,
-// partial[blk][1][c] = sum dy over the rows of the block (fixed order: rows ascending per wave, then waves 0..3)
+// partial[blk][1][c] = sum dy over the rows of the block: every lane sums its rows in ascending order, then the block's
+// 4 * (64 / lpr) row groups are folded through LDS in group order.
 template <typename T>
 __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float2* __restrict__ stats, const float* __restrict__ gamma,
                                                           const T* __restrict__ add, T* __restrict__ dx,
-                                                          float* __restrict__ partial, size_t M, int C, int ld) {
-    __shared__ float red[4][2][64 * SW_MAXV / 4];  // reused in two halves below (ld <= 1536 -> at most 24 per lane)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = ld >> 6;
-    float ag[SW_MAXV], ab[SW_MAXV];
+                                                          float* __restrict__ partial, size_t M, int C, int ld, int lpr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ln_smem[];
+    float* red = (float*)ln_smem;  // [groups][2][ld]
+    constexpr int EPC = TT<T>::EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & (lpr - 1), rpw = 64 / lpr;
+    const int vpr = ld / EPC;
+    const float invC = 1.f / (float)C;
+    float ag[SW_MAXVPL][EPC], ab[SW_MAXVPL][EPC], gm[SW_MAXVPL][EPC];
 #pragma unroll
-    for (int i = 0; i < SW_MAXV; ++i) ag[i] = ab[i] = 0.f;
-    for (size_t row = (size_t)blockIdx.x * 4 + wave; row < M; row += (size_t)gridDim.x * 4) {
+    for (int i = 0; i < SW_MAXVPL; ++i) {
+        const int c0 = (sub + lpr * i) * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            ag[i][e] = ab[i][e] = 0.f;
+            gm[i][e] = (sub + lpr * i < vpr && c0 + e < C) ? gamma[c0 + e] : 0.f;
+        }
+    }
+    for (size_t row = ((size_t)blockIdx.x * 4 + wave) * rpw + lane / lpr; row < M; row += (size_t)gridDim.x * 4 * rpw) {
         const float2 st = stats[row];
-        float xh[SW_MAXV], g[SW_MAXV];
+        const uint4 *dr = (const uint4*)(dy + row * ld), *xr = (const uint4*)(x + row * ld);
+        float xh[SW_MAXVPL][EPC], g[SW_MAXVPL][EPC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < SW_MAXV; ++i)
-            if (i < nv) {
-                const int c = lane + 64 * i;
-                const float d = loadT(dy + row * ld + c);
-                xh[i] = c < C ? (loadT(x + row * ld + c) - st.x) * st.y : 0.f;
-                g[i] = c < C ? d * gamma[c] : 0.f;
-                s1 += g[i];
-                s2 += g[i] * xh[i];
-                ag[i] += d * xh[i];
-                ab[i] += c < C ? d : 0.f;
-            }
-        const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+        for (int i = 0; i < SW_MAXVPL; ++i)
+            if (sub + lpr * i < vpr) {
+                const int c0 = (sub + lpr * i) * EPC;
+                float d[EPC], xv[EPC];
+                unpack16<T>(dr[sub + lpr * i], d);
+                unpack16<T>(xr[sub + lpr * i], xv);
 #pragma unroll
-        for (int i = 0; i < SW_MAXV; ++i)
-            if (i < nv) {
-                const int c = lane + 64 * i;
-                float o = c < C ? st.y * (g[i] - m1 - xh[i] * m2) : 0.f;
-                if (add) o += loadT(add + row * ld + c);
-                storeT(dx + row * ld + c, o);
+                for (int e = 0; e < EPC; ++e) {
+                    const bool real = c0 + e < C;
+                    xh[i][e] = real ? (xv[e] - st.x) * st.y : 0.f;
+                    g[i][e] = d[e] * gm[i][e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                    ag[i][e] += d[e] * xh[i][e];
+                    ab[i][e] += real ? d[e] : 0.f;
+                }
+            }
+        const float m1 = group_sum(s1, lpr) * invC, m2 = group_sum(s2, lpr) * invC;
+        uint4* outr = (uint4*)(dx + row * ld);
+        const uint4* ar = add ? (const uint4*)(add + row * ld) : nullptr;
+#pragma unroll
+        for (int i = 0; i < SW_MAXVPL; ++i)
+            if (sub + lpr * i < vpr) {
+                const int c0 = (sub + lpr * i) * EPC;
+                float o[EPC], av[EPC];
+                if (ar) unpack16<T>(ar[sub + lpr * i], av);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    o[e] = c0 + e < C ? st.y * (g[i][e] - m1 - xh[i][e] * m2) : 0.f;
+                    if (ar) o[e] += av[e];
+                }
+                outr[sub + lpr * i] = pack16<T>(o);
             }
     }
-    // block partials: waves 0..3 in order, 6 columns-per-lane at a time through LDS
-    float* outp = partial + (size_t)blockIdx.x * 2 * ld;
-    for (int i0 = 0; i0 < nv; i0 += 6) {
-        __syncthreads();
+    // block partials: groups (wave, row group) in order
+    const int grp = wave * rpw + lane / lpr, ngrp = 4 * rpw;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (i0 + i < nv) {
-                red[wave][0][i * 64 + lane] = ag[i0 + i];
-                red[wave][1][i * 64 + lane] = ab[i0 + i];
+    for (int i = 0; i < SW_MAXVPL; ++i)
+        if (sub + lpr * i < vpr) {
+            const int c0 = (sub + lpr * i) * EPC;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                red[((size_t)grp * 2 + 0) * ld + c0 + e] = ag[i][e];
+                red[((size_t)grp * 2 + 1) * ld + c0 + e] = ab[i][e];
             }
-        __syncthreads();
-        if (wave == 0)
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                if (i0 + i < nv) {
-                    const int c = lane + 64 * (i0 + i);
-                    outp[c] = ((red[0][0][i * 64 + lane] + red[1][0][i * 64 + lane]) + red[2][0][i * 64 + lane]) + red[3][0][i * 64 + lane];
-                    outp[ld + c] = ((red[0][1][i * 64 + lane] + red[1][1][i * 64 + lane]) + red[2][1][i * 64 + lane]) + red[3][1][i * 64 + lane];
-                }
+        }
+    __syncthreads();
+    float* outp = partial + (size_t)blockIdx.x * 2 * ld;
+    for (int c = threadIdx.x; c < 2 * ld; c += 256) {
+        float sum = red[c];
+        for (int k = 1; k < ngrp; ++k) sum += red[(size_t)k * 2 * ld + c];
+        outp[c] = sum;
     }
 }
 
@@ -200,35 +244,50 @@ __global__ __launch_bounds__(256) void swin_partial_reduce_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (+ GELU')
-// GELU = 1: g <- g * gelu'(u) in place first.  partial[blk][c] = sum over the block's rows (rows ascending, fixed).
-// Block = 256 threads = 4 row groups x 64 column lanes of 16-byte vectors... kept simple: thread = one column vector,
-// the block walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; ld / EPC <= 256 vector columns per pass.
+// GELU = 1: g <- g * gelu'(u) in place first.  partial[blk][c] = sum over the block's rows, fixed order.  A thread owns one
+// 16-byte column vector of one of the block's `rpb` = 256 / (vectors per row) concurrent rows (a 128-channel bf16 row is
+// only 16 vectors: one row at a time would leave 240 threads idle); the row groups are folded through LDS in index order.
 template <typename T, int GELU>
 __global__ __launch_bounds__(256) void swin_colsum_kernel(T* __restrict__ g, const T* __restrict__ u, float* __restrict__ partial,
                                                           size_t M, int ld) {
     constexpr int EPC = TT<T>::EPC;
+    __shared__ float red[256][EPC + 1];
     const int vpr = ld / EPC;
+    const int rpb = vpr <= 256 ? 256 / vpr : 1;
     for (int v0 = 0; v0 < vpr; v0 += 256) {
-        const int vc = v0 + threadIdx.x;
-        if (vc >= vpr) continue;
+        const int rsub = vpr <= 256 ? threadIdx.x / vpr : 0;
+        const int vc = vpr <= 256 ? threadIdx.x % vpr : v0 + threadIdx.x;
+        const bool live = rsub < rpb && vc < vpr;
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-        for (size_t row = blockIdx.x; row < M; row += gridDim.x) {
-            float f[EPC];
-            unpack16<T>(((const uint4*)g)[row * vpr + vc], f);
-            if (GELU) {
-                float uu[EPC];
-                unpack16<T>(((const uint4*)u)[row * vpr + vc], uu);
+        if (live)
+            for (size_t row = (size_t)blockIdx.x * rpb + rsub; row < M; row += (size_t)gridDim.x * rpb) {
+                float f[EPC];
+                unpack16<T>(((const uint4*)g)[row * vpr + vc], f);
+                if (GELU) {
+                    float uu[EPC];
+                    unpack16<T>(((const uint4*)u)[row * vpr + vc], uu);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_df(uu[e]));
-                ((uint4*)g)[row * vpr + vc] = pack16<T>(f);
+                    for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_df(uu[e]));
+                    ((uint4*)g)[row * vpr + vc] = pack16<T>(f);
+                }
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) acc[e] += f[e];
             }
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+        for (int e = 0; e < EPC; ++e) red[threadIdx.x][e] = acc[e];
+        __syncthreads();
+        if (live && rsub == 0) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float sum = red[threadIdx.x][e];
+                for (int r = 1; r < rpb; ++r) sum += red[threadIdx.x + r * vpr][e];
+                partial[(size_t)blockIdx.x * ld + vc * EPC + e] = sum;
+            }
         }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) partial[(size_t)blockIdx.x * ld + vc * EPC + e] = acc[e];
+        if (vpr <= 256) break;
     }
 }
 
@@ -255,7 +314,7 @@ __device__ __forceinline__ int sw_token(const SwinAttnGeom& g, int w, int i, int
 template <typename T>
 __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table,
                                                             T* __restrict__ out, SwinAttnGeom g, int n_img) {
-    __shared__ float Ks[4][SW_MAXT][SW_HD + 1], Vs[4][SW_MAXT][SW_HD + 1];
+    __shared__ __attribute__((aligned(16))) float Ks[4][SW_MAXT][SW_PD], Vs[4][SW_MAXT][SW_PD];
     __shared__ int regs[4][SW_MAXT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Tn = g.ws * g.ws, L = g.H * g.W;
@@ -289,8 +348,12 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict_
     for (int j = 0; j < SW_MAXT; ++j)
         if (j < Tn) {
             float a = 0.f;
+            const float4* kr = (const float4*)Ks[wave][j];
 #pragma unroll
-            for (int d = 0; d < SW_HD; ++d) a += q[d] * Ks[wave][j][d];
+            for (int d4 = 0; d4 < SW_HD / 4; ++d4) {
+                const float4 kv = kr[d4];
+                a += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
+            }
             const int rj = j / g.ws, cj = j % g.ws;
             a += table[((ri - rj + g.ws - 1) * tw + (ci - cj + g.ws - 1)) * g.nh + h];
             if (g.shift && regs[wave][j] != reg) a -= 100.f;
@@ -312,8 +375,12 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict_
     for (int j = 0; j < SW_MAXT; ++j)
         if (j < Tn) {
             const float p = s[j] * inv;
+            const float4* vr = (const float4*)Vs[wave][j];
 #pragma unroll
-            for (int d = 0; d < SW_HD; ++d) o[d] += p * Vs[wave][j][d];
+            for (int d4 = 0; d4 < SW_HD / 4; ++d4) {
+                const float4 vv = vr[d4];
+                o[4 * d4] += p * vv.x, o[4 * d4 + 1] += p * vv.y, o[4 * d4 + 2] += p * vv.z, o[4 * d4 + 3] += p * vv.w;
+            }
         }
     T* ob = out + row * g.ld + h * SW_HD;
 #pragma unroll
@@ -357,7 +424,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
                                                            const T* __restrict__ dout, T* __restrict__ dqkv,
                                                            float* __restrict__ tpart, SwinAttnGeom g, int G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
-    constexpr int PD = SW_HD + 1, PT = SW_MAXT + 1;
+    constexpr int PD = SW_PD, PT = SW_MAXT + 1;
     float(*Qs)[PD] = (float(*)[PD])sw_smem;  // scaled queries
     float(*Ks)[PD] = Qs + SW_MAXT;
     float(*Vs)[PD] = Ks + SW_MAXT;
@@ -408,10 +475,12 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
             for (int j = 0; j < SW_MAXT; ++j)
                 if (j < Tn) {
                     float a = 0.f, b = 0.f;
+                    const float4 *kr = (const float4*)Ks[j], *vr = (const float4*)Vs[j];
 #pragma unroll
-                    for (int d = 0; d < SW_HD; ++d) {
-                        a += q[d] * Ks[j][d];
-                        b += go[d] * Vs[j][d];
+                    for (int d4 = 0; d4 < SW_HD / 4; ++d4) {
+                        const float4 kv = kr[d4], vv = vr[d4];
+                        a += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
+                        b += go[4 * d4] * vv.x + go[4 * d4 + 1] * vv.y + go[4 * d4 + 2] * vv.z + go[4 * d4 + 3] * vv.w;
                     }
                     a += tab[(ri - rj + g.ws - 1) * tw + (ci - cj + g.ws - 1)];
                     if (g.shift && regs[j] != reg) a -= 100.f;
@@ -439,8 +508,12 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
             for (int j = 0; j < SW_MAXT; ++j)
                 if (j < Tn) {
                     const float ds = s[j] * inv * (dp[j] - pd);
+                    const float4* kr = (const float4*)Ks[j];
 #pragma unroll
-                    for (int d = 0; d < SW_HD; ++d) dq[d] += ds * Ks[j][d];
+                    for (int d4 = 0; d4 < SW_HD / 4; ++d4) {
+                        const float4 kv = kr[d4];
+                        dq[4 * d4] += ds * kv.x, dq[4 * d4 + 1] += ds * kv.y, dq[4 * d4 + 2] += ds * kv.z, dq[4 * d4 + 3] += ds * kv.w;
+                    }
                 }
             rmax[lane] = mx;
             rinv[lane] = inv;
@@ -459,10 +532,14 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
             int rq = 0, cq = 0;
             for (int i = 0; i < Tn; ++i) {
                 float a = 0.f, b = 0.f;
+                const float4 *qr = (const float4*)Qs[i], *orow = (const float4*)Os[i];
+                float4 qv[SW_HD / 4], ov[SW_HD / 4];
 #pragma unroll
-                for (int d = 0; d < SW_HD; ++d) {
-                    a += Qs[i][d] * k[d];
-                    b += Os[i][d] * v[d];
+                for (int d4 = 0; d4 < SW_HD / 4; ++d4) {
+                    qv[d4] = qr[d4];
+                    ov[d4] = orow[d4];
+                    a += qv[d4].x * k[4 * d4] + qv[d4].y * k[4 * d4 + 1] + qv[d4].z * k[4 * d4 + 2] + qv[d4].w * k[4 * d4 + 3];
+                    b += ov[d4].x * v[4 * d4] + ov[d4].y * v[4 * d4 + 1] + ov[d4].z * v[4 * d4 + 2] + ov[d4].w * v[4 * d4 + 3];
                 }
                 a += tab[(rq - ri + g.ws - 1) * tw + (cq - ci + g.ws - 1)];
                 if (g.shift && regs[i] != reg) a -= 100.f;
@@ -470,9 +547,9 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_kernel(const T* __restrict__
                 const float ds = p * (b - rpd[i]);
                 Da[i][lane] += ds;
 #pragma unroll
-                for (int d = 0; d < SW_HD; ++d) {
-                    dv[d] += p * Os[i][d];
-                    dk[d] += ds * Qs[i][d];  // Qs carries the scale
+                for (int d4 = 0; d4 < SW_HD / 4; ++d4) {  // (Qs carries the scale)
+                    dv[4 * d4] += p * ov[d4].x, dv[4 * d4 + 1] += p * ov[d4].y, dv[4 * d4 + 2] += p * ov[d4].z, dv[4 * d4 + 3] += p * ov[d4].w;
+                    dk[4 * d4] += ds * qv[d4].x, dk[4 * d4 + 1] += ds * qv[d4].y, dk[4 * d4 + 2] += ds * qv[d4].z, dk[4 * d4 + 3] += ds * qv[d4].w;
                 }
                 if (++cq == g.ws) cq = 0, ++rq;
             }
@@ -637,13 +714,21 @@ int swin_bias_act(int dt, void* y, const float* bias, void* u, const void* res, 
     return bias_act_t<bf16>((bf16*)y, bias, (bf16*)u, (const bf16*)res, M, ld, mode, st);
 }
 
+// lanes per row of the LayerNorm kernels: the power of two >= the row's 16-byte vectors, at most 64
+static int ln_lpr(int dt, int ld) {
+    const int vpr = ld / (dt == GDL_F32 ? 4 : 8);
+    int l = 16;
+    while (l < vpr && l < 64) l <<= 1;
+    return l;
+}
 int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
                 hipStream_t st) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld, "swin_ln_fwd: width %d / %d", C, ld);
-    const int g = sw_grid(M, 4, 256 * 32);
+    const int lpr = ln_lpr(dt, ld);
+    const int g = sw_grid(M, 4 * (64 / lpr), 256 * 32);
     ProfScope prof("gdl::swin_ln_fwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 8 : 4));
-    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, (float2*)stats, M, C, ld),
-                hipLaunchKernelGGL(swin_ln_fwd_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, (float2*)stats, M, C, ld));
+    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, (float2*)stats, M, C, ld, lpr),
+                hipLaunchKernelGGL(swin_ln_fwd_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, (float2*)stats, M, C, ld, lpr));
     GDL_CHECK_LAUNCH("swin_ln_fwd_kernel");
     return GDL_OK;
 }
@@ -661,12 +746,22 @@ static int partial_reduce(const float* partial, float* out, int nblk, int width,
 int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
                 float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld && partial, "swin_ln_bwd: width %d / %d", C, ld);
-    int g = (int)((M + 3) / 4);
-    if (g > SW_PARTIAL_BLOCKS) g = SW_PARTIAL_BLOCKS;
+    const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr;
+    const size_t gg = (M + 4 * rpw - 1) / (4 * rpw);
+    const int g = (int)(gg > (size_t)SW_PARTIAL_BLOCKS ? (size_t)SW_PARTIAL_BLOCKS : gg);
+    const size_t lds = (size_t)4 * rpw * 2 * ld * sizeof(float);
     {
+        static bool attr[2] = {false, false};
+        const int di = dt == GDL_F32 ? 0 : 1;
+        if (!attr[di]) {
+            hipError_t e = dt == GDL_F32 ? hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
+                                         : hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_ln_bwd)");
+            attr[di] = true;
+        }
         ProfScope prof("gdl::swin_ln_bwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (add ? 4 : 3));
-        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_bwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float2*)stats, gamma, (const float*)add, (float*)dx, partial, M, C, ld),
-                    hipLaunchKernelGGL(swin_ln_bwd_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const float2*)stats, gamma, (const bf16*)add, (bf16*)dx, partial, M, C, ld));
+        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dy, (const float*)x, (const float2*)stats, gamma, (const float*)add, (float*)dx, partial, M, C, ld, lpr),
+                    hipLaunchKernelGGL(swin_ln_bwd_kernel<bf16>, dim3(g), dim3(256), lds, st, (const bf16*)dy, (const bf16*)x, (const float2*)stats, gamma, (const bf16*)add, (bf16*)dx, partial, M, C, ld, lpr));
         GDL_CHECK_LAUNCH("swin_ln_bwd_kernel");
     }
     return partial_reduce(partial, dgamma_dbeta, g, 2 * ld, st);
@@ -675,7 +770,9 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
 // db[ld] = column sums of g; gelu != 0: g <- g * gelu'(u) first
 int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st) {
     GDL_REQUIRE(ld % 64 == 0 && partial, "swin_colsum: bad arguments");
-    int nb = (int)(M < (size_t)SW_PARTIAL_BLOCKS ? M : (size_t)SW_PARTIAL_BLOCKS);
+    const int vpr = ld / (dt == GDL_F32 ? 4 : 8), rpb = vpr <= 256 ? 256 / vpr : 1;
+    const size_t passes = (M + rpb - 1) / rpb;
+    int nb = (int)(passes < (size_t)SW_PARTIAL_BLOCKS ? passes : (size_t)SW_PARTIAL_BLOCKS);
     {
         ProfScope prof("gdl::swin_colsum_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (u ? 3 : 1));
         if (dt == GDL_F32) {
@@ -725,7 +822,7 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
     int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
     if (rc) return rc;
     GDL_REQUIRE(tpart && dtable, "swin_attn_bwd: null workspace");
-    const size_t lds = (size_t)4 * SW_MAXT * (SW_HD + 1) * 4 + (size_t)SW_MAXT * (SW_MAXT + 1) * 4 + 3 * SW_MAXT * 4 + 169 * 4 + SW_MAXT * 4;
+    const size_t lds = (size_t)4 * SW_MAXT * SW_PD * 4 + (size_t)SW_MAXT * (SW_MAXT + 1) * 4 + 3 * SW_MAXT * 4 + 169 * 4 + SW_MAXT * 4;
     const int G = attn_bwd_group(g.nwin), ngrp = (g.nwin + G - 1) / G;
     static bool attr[2] = {false, false};
     const int di = dt == GDL_F32 ? 0 : 1;
