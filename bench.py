@@ -38,8 +38,8 @@ WORKLOADS = {
            "name": "Kinetics-Sounds DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x129x626 + frames 3x3x224x224, "
                    "34 logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
            "metric": "audio-visual samples/sec, Kinetics-Sounds DGL train step (whole job)"},
-    # configs[4]'s data shapes (VGGSound: the Kinetics-Sounds shapes with 309 logits) on the ResNet18 visual branch -- the
-    # Swin-T branch of that configuration is not reachable from main_dgl.py and is not built
+    # configs[4]'s data shapes (VGGSound: the Kinetics-Sounds shapes with 309 logits) on the ResNet18 visual branch (the
+    # Swin-T branch of that configuration is the next entry)
     "vggsound": {"dataset": "VGGSound", "n_classes": 309, "spec": (129, 626), "alpha": 2.0, "gflop": 50.563,
                  "name": "VGGSound-shaped DGL (main_dgl.py, ConcatFusion_DGL) ResNet18 a+v, spec 1x129x626 + frames 3x3x224x224, "
                          "309 logits, alpha=2, SGD lr 2e-3 mom .9 wd 1e-4, clip 40",
