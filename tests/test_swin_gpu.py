@@ -180,3 +180,33 @@ def test_swin_dgl_native_step_golden(golden_dir, dtype):
             np.testing.assert_allclose(sd[n].double().abs().sum().item(), ps[i][1], rtol=1e-3, err_msg=n)
     acc = tr.valid([_batch(cfg, 1000)])
     assert all(0.0 <= a <= 1.0 for a in acc)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_swin_engine_vs_oracle_16_frames(dtype):
+    """Swin-T on 16 frames (B = 8, T = 2) against the CPU oracle: 50 176 stage-1 tokens, so the LayerNorm / column-sum
+    kernels run their capped grids with several rows per lane and the reductions fold 512 partial rows -- paths the
+    2-frame goldens do not reach.  Also the frame-pooled form ([B, 768] features) the DGL composition uses."""
+    from oracle import swin_oracle as so
+
+    cfg, B, T = fx.SWIN_T, 8, 2
+    P = fx.make_state(fx.swin_param_shapes(cfg))
+    x = fx.swin_input(cfg, B, T, seed=7)
+    dy = np.random.default_rng(11).standard_normal((B * T, 768), dtype=np.float32)
+    want_y, want_g = so.forward_backward(x, P, cfg, dy)
+    y, grads, eng = _run(cfg, B, T, 7, dy, dtype)
+    f32 = dtype == "f32"
+    ey = _relerr(y, want_y)
+    worst, worst_k = 0.0, None
+    for k, v in grads.items():
+        e = max(_relerr(v, want_g[k]), abs(np.linalg.norm(v.astype(np.float64)) - np.linalg.norm(want_g[k].astype(np.float64))) /
+                np.linalg.norm(want_g[k].astype(np.float64)))
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"swin 16 frames {dtype}: features {ey:.2e}, worst gradient {worst:.2e} ({worst_k})")
+    assert ey < (5e-6 if f32 else 2e-2), ey
+    assert worst < (5e-5 if f32 else 8e-2), (worst_k, worst)
+    # pooled over the frames of a sample: the mean of the per-frame features
+    xp = torch.from_numpy(x).to(DEV)
+    yp = eng.forward(xp, pool_frames=True).cpu().numpy()
+    np.testing.assert_allclose(yp, y.reshape(B, T, -1).mean(1), rtol=0, atol=(1e-6 if f32 else 1e-6) * max(1.0, np.abs(y).max()))
