@@ -389,6 +389,335 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict_
         for (int c = g.nh * SW_HD; c < g.ld; ++c) storeT(out + row * g.ld + c, 0.f);
 }
 
+// ---- bf16 forward on the matrix cores.  One wave per (image, window, head): S = Q K^T as 4 x 4 MFMA tiles
+// (mfma_f32_16x16x32_bf16; the 32-wide reduction is the head dimension, Q / K fragments are 16-byte loads straight from
+// the QKV rows), softmax on the accumulator layout (a row's 64 columns live in 16 lanes x 4 tiles: xor-shuffle reductions),
+// P rounded to bf16 through LDS (row-major, the A operand of the second product), V transposed through LDS (its B
+// operand), O = P V as 4 x 2 tiles x 2 K-steps.  Rows / columns 49..63 are padding: zero Q / K / V rows, -inf scores.
+constexpr int SW_TP = 64;       // window tokens padded to the MFMA tile grid
+constexpr int SW_PP = SW_TP + 8;  // LDS pitch (bf16 elements) of a 64-wide row: 144 B, 16-byte aligned, rows 4 banks apart
+struct SwinMfmaLds {              // per wave
+    uint16_t Ps[SW_TP][SW_PP];    // probabilities, [query][key]
+    uint16_t Vt[SW_HD][SW_PP];    // V transposed, [channel][key]
+    float tab[(2 * 7 - 1) * (2 * 7 - 1)];
+    int tok[SW_TP];               // slot -> token row of the image (-1: padding slot)
+    uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];  // slot -> window row, column, mask region
+};
+__device__ __forceinline__ bf16x8_t sw_ld_frag(const bf16* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
+__device__ __forceinline__ bf16x8_t sw_zero_frag() { return __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u)); }
+
+__global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
+                                                                 bf16* __restrict__ out, SwinAttnGeom g, int n_img) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SwinMfmaLds& S = ((SwinMfmaLds*)swm_smem)[wave];
+    const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
+    const long unit = (long)blockIdx.x * 4 + wave, nunits = (long)n_img * g.nwin * g.nh;
+    const bool live = unit < nunits;
+    const int h = live ? (int)(unit % g.nh) : 0;
+    const int w = live ? (int)((unit / g.nh) % g.nwin) : 0;
+    const size_t img_row0 = live ? (size_t)(unit / ((long)g.nh * g.nwin)) * L : 0;
+    const int l16 = lane & 15, lq = lane >> 4;
+    // slot bookkeeping + the head's bias column + V transposed
+    {
+        int reg = 0;
+        const int tok = lane < Tn ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : -1;
+        S.tok[lane] = tok;
+        S.rr[lane] = (uint8_t)(lane / g.ws);
+        S.cc[lane] = (uint8_t)(lane % g.ws);
+        S.reg[lane] = (uint8_t)reg;
+        for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
+        uint4 v[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        if (live && tok >= 0) {
+            const uint4* vp = (const uint4*)(qkv + (img_row0 + tok) * 3 * g.ld + 2 * g.ld + h * SW_HD);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) v[q4] = vp[q4];
+        }
+        const uint32_t* vw = (const uint32_t*)v;
+#pragma unroll
+        for (int d2 = 0; d2 < SW_HD / 2; ++d2) {
+            S.Vt[2 * d2][lane] = (uint16_t)(vw[d2] & 0xffffu);
+            S.Vt[2 * d2 + 1][lane] = (uint16_t)(vw[d2] >> 16);
+        }
+    }
+    __syncthreads();
+    // Q / K fragments: tile t covers slots 16 t + l16; this lane's 8 channels start at 8 lq
+    bf16x8_t qf[4], kf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tok = S.tok[16 * t + l16];
+        if (live && tok >= 0) {
+            const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
+            qf[t] = sw_ld_frag(base);
+            kf[t] = sw_ld_frag(base + g.ld);
+        } else {
+            qf[t] = kf[t] = sw_zero_frag();
+        }
+    }
+    // scores: acc[it][jt][r] = S[i = 16 it + 4 lq + r][j = 16 jt + l16]
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const float scale = 0.17677669529663687f;
+    int rj[4], cj[4], gj[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const int j = 16 * jt + l16;
+        rj[jt] = S.rr[j], cj[jt] = S.cc[j], gj[jt] = S.reg[j];
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * lq + r;
+            const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                float a = acc[it][jt][r] * scale;
+                if (16 * jt + l16 >= Tn)
+                    a = -3.0e38f;
+                else if (i < Tn) {
+                    a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
+                    if (g.shift && gi != gj[jt]) a -= 100.f;
+                }
+                acc[it][jt][r] = a;
+                mx = fmaxf(mx, a);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float den = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const float e = 16 * jt + l16 < Tn ? __expf(acc[it][jt][r] - mx) : 0.f;
+                acc[it][jt][r] = e;
+                den += e;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+            const float inv = 1.f / den;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) S.Ps[i][16 * jt + l16] = f2bf(acc[it][jt][r] * inv);
+        }
+    __syncthreads();
+    // O = P V: tile (it, nt), K-steps of 32 keys
+    f32x4_t o[4][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            o[it][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Ps[16 * it + l16][32 * ks + 8 * lq]);
+                const bf16x8_t vb = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Vt[16 * nt + l16][32 * ks + 8 * lq]);
+                o[it][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[it][nt], 0, 0, 0);
+            }
+        }
+    if (!live) return;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * lq + r;
+            if (i >= Tn) continue;
+            bf16* ob = out + (img_row0 + S.tok[i]) * g.ld + h * SW_HD + l16;
+            ob[0].v = f2bf(o[it][0][r]);
+            ob[16].v = f2bf(o[it][1][r]);
+        }
+    if (h == 0 && lane < Tn)  // the row's padding columns stay zero
+        for (int c = g.nh * SW_HD; c < g.ld; ++c) out[(img_row0 + S.tok[lane]) * g.ld + c].v = 0;
+}
+
+// ---- bf16 backward on the matrix cores.  One wave (block of 64) per (image, group of G windows, head).  Per window:
+// S and dP = dO V^T as 4 x 4 MFMA tiles from 16-byte fragment loads of the Q / K / dO / V rows; P, pd_i = sum_j P dP and
+// dS = P (dP - pd) on the accumulator layout; dS (row-major and transposed), P transposed and the transposed Q / K / dO
+// rows go through LDS as bf16 to become the operands of  dQ = dS K,  dK = dS^T Q,  dV = P^T dO  (4 x 2 tiles x 2 K-steps
+// each).  dS is also added in fp32 to the block's [T][T] accumulator, folded into d(table) at the end as in the FMA kernel.
+struct SwinMfmaBwdLds {
+    uint16_t Ds[SW_TP][SW_PP], Dt[SW_TP][SW_PP], Pt[SW_TP][SW_PP];  // dS [i][j], dS^T [j][i], P^T [j][i]
+    uint16_t Kt[SW_HD][SW_PP], Qt[SW_HD][SW_PP], Ot[SW_HD][SW_PP];  // K^T [d][j], Q^T [d][i], dO^T [d][i]
+    float Da[SW_MAXT][SW_MAXT + 1];
+    float tab[(2 * 7 - 1) * (2 * 7 - 1)];
+    int tok[SW_TP];
+    uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
+};
+__device__ __forceinline__ void sw_scatter_t(uint16_t (*dst)[SW_PP], const uint4* row, int col) {
+    const uint32_t* w = (const uint32_t*)row;
+#pragma unroll
+    for (int d2 = 0; d2 < SW_HD / 2; ++d2) {
+        dst[2 * d2][col] = (uint16_t)(w[d2] & 0xffffu);
+        dst[2 * d2 + 1][col] = (uint16_t)(w[d2] >> 16);
+    }
+}
+__global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
+                                                                const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
+                                                                float* __restrict__ tpart, SwinAttnGeom g, int G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
+    SwinMfmaBwdLds& S = *(SwinMfmaBwdLds*)swm_smem;
+    const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
+    const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
+    const int ngrp = (g.nwin + G - 1) / G;
+    const int h = blockIdx.x % g.nh, grp = (blockIdx.x / g.nh) % ngrp;
+    const size_t img_row0 = (size_t)(blockIdx.x / (g.nh * ngrp)) * L;
+    const float scale = 0.17677669529663687f;
+    for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
+    if (lane < Tn)
+        for (int j = 0; j < Tn; ++j) S.Da[j][lane] = 0.f;
+    for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
+        __syncthreads();  // (the previous window's operand tiles are no longer read)
+        {
+            int reg = 0;
+            const int tok = lane < Tn ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : -1;
+            S.tok[lane] = tok;
+            S.rr[lane] = (uint8_t)(lane / g.ws);
+            S.cc[lane] = (uint8_t)(lane % g.ws);
+            S.reg[lane] = (uint8_t)reg;
+            uint4 q[4], k[4], o[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) q[q4] = k[q4] = o[q4] = make_uint4(0, 0, 0, 0);
+            if (tok >= 0) {
+                const uint4* base = (const uint4*)(qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD);
+                const uint4* kb = (const uint4*)(qkv + (img_row0 + tok) * 3 * g.ld + g.ld + h * SW_HD);
+                const uint4* ob = (const uint4*)(dout + (img_row0 + tok) * g.ld + h * SW_HD);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) q[q4] = base[q4], k[q4] = kb[q4], o[q4] = ob[q4];
+            }
+            sw_scatter_t(S.Qt, q, lane);
+            sw_scatter_t(S.Kt, k, lane);
+            sw_scatter_t(S.Ot, o, lane);
+        }
+        __syncthreads();
+        bf16x8_t qf[4], kf[4], of[4], vf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int tok = S.tok[16 * t + l16];
+            if (tok >= 0) {
+                const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
+                qf[t] = sw_ld_frag(base);
+                kf[t] = sw_ld_frag(base + g.ld);
+                vf[t] = sw_ld_frag(base + 2 * g.ld);
+                of[t] = sw_ld_frag(dout + (img_row0 + tok) * g.ld + h * SW_HD + 8 * lq);
+            } else {
+                qf[t] = kf[t] = vf[t] = of[t] = sw_zero_frag();
+            }
+        }
+        f32x4_t acc[4][4], dp[4][4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[it], vf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+        int rj[4], cj[4], gj[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int j = 16 * jt + l16;
+            rj[jt] = S.rr[j], cj[jt] = S.cc[j], gj[jt] = S.reg[j];
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * lq + r;
+                const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    float a = acc[it][jt][r] * scale;
+                    if (16 * jt + l16 >= Tn)
+                        a = -3.0e38f;
+                    else if (i < Tn) {
+                        a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
+                        if (g.shift && gi != gj[jt]) a -= 100.f;
+                    }
+                    acc[it][jt][r] = a;
+                    mx = fmaxf(mx, a);
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                float den = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const float e = 16 * jt + l16 < Tn ? __expf(acc[it][jt][r] - mx) : 0.f;
+                    acc[it][jt][r] = e;
+                    den += e;
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+                const float inv = 1.f / den;
+                float pd = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    acc[it][jt][r] *= inv;  // P
+                    pd += acc[it][jt][r] * dp[it][jt][r];
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) {
+                    const int j = 16 * jt + l16;
+                    const float p = acc[it][jt][r];
+                    const float ds = (i < Tn && j < Tn) ? p * (dp[it][jt][r] - pd) : 0.f;
+                    const uint16_t db = f2bf(ds);
+                    S.Ds[i][j] = db;
+                    S.Dt[j][i] = db;
+                    S.Pt[j][i] = f2bf((i < Tn && j < Tn) ? p : 0.f);
+                    if (i < Tn && j < Tn) S.Da[i][j] += ds;
+                }
+            }
+        __syncthreads();
+        // dQ = scale dS K (rows i), dK = scale dS^T Q (rows j), dV = P^T dO (rows j): tile (t, nt), K-steps of 32
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            uint16_t(*A)[SW_PP] = which == 0 ? S.Ds : (which == 1 ? S.Dt : S.Pt);
+            uint16_t(*Bm)[SW_PP] = which == 0 ? S.Kt : (which == 1 ? S.Qt : S.Ot);
+            const float mul = which == 2 ? 1.f : scale;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)&A[16 * t + l16][32 * ks + 8 * lq]);
+                        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[16 * nt + l16][32 * ks + 8 * lq]);
+                        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int slot = 16 * t + 4 * lq + r;
+                        if (slot < Tn)
+                            dqkv[(img_row0 + S.tok[slot]) * 3 * g.ld + which * g.ld + h * SW_HD + 16 * nt + l16].v = f2bf(o[r] * mul);
+                    }
+                }
+        }
+        if (h == 0 && lane < Tn)  // padding columns of the three segments stay zero
+            for (int sgm = 0; sgm < 3; ++sgm)
+                for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
+    }
+    __syncthreads();
+    float* tp = tpart + (size_t)blockIdx.x * tw * tw;
+    for (int r = lane; r < tw * tw; r += 64) {
+        const int dh = r / tw - (g.ws - 1), dw = r % tw - (g.ws - 1);
+        float a = 0.f;
+        for (int rj2 = 0; rj2 < g.ws; ++rj2) {
+            const int rr2 = rj2 + dh;
+            if (rr2 < 0 || rr2 >= g.ws) continue;
+            for (int cj2 = 0; cj2 < g.ws; ++cj2) {
+                const int cc2 = cj2 + dw;
+                if (cc2 < 0 || cc2 >= g.ws) continue;
+                a += S.Da[rr2 * g.ws + cc2][rj2 * g.ws + cj2];
+            }
+        }
+        tp[r] = a;
+    }
+}
+
 // 32 consecutive channels of a token row -> LDS row (float)
 template <typename T>
 __device__ __forceinline__ void sw_row_to_lds(const T* __restrict__ src, float* dst) {
@@ -791,6 +1120,14 @@ int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_
     return partial_reduce(partial, db, nb, ld, st);
 }
 
+static bool swin_mfma_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_SWIN_MFMA");  // tuning aid: 0 = the plain-FMA attention kernels for bf16 too
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
 static int attn_geom(SwinAttnGeom* g, int H, int W, int ws, int shift, int nh, int ld) {
     GDL_REQUIRE(ws >= 1 && ws * ws <= SW_MAXT && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws && nh * SW_HD <= ld,
                 "swin_attn: window %d (shift %d) on %dx%d tokens, %d heads in %d channels", ws, shift, H, W, nh, ld);
@@ -804,6 +1141,19 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
     int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
     if (rc) return rc;
     const long units = (long)n_img * g.nwin * nh;
+    if (dt == GDL_BF16 && swin_mfma_on()) {  // matrix-core form (bf16 storage only: the f32 mode stays an fp32 FMA chain)
+        const size_t lds = 4 * sizeof(SwinMfmaLds);
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)swin_attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_fwd_mfma)");
+            attr = true;
+        }
+        ProfScope prof("gdl::swin_attn_fwd_mfma_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 4);
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, (const bf16*)qkv, table, (bf16*)out, g, n_img);
+        GDL_CHECK_LAUNCH("swin_attn_fwd_mfma_kernel");
+        return GDL_OK;
+    }
     ProfScope prof("gdl::swin_attn_fwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 4);
     SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_fwd_kernel<float>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const float*)qkv, table, (float*)out, g, n_img),
                 hipLaunchKernelGGL(swin_attn_fwd_kernel<bf16>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const bf16*)qkv, table, (bf16*)out, g, n_img));
@@ -832,7 +1182,19 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_bwd)");
         attr[di] = true;
     }
-    {
+    if (dt == GDL_BF16 && swin_mfma_on()) {
+        const size_t ldsm = sizeof(SwinMfmaBwdLds);
+        static bool attrm = false;
+        if (!attrm) {
+            hipError_t e = hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
+            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_bwd_mfma)");
+            attrm = true;
+        }
+        ProfScope prof("gdl::swin_attn_bwd_mfma_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 7);
+        hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(n_img * ngrp * nh), dim3(64), ldsm, st, (const bf16*)qkv, table, (const bf16*)dout,
+                           (bf16*)dqkv, tpart, g, G);
+        GDL_CHECK_LAUNCH("swin_attn_bwd_mfma_kernel");
+    } else {
         ProfScope prof("gdl::swin_attn_bwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 7);
         SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_bwd_kernel<float>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const float*)qkv, table, (const float*)dout, (float*)dqkv, tpart, g, G),
                     hipLaunchKernelGGL(swin_attn_bwd_kernel<bf16>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, tpart, g, G));
