@@ -400,6 +400,9 @@ int gdl_swin_pack_matrix(int dtype, const float* src, void* dst, void* dstT, int
     GDL_REQUIRE(dt_ok(dtype) && src && dst, "swin_pack_matrix: bad arguments");
     return swin_pack_matrix(dtype, src, dst, dstT, n, k, nseg, nseg_pad, kseg, kseg_pad, (hipStream_t)stream);
 }
+int gdl_swin_pack_batched(const void* descs, int n_desc, int total_blocks, int dir, void* stream) {
+    return swin_pack_batched(descs, n_desc, total_blocks, dir, (hipStream_t)stream);
+}
 int gdl_swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad, void* stream) {
     GDL_REQUIRE(src && dst, "swin_unpack_matrix: null pointer");
     return swin_unpack_matrix(src, dst, n, k, nseg, nseg_pad, kseg, kseg_pad, (hipStream_t)stream);

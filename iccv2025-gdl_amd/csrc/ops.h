@@ -172,6 +172,7 @@ int swin_token_mean(int dt, const void* x, float* y, int N, int L, int C, int ld
 int swin_token_mean_bwd(int dt, const float* dy, void* dx, int N, int L, int C, int ld, hipStream_t st);
 int swin_pack_matrix(int dt, const float* src, void* dst, void* dstT, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad,
                      hipStream_t st);
+int swin_pack_batched(const void* descs, int nd, int total_blocks, int dir, hipStream_t st);
 int swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad, hipStream_t st);
 
 }  // namespace gdl

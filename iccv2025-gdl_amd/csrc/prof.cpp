@@ -80,6 +80,11 @@ int gdl_prof_enable(int on) {
     return GDL_OK;
 }
 
+int gdl_prof_enabled(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_on ? 1 : 0;
+}
+
 int gdl_prof_set_filter(const char* name) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_filter = name ? name : "";

@@ -233,14 +233,24 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
     }
 }
 
-// out[j] = sum_b partial[b][j], b ascending (j < width)
+// out[j] = sum_b partial[b][j]: a 16-lane group per column (lane k sums rows k, k+16, ... ascending, then a fixed
+// butterfly), 16 columns per block -- coalesced 64-byte reads; a thread per column walking 512 rows was ~100 us of latency
+// per launch, 78 launches per backward
 __global__ __launch_bounds__(256) void swin_partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                                   int nblk, int width) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= width) return;
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15), k = threadIdx.x >> 4;
+    __shared__ float red[16][17];
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * width + j];
-    out[j] = s;
+    if (j < width)
+        for (int b = k; b < nblk; b += 16) s += partial[(size_t)b * width + j];
+    red[k][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (k == 0 && j < width) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[q][threadIdx.x];
+        out[j] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ column sums (+ GELU')
@@ -999,6 +1009,54 @@ __global__ __launch_bounds__(256) void swin_unpack_kernel(const float* __restric
     }
 }
 
+// All of a step's layout conversions in ONE launch each way (Swin-T has 171 parameter tensors: one launch per tensor was
+// 340 tiny kernels per step, ~8 ms of launch gaps).  A descriptor per tensor; block b serves the descriptor whose
+// [blk0, next blk0) holds b, 1024 elements per block.  `dir` 0: pack (src float32 real -> dst `dt` padded, dstT optional),
+// 1: unpack (src float32 padded -> dst float32 real).
+struct SwinPackDesc {
+    const float* src;
+    void* dst;
+    void* dstT;
+    SwinSeg s;
+    int dt;
+    int blk0;
+};
+static_assert(sizeof(SwinPackDesc) == 64, "SwinPackDesc layout (mirrored by gdl/swin.py)");
+__global__ __launch_bounds__(256) void swin_pack_batched_kernel(const SwinPackDesc* __restrict__ descs, int nd, int dir) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {  // last descriptor with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk0 <= (int)blockIdx.x)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const SwinPackDesc d = descs[lo];
+    const SwinSeg s = d.s;
+    const size_t total = dir == 0 ? (size_t)s.np * s.kp : (size_t)s.n * s.k;
+    for (int u = 0; u < 4; ++u) {
+        const size_t i = ((size_t)(blockIdx.x - d.blk0) * 4 + u) * 256 + threadIdx.x;
+        if (i >= total) return;
+        if (dir == 0) {
+            const int pk = (int)(i % s.kp), pn = (int)(i / s.kp);
+            const int sn = pn / s.nseg_pad, on = pn % s.nseg_pad, sk = pk / s.kseg_pad, ok = pk % s.kseg_pad;
+            const int rn = sn * s.nseg + on, rk = sk * s.kseg + ok;
+            const float v = (on < s.nseg && ok < s.kseg && rn < s.n && rk < s.k) ? d.src[(size_t)rn * s.k + rk] : 0.f;
+            if (d.dt == GDL_F32) {
+                ((float*)d.dst)[i] = v;
+                if (d.dstT) ((float*)d.dstT)[(size_t)pk * s.np + pn] = v;
+            } else {
+                storeT((bf16*)d.dst + i, v);
+                if (d.dstT) storeT((bf16*)d.dstT + (size_t)pk * s.np + pn, v);
+            }
+        } else {
+            const int rk = (int)(i % s.k), rn = (int)(i / s.k);
+            const int pn = (rn / s.nseg) * s.nseg_pad + rn % s.nseg, pk = (rk / s.kseg) * s.kseg_pad + rk % s.kseg;
+            ((float*)d.dst)[i] = d.src[(size_t)pn * s.kp + pk];
+        }
+    }
+}
+
 // ================================================================================================ host side
 static int sw_grid(size_t work, int per_block = 256, int cap = 256 * 16) {
     const size_t b = (work + per_block - 1) / per_block;
@@ -1066,7 +1124,7 @@ constexpr int SW_PARTIAL_BLOCKS = 512;  // blocks (= partial rows) of the LayerN
 size_t swin_partial_bytes(int ld) { return (size_t)SW_PARTIAL_BLOCKS * 2 * ld * sizeof(float); }
 
 static int partial_reduce(const float* partial, float* out, int nblk, int width, hipStream_t st) {
-    hipLaunchKernelGGL(swin_partial_reduce_kernel, dim3((width + 255) / 256), dim3(256), 0, st, partial, out, nblk, width);
+    hipLaunchKernelGGL(swin_partial_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, st, partial, out, nblk, width);
     GDL_CHECK_LAUNCH("swin_partial_reduce_kernel");
     return GDL_OK;
 }
@@ -1267,6 +1325,13 @@ int swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int
     if (rc) return rc;
     hipLaunchKernelGGL(swin_unpack_kernel, dim3(sw_grid((size_t)n * k)), dim3(256), 0, st, src, dst, s);
     GDL_CHECK_LAUNCH("swin_unpack_kernel");
+    return GDL_OK;
+}
+
+int swin_pack_batched(const void* descs, int nd, int total_blocks, int dir, hipStream_t st) {
+    GDL_REQUIRE(descs && nd > 0 && total_blocks > 0 && (dir == 0 || dir == 1), "swin_pack_batched: bad arguments");
+    hipLaunchKernelGGL(swin_pack_batched_kernel, dim3(total_blocks), dim3(256), 0, st, (const SwinPackDesc*)descs, nd, dir);
+    GDL_CHECK_LAUNCH("swin_pack_batched_kernel");
     return GDL_OK;
 }
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "gdl_swin_token_mean": ("i", "ipp" + "iiii" + "p"),
     "gdl_swin_token_mean_bwd": ("i", "ipp" + "iiii" + "p"),
     "gdl_swin_pack_matrix": ("i", "ippp" + "iiiiii" + "p"),
+    "gdl_swin_pack_batched": ("i", "piii" + "p"),
     "gdl_swin_unpack_matrix": ("i", "pp" + "iiiiii" + "p"),
     "gdl_fold_workspace_bytes": ("z", ""),
     "gdl_fold_workspace_init": ("i", "pzp"),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "gdl_encoder_backward": ("i", "ppppp"),
     "gdl_encoder_forward_serial": ("l", "p"),
     "gdl_prof_enable": ("i", "i"),
+    "gdl_prof_enabled": ("i", ""),
     "gdl_prof_set_filter": ("i", "s"),
     "gdl_debug_timing_buffer": ("i", "p"),
     "gdl_prof_nslots": ("i", ""),

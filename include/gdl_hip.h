@@ -381,6 +381,7 @@ GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
  * the device and returns per-slot totals: launches[s], ms[s], work[s], s < gdl_prof_nslots().
  * gdl_prof_slot_bound: 1 = MFMA-bound (work in flops), 0 = HBM-bound (work in bytes). */
 GDL_API int gdl_prof_enable(int on);
+GDL_API int gdl_prof_enabled(void); /* 1 while the tap records (callers that replay captured graphs run eagerly then) */
 /* tuning aid: in a -DGDL_TIMING build the conv kernels write per-block s_memtime stamps to buf[block][8]
  * (uint64); in the normal build this returns GDL_ERR_ARG */
 GDL_API int gdl_debug_timing_buffer(void* buf);
@@ -431,6 +432,11 @@ GDL_API int gdl_swin_token_mean(int dtype, const void* x, float* y, int N, int L
 GDL_API int gdl_swin_token_mean_bwd(int dtype, const float* dy, void* dx, int N, int L, int C, int ld, void* stream);
 GDL_API int gdl_swin_pack_matrix(int dtype, const float* src, void* dst, void* dstT, int n, int k, int nseg, int nseg_pad,
                                  int kseg, int kseg_pad, void* stream);
+/* every layout conversion of a step in one launch: `descs` = device array of n_desc 64-byte records
+ *   { const float* src; void* dst; void* dstT; int n, k, nseg, nseg_pad, kseg, kseg_pad, np, kp; int dtype; int blk0; }
+ * (np / kp = padded sizes, blk0 = first block of the record, 1024 elements per block, ascending; total_blocks = their sum);
+ * dir 0 = gdl_swin_pack_matrix per record, dir 1 = gdl_swin_unpack_matrix per record (dstT, dtype ignored) */
+GDL_API int gdl_swin_pack_batched(const void* descs, int n_desc, int total_blocks, int dir, void* stream);
 GDL_API int gdl_swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad,
                                    void* stream);
 

@@ -67,3 +67,4 @@ tot = sum(r[0] for r in rows)
 print(f"kernel time {tot:.2f} ms in {sum(r[1] for r in rows)} launches")
 for ms, n, name in rows[:14]:
     print(f"  {name[:66]:66s} n={n:4d}  {ms:7.3f} ms")
+print("graphs:", {k[0]: (v["n"], v["g"] is not None) for k, v in eng._graphs.items()}, "use_graph", eng.use_graph)
