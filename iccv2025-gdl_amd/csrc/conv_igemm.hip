@@ -1023,7 +1023,12 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
             }
         }
     }
-    const TileCfg c = pick_cfg(M, OC, dtype);
+    TileCfg c = pick_cfg(M, OC, dtype);
+    // plain GEMMs (1x1, stride 1: the Swin encoder's Linears -- the ResNets have none): the 128x128 tile is the faster one
+    // alone (8 DMA pieces per 32 MFMAs instead of 10, each A row gathered for half as many N-tiles), and these run without
+    // a second MFMA-bound stream beside them
+    if (R == 1 && S == 1 && stride == 1 && forced_cfg() == 0 && OC % 128 == 0 && (long)((M + 127) / 128) * (OC / 128) >= 256)
+        c = {128, 128};
     p.slab = 0;
     p.bm = c.bm;
     p.bn = c.bn;

@@ -80,9 +80,12 @@ __global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, c
         float f[EPC], r[EPC];
         unpack16<T>(((const uint4*)y)[i], f);
         if (MODE == 2) unpack16<T>(((const uint4*)res)[i], r);
+        float bv[EPC];
+#pragma unroll
+        for (int e4 = 0; e4 < EPC / 4; ++e4) *(float4*)&bv[4 * e4] = *(const float4*)(bias + c0 + 4 * e4);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            f[e] += bias[c0 + e];
+            f[e] += bv[e];
             if (MODE == 2) f[e] += r[e];
         }
         if (MODE == 1) {
@@ -112,6 +115,16 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
     const int lane = threadIdx.x & 63, sub = lane & (lpr - 1), rpw = 64 / lpr;
     const int vpr = ld / EPC;
     const float invC = 1.f / (float)C;
+    float gm[SW_MAXVPL][EPC], bt[SW_MAXVPL][EPC];  // this lane's columns are the same for every row
+#pragma unroll
+    for (int i = 0; i < SW_MAXVPL; ++i)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = (sub + lpr * i) * EPC + e;
+            const bool real = sub + lpr * i < vpr && c < C;
+            gm[i][e] = real ? gamma[c] : 0.f;
+            bt[i][e] = real ? beta[c] : 0.f;
+        }
     for (size_t row = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr; row < M; row += (size_t)gridDim.x * 4 * rpw) {
         const uint4* xr = (const uint4*)(x + row * ld);
         float v[SW_MAXVPL][EPC];
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
                 const int c0 = (sub + lpr * i) * EPC;
                 float o[EPC];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[i][e] - mu) * rstd * gamma[c0 + e] + beta[c0 + e] : 0.f;
+                for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[i][e] - mu) * rstd * gm[i][e] + bt[i][e] : 0.f;
                 yr[sub + lpr * i] = pack16<T>(o);
             }
     }
