@@ -173,3 +173,36 @@ def test_reference_script_starts_on_the_dropin_modules():
     r = subprocess.run([sys.executable, "-c", probe], cwd="/tmp", capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count(pkg) == 3
+
+
+def test_swin_mirror_matches_reference_layout():
+    """The Swin mirror registers the reference's parameters in the reference's order (the order fx.swin_param_shapes
+    restates; tests/golden/make_golden.py asserted it against the imported SwinTransformer when the goldens were made) and
+    offers the reference's buffers; unsupported constructor arguments are refused rather than ignored."""
+    import argparse
+
+    import pytest
+    from models.basic_model import AVClassifier_DGL_Swin
+    from models.swin_transformer import SwinTransformer
+
+    from oracle import fixtures as fx
+
+    args = argparse.Namespace(pe=0)
+    for cfg in (fx.SWIN_T, fx.SWIN_TINY2):
+        net = SwinTransformer(args, "visual", img_size=cfg["img"], patch_size=cfg["patch"], embed_dim=cfg["embed"],
+                              depths=list(cfg["depths"]), num_heads=list(cfg["heads"]), window_size=cfg["window"],
+                              mlp_ratio=float(cfg["mlp"]), drop_path_rate=0.)
+        want = fx.swin_param_shapes(cfg)
+        assert [(n, tuple(p.shape)) for n, p in net.named_parameters()] == [(n, tuple(s)) for n, s in want.items()]
+        bufs = dict(net.named_buffers())
+        assert "layers.0.blocks.0.attn.relative_position_index" in bufs and "layers.0.blocks.1.attn_mask" in bufs
+        assert "layers.0.blocks.0.attn_mask" not in bufs  # un-shifted blocks have none (a None buffer is not in the state)
+        assert net.num_features == cfg["embed"] << (len(cfg["depths"]) - 1)
+    with pytest.raises(NotImplementedError):
+        SwinTransformer(args, "visual")  # the reference's default drop_path_rate = 0.1 is stochastic
+    with pytest.raises(NotImplementedError):
+        SwinTransformer(argparse.Namespace(pe=1), "visual", drop_path_rate=0.)
+    m = AVClassifier_DGL_Swin(argparse.Namespace(fusion_method="concat", dataset="VGGSound", modality="full", pe=0))
+    P, _ = fx.swin_dgl_state(309, fx.SWIN_T)
+    assert [n for n, _ in m.named_parameters()] == list(P)
+    assert m.fusion_module.fc_out.weight.shape == (309, 512 + 768)
