@@ -935,8 +935,10 @@ static long slab_big_min() {
 static long slab_bn128_min() {
     static long v = -1;
     if (v < 0) {
-        const char* e = tune_env("GDL_SLAB_BN128_MIN");  // tuning aid: fewest blocks for which the 128-channel tile is used
-        v = e ? atol(e) : 100;
+        // fewest blocks for which the 128-channel tile is used: the small layers (visual layer 4, audio layers 3 / 4) keep
+        // 64-wide tiles -- twice the blocks (knob sweep of round 2: 100 -> 384 is -0.5 % step time)
+        const char* e = tune_env("GDL_SLAB_BN128_MIN");  // tuning aid
+        v = e ? atol(e) : 384;
     }
     return v;
 }

@@ -370,19 +370,22 @@ struct WgradPlan {
     int tk, tc, nsplit, chunk;
 };
 
-static WgradPlan plan_wgrad(int M, int C, int K, int RS) {
+static WgradPlan plan_wgrad(int M, int C, int K, int RS, bool gemm = false) {
     WgradPlan p;
     p.tk = (K % 128 == 0) ? 128 : 64;
     p.tc = (C % 128 == 0) ? 128 : 64;
     const int tiles = (K / p.tk) * (C / p.tc) * RS;
-    // Every block leaves a TKxTC fp32 partial tile, so partial traffic = blocks x 16..64 KB: aim at
-    // one resident wave of blocks (~3 per CU), at least 2 stages of work per block, split count a
-    // multiple of 8 (XCD mapping).  GDL_WGRAD_BLOCKS overrides the target (tuning aid).
-    static int target = -1;
-    if (target < 0) {
+    // Every block leaves a TKxTC fp32 partial tile, so partial traffic = blocks x 16..64 KB; at least 2 stages of work per
+    // block, split count a multiple of 8 (XCD mapping).  Target block count: 128 inside the ResNet step, where these
+    // weight gradients (stride-2 3x3, 1x1 downsample) run on the side stream beside the data-gradient chain (knob sweep of
+    // round 2: 6.18 -> 6.14 ms against 384); 384 -- one resident wave of blocks -- for the plain GEMMs (1x1, stride 1: the
+    // Swin encoder's Linears), which have the device to themselves.  GDL_WGRAD_BLOCKS overrides both (tuning aid).
+    static int forced = -1;
+    if (forced < 0) {
         const char* e = tune_env("GDL_WGRAD_BLOCKS");
-        target = e ? atoi(e) : 384;
+        forced = e ? atoi(e) : 0;
     }
+    const int target = forced > 0 ? forced : (gemm ? 384 : 128);
     int ns = (target + tiles - 1) / tiles;
     const int max_ns = (M + 2 * WG_BP - 1) / (2 * WG_BP);
     if (ns > max_ns) ns = max_ns;
@@ -396,7 +399,7 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS) {
 }
 
 size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS) {
-    const WgradPlan p = plan_wgrad(M, C, K, RS);
+    const WgradPlan p = plan_wgrad(M, C, K, RS, RS == 1);  // (the larger of the two split targets: an upper bound)
     size_t b = (size_t)p.nsplit * K * RS * C * sizeof(float);
     if (RS == 9 && conv_wgrad9_enabled()) {  // the 9-tap kernel's slices (geometry-independent upper bound)
         const size_t b9 = conv_wgrad9_ws_bytes(M, C, K);
@@ -453,7 +456,7 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
     GDL_REQUIRE((size_t)a.M * K * esz < (1UL << 31), "wgrad: dy exceeds 2 GiB");
     a.dy_bytes = (unsigned)((size_t)a.M * K * esz);
     a.x_bytes = (unsigned)((size_t)N * H * W * C * esz);
-    const WgradPlan p = plan_wgrad(a.M, C, K, R * S);
+    const WgradPlan p = plan_wgrad(a.M, C, K, R * S, R == 1 && S == 1 && stride == 1);
     a.nsplit = p.nsplit;
     a.chunk = p.chunk;
     a.tiles_k = K / p.tk;
