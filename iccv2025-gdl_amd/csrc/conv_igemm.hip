@@ -956,6 +956,25 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     }
     // LDS budget of the slab kernel: 80 KB (two blocks per CU); a layer too wide for that (the 79-pixel audio layer 2 of the
     // Kinetics-Sounds shapes) still runs better on it with one block per CU than on the flat kernel (+0.7 % of that step)
+    // tuning aid: GDL_PLAN="M:OC:BM:BN,..." forces the slab tile of the stride-1 3x3 layers with that many GEMM rows and
+    // output channels (forward and data gradient share it); tools/plan_search.py walks it
+    if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
+        static const char* plan_env = tune_env("GDL_PLAN");
+        for (const char* q = plan_env; q && *q;) {
+            int m = 0, oc = 0, bm = 0, bn = 0;
+            if (sscanf(q, "%d:%d:%d:%d", &m, &oc, &bm, &bn) == 4 && m == M && oc == OC && OC % bn == 0 &&
+                (bm == 128 || bm == 256 || (bm == 192 && bn == 128)) && (bn == 64 || bn == 128) && (dtype == GDL_BF16 || bm != 192)) {
+                const bool single = bn == 128 && bm != 128;
+                const size_t lds = slab_lds_bytes(bm, bn, W, IC, dtype, single);
+                if (lds <= (size_t)112 * 1024 && (dtype == GDL_BF16 || !single)) {
+                    p.slab = 1, p.bm = bm, p.bn = bn, p.single = single, p.lds = lds;
+                    return p;
+                }
+            }
+            q = strchr(q, ',');
+            if (q) ++q;
+        }
+    }
     for (const size_t slab_cap : {(size_t)80 * 1024, (size_t)112 * 1024})
     if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
         // Measured end to end (bench.py, four streams sharing the CUs): the 128-row tile (48 KB of LDS, three

@@ -102,12 +102,15 @@ __global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, c
 // share a row, 64 / lpr rows per wave, each lane up to SW_MAXVPL vectors (vector sub + lpr*i).  A 128-channel bf16 row is
 // 16 vectors: four rows per wave and one 16-byte load per lane instead of 2-byte loads.  stats[row] = (mean, rstd),
 // two-pass over the C real channels (padding columns hold zeros and are written as zeros).
-constexpr int SW_MAXVPL = 6;
+
 __device__ __forceinline__ float group_sum(float v, int lpr) {
     for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-template <typename T>
+// VPL: vectors per lane (compile-time bound of ceil(vectors per row / lpr)); U: row groups in flight per wave and
+// iteration -- all their loads are issued before the first reduction, so a lane keeps U x VPL 16-byte loads in flight
+// instead of one (the one-row form ran at ~1 TB/s).
+template <typename T, int VPL, int U>
 __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, T* __restrict__ y,
                                                           float2* __restrict__ stats, size_t M, int C, int ld, int lpr) {
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
     const int lane = threadIdx.x & 63, sub = lane & (lpr - 1), rpw = 64 / lpr;
     const int vpr = ld / EPC;
     const float invC = 1.f / (float)C;
-    float gm[SW_MAXVPL][EPC], bt[SW_MAXVPL][EPC];  // this lane's columns are the same for every row
+    float gm[VPL][EPC], bt[VPL][EPC];  // this lane's columns are the same for every row
 #pragma unroll
-    for (int i = 0; i < SW_MAXVPL; ++i)
+    for (int i = 0; i < VPL; ++i)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             const int c = (sub + lpr * i) * EPC + e;
@@ -125,46 +128,59 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
             gm[i][e] = real ? gamma[c] : 0.f;
             bt[i][e] = real ? beta[c] : 0.f;
         }
-    for (size_t row = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr; row < M; row += (size_t)gridDim.x * 4 * rpw) {
-        const uint4* xr = (const uint4*)(x + row * ld);
-        float v[SW_MAXVPL][EPC];
-        float s = 0.f;
+    const size_t stride = (size_t)gridDim.x * 4 * rpw;
+    for (size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr; base < M; base += stride * U) {
+        float v[U][VPL][EPC];
 #pragma unroll
-        for (int i = 0; i < SW_MAXVPL; ++i)
-            if (sub + lpr * i < vpr) {
-                unpack16<T>(xr[sub + lpr * i], v[i]);
+        for (int u = 0; u < U; ++u) {
+            const size_t row = base + u * stride;
+            if (row < M) {
+                const uint4* xr = (const uint4*)(x + row * ld);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) s += v[i][e];  // padding columns are zero
+                for (int i = 0; i < VPL; ++i)
+                    if (sub + lpr * i < vpr) unpack16<T>(xr[sub + lpr * i], v[u][i]);
             }
-        const float mu = group_sum(s, lpr) * invC;
-        float q = 0.f;
+        }
 #pragma unroll
-        for (int i = 0; i < SW_MAXVPL; ++i)
-            if (sub + lpr * i < vpr) {
-                const int c0 = (sub + lpr * i) * EPC;
+        for (int u = 0; u < U; ++u) {
+            const size_t row = base + u * stride;
+            if (row >= M) continue;  // (whole row groups drop out together: the shuffles below stay inside a group)
+            float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e)
-                    if (c0 + e < C) q += (v[i][e] - mu) * (v[i][e] - mu);
-            }
-        const float rstd = rsqrtf(group_sum(q, lpr) * invC + 1e-5f);
-        if (sub == 0) stats[row] = make_float2(mu, rstd);
-        uint4* yr = (uint4*)(y + row * ld);
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr)
 #pragma unroll
-        for (int i = 0; i < SW_MAXVPL; ++i)
-            if (sub + lpr * i < vpr) {
-                const int c0 = (sub + lpr * i) * EPC;
-                float o[EPC];
+                    for (int e = 0; e < EPC; ++e) s += v[u][i][e];  // padding columns are zero
+            const float mu = group_sum(s, lpr) * invC;
+            float q = 0.f;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[i][e] - mu) * rstd * gm[i][e] + bt[i][e] : 0.f;
-                yr[sub + lpr * i] = pack16<T>(o);
-            }
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr) {
+                    const int c0 = (sub + lpr * i) * EPC;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e)
+                        if (c0 + e < C) q += (v[u][i][e] - mu) * (v[u][i][e] - mu);
+                }
+            const float rstd = rsqrtf(group_sum(q, lpr) * invC + 1e-5f);
+            if (sub == 0) stats[row] = make_float2(mu, rstd);
+            uint4* yr = (uint4*)(y + row * ld);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr) {
+                    const int c0 = (sub + lpr * i) * EPC;
+                    float o[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[u][i][e] - mu) * rstd * gm[i][e] + bt[i][e] : 0.f;
+                    yr[sub + lpr * i] = pack16<T>(o);
+                }
+        }
     }
 }
 
 // dx = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial[blk][0][c] = sum dy*xhat,
 // partial[blk][1][c] = sum dy over the rows of the block: every lane sums its rows in ascending order, then the block's
 // 4 * (64 / lpr) row groups are folded through LDS in group order.
-template <typename T>
+template <typename T, int VPL, int U>
 __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float2* __restrict__ stats, const float* __restrict__ gamma,
                                                           const T* __restrict__ add, T* __restrict__ dx,
@@ -175,9 +191,9 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & (lpr - 1), rpw = 64 / lpr;
     const int vpr = ld / EPC;
     const float invC = 1.f / (float)C;
-    float ag[SW_MAXVPL][EPC], ab[SW_MAXVPL][EPC], gm[SW_MAXVPL][EPC];
+    float ag[VPL][EPC], ab[VPL][EPC], gm[VPL][EPC];
 #pragma unroll
-    for (int i = 0; i < SW_MAXVPL; ++i) {
+    for (int i = 0; i < VPL; ++i) {
         const int c0 = (sub + lpr * i) * EPC;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -185,50 +201,69 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
             gm[i][e] = (sub + lpr * i < vpr && c0 + e < C) ? gamma[c0 + e] : 0.f;
         }
     }
-    for (size_t row = ((size_t)blockIdx.x * 4 + wave) * rpw + lane / lpr; row < M; row += (size_t)gridDim.x * 4 * rpw) {
-        const float2 st = stats[row];
-        const uint4 *dr = (const uint4*)(dy + row * ld), *xr = (const uint4*)(x + row * ld);
-        float xh[SW_MAXVPL][EPC], g[SW_MAXVPL][EPC];
-        float s1 = 0.f, s2 = 0.f;
+    const size_t stride = (size_t)gridDim.x * 4 * rpw;
+    for (size_t base = ((size_t)blockIdx.x * 4 + wave) * rpw + lane / lpr; base < M; base += stride * U) {
+        float d[U][VPL][EPC], xv[U][VPL][EPC];
+        float2 st[U];
 #pragma unroll
-        for (int i = 0; i < SW_MAXVPL; ++i)
-            if (sub + lpr * i < vpr) {
-                const int c0 = (sub + lpr * i) * EPC;
-                float d[EPC], xv[EPC];
-                unpack16<T>(dr[sub + lpr * i], d);
-                unpack16<T>(xr[sub + lpr * i], xv);
+        for (int u = 0; u < U; ++u) {
+            const size_t row = base + u * stride;
+            if (row < M) {
+                st[u] = stats[row];
+                const uint4 *dr = (const uint4*)(dy + row * ld), *xr = (const uint4*)(x + row * ld);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const bool real = c0 + e < C;
-                    xh[i][e] = real ? (xv[e] - st.x) * st.y : 0.f;
-                    g[i][e] = d[e] * gm[i][e];
-                    s1 += g[i][e];
-                    s2 += g[i][e] * xh[i][e];
-                    ag[i][e] += d[e] * xh[i][e];
-                    ab[i][e] += real ? d[e] : 0.f;
-                }
+                for (int i = 0; i < VPL; ++i)
+                    if (sub + lpr * i < vpr) {
+                        unpack16<T>(dr[sub + lpr * i], d[u][i]);
+                        unpack16<T>(xr[sub + lpr * i], xv[u][i]);
+                    }
             }
-        const float m1 = group_sum(s1, lpr) * invC, m2 = group_sum(s2, lpr) * invC;
-        uint4* outr = (uint4*)(dx + row * ld);
-        const uint4* ar = add ? (const uint4*)(add + row * ld) : nullptr;
+        }
 #pragma unroll
-        for (int i = 0; i < SW_MAXVPL; ++i)
-            if (sub + lpr * i < vpr) {
-                const int c0 = (sub + lpr * i) * EPC;
-                float o[EPC], av[EPC];
-                if (ar) unpack16<T>(ar[sub + lpr * i], av);
+        for (int u = 0; u < U; ++u) {
+            const size_t row = base + u * stride;
+            if (row >= M) continue;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    o[e] = c0 + e < C ? st.y * (g[i][e] - m1 - xh[i][e] * m2) : 0.f;
-                    if (ar) o[e] += av[e];
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr) {
+                    const int c0 = (sub + lpr * i) * EPC;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const bool real = c0 + e < C;
+                        const float dd = d[u][i][e];
+                        const float xh = real ? (xv[u][i][e] - st[u].x) * st[u].y : 0.f;
+                        const float g = dd * gm[i][e];
+                        xv[u][i][e] = xh;  // (reuse: xhat)
+                        d[u][i][e] = g;    // (reuse: g)
+                        s1 += g;
+                        s2 += g * xh;
+                        ag[i][e] += dd * xh;
+                        ab[i][e] += real ? dd : 0.f;
+                    }
                 }
-                outr[sub + lpr * i] = pack16<T>(o);
-            }
+            const float m1 = group_sum(s1, lpr) * invC, m2 = group_sum(s2, lpr) * invC;
+            uint4* outr = (uint4*)(dx + row * ld);
+            const uint4* ar = add ? (const uint4*)(add + row * ld) : nullptr;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr) {
+                    const int c0 = (sub + lpr * i) * EPC;
+                    float o[EPC], av[EPC];
+                    if (ar) unpack16<T>(ar[sub + lpr * i], av);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        o[e] = c0 + e < C ? st[u].y * (d[u][i][e] - m1 - xv[u][i][e] * m2) : 0.f;
+                        if (ar) o[e] += av[e];
+                    }
+                    outr[sub + lpr * i] = pack16<T>(o);
+                }
+        }
     }
     // block partials: groups (wave, row group) in order
     const int grp = wave * rpw + lane / lpr, ngrp = 4 * rpw;
 #pragma unroll
-    for (int i = 0; i < SW_MAXVPL; ++i)
+    for (int i = 0; i < VPL; ++i)
         if (sub + lpr * i < vpr) {
             const int c0 = (sub + lpr * i) * EPC;
 #pragma unroll
@@ -284,20 +319,33 @@ __global__ __launch_bounds__(256) void swin_colsum_kernel(T* __restrict__ g, con
         float acc[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
-        if (live)
-            for (size_t row = (size_t)blockIdx.x * rpb + rsub; row < M; row += (size_t)gridDim.x * rpb) {
-                float f[EPC];
-                unpack16<T>(((const uint4*)g)[row * vpr + vc], f);
-                if (GELU) {
-                    float uu[EPC];
-                    unpack16<T>(((const uint4*)u)[row * vpr + vc], uu);
+        if (live) {
+            const size_t stride = (size_t)gridDim.x * rpb;
+            for (size_t base = (size_t)blockIdx.x * rpb + rsub; base < M; base += 4 * stride) {  // four rows in flight
+                uint4 gv[4], uv[4];
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_df(uu[e]));
-                    ((uint4*)g)[row * vpr + vc] = pack16<T>(f);
-                }
+                for (int q = 0; q < 4; ++q)
+                    if (base + q * stride < M) {
+                        gv[q] = ((const uint4*)g)[(base + q * stride) * vpr + vc];
+                        if (GELU) uv[q] = ((const uint4*)u)[(base + q * stride) * vpr + vc];
+                    }
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+                for (int q = 0; q < 4; ++q)
+                    if (base + q * stride < M) {  // (rows ascending: the summation order does not depend on the unroll)
+                        float f[EPC];
+                        unpack16<T>(gv[q], f);
+                        if (GELU) {
+                            float uu[EPC];
+                            unpack16<T>(uv[q], uu);
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_df(uu[e]));
+                            ((uint4*)g)[(base + q * stride) * vpr + vc] = pack16<T>(f);
+                        }
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+                    }
             }
+        }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < EPC; ++e) red[threadIdx.x][e] = acc[e];
@@ -1124,11 +1172,18 @@ static int ln_lpr(int dt, int ld) {
 int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
                 hipStream_t st) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld, "swin_ln_fwd: width %d / %d", C, ld);
-    const int lpr = ln_lpr(dt, ld);
-    const int g = sw_grid(M, 4 * (64 / lpr), 256 * 32);
+    const int lpr = ln_lpr(dt, ld), vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
+    const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
+    const int g = sw_grid(M, 4 * (64 / lpr) * uu, 256 * 32);
     ProfScope prof("gdl::swin_ln_fwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 8 : 4));
-    SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, gamma, beta, (float*)y, (float2*)stats, M, C, ld, lpr),
-                hipLaunchKernelGGL(swin_ln_fwd_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, (float2*)stats, M, C, ld, lpr));
+#define SW_LN_FWD(T, V, U_) \
+    hipLaunchKernelGGL((swin_ln_fwd_kernel<T, V, U_>), dim3(g), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, (float2*)stats, M, C, ld, lpr)
+    if (dt == GDL_F32) {
+        if (vpl == 1) SW_LN_FWD(float, 1, 4); else if (vpl == 2) SW_LN_FWD(float, 2, 2); else if (vpl == 3) SW_LN_FWD(float, 3, 1); else SW_LN_FWD(float, 6, 1);
+    } else {
+        if (vpl == 1) SW_LN_FWD(bf16, 1, 4); else if (vpl == 2) SW_LN_FWD(bf16, 2, 2); else SW_LN_FWD(bf16, 3, 1);
+    }
+#undef SW_LN_FWD
     GDL_CHECK_LAUNCH("swin_ln_fwd_kernel");
     return GDL_OK;
 }
@@ -1146,22 +1201,30 @@ static int partial_reduce(const float* partial, float* out, int nblk, int width,
 int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
                 float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld && partial, "swin_ln_bwd: width %d / %d", C, ld);
-    const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr;
-    const size_t gg = (M + 4 * rpw - 1) / (4 * rpw);
+    const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr, vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
+    const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
+    const size_t gg = (M + (size_t)4 * rpw * uu - 1) / ((size_t)4 * rpw * uu);
     const int g = (int)(gg > (size_t)SW_PARTIAL_BLOCKS ? (size_t)SW_PARTIAL_BLOCKS : gg);
     const size_t lds = (size_t)4 * rpw * 2 * ld * sizeof(float);
     {
-        static bool attr[2] = {false, false};
-        const int di = dt == GDL_F32 ? 0 : 1;
-        if (!attr[di]) {
-            hipError_t e = dt == GDL_F32 ? hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)
-                                         : hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_ln_bwd)");
-            attr[di] = true;
-        }
         ProfScope prof("gdl::swin_ln_bwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (add ? 4 : 3));
-        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_ln_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dy, (const float*)x, (const float2*)stats, gamma, (const float*)add, (float*)dx, partial, M, C, ld, lpr),
-                    hipLaunchKernelGGL(swin_ln_bwd_kernel<bf16>, dim3(g), dim3(256), lds, st, (const bf16*)dy, (const bf16*)x, (const float2*)stats, gamma, (const bf16*)add, (bf16*)dx, partial, M, C, ld, lpr));
+#define SW_LN_BWD(T, V, U_)                                                                                                         \
+    do {                                                                                                                            \
+        static bool attr = false;                                                                                                   \
+        if (!attr) {                                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<T, V, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_ln_bwd)");                                          \
+            attr = true;                                                                                                            \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((swin_ln_bwd_kernel<T, V, U_>), dim3(g), dim3(256), lds, st, (const T*)dy, (const T*)x, (const float2*)stats, gamma, \
+                           (const T*)add, (T*)dx, partial, M, C, ld, lpr);                                                          \
+    } while (0)
+        if (dt == GDL_F32) {
+            if (vpl == 1) SW_LN_BWD(float, 1, 4); else if (vpl == 2) SW_LN_BWD(float, 2, 2); else if (vpl == 3) SW_LN_BWD(float, 3, 1); else SW_LN_BWD(float, 6, 1);
+        } else {
+            if (vpl == 1) SW_LN_BWD(bf16, 1, 4); else if (vpl == 2) SW_LN_BWD(bf16, 2, 2); else SW_LN_BWD(bf16, 3, 1);
+        }
+#undef SW_LN_BWD
         GDL_CHECK_LAUNCH("swin_ln_bwd_kernel");
     }
     return partial_reduce(partial, dgamma_dbeta, g, 2 * ld, st);
