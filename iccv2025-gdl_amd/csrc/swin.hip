@@ -525,54 +525,55 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
             qf[t] = kf[t] = sw_zero_frag();
         }
     }
-    // scores: acc[it][jt][r] = S[i = 16 it + 4 lq + r][j = 16 jt + l16]
+    // scores, TRANSPOSED tiles: acc[jt][it][r] = S[i = 16 it + l16][j = 16 jt + 4 lq + r] -- a lane owns four consecutive keys
+    // of one query, so P goes to LDS (row-major [query][key], the A operand of P V) in 8-byte stores; a query's 64 keys
+    // live in 4 lanes (lq) x 4 tiles x 4 registers: the row reductions are xor-shuffles over lanes 16 and 32
     f32x4_t acc[4][4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            acc[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    const float scale = 0.17677669529663687f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = 16 * it + l16;
+        const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
+        float mx = -3.0e38f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
-            acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    const float scale = 0.17677669529663687f;
-    int rj[4], cj[4], gj[4];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-        const int j = 16 * jt + l16;
-        rj[jt] = S.rr[j], cj[jt] = S.cc[j], gj[jt] = S.reg[j];
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * it + 4 * lq + r;
-            const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                float a = acc[it][jt][r] * scale;
-                if (16 * jt + l16 >= Tn)
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * lq + r;
+                float a = acc[jt][it][r] * scale;
+                if (j >= Tn)
                     a = -3.0e38f;
                 else if (i < Tn) {
-                    a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
-                    if (g.shift && gi != gj[jt]) a -= 100.f;
+                    a += S.tab[(ri - (int)S.rr[j] + g.ws - 1) * tw + (ci - (int)S.cc[j] + g.ws - 1)];
+                    if (g.shift && gi != (int)S.reg[j]) a -= 100.f;
                 }
-                acc[it][jt][r] = a;
+                acc[jt][it][r] = a;
                 mx = fmaxf(mx, a);
             }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float den = 0.f;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float den = 0.f;
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const float e = 16 * jt + l16 < Tn ? __expf(acc[it][jt][r] - mx) : 0.f;
-                acc[it][jt][r] = e;
+            for (int r = 0; r < 4; ++r) {
+                const float e = 16 * jt + 4 * lq + r < Tn ? __expf(acc[jt][it][r] - mx) : 0.f;
+                acc[jt][it][r] = e;
                 den += e;
             }
+        den += __shfl_xor(den, 16, 64);
+        den += __shfl_xor(den, 32, 64);
+        const float inv = 1.f / den;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
-            const float inv = 1.f / den;
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) S.Ps[i][16 * jt + l16] = f2bf(acc[it][jt][r] * inv);
-        }
+        for (int jt = 0; jt < 4; ++jt)
+            *(uint2*)&S.Ps[i][16 * jt + 4 * lq] = make_uint2(pack2bf(acc[jt][it][0] * inv, acc[jt][it][1] * inv),
+                                                             pack2bf(acc[jt][it][2] * inv, acc[jt][it][3] * inv));
+    }
     __syncthreads();
     // O = P V: tile (it, nt), K-steps of 32 keys
     f32x4_t o[4][2];
@@ -732,14 +733,23 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
                     const int j = 16 * jt + l16;
-                    const float p = acc[it][jt][r];
-                    const float ds = (i < Tn && j < Tn) ? p * (dp[it][jt][r] - pd) : 0.f;
-                    const uint16_t db = f2bf(ds);
-                    S.Ds[i][j] = db;
-                    S.Dt[j][i] = db;
-                    S.Pt[j][i] = f2bf((i < Tn && j < Tn) ? p : 0.f);
+                    const float p = (i < Tn && j < Tn) ? acc[it][jt][r] : 0.f;
+                    const float ds = p * (dp[it][jt][r] - pd);
+                    S.Ds[i][j] = f2bf(ds);
                     if (i < Tn && j < Tn) S.Da[i][j] += ds;
+                    acc[it][jt][r] = p;   // keep P and dS for the transposed (packed) stores below
+                    dp[it][jt][r] = ds;
                 }
+            }
+        // transposed copies: a lane owns rows 4 lq .. 4 lq + 3 of column j, i.e. four consecutive elements of row j of the
+        // transposed tile: one 8-byte store instead of four 2-byte ones
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int j = 16 * jt + l16, i0 = 16 * it + 4 * lq;
+                *(uint2*)&S.Dt[j][i0] = make_uint2(pack2bf(dp[it][jt][0], dp[it][jt][1]), pack2bf(dp[it][jt][2], dp[it][jt][3]));
+                *(uint2*)&S.Pt[j][i0] = make_uint2(pack2bf(acc[it][jt][0], acc[it][jt][1]), pack2bf(acc[it][jt][2], acc[it][jt][3]));
             }
         __syncthreads();
         // dQ = scale dS K (rows i), dK = scale dS^T Q (rows j), dV = P^T dO (rows j): tile (t, nt), K-steps of 32
