@@ -612,7 +612,6 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
 struct SwinMfmaBwdLds {
     uint16_t Ds[SW_TP][SW_PP], Dt[SW_TP][SW_PP], Pt[SW_TP][SW_PP];  // dS [i][j], dS^T [j][i], P^T [j][i]
     uint16_t Kt[SW_HD][SW_PP], Qt[SW_HD][SW_PP], Ot[SW_HD][SW_PP];  // K^T [d][j], Q^T [d][i], dO^T [d][i]
-    float Da[SW_MAXT][SW_MAXT + 1];
     float tab[(2 * 7 - 1) * (2 * 7 - 1)];
     int tok[SW_TP];
     uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
@@ -623,6 +622,16 @@ __device__ __forceinline__ void sw_scatter_t(uint16_t (*dst)[SW_PP], const uint4
     for (int d2 = 0; d2 < SW_HD / 2; ++d2) {
         dst[2 * d2][col] = (uint16_t)(w[d2] & 0xffffu);
         dst[2 * d2 + 1][col] = (uint16_t)(w[d2] >> 16);
+    }
+}
+// fragment of tile t (row = slot 16 t + l16, channels 8 lq ..) -> transposed LDS copy [channel][slot]
+__device__ __forceinline__ void sw_scatter_frag(uint16_t (*dst)[SW_PP], bf16x8_t f, int slot, int lq) {
+    const uint4 v = __builtin_bit_cast(uint4, f);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+        dst[8 * lq + 2 * e2][slot] = (uint16_t)(w[e2] & 0xffffu);
+        dst[8 * lq + 2 * e2 + 1][slot] = (uint16_t)(w[e2] >> 16);
     }
 }
 __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
@@ -637,8 +646,11 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
     const size_t img_row0 = (size_t)(blockIdx.x / (g.nh * ngrp)) * L;
     const float scale = 0.17677669529663687f;
     for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
-    if (lane < Tn)
-        for (int j = 0; j < Tn; ++j) S.Da[j][lane] = 0.f;
+    f32x4_t da[4][4];  // d(bias) of this lane's (i, j) pairs, summed over the block's windows (fp32)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) da[it][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
         __syncthreads();  // (the previous window's operand tiles are no longer read)
         {
@@ -648,26 +660,15 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
             S.rr[lane] = (uint8_t)(lane / g.ws);
             S.cc[lane] = (uint8_t)(lane % g.ws);
             S.reg[lane] = (uint8_t)reg;
-            uint4 q[4], k[4], o[4];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) q[q4] = k[q4] = o[q4] = make_uint4(0, 0, 0, 0);
-            if (tok >= 0) {
-                const uint4* base = (const uint4*)(qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD);
-                const uint4* kb = (const uint4*)(qkv + (img_row0 + tok) * 3 * g.ld + g.ld + h * SW_HD);
-                const uint4* ob = (const uint4*)(dout + (img_row0 + tok) * g.ld + h * SW_HD);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) q[q4] = base[q4], k[q4] = kb[q4], o[q4] = ob[q4];
-            }
-            sw_scatter_t(S.Qt, q, lane);
-            sw_scatter_t(S.Kt, k, lane);
-            sw_scatter_t(S.Ot, o, lane);
         }
-        __syncthreads();
+        // fragments straight from the rows (token of slot 16 t + l16 computed here: no LDS round trip before the loads);
+        // the transposed copies the second set of products needs are scattered from the same registers
         bf16x8_t qf[4], kf[4], of[4], vf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int tok = S.tok[16 * t + l16];
-            if (tok >= 0) {
+            const int slot = 16 * t + l16;
+            if (slot < Tn) {
+                const int tok = sw_token(g, w, slot, nullptr);
                 const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
                 qf[t] = sw_ld_frag(base);
                 kf[t] = sw_ld_frag(base + g.ld);
@@ -677,6 +678,13 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
                 qf[t] = kf[t] = vf[t] = of[t] = sw_zero_frag();
             }
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sw_scatter_frag(S.Qt, qf[t], 16 * t + l16, lq);
+            sw_scatter_frag(S.Kt, kf[t], 16 * t + l16, lq);
+            sw_scatter_frag(S.Ot, of[t], 16 * t + l16, lq);
+        }
+        __syncthreads();
         f32x4_t acc[4][4], dp[4][4];
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
                     const float p = (i < Tn && j < Tn) ? acc[it][jt][r] : 0.f;
                     const float ds = p * (dp[it][jt][r] - pd);
                     S.Ds[i][j] = f2bf(ds);
-                    if (i < Tn && j < Tn) S.Da[i][j] += ds;
+                    da[it][jt][r] += ds;  // (zero outside the window: p is)
                     acc[it][jt][r] = p;   // keep P and dS for the transposed (packed) stores below
                     dp[it][jt][r] = ds;
                 }
@@ -782,6 +790,17 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
                 for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
     }
     __syncthreads();
+    float(*Da)[SW_MAXT + 1] = (float(*)[SW_MAXT + 1]) & S.Ds[0][0];  // (the operand tiles are dead: reuse their space)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + 4 * lq + r, j = 16 * jt + l16;
+                if (i < Tn && j < Tn) Da[i][j] = da[it][jt][r];
+            }
+    __syncthreads();
     float* tp = tpart + (size_t)blockIdx.x * tw * tw;
     for (int r = lane; r < tw * tw; r += 64) {
         const int dh = r / tw - (g.ws - 1), dw = r % tw - (g.ws - 1);
@@ -792,7 +811,7 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
             for (int cj2 = 0; cj2 < g.ws; ++cj2) {
                 const int cc2 = cj2 + dw;
                 if (cc2 < 0 || cc2 >= g.ws) continue;
-                a += S.Da[rr2 * g.ws + cc2][rj2 * g.ws + cj2];
+                a += Da[rr2 * g.ws + cc2][rj2 * g.ws + cj2];
             }
         }
         tp[r] = a;
@@ -1092,6 +1111,8 @@ struct SwinPackDesc {
     int dt;
     int blk0;
 };
+static_assert(sizeof(((SwinMfmaBwdLds*)nullptr)->Ds) + sizeof(((SwinMfmaBwdLds*)nullptr)->Dt) >= SW_MAXT * (SW_MAXT + 1) * sizeof(float),
+              "the fp32 d(bias) tile is folded in the dS / dS^T area");
 static_assert(sizeof(SwinPackDesc) == 64, "SwinPackDesc layout (mirrored by gdl/swin.py)");
 __global__ __launch_bounds__(256) void swin_pack_batched_kernel(const SwinPackDesc* __restrict__ descs, int nd, int dir) {
     int lo = 0, hi = nd - 1;
