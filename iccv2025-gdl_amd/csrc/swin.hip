@@ -10,17 +10,21 @@
 //   patch_gather       4x4 patches of the [B,3,T,H,W] float32 frames -> GEMM rows [N*Hp*Wp][64] (48 real columns,
 //                      order (c, kh, kw) = the flattened Conv2d weight, swin_transformer.py:463,480)
 //   bias_act           y += b  |  u = y + b, y = gelu(u)  |  y = y + b + residual           (Mlp :26-42, block :287-290)
-//   layernorm fwd/bwd  one wave per token, two-pass statistics over the real channels, rows kept in registers;
-//                      backward adds the residual gradient and leaves per-block partials of d(gamma), d(beta)
+//   layernorm fwd/bwd  16 / 32 / 64 lanes per token row of 16-byte vectors, up to four row groups of loads in flight,
+//                      two-pass statistics over the real channels in registers; the backward adds the residual
+//                      gradient and leaves per-block partials of d(gamma), d(beta)
 //   colsum / gelu_bwd  bias gradients (column sums, fixed order), fused with the GELU derivative where one precedes it
 //   window attention   (S)W-MSA without materialising rolled / partitioned copies (:124-157, :256-285): a window slot is
 //                      mapped to its token of the un-rolled grid on the fly, the shift mask comes from the slots' region
 //                      ids (:222-240), the relative-position bias from the (2ws-1)^2 table (:103-113).  One wave per
-//                      (window, head): 49 x 49 x 32 products are plain FMAs (0.2 % of the model's arithmetic).  The
-//                      backward recomputes the probabilities, and sums d(bias table) per (image, head) in fixed order.
+//                      (window, head).  bf16: the 49 x 49 x 32 products run on the matrix cores (tokens padded to a
+//                      64 x 64 grid of 16x16x32 MFMA tiles, softmax on the accumulator layout); f32: plain FMAs, the
+//                      exact-mode arithmetic.  The backward recomputes the probabilities and sums d(bias table) per
+//                      (image, window group, head) in fixed order.
 //   merge gather / scatter   PatchMerging's 2x2 concatenation (:336-344) and its adjoint
 //   token mean fwd / bwd     the final AdaptiveAvgPool2d over the 7x7 tokens (:629-631)
-//   pack / unpack            float32 parameters [n][k] <-> zero-padded (and transposed) kernel layouts, segment-wise
+//   pack / unpack            float32 parameters [n][k] <-> zero-padded (and transposed) kernel layouts, segment-wise;
+//                            all of a step's conversions in one launch each way (descriptor table)
 //
 // All reductions are fixed-order (partials + a second kernel): two runs are bit-identical.
 #include "common.h"

@@ -210,3 +210,37 @@ def test_swin_engine_vs_oracle_16_frames(dtype):
     xp = torch.from_numpy(x).to(DEV)
     yp = eng.forward(xp, pool_frames=True).cpu().numpy()
     np.testing.assert_allclose(yp, y.reshape(B, T, -1).mean(1), rtol=0, atol=(1e-6 if f32 else 1e-6) * max(1.0, np.abs(y).max()))
+
+
+def test_swin_trainer_graph_replay_equals_eager(golden_dir):
+    """From the third step on SwinEngine replays captured HIP graphs of its forward / backward launch sequences: five steps
+    with the replay must be bit-identical to five steps launched eagerly."""
+    from gdl.trainer import DGLTrainer
+    from test_step_gpu import _batch
+
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+
+    def run(use_graph):
+        model = _swin_dgl_model(cfg, "bf16")
+        model.train()
+        tr = DGLTrainer(model, lr=cfg["lr"], alpha=cfg["alpha"], mode="dgl", dtype="bf16")
+        outs = []
+        for st in range(5):
+            spec, image, label = _batch(cfg, st % 2)
+            if st == 0:
+                tr._prepare(spec, image)
+                tr.eng_v.eng.use_graph = use_graph
+            tr.step(spec, image, label)
+            r = tr.read()
+            outs.append((r["out"].copy(), r["total_norm"], r["loss_f"]))
+        captured = sum(1 for v in tr.eng_v.eng._graphs.values() if v["g"] is not None)
+        return outs, tr.params.detach().cpu().numpy().copy(), captured
+
+    a, pa, ca = run(True)
+    b, pb, cb = run(False)
+    assert cb == 0 and ca >= 2, (ca, cb)  # forward and backward graphs were captured and replayed
+    for (oa, na, la), (ob, nb, lb) in zip(a, b):
+        np.testing.assert_array_equal(oa, ob)
+        assert na == nb and la == lb
+    np.testing.assert_array_equal(pa, pb)
