@@ -26,6 +26,8 @@ dev = "cuda:0"
 lib = L.load()
 cfg = fx.SWIN_T
 eng = SwinEngine(cfg, a.dtype, a.batch, a.frames, dev)
+if os.environ.get("GDL_NOGRAPH"):
+    eng.use_graph = False
 params = [torch.randn(s, device=dev) * 0.02 for _, s in eng.param_shapes()]
 for (n, _), p in zip(eng.param_shapes(), params):
     if n.endswith("norm1.weight") or n.endswith("norm2.weight") or n.endswith("norm.weight"):
