@@ -30,6 +30,11 @@ SIGNATURES = {
     "gdl_bn_act_bits": ("i", "ippp" + "ppp" + "pp" + "zi" + "p"),
     "gdl_conv_dgrad_relu": ("i", "ipppppp" + "iiiiiiiii" + "p"),
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
+    "gdl_comm_unique_id": ("i", "p"),
+    "gdl_comm_init": ("i", "piip"),
+    "gdl_comm_world": ("i", "p"),
+    "gdl_comm_allreduce_bucket": ("i", "ppz" + "p"),
+    "gdl_comm_destroy": ("i", "p"),
     "gdl_head_concat_xy_fwd": ("i", "ppppppp" + "iiii" + "p"),
     "gdl_head_concat_xy_bwd": ("i", "pppppp" + "ii" + "pppp" + "iiii" + "p"),
     "gdl_swin_patch_gather": ("i", "ipp" + "iiiii" + "p"),

@@ -23,12 +23,42 @@ import torch.distributed as dist
 
 
 class BucketReducer:
-    def __init__(self, flat_grads, buckets, process_group=None):
-        """flat_grads: 1-D tensor; buckets: {name: (lo, hi)} element ranges into it."""
+    def __init__(self, flat_grads, buckets, process_group=None, backend="torch", force_comm=False):
+        """flat_grads: 1-D tensor; buckets: {name: (lo, hi)} element ranges into it.
+        backend "torch": torch.distributed all_reduce on the group (nccl = RCCL on ROCm; gloo on CPU).
+        backend "abi":   the library's own communicator (include/gdl_hip.h gdl_comm_*: RCCL bound by the extension),
+                         bootstrapped through the process group -- rank 0's unique id is broadcast as an object -- and
+                         issued on a dedicated stream behind the producing stream's event.
+        force_comm: run the collectives even in a world of one (tests)."""
         self.flat = flat_grads
         self.buckets = dict(buckets)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.backend = backend
+        self.force_comm = bool(force_comm)
+        self.comm = None
+        if backend == "abi" and (self.world > 1 or self.force_comm):
+            import ctypes
+
+            from . import _lib as L
+
+            if not flat_grads.is_cuda or flat_grads.dtype != torch.float32:
+                raise ValueError("BucketReducer: the 'abi' backend needs a float32 gradient arena on the GPU")
+            rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+            ident = [None]
+            if rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                L.call("gdl_comm_unique_id", buf)
+                ident[0] = bytes(buf.raw)
+            if dist.is_initialized() and self.world > 1:
+                dist.broadcast_object_list(ident, src=0, group=process_group)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(flat_grads.device):
+                L.call("gdl_comm_init", ctypes.byref(h), rank, self.world, ctypes.create_string_buffer(ident[0], 128))
+                self.cstream = torch.cuda.Stream(device=flat_grads.device)
+            self.comm, self._L = h, L
+        elif backend not in ("torch", "abi"):
+            raise ValueError(f"BucketReducer: unknown backend {backend!r}")
         self.pending = {}
         self.enabled = True  # False: launch() / wait_all() keep their bookkeeping but move no data (bench.py times the
         #                      step without its collectives to report how much of them the backward hides)
@@ -47,8 +77,15 @@ class BucketReducer:
         if name in self.pending:
             raise RuntimeError(f"BucketReducer: bucket {name!r} reduced twice in one step")
         lo, hi = self.buckets[name]
-        if self.world == 1 or not self.enabled:
+        if (self.world == 1 and not self.force_comm) or not self.enabled or hi <= lo:
             self.pending[name] = None
+            return
+        if self.comm is not None:
+            cur = torch.cuda.current_stream(self.flat.device)
+            self.cstream.wait_stream(cur)
+            seg = self.flat[lo:hi]
+            self._L.call("gdl_comm_allreduce_bucket", self.comm, seg.data_ptr(), hi - lo, self.cstream.cuda_stream)
+            self.pending[name] = self.cstream.record_event()
             return
         self.pending[name] = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
@@ -59,9 +96,19 @@ class BucketReducer:
         if missing:
             raise RuntimeError(f"BucketReducer: buckets never reduced this step: {sorted(missing)}")
         for w in self.pending.values():
-            if w is not None:
+            if w is None:
+                continue
+            if self.comm is not None:
+                torch.cuda.current_stream(self.flat.device).wait_event(w)
+            else:
                 w.wait()
         self.pending = {}
+
+    def close(self):
+        if self.comm is not None:
+            torch.cuda.synchronize(self.flat.device)
+            self._L.call("gdl_comm_destroy", self.comm)
+            self.comm = None
 
     def broadcast_buffers(self, tensors, src=0):
         """Mirror 'replica 0 persists' for BatchNorm running statistics before eval / checkpoint

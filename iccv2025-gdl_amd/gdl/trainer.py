@@ -49,7 +49,9 @@ class _SwinAdapter:
 
 class DGLTrainer:
     def __init__(self, model, lr, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, mode="dgl", dtype=None,
-                 process_group=None):
+                 process_group=None, comm_backend="torch"):
+        """comm_backend: "torch" -- torch.distributed all_reduce on `process_group` (nccl = RCCL); "abi" -- the library's own
+        RCCL communicator (gdl_comm_*), bootstrapped through `process_group`."""
         self.lib = L.load()
         self.model = model
         self.mode = mode
@@ -130,7 +132,7 @@ class DGLTrainer:
         if process_group is not None:
             from .ddp import BucketReducer
 
-            self.reducer = BucketReducer(self.grads, self.bucket, process_group)
+            self.reducer = BucketReducer(self.grads, self.bucket, process_group, backend=comm_backend)
             self.world = self.reducer.world
             # Replica state follows rank 0 (parameters, momentum, BatchNorm running statistics / counters): a seed
             # that differs between ranks or a rank-0-only checkpoint load must not diverge silently.  fc_auxi (and the

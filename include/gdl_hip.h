@@ -440,6 +440,22 @@ GDL_API int gdl_swin_pack_batched(const void* descs, int n_desc, int total_block
 GDL_API int gdl_swin_unpack_matrix(const float* src, float* dst, int n, int k, int nseg, int nseg_pad, int kseg, int kseg_pad,
                                    void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step over RCCL / xGMI (the reference's nn.DataParallel, main_dgl.py:244, as one
+ * process per GPU; SURVEY 8(b) comm_init / allreduce_bucket / comm_destroy).  RCCL is bound at run time (dlopen), so the
+ * library has no link-time dependency on it.  Bootstrap: rank 0 calls gdl_comm_unique_id and ships the 128 bytes to the
+ * other ranks by any means (gdl/ddp.py uses the torch.distributed store); every rank then calls gdl_comm_init on ITS
+ * device.  gdl_comm_allreduce_bucket sums `count` float32 gradients in place over all ranks, enqueued on `stream`
+ * (collectives of one communicator execute in issue order: issue them in the same order on every rank).
+ * ------------------------------------------------------------------------------------------------------------------- */
+#define GDL_COMM_ID_BYTES 128
+typedef struct gdl_comm gdl_comm_t;
+GDL_API int gdl_comm_unique_id(void* id128);
+GDL_API int gdl_comm_init(gdl_comm_t** out, int rank, int world, const void* id128);
+GDL_API int gdl_comm_world(const gdl_comm_t* c);
+GDL_API int gdl_comm_allreduce_bucket(gdl_comm_t* c, float* grads, size_t count, void* stream);
+GDL_API int gdl_comm_destroy(gdl_comm_t* c);
+
 #ifdef __cplusplus
 }
 #endif

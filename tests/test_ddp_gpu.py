@@ -118,3 +118,41 @@ def test_bench_two_rank_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert d["roofline"] and d["roofline"]["achieved"] > 0 and d["cpu_baseline"] is None
+
+
+@pytest.mark.gpu
+def test_comm_abi_single_rank():
+    """gdl_comm_* (RCCL bound by the extension): a one-rank communicator sums a bucket in place (values unchanged), through
+    the C ABI directly and through BucketReducer's 'abi' backend with its stream / event ordering."""
+    import ctypes
+
+    import torch
+
+    from gdl import _lib as L
+    from gdl.ddp import BucketReducer
+
+    buf = ctypes.create_string_buffer(128)
+    L.call("gdl_comm_unique_id", buf)
+    h = ctypes.c_void_p()
+    L.call("gdl_comm_init", ctypes.byref(h), 0, 1, buf)
+    assert L.load().gdl_comm_world(h) == 1
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda:0")
+    want = x.clone()
+    L.call("gdl_comm_allreduce_bucket", h, x.data_ptr(), x.numel(), L.cur_stream())
+    torch.cuda.synchronize()
+    assert torch.equal(x, want)
+    L.call("gdl_comm_destroy", h)
+    flat = torch.randn(3000, device="cuda:0")
+    ref = flat.clone()
+    red = BucketReducer(flat, {"a": (0, 1000), "b": (1000, 3000)}, None, backend="abi", force_comm=True)
+    flat.mul_(2.0)  # producer work on the current stream: the collective must wait for it
+    red.launch("a")
+    red.launch("b")
+    red.wait_all()
+    torch.cuda.synchronize()
+    assert torch.equal(flat, ref * 2.0)
+    with pytest.raises(RuntimeError):
+        red.launch("a")
+        red.launch("a")
+    red.pending = {}
+    red.close()
