@@ -609,25 +609,22 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
 }
 
 // ---- bf16 backward on the matrix cores.  One wave (block of 64) per (image, group of G windows, head).  Per window:
-// S and dP = dO V^T as 4 x 4 MFMA tiles from 16-byte fragment loads of the Q / K / dO / V rows; P, pd_i = sum_j P dP and
-// dS = P (dP - pd) on the accumulator layout; dS (row-major and transposed), P transposed and the transposed Q / K / dO
-// rows go through LDS as bf16 to become the operands of  dQ = dS K,  dK = dS^T Q,  dV = P^T dO  (4 x 2 tiles x 2 K-steps
-// each).  dS is also added in fp32 to the block's [T][T] accumulator, folded into d(table) at the end as in the FMA kernel.
+// S and dP = dO V^T as 16x16x32 MFMA tiles from 16-byte fragment loads of the Q / K / dO / V rows, one strip of 16 queries
+// at a time; P, pd_i = sum_j P dP and dS = P (dP - pd) on the accumulator layout, kept as packed bf16 pairs (a lane owns
+// four consecutive queries of one key: exactly one 8-byte run of a TRANSPOSED row).  ONE 64 x 64 bf16 tile of LDS then
+// carries, in turn, dS (A operand of dQ = dS K), dS^T (of dK = dS^T Q) and P^T (of dV = P^T dO); their B operands are the
+// transposed Q / K / dO rows, scattered once from the fragments.  dS also accumulates in fp32 registers over the block's
+// windows and is folded into d(table) at the end.  24 KB of LDS and <= 256 registers: six to eight waves per CU (the
+// first form kept three tiles and every accumulator live: 43 KB, 401 registers, three waves per CU).
 struct SwinMfmaBwdLds {
-    uint16_t Ds[SW_TP][SW_PP], Dt[SW_TP][SW_PP], Pt[SW_TP][SW_PP];  // dS [i][j], dS^T [j][i], P^T [j][i]
+    uint16_t Tl[SW_TP][SW_PP];                                       // dS [i][j], then dS^T [j][i], then P^T [j][i]
     uint16_t Kt[SW_HD][SW_PP], Qt[SW_HD][SW_PP], Ot[SW_HD][SW_PP];  // K^T [d][j], Q^T [d][i], dO^T [d][i]
     float tab[(2 * 7 - 1) * (2 * 7 - 1)];
     int tok[SW_TP];
     uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
 };
-__device__ __forceinline__ void sw_scatter_t(uint16_t (*dst)[SW_PP], const uint4* row, int col) {
-    const uint32_t* w = (const uint32_t*)row;
-#pragma unroll
-    for (int d2 = 0; d2 < SW_HD / 2; ++d2) {
-        dst[2 * d2][col] = (uint16_t)(w[d2] & 0xffffu);
-        dst[2 * d2 + 1][col] = (uint16_t)(w[d2] >> 16);
-    }
-}
+static_assert(sizeof(((SwinMfmaBwdLds*)nullptr)->Tl) + 3 * sizeof(((SwinMfmaBwdLds*)nullptr)->Kt) >= SW_MAXT * (SW_MAXT + 1) * sizeof(float),
+              "the fp32 d(bias) tile is folded in the operand area");
 // fragment of tile t (row = slot 16 t + l16, channels 8 lq ..) -> transposed LDS copy [channel][slot]
 __device__ __forceinline__ void sw_scatter_frag(uint16_t (*dst)[SW_PP], bf16x8_t f, int slot, int lq) {
     const uint4 v = __builtin_bit_cast(uint4, f);
@@ -638,9 +635,32 @@ __device__ __forceinline__ void sw_scatter_frag(uint16_t (*dst)[SW_PP], bf16x8_t
         dst[8 * lq + 2 * e2 + 1][slot] = (uint16_t)(w[e2] >> 16);
     }
 }
-__global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
-                                                                const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
-                                                                float* __restrict__ tpart, SwinAttnGeom g, int G) {
+// out rows (slot 16 t + 4 lq + r) x 32 channels = A (the LDS tile, rows = slots) . B (a transposed operand), written to
+// segment `seg` of dqkv
+__device__ __forceinline__ void sw_bwd_product(const SwinMfmaBwdLds& S, const uint16_t (*Bm)[SW_PP], bf16* __restrict__ dqkv,
+                                               size_t img_row0, const SwinAttnGeom& g, int h, int seg, float mul, int Tn, int l16,
+                                               int lq) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Tl[16 * t + l16][32 * ks + 8 * lq]);
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[16 * nt + l16][32 * ks + 8 * lq]);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int slot = 16 * t + 4 * lq + r;
+                if (slot < Tn) dqkv[(img_row0 + S.tok[slot]) * 3 * g.ld + seg * g.ld + h * SW_HD + 16 * nt + l16].v = f2bf(o[r] * mul);
+            }
+        }
+}
+__global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
+                                                                   const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
+                                                                   float* __restrict__ tpart, SwinAttnGeom g, int G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
     SwinMfmaBwdLds& S = *(SwinMfmaBwdLds*)swm_smem;
     const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
@@ -665,136 +685,134 @@ __global__ __launch_bounds__(64) void swin_attn_bwd_mfma_kernel(const bf16* __re
             S.cc[lane] = (uint8_t)(lane % g.ws);
             S.reg[lane] = (uint8_t)reg;
         }
-        // fragments straight from the rows (token of slot 16 t + l16 computed here: no LDS round trip before the loads);
-        // the transposed copies the second set of products needs are scattered from the same registers
-        bf16x8_t qf[4], kf[4], of[4], vf[4];
+        uint2 pkp[4][4], pkd[4][4];  // P and dS of tile (it, jt), rows 4 lq .. 4 lq + 3 of column 16 jt + l16, as bf16
+        {
+            // fragments straight from the rows (the token of slot 16 t + l16 is computed here: no LDS round trip before
+            // the loads); the transposed copies the second set of products needs are scattered from the same registers
+            bf16x8_t qf[4], kf[4], of[4], vf[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int slot = 16 * t + l16;
-            if (slot < Tn) {
-                const int tok = sw_token(g, w, slot, nullptr);
-                const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
-                qf[t] = sw_ld_frag(base);
-                kf[t] = sw_ld_frag(base + g.ld);
-                vf[t] = sw_ld_frag(base + 2 * g.ld);
-                of[t] = sw_ld_frag(dout + (img_row0 + tok) * g.ld + h * SW_HD + 8 * lq);
-            } else {
-                qf[t] = kf[t] = vf[t] = of[t] = sw_zero_frag();
+            for (int t = 0; t < 4; ++t) {
+                const int slot = 16 * t + l16;
+                if (slot < Tn) {
+                    const int tok = sw_token(g, w, slot, nullptr);
+                    const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
+                    qf[t] = sw_ld_frag(base);
+                    kf[t] = sw_ld_frag(base + g.ld);
+                    vf[t] = sw_ld_frag(base + 2 * g.ld);
+                    of[t] = sw_ld_frag(dout + (img_row0 + tok) * g.ld + h * SW_HD + 8 * lq);
+                } else {
+                    qf[t] = kf[t] = vf[t] = of[t] = sw_zero_frag();
+                }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            sw_scatter_frag(S.Qt, qf[t], 16 * t + l16, lq);
-            sw_scatter_frag(S.Kt, kf[t], 16 * t + l16, lq);
-            sw_scatter_frag(S.Ot, of[t], 16 * t + l16, lq);
-        }
-        __syncthreads();
-        f32x4_t acc[4][4], dp[4][4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
+            for (int t = 0; t < 4; ++t) {
+                sw_scatter_frag(S.Qt, qf[t], 16 * t + l16, lq);
+                sw_scatter_frag(S.Kt, kf[t], 16 * t + l16, lq);
+                sw_scatter_frag(S.Ot, of[t], 16 * t + l16, lq);
+            }
+            __syncthreads();  // (slot bookkeeping visible)
+            int rj[4], cj[4], gj[4];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
-                acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dp[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[it], vf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const int j = 16 * jt + l16;
+                rj[jt] = S.rr[j], cj[jt] = S.cc[j], gj[jt] = S.reg[j];
             }
-        int rj[4], cj[4], gj[4];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-            const int j = 16 * jt + l16;
-            rj[jt] = S.rr[j], cj[jt] = S.cc[j], gj[jt] = S.reg[j];
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * it + 4 * lq + r;
-                const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
-                float mx = -3.0e38f;
+            for (int it = 0; it < 4; ++it) {  // one strip of 16 queries at a time
+                f32x4_t acc[4], dp[4];
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
-                    float a = acc[it][jt][r] * scale;
-                    if (16 * jt + l16 >= Tn)
-                        a = -3.0e38f;
-                    else if (i < Tn) {
-                        a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
-                        if (g.shift && gi != gj[jt]) a -= 100.f;
+                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[it], vf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + 4 * lq + r;
+                    const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        float a = acc[jt][r] * scale;
+                        if (16 * jt + l16 >= Tn)
+                            a = -3.0e38f;
+                        else if (i < Tn) {
+                            a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
+                            if (g.shift && gi != gj[jt]) a -= 100.f;
+                        }
+                        acc[jt][r] = a;
+                        mx = fmaxf(mx, a);
                     }
-                    acc[it][jt][r] = a;
-                    mx = fmaxf(mx, a);
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    float den = 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        const float e = 16 * jt + l16 < Tn ? __expf(acc[jt][r] - mx) : 0.f;
+                        acc[jt][r] = e;
+                        den += e;
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+                    const float inv = 1.f / den;
+                    float pd = 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        acc[jt][r] *= inv;  // P
+                        pd += acc[jt][r] * dp[jt][r];
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) {
+                        const float p = (i < Tn && 16 * jt + l16 < Tn) ? acc[jt][r] : 0.f;
+                        const float ds = p * (dp[jt][r] - pd);
+                        da[it][jt][r] += ds;  // (zero outside the window: p is)
+                        acc[jt][r] = p;
+                        dp[jt][r] = ds;
+                    }
                 }
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                float den = 0.f;
-#pragma unroll
                 for (int jt = 0; jt < 4; ++jt) {
-                    const float e = 16 * jt + l16 < Tn ? __expf(acc[it][jt][r] - mx) : 0.f;
-                    acc[it][jt][r] = e;
-                    den += e;
-                }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
-                const float inv = 1.f / den;
-                float pd = 0.f;
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    acc[it][jt][r] *= inv;  // P
-                    pd += acc[it][jt][r] * dp[it][jt][r];
-                }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    const int j = 16 * jt + l16;
-                    const float p = (i < Tn && j < Tn) ? acc[it][jt][r] : 0.f;
-                    const float ds = p * (dp[it][jt][r] - pd);
-                    S.Ds[i][j] = f2bf(ds);
-                    da[it][jt][r] += ds;  // (zero outside the window: p is)
-                    acc[it][jt][r] = p;   // keep P and dS for the transposed (packed) stores below
-                    dp[it][jt][r] = ds;
+                    pkp[it][jt] = make_uint2(pack2bf(acc[jt][0], acc[jt][1]), pack2bf(acc[jt][2], acc[jt][3]));
+                    pkd[it][jt] = make_uint2(pack2bf(dp[jt][0], dp[jt][1]), pack2bf(dp[jt][2], dp[jt][3]));
                 }
             }
-        // transposed copies: a lane owns rows 4 lq .. 4 lq + 3 of column j, i.e. four consecutive elements of row j of the
-        // transposed tile: one 8-byte store instead of four 2-byte ones
+        }
+        // ---- dQ = scale dS K: the tile holds dS row-major [i][j] (2-byte stores: a lane's four values are four rows)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
                 const int j = 16 * jt + l16, i0 = 16 * it + 4 * lq;
-                *(uint2*)&S.Dt[j][i0] = make_uint2(pack2bf(dp[it][jt][0], dp[it][jt][1]), pack2bf(dp[it][jt][2], dp[it][jt][3]));
-                *(uint2*)&S.Pt[j][i0] = make_uint2(pack2bf(acc[it][jt][0], acc[it][jt][1]), pack2bf(acc[it][jt][2], acc[it][jt][3]));
+                S.Tl[i0][j] = (uint16_t)(pkd[it][jt].x & 0xffffu);
+                S.Tl[i0 + 1][j] = (uint16_t)(pkd[it][jt].x >> 16);
+                S.Tl[i0 + 2][j] = (uint16_t)(pkd[it][jt].y & 0xffffu);
+                S.Tl[i0 + 3][j] = (uint16_t)(pkd[it][jt].y >> 16);
             }
         __syncthreads();
-        // dQ = scale dS K (rows i), dK = scale dS^T Q (rows j), dV = P^T dO (rows j): tile (t, nt), K-steps of 32
+        sw_bwd_product(S, S.Kt, dqkv, img_row0, g, h, 0, scale, Tn, l16, lq);
+        __syncthreads();
+        // ---- dK = scale dS^T Q: the tile holds dS^T [j][i]: one 8-byte store per (it, jt)
 #pragma unroll
-        for (int which = 0; which < 3; ++which) {
-            uint16_t(*A)[SW_PP] = which == 0 ? S.Ds : (which == 1 ? S.Dt : S.Pt);
-            uint16_t(*Bm)[SW_PP] = which == 0 ? S.Kt : (which == 1 ? S.Qt : S.Ot);
-            const float mul = which == 2 ? 1.f : scale;
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkd[it][jt];
+        __syncthreads();
+        sw_bwd_product(S, S.Qt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
+        __syncthreads();
+        // ---- dV = P^T dO
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)&A[16 * t + l16][32 * ks + 8 * lq]);
-                        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[16 * nt + l16][32 * ks + 8 * lq]);
-                        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int slot = 16 * t + 4 * lq + r;
-                        if (slot < Tn)
-                            dqkv[(img_row0 + S.tok[slot]) * 3 * g.ld + which * g.ld + h * SW_HD + 16 * nt + l16].v = f2bf(o[r] * mul);
-                    }
-                }
-        }
+            for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkp[it][jt];
+        __syncthreads();
+        sw_bwd_product(S, S.Ot, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
         if (h == 0 && lane < Tn)  // padding columns of the three segments stay zero
             for (int sgm = 0; sgm < 3; ++sgm)
                 for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
     }
     __syncthreads();
-    float(*Da)[SW_MAXT + 1] = (float(*)[SW_MAXT + 1]) & S.Ds[0][0];  // (the operand tiles are dead: reuse their space)
+    float(*Da)[SW_MAXT + 1] = (float(*)[SW_MAXT + 1]) & S.Tl[0][0];  // (the operand tiles are dead: reuse their space)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -1115,8 +1133,6 @@ struct SwinPackDesc {
     int dt;
     int blk0;
 };
-static_assert(sizeof(((SwinMfmaBwdLds*)nullptr)->Ds) + sizeof(((SwinMfmaBwdLds*)nullptr)->Dt) >= SW_MAXT * (SW_MAXT + 1) * sizeof(float),
-              "the fp32 d(bias) tile is folded in the dS / dS^T area");
 static_assert(sizeof(SwinPackDesc) == 64, "SwinPackDesc layout (mirrored by gdl/swin.py)");
 __global__ __launch_bounds__(256) void swin_pack_batched_kernel(const SwinPackDesc* __restrict__ descs, int nd, int dir) {
     int lo = 0, hi = nd - 1;
