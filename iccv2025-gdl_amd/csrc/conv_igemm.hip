@@ -39,6 +39,7 @@ struct ConvArgs {
     const void* wt;            // [OC][ntaps][IC]
     void* out;                 // NHWC rows of OC channels, row m = GEMM row m
     const void* addend;        // optional, like out
+    const float* bias;         // optional [OC] float32, added with the addend (nn.Linear bias of the Swin GEMMs)
     const uint8_t* relu_bits;  // optional: one byte per 16-byte vector of out; the stored value is zeroed where its bit is 0
     float* stats;              // optional [mtiles][OC][2]
     const GatherEntry* table;  // [M]
@@ -232,13 +233,23 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
         const int row = er0 + p * RPI;
         uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
         const size_t goff = (size_t)om[p] * a.OC + n0 + ec * EPC;
-        if (gadd) {
-            float f[EPC], g[EPC];
+        if (gadd || a.bias) {
+            float f[EPC];
             unpack16<T>(v, f);
-            const uint4 w = *(const uint4*)(gadd + goff);
-            unpack16<T>(w, g);
+            if (a.bias) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] += g[e];
+                for (int e4 = 0; e4 < EPC / 4; ++e4) {
+                    const float4 b = *(const float4*)(a.bias + n0 + ec * EPC + 4 * e4);
+                    f[4 * e4] += b.x, f[4 * e4 + 1] += b.y, f[4 * e4 + 2] += b.z, f[4 * e4 + 3] += b.w;
+                }
+            }
+            if (gadd) {
+                float g[EPC];
+                const uint4 w = *(const uint4*)(gadd + goff);
+                unpack16<T>(w, g);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] += g[e];
+            }
             v = pack16<T>(f);
         }
         if (a.relu_bits) {  // ReLU backward of the tensor this is the gradient of, folded into the store
@@ -1094,7 +1105,8 @@ static FinTrain make_fin(const BnFinTrain& b, float eps, float momentum) {
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
-                    const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr) {
+                    const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
+                    const float* bias = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1111,6 +1123,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     a.wt = wt;
     a.out = out;
     a.addend = addend;
+    a.bias = bias;
     a.relu_bits = relu_bits;
     a.stats = stats;
     a.table = (const GatherEntry*)table;
@@ -1258,6 +1271,13 @@ int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const vo
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits) {
     return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
                     nullptr, relu_bits);
+}
+
+// forward with the epilogue's bias / residual: y = conv(x, w) + bias (+ addend), each optional (the Swin Linears)
+int conv_fwd_bias(int dtype, const void* x, const void* w, void* y, const float* bias, const void* addend, const void* table, int N,
+                  int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
+    return run_conv(GATHER_FWD, dtype, x, w, y, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, bias);
 }
 
 int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,

@@ -66,6 +66,12 @@ class _Linear:
         L.call("gdl_conv_fwd", e.dt, L.ptr(x), L.ptr(self.w), L.ptr(y), None, L.ptr(e.table(L.GATHER_FWD, M, self.kp, self.np)), M, 1,
                1, self.kp, self.np, 1, 1, 1, 0, st)
 
+    # y = x . w^T + b (+ res): bias and residual in the GEMM's epilogue
+    def fwd_bias(self, x, y, res, M, st):
+        e = self.eng
+        L.call("gdl_conv_fwd_bias", e.dt, L.ptr(x), L.ptr(self.w), L.ptr(y), L.ptr(self.b), L.ptr(res) if res is not None else None,
+               L.ptr(e.table(L.GATHER_FWD, M, self.kp, self.np)), M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
+
     # dx[M][kp] = dy[M][np] . w
     def dgrad(self, dy, dx, M, st):
         e = self.eng
@@ -328,8 +334,7 @@ class SwinEngine:
         P = self._params
         self._pack_all(st)  # float32 masters -> kernel layouts (one launch per step, like the encoder's weight pack)
         M0 = self.pe_rows.shape[0]
-        self.pe.fwd(self.pe_rows, self.pe_out, M0, st)
-        L.call("gdl_swin_bias_act", dt, L.ptr(self.pe_out), L.ptr(self.pe.b), None, None, M0, self.pe.np, 0, st)
+        self.pe.fwd_bias(self.pe_rows, self.pe_out, None, M0, st)
         xcur = self.x0
         self.pe_norm.fwd(self.pe_out, xcur, self.pe_stats, M0, st)
         for s in self.stages:
@@ -337,17 +342,14 @@ class SwinEngine:
             for b in s["blocks"]:
                 b["x_in"] = xcur
                 b["norm1"].fwd(xcur, b["h"], b["stats1"], M, st)
-                b["qkv"].fwd(b["h"], b["qkv_a"], M, st)
-                L.call("gdl_swin_bias_act", dt, L.ptr(b["qkv_a"]), L.ptr(b["qkv"].b), None, None, M, 3 * ld, 0, st)
+                b["qkv"].fwd_bias(b["h"], b["qkv_a"], None, M, st)
                 L.call("gdl_swin_attn_fwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(b["attn"]), N, r, r, s["ws"],
                        b["shift"], s["nh"], ld, st)
-                b["proj"].fwd(b["attn"], b["x_mid"], M, st)
-                L.call("gdl_swin_bias_act", dt, L.ptr(b["x_mid"]), L.ptr(b["proj"].b), None, L.ptr(xcur), M, ld, 2, st)
+                b["proj"].fwd_bias(b["attn"], b["x_mid"], xcur, M, st)
                 b["norm2"].fwd(b["x_mid"], b["m"], b["stats2"], M, st)
                 b["fc1"].fwd(b["m"], b["a"], M, st)
                 L.call("gdl_swin_bias_act", dt, L.ptr(b["a"]), L.ptr(b["fc1"].b), L.ptr(b["u"]), None, M, b["fc1"].np, 1, st)
-                b["fc2"].fwd(b["a"], b["x_out"], M, st)
-                L.call("gdl_swin_bias_act", dt, L.ptr(b["x_out"]), L.ptr(b["fc2"].b), None, L.ptr(b["x_mid"]), M, ld, 2, st)
+                b["fc2"].fwd_bias(b["a"], b["x_out"], b["x_mid"], M, st)
                 xcur = b["x_out"]
             if "red" in s:
                 L.call("gdl_swin_merge", dt, L.ptr(xcur), L.ptr(s["cat"]), N, r, r, s["C"], ld, 0, st)
