@@ -1,0 +1,272 @@
+"""The Swin operators of csrc/swin.hip one by one through the C ABI (gdl_swin_*, gdl_conv_fwd_bias, gdl_head_concat_xy_*)
+against float64 restatements written here / oracle/swin_oracle.py's index helpers.  f32 storage: fp32-level agreement;
+bf16 storage: inputs are rounded to bf16 first, so the bounds only carry the output rounding and fp32 accumulation."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, L, bf16_round
+
+from oracle import swin_oracle as so
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(20260)
+DTS = ["f32", "bf16"]
+
+
+def _td(dt):
+    return torch.float32 if dt == "f32" else torch.bfloat16
+
+
+def _q(a, dt):
+    return a.astype(np.float32) if dt == "f32" else bf16_round(a.astype(np.float32))
+
+
+def _dev(a, dt):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(_td(dt))
+
+
+def _np(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+def _tol(dt, f32, bf16):
+    return f32 if dt == "f32" else bf16
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,C,ld", [(37, 96, 128), (1000, 192, 192), (9000, 384, 384), (70, 768, 768), (33, 1536, 1536)])
+def test_layernorm_fwd_bwd(dt, M, C, ld):
+    dc = L.dtype_code(dt)
+    x = np.zeros((M, ld), np.float32)
+    x[:, :C] = _q(rng.standard_normal((M, C)) * 1.5 + 0.3, dt)
+    dy = np.zeros((M, ld), np.float32)
+    dy[:, :C] = _q(rng.standard_normal((M, C)), dt)
+    add = _q(rng.standard_normal((M, ld)), dt)
+    add[:, C:] = 0
+    g = np.zeros(ld, np.float32)
+    b = np.zeros(ld, np.float32)
+    g[:C] = 1 + 0.1 * rng.standard_normal(C)
+    b[:C] = 0.1 * rng.standard_normal(C)
+    xd, dyd, addd = _dev(x, dt), _dev(dy, dt), _dev(add, dt)
+    gd, bd = torch.from_numpy(g).to(DEV), torch.from_numpy(b).to(DEV)
+    y = torch.full((M, ld), float("nan"), device=DEV, dtype=_td(dt))
+    stats = torch.empty((M, 2), device=DEV)
+    st = L.cur_stream()
+    L.call("gdl_swin_ln_fwd", dc, L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(y), L.ptr(stats), M, C, ld, st)
+    x64 = x[:, :C].astype(np.float64)
+    mu = x64.mean(1, keepdims=True)
+    var = ((x64 - mu) ** 2).mean(1, keepdims=True)
+    rstd = 1 / np.sqrt(var + 1e-5)
+    xh = (x64 - mu) * rstd
+    want = xh * g[:C] + b[:C]
+    got = _np(y)
+    assert np.abs(got[:, :C] - want).max() < _tol(dt, 2e-5, 4e-2) and np.all(got[:, C:] == 0)
+    np.testing.assert_allclose(_np(stats)[:, 0], mu[:, 0], atol=1e-5)
+    np.testing.assert_allclose(_np(stats)[:, 1], rstd[:, 0], rtol=1e-4)
+    dx = torch.full((M, ld), float("nan"), device=DEV, dtype=_td(dt))
+    dgb = torch.empty((2, ld), device=DEV)
+    part = torch.empty(L.load().gdl_swin_partial_bytes(ld), dtype=torch.uint8, device=DEV)
+    L.call("gdl_swin_ln_bwd", dc, L.ptr(dyd), L.ptr(xd), L.ptr(stats), L.ptr(gd), L.ptr(addd), L.ptr(dx), L.ptr(dgb), L.ptr(part), M, C,
+           ld, st)
+    gg = dy[:, :C].astype(np.float64) * g[:C]
+    want_dx = rstd * (gg - gg.mean(1, keepdims=True) - xh * (gg * xh).mean(1, keepdims=True)) + add[:, :C]
+    gdx = _np(dx)
+    assert np.abs(gdx[:, :C] - want_dx).max() < _tol(dt, 5e-5, 6e-2) * max(1.0, np.abs(want_dx).max())
+    assert np.all(gdx[:, C:] == 0)
+    dgam, dbet = (dy[:, :C].astype(np.float64) * xh).sum(0), dy[:, :C].astype(np.float64).sum(0)
+    sc = max(1.0, np.sqrt(M))
+    np.testing.assert_allclose(_np(dgb)[0, :C], dgam, atol=3e-5 * sc * 10)
+    np.testing.assert_allclose(_np(dgb)[1, :C], dbet, atol=3e-5 * sc * 10)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,ld", [(50, 128), (3000, 384), (700, 3072)])
+def test_bias_act_and_colsum(dt, M, ld):
+    dc = L.dtype_code(dt)
+    st = L.cur_stream()
+    y0 = _q(rng.standard_normal((M, ld)), dt)
+    bias = (0.3 * rng.standard_normal(ld)).astype(np.float32)
+    res = _q(rng.standard_normal((M, ld)), dt)
+    bd = torch.from_numpy(bias).to(DEV)
+    # mode 2: y + b + res
+    y = _dev(y0, dt)
+    L.call("gdl_swin_bias_act", dc, L.ptr(y), L.ptr(bd), None, L.ptr(_keep(_dev(res, dt))), M, ld, 2, st)
+    assert np.abs(_np(y) - (y0.astype(np.float64) + bias + res)).max() < _tol(dt, 1e-6, 3e-2)
+    # mode 1: u = y + b stored, y = gelu(u)
+    y, u = _dev(y0, dt), torch.empty((M, ld), device=DEV, dtype=_td(dt))
+    L.call("gdl_swin_bias_act", dc, L.ptr(y), L.ptr(bd), L.ptr(u), None, M, ld, 1, st)
+    uu = _np(u)
+    assert np.abs(uu - (y0.astype(np.float64) + bias)).max() < _tol(dt, 1e-6, 2e-2)
+    import math
+
+    erf = np.vectorize(math.erf)
+    assert np.abs(_np(y) - 0.5 * uu * (1 + erf(uu / math.sqrt(2)))).max() < _tol(dt, 2e-6, 2e-2)
+    # column sums, with and without the GELU derivative
+    gq = _q(rng.standard_normal((M, ld)), dt)
+    gdv = _dev(gq, dt)
+    db = torch.empty(ld, device=DEV)
+    part = torch.empty(L.load().gdl_swin_partial_bytes(ld), dtype=torch.uint8, device=DEV)
+    L.call("gdl_swin_colsum", dc, L.ptr(gdv), None, L.ptr(db), L.ptr(part), M, ld, st)
+    np.testing.assert_allclose(_np(db), gq.astype(np.float64).sum(0), atol=2e-4 * np.sqrt(M))
+    L.call("gdl_swin_colsum", dc, L.ptr(gdv), L.ptr(u), L.ptr(db), L.ptr(part), M, ld, st)
+    dgelu = 0.5 * (1 + erf(uu / math.sqrt(2))) + uu * np.exp(-0.5 * uu * uu) / math.sqrt(2 * math.pi)
+    want = gq.astype(np.float64) * dgelu
+    assert np.abs(_np(gdv) - want).max() < _tol(dt, 3e-6, 3e-2)
+    np.testing.assert_allclose(_np(db), _np(gdv).sum(0), atol=2e-4 * np.sqrt(M))
+
+
+_KEEP = []
+
+
+def _keep(t):
+    _KEEP.append(t)
+    del _KEEP[:-8]
+    return t
+
+
+def _attn_ref(qkv, table, n_img, H, W, ws, shift, nh, ld):
+    """float64 window attention on QKV rows [n_img*H*W][3*ld] via the oracle's index lists; returns out [rows][ld]."""
+    C = nh * 32
+    q = torch.from_numpy(qkv).double().reshape(n_img, H * W, 3, ld)[..., :C].reshape(n_img, H * W, 3, nh, 32).requires_grad_(True)
+    idx = so.window_tokens(H, W, ws, shift)
+    nW, T = idx.shape
+    g = q[:, idx.reshape(-1)].reshape(n_img, nW, T, 3, nh, 32)
+    qq, kk, vv = (g[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))
+    s = (qq * 32 ** -0.5) @ kk.transpose(-2, -1)
+    s = s + torch.from_numpy(table).double()[so.relative_index(ws).reshape(-1)].reshape(T, T, nh).permute(2, 0, 1)
+    if shift:
+        reg = so.window_regions(H, W, ws, shift)
+        s = s + torch.where(reg[:, :, None] != reg[:, None, :], -100.0, 0.0).double()[None, :, None]
+    o = (torch.softmax(s, -1) @ vv).permute(0, 1, 3, 2, 4).reshape(n_img, nW * T, C)
+    out = torch.zeros(n_img, H * W, C, dtype=torch.float64).index_add(1, idx.reshape(-1), o)
+    return q, out
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("H,ws,shift,nh", [(14, 7, 0, 3), (14, 7, 3, 3), (7, 7, 0, 6), (28, 7, 3, 3), (4, 2, 1, 2)])
+def test_window_attention(dt, H, ws, shift, nh):
+    dc = L.dtype_code(dt)
+    n_img, W, ld = 3, H, 128 if nh * 32 <= 128 else 192
+    C = nh * 32
+    rows = n_img * H * W
+    qkv = np.zeros((rows, 3, ld), np.float32)
+    qkv[:, :, :C] = _q(rng.standard_normal((rows, 3, C)), dt)
+    qkv = qkv.reshape(rows, 3 * ld)
+    table = (0.5 * rng.standard_normal(((2 * ws - 1) ** 2, nh))).astype(np.float32)
+    dout = np.zeros((rows, ld), np.float32)
+    dout[:, :C] = _q(rng.standard_normal((rows, C)), dt)
+    qd, td_, dd = _dev(qkv, dt), torch.from_numpy(table).to(DEV), _dev(dout, dt)
+    out = torch.full((rows, ld), float("nan"), device=DEV, dtype=_td(dt))
+    st = L.cur_stream()
+    L.call("gdl_swin_attn_fwd", dc, L.ptr(qd), L.ptr(td_), L.ptr(out), n_img, H, W, ws, shift, nh, ld, st)
+    qref, oref = _attn_ref(qkv, table, n_img, H, W, ws, shift, nh, ld)
+    got = _np(out).reshape(n_img, H * W, ld)
+    assert np.abs(got[..., :C] - oref.detach().numpy()).max() < _tol(dt, 3e-6, 3e-2) and np.all(got[..., C:] == 0)
+    dq = torch.full((rows, 3 * ld), float("nan"), device=DEV, dtype=_td(dt))
+    dtab = torch.empty_like(td_)
+    ws_b = torch.empty(max(L.load().gdl_swin_attn_bwd_workspace_bytes(n_img, H, W, ws, nh), 4), dtype=torch.uint8, device=DEV)
+    L.call("gdl_swin_attn_bwd", dc, L.ptr(qd), L.ptr(td_), L.ptr(dd), L.ptr(dq), L.ptr(dtab), L.ptr(ws_b), n_img, H, W, ws, shift, nh,
+           ld, st)
+    tt = torch.from_numpy(table).double().requires_grad_(True)
+    # gradients of the reference (table included): redo the forward with the table as a leaf
+    idx = so.window_tokens(H, W, ws, shift)
+    nW, T = idx.shape
+    g = qref[:, idx.reshape(-1)].reshape(n_img, nW, T, 3, nh, 32)
+    qq, kk, vv = (g[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))
+    s = (qq * 32 ** -0.5) @ kk.transpose(-2, -1) + tt[so.relative_index(ws).reshape(-1)].reshape(T, T, nh).permute(2, 0, 1)
+    if shift:
+        reg = so.window_regions(H, W, ws, shift)
+        s = s + torch.where(reg[:, :, None] != reg[:, None, :], -100.0, 0.0).double()[None, :, None]
+    o = (torch.softmax(s, -1) @ vv).permute(0, 1, 3, 2, 4).reshape(n_img, nW * T, C)
+    o2 = torch.zeros(n_img, H * W, C, dtype=torch.float64).index_add(1, idx.reshape(-1), o)
+    (o2 * torch.from_numpy(dout[:, :C].reshape(n_img, H * W, C)).double()).sum().backward()
+    want_dq = qref.grad.numpy().reshape(rows, 3, C)
+    gdq = _np(dq).reshape(rows, 3, ld)
+    sc = max(1.0, np.abs(want_dq).max())
+    assert np.abs(gdq[..., :C] - want_dq).max() < _tol(dt, 1e-5, 4e-2) * sc and np.all(gdq[..., C:] == 0)
+    np.testing.assert_allclose(_np(dtab), tt.grad.numpy(), atol=_tol(dt, 2e-4, 6e-2) * max(1.0, np.abs(tt.grad.numpy()).max()))
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_merge_tokenmean_pack(dt):
+    dc = L.dtype_code(dt)
+    st = L.cur_stream()
+    N, H, W, C, ld = 2, 6, 4, 96, 128
+    x = np.zeros((N, H, W, ld), np.float32)
+    x[..., :C] = _q(rng.standard_normal((N, H, W, C)), dt)
+    xd = _dev(x.reshape(-1, ld), dt)
+    cat = torch.empty((N * H * W // 4, 4 * C), device=DEV, dtype=_td(dt))
+    L.call("gdl_swin_merge", dc, L.ptr(xd), L.ptr(cat), N, H, W, C, ld, 0, st)
+    g = x[..., :C].reshape(N, H // 2, 2, W // 2, 2, C)
+    want = np.concatenate([g[:, :, 0, :, 0], g[:, :, 1, :, 0], g[:, :, 0, :, 1], g[:, :, 1, :, 1]], -1).reshape(-1, 4 * C)
+    np.testing.assert_array_equal(_np(cat), want)
+    back = torch.full((N * H * W, ld), float("nan"), device=DEV, dtype=_td(dt))
+    L.call("gdl_swin_merge", dc, L.ptr(cat), L.ptr(back), N, H, W, C, ld, 1, st)
+    np.testing.assert_array_equal(_np(back), x.reshape(-1, ld))  # the adjoint of a permutation is its inverse
+    feat = torch.empty((N, C), device=DEV)
+    L.call("gdl_swin_token_mean", dc, L.ptr(xd), L.ptr(feat), N, H * W, C, ld, st)
+    np.testing.assert_allclose(_np(feat), x[..., :C].astype(np.float64).reshape(N, -1, C).mean(1), atol=1e-6)
+    dfe = torch.from_numpy(rng.standard_normal((N, C)).astype(np.float32)).to(DEV)
+    dx = torch.full((N * H * W, ld), float("nan"), device=DEV, dtype=_td(dt))
+    L.call("gdl_swin_token_mean_bwd", dc, L.ptr(dfe), L.ptr(dx), N, H * W, C, ld, st)
+    wantdx = np.zeros((N, H * W, ld))
+    wantdx[..., :C] = (_np(dfe) / (H * W))[:, None, :]
+    assert np.abs(_np(dx).reshape(N, H * W, ld) - wantdx).max() < _tol(dt, 1e-7, 5e-3)
+    # QKV-style packing: 3 segments of 96 rows -> pitch 128, columns 96 -> 128; transposed copy; and back
+    w = rng.standard_normal((288, 96)).astype(np.float32)
+    wd = torch.from_numpy(w).to(DEV)
+    pk, pkT = torch.full((384, 128), float("nan"), device=DEV, dtype=_td(dt)), torch.full((128, 384), float("nan"), device=DEV, dtype=_td(dt))
+    L.call("gdl_swin_pack_matrix", dc, L.ptr(wd), L.ptr(pk), L.ptr(pkT), 288, 96, 96, 128, 96, 128, st)
+    wantp = np.zeros((3, 128, 128))
+    wantp[:, :96, :96] = _q(w, dt).reshape(3, 96, 96)
+    np.testing.assert_array_equal(_np(pk), wantp.reshape(384, 128))
+    np.testing.assert_array_equal(_np(pkT), wantp.reshape(384, 128).T)
+    if dt == "f32":
+        rt = torch.empty((288, 96), device=DEV)
+        L.call("gdl_swin_unpack_matrix", L.ptr(pk), L.ptr(rt), 288, 96, 96, 128, 96, 128, st)
+        np.testing.assert_array_equal(_np(rt), w)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_linear_with_bias_and_residual(dt):
+    """gdl_conv_fwd_bias as an nn.Linear: y = x W^T + b + res on padded rows (1x1 convolution of the library)."""
+    from gpu_util import gather_table
+
+    dc = L.dtype_code(dt)
+    M, K, N = 777, 128, 384
+    x, w = _q(rng.standard_normal((M, K)), dt), _q(rng.standard_normal((N, K)) * 0.1, dt)
+    b = rng.standard_normal(N).astype(np.float32)
+    res = _q(rng.standard_normal((M, N)), dt)
+    tab = gather_table(L.GATHER_FWD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    y = torch.empty((M, N), device=DEV, dtype=_td(dt))
+    xd, wd, rd, bd = _dev(x, dt), _dev(w, dt), _dev(res, dt), torch.from_numpy(b).to(DEV)
+    L.call("gdl_conv_fwd_bias", dc, L.ptr(xd), L.ptr(wd), L.ptr(y), L.ptr(bd), L.ptr(rd), L.ptr(tab), M, 1, 1, K, N, 1, 1, 1, 0,
+           L.cur_stream())
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b + res
+    assert np.abs(_np(y) - want).max() < _tol(dt, 2e-5, 6e-2)
+
+
+def test_head_concat_xy():
+    """The concat DGL head at 512 + 768 features against the float64 formulas of fusion_modules.py:51-59 and their
+    autograd with the DGL truncation flags."""
+    B, n, dx_, dy_ = 5, 7, 512, 768
+    x, y = rng.standard_normal((B, dx_)).astype(np.float32), rng.standard_normal((B, dy_)).astype(np.float32)
+    W, b = (0.05 * rng.standard_normal((n, dx_ + dy_))).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    gx, gy, go = (rng.standard_normal((B, n)).astype(np.float32) for _ in range(3))
+    t = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
+    xd, yd, Wd, bd, gxd, gyd, god = map(t, (x, y, W, b, gx, gy, go))
+    out, xo, yo = (torch.empty((B, n), device=DEV) for _ in range(3))
+    st = L.cur_stream()
+    L.call("gdl_head_concat_xy_fwd", L.ptr(xd), L.ptr(yd), L.ptr(Wd), L.ptr(bd), L.ptr(out), L.ptr(xo), L.ptr(yo), B, n, dx_, dy_, st)
+    pa, pv = x.astype(np.float64) @ W[:, :dx_].T.astype(np.float64), y.astype(np.float64) @ W[:, dx_:].T.astype(np.float64)
+    np.testing.assert_allclose(_np(out), pa + pv + b, atol=1e-4)
+    np.testing.assert_allclose(_np(xo), pa + b, atol=1e-4)
+    np.testing.assert_allclose(_np(yo), pv + b, atol=1e-4)
+    dxd, dyd, dW, db = torch.empty_like(xd), torch.empty_like(yd), torch.empty_like(Wd), torch.empty_like(bd)
+    L.call("gdl_head_concat_xy_bwd", L.ptr(xd), L.ptr(yd), L.ptr(Wd), L.ptr(gxd), L.ptr(gyd), L.ptr(god), 0, 0, L.ptr(dxd), L.ptr(dyd),
+           L.ptr(dW), L.ptr(db), B, n, dx_, dy_, st)  # the DGL step: features see only the unimodal losses, fc_out only loss_f
+    np.testing.assert_allclose(_np(dxd), gx.astype(np.float64) @ W[:, :dx_], atol=1e-4)
+    np.testing.assert_allclose(_np(dyd), gy.astype(np.float64) @ W[:, dx_:], atol=1e-4)
+    np.testing.assert_allclose(_np(dW), go.astype(np.float64).T @ np.concatenate([x, y], 1), atol=1e-4)
+    np.testing.assert_allclose(_np(db), go.astype(np.float64).sum(0), atol=1e-5)
