@@ -337,9 +337,19 @@ def test_maxpool(N, H, W, dt):
     gotb = from_nhwc(dxd)
     if dt == L.GDL_F32:
         np.testing.assert_allclose(gotb * mask, dref * mask, rtol=1e-5, atol=1e-6)
-    else:  # bf16 ties between positive neighbours may route differently; totals must still agree
-        np.testing.assert_allclose(gotb.sum((2, 3)), quant(dref, dt).sum((2, 3)), rtol=5e-2, atol=0.3)
-        assert relerr(gotb * mask, dref * mask) < 0.15
+    else:
+        # bf16: ties between equal rounded neighbours may route to another position than the oracle's first maximum, so
+        # the exact check is against the DEVICE's own routing: scatter dout by the stored window codes (r*3+s) in float64
+        # and round once -- every input position must agree to one bf16 ulp (up to four gradients meet in one position)
+        want = np.zeros((N, H, W, C), np.float64)
+        dn = np.transpose(dout, (0, 2, 3, 1)).astype(np.float64)
+        nn_, cc_ = np.arange(N)[:, None, None, None], np.arange(C)[None, None, None, :]
+        ih_raw, iw_raw = 2 * pp[None, :, :, None] - 1 + code // 3, 2 * qq[None, :, :, None] - 1 + code % 3
+        assert ih_raw.min() >= 0 and ih_raw.max() < H and iw_raw.min() >= 0 and iw_raw.max() < W  # codes point inside the image
+        np.add.at(want, (np.broadcast_to(nn_, code.shape), ih_raw, iw_raw, np.broadcast_to(cc_, code.shape)), dn)
+        got_nhwc = np.transpose(gotb, (0, 2, 3, 1)).astype(np.float64)
+        np.testing.assert_allclose(got_nhwc, want, rtol=2.0 ** -7, atol=1e-6)
+        np.testing.assert_allclose(gotb.sum((2, 3)), quant(dref, dt).sum((2, 3)), rtol=2e-2, atol=0.1)  # and the totals vs the oracle
 
 
 @pytest.mark.parametrize("dt", DTS)
