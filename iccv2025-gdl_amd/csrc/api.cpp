@@ -65,10 +65,10 @@ int gdl_conv_dgrad_relu(int dtype, const void* dy, const void* w_crsk, void* dx,
     GDL_REQUIRE(dy && w_crsk && dx && relu_bits, "conv_dgrad_relu: null pointer");
     return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits);
 }
-int gdl_conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend,
+int gdl_conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend, void* gelu_out,
                       const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
     GDL_REQUIRE(x && w_krsc && y, "conv_fwd_bias: null pointer");
-    return conv_fwd_bias(dtype, x, w_krsc, y, bias, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+    return conv_fwd_bias(dtype, x, w_krsc, y, bias, addend, gelu_out, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
 }
 int gdl_conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
                       const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, void* stream) {

@@ -40,6 +40,7 @@ struct ConvArgs {
     void* out;                 // NHWC rows of OC channels, row m = GEMM row m
     const void* addend;        // optional, like out
     const float* bias;         // optional [OC] float32, added with the addend (nn.Linear bias of the Swin GEMMs)
+    void* gelu_out;            // optional, like out: out keeps the (biased) value u, gelu_out gets gelu(u) (Swin Mlp.fc1 + act)
     const uint8_t* relu_bits;  // optional: one byte per 16-byte vector of out; the stored value is zeroed where its bit is 0
     float* stats;              // optional [mtiles][OC][2]
     const GatherEntry* table;  // [M]
@@ -270,6 +271,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             }
         }
         *(uint4*)(gout + goff) = v;
+        if (a.gelu_out) {  // exact GELU of the value as stored
+            float f[EPC];
+            unpack16<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) f[e] = 0.5f * f[e] * (1.f + erff(f[e] * 0.70710678118654752f));
+            *(uint4*)((T*)a.gelu_out + goff) = pack16<T>(f);
+        }
     }
     if (a.stats) {
         // lanes with equal (lane % CH) hold the same channels: fold them, then fold the 4 waves in fixed order
@@ -1106,7 +1114,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
                     const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
-                    const float* bias = nullptr) {
+                    const float* bias = nullptr, void* gelu_out = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1124,6 +1132,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     a.out = out;
     a.addend = addend;
     a.bias = bias;
+    a.gelu_out = gelu_out;
     a.relu_bits = relu_bits;
     a.stats = stats;
     a.table = (const GatherEntry*)table;
@@ -1274,10 +1283,10 @@ int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const vo
 }
 
 // forward with the epilogue's bias / residual: y = conv(x, w) + bias (+ addend), each optional (the Swin Linears)
-int conv_fwd_bias(int dtype, const void* x, const void* w, void* y, const float* bias, const void* addend, const void* table, int N,
-                  int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
+int conv_fwd_bias(int dtype, const void* x, const void* w, void* y, const float* bias, const void* addend, void* gelu_out,
+                  const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
     return run_conv(GATHER_FWD, dtype, x, w, y, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr, nullptr, nullptr,
-                    nullptr, nullptr, bias);
+                    nullptr, nullptr, bias, gelu_out);
 }
 
 int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,

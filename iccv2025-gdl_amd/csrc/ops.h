@@ -32,8 +32,8 @@ int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
              int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold = nullptr,
              const BnFinTrain* bn = nullptr);
-int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend, const void* table,
-                  int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
+int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend, void* gelu_out,
+                  const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr);

@@ -29,7 +29,7 @@ SIGNATURES = {
     "gdl_conv_dgrad": ("i", "ippppp" + "iiiiiiiii" + "p"),
     "gdl_bn_act_bits": ("i", "ippp" + "ppp" + "pp" + "zi" + "p"),
     "gdl_conv_dgrad_relu": ("i", "ipppppp" + "iiiiiiiii" + "p"),
-    "gdl_conv_fwd_bias": ("i", "ipppppp" + "iiiiiiiii" + "p"),
+    "gdl_conv_fwd_bias": ("i", "ippppppp" + "iiiiiiiii" + "p"),
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
     "gdl_comm_unique_id": ("i", "p"),
     "gdl_comm_init": ("i", "piip"),

@@ -67,10 +67,11 @@ class _Linear:
                1, self.kp, self.np, 1, 1, 1, 0, st)
 
     # y = x . w^T + b (+ res): bias and residual in the GEMM's epilogue
-    def fwd_bias(self, x, y, res, M, st):
+    def fwd_bias(self, x, y, res, M, st, gelu_out=None):
         e = self.eng
         L.call("gdl_conv_fwd_bias", e.dt, L.ptr(x), L.ptr(self.w), L.ptr(y), L.ptr(self.b), L.ptr(res) if res is not None else None,
-               L.ptr(e.table(L.GATHER_FWD, M, self.kp, self.np)), M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
+               L.ptr(gelu_out) if gelu_out is not None else None, L.ptr(e.table(L.GATHER_FWD, M, self.kp, self.np)), M, 1, 1, self.kp,
+               self.np, 1, 1, 1, 0, st)
 
     # dx[M][kp] = dy[M][np] . w
     def dgrad(self, dy, dx, M, st):
@@ -347,8 +348,7 @@ class SwinEngine:
                        b["shift"], s["nh"], ld, st)
                 b["proj"].fwd_bias(b["attn"], b["x_mid"], xcur, M, st)
                 b["norm2"].fwd(b["x_mid"], b["m"], b["stats2"], M, st)
-                b["fc1"].fwd(b["m"], b["a"], M, st)
-                L.call("gdl_swin_bias_act", dt, L.ptr(b["a"]), L.ptr(b["fc1"].b), L.ptr(b["u"]), None, M, b["fc1"].np, 1, st)
+                b["fc1"].fwd_bias(b["m"], b["u"], None, M, st, gelu_out=b["a"])  # u = fc1(m) + b, a = gelu(u)
                 b["fc2"].fwd_bias(b["a"], b["x_out"], b["x_mid"], M, st)
                 xcur = b["x_out"]
             if "red" in s:

@@ -80,11 +80,12 @@ GDL_API int gdl_bn_act_bits(int dtype, const void* y, const float* scale, const 
 GDL_API int gdl_conv_dgrad_relu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
                                 const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
                                 int stride, int pad, void* stream);
-/* gdl_conv_fwd with the epilogue's optional extras: y = conv(x, w) + bias[K] (float32) + addend (like y) -- nn.Linear with its
- * bias and the residual connection of a Swin block in one launch (swin_transformer.py:150-152, 287-290), R = S = 1. */
+/* gdl_conv_fwd with the epilogue's optional extras: y = conv(x, w) + bias[K] (float32) + addend (like y), and
+ * gelu_out = gelu(y) (exact erf form, of the value as stored) -- nn.Linear with its bias, the residual connection of a Swin
+ * block, Mlp.fc1 + act in one launch (swin_transformer.py:26-42, 150-152, 287-290), R = S = 1. */
 GDL_API int gdl_conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend,
-                              const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                              void* stream);
+                              void* gelu_out, const void* table, int N, int H, int W, int C, int K, int R, int S, int stride,
+                              int pad, void* stream);
 /* First block of layers 2-4 (backbone.py:119-124, 141-146: conv1 is 3x3 stride 2, the shortcut a 1x1 stride-2 conv +
  * BatchNorm): the gradient of the block input is the sum of two data gradients,
  *   dx = conv1^T(dy [N][P][Q][K], w_crsk [C][3][3][K]) + downsample^T(dy_ds [N][P][Q][K], w_ds_ck [C][K]),

@@ -241,10 +241,15 @@ def test_linear_with_bias_and_residual(dt):
     tab = gather_table(L.GATHER_FWD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
     y = torch.empty((M, N), device=DEV, dtype=_td(dt))
     xd, wd, rd, bd = _dev(x, dt), _dev(w, dt), _dev(res, dt), torch.from_numpy(b).to(DEV)
-    L.call("gdl_conv_fwd_bias", dc, L.ptr(xd), L.ptr(wd), L.ptr(y), L.ptr(bd), L.ptr(rd), L.ptr(tab), M, 1, 1, K, N, 1, 1, 1, 0,
-           L.cur_stream())
+    ge = torch.empty((M, N), device=DEV, dtype=_td(dt))
+    L.call("gdl_conv_fwd_bias", dc, L.ptr(xd), L.ptr(wd), L.ptr(y), L.ptr(bd), L.ptr(rd), L.ptr(ge), L.ptr(tab), M, 1, 1, K, N, 1, 1, 1,
+           0, L.cur_stream())
     want = x.astype(np.float64) @ w.astype(np.float64).T + b + res
     assert np.abs(_np(y) - want).max() < _tol(dt, 2e-5, 6e-2)
+    import math
+
+    yy = _np(y)
+    assert np.abs(_np(ge) - 0.5 * yy * (1 + np.vectorize(math.erf)(yy / math.sqrt(2)))).max() < _tol(dt, 3e-6, 3e-2)
 
 
 def test_head_concat_xy():
