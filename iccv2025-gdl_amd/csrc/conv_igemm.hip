@@ -834,6 +834,330 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
 #endif
 }
 
+// =====================================================================================================
+// 3x3 stride-1 convolution between 64 and 64 channels (layer 1 of both encoders: forward and data gradient; bf16),
+// persistent, weights in registers.
+//
+// With 64 input channels the slab kernel's K-loop is 9 K-steps: its blocks spend half their life in the prologue (slab
+// DMA from HBM) and the epilogue, and every K-step pays a barrier, a weight-tile DMA and 6 fragment reads per 8 MFMAs
+// (tools/timing_probe.py: 21 % MFMA duty per wave, the LDS array the busiest unit).  Here the WHOLE filter of a wave's
+// 32 output channels (9 taps x 64 channels = 36 MFMA operands, 144 VGPRs) is loaded once and stays in registers, a block
+// walks over M-tiles, and the next tile's slab is in flight (LDS-DMA into the other slab buffer) while the current one is
+// multiplied: no weight traffic, no barrier and no DMA inside a tile's K-loop, 4 fragment reads per 8 MFMAs, HBM latency
+// hidden.  4 waves = 2 (64-pixel halves) x 2 (32-channel halves) of a 128 x 64 tile, two blocks per CU.
+// Per tile: K-loop | barrier | accumulators -> LDS (over the slab just consumed) | barrier | wait for the prefetched
+// slab | rows -> HBM (addend / ReLU bits / statistics as in conv_epilogue) | barrier.  The tile's stores are only waited
+// for one tile later.  BatchNorm statistics accumulate in registers ACROSS the block's tiles; the block leaves ONE
+// partial row (stats[blockIdx.x][64][2]): conv_tiles_m() reports C64_GRID rows for these layers.
+// LDS: [slab 0][slab 1][1 KiB of zeros][statistics accumulators, 16 KiB].
+// =====================================================================================================
+constexpr int C64_BM = 128;
+constexpr int C64_GRID = 512;  // two blocks per CU of an MI355X; also the number of BatchNorm partial rows
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = C64_BM, PITCH = 64 * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int frow = lane & 15, fg = lane >> 4;
+    GDL_STAMP(0);
+    // tiles of this block: XCD x owns a contiguous range, its blocks take every (gridDim/8)-th tile of it
+    const int xcd = blockIdx.x & 7, bj = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int mt_per_xcd = (a.mtiles + 7) >> 3;
+    const int t_end = min(a.mtiles, (xcd + 1) * mt_per_xcd);
+    int tile = xcd * mt_per_xcd + bj;
+    const int nins = (a.slab_rows + 7) >> 3;
+    const int slab_bytes = nins * 1024;
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned zrow = smem_base + 2 * slab_bytes;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+
+    // this wave's filter: operand (tap, 32-channel half h, 16-output-channel fragment n) = 8 input channels
+    // h*32 + fg*8.. of output channel wn*32 + n*16 + frow
+    // The 72 KiB filter comes through LDS ONCE per block (72 DMA pieces, a straight copy of [oc][tap][64 c]) and each wave picks
+    // its 36 operands from there: four waves fetching them from L2 themselves asked the same 576 lines 8 times per CU, and with
+    // every block of the launch starting at once that request rate, not the bytes, made the prologue 18 000 clk.
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t wreg[9][2][2];
+    {
+        const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+        for (int p = wave; p < 72; p += 4) dma16(rwt, smem + p * 1024, p * 1024 + lane * 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const unsigned ad = smem_base + ((wn * 32 + n * 16 + frow) * 9 + tap) * 128 + (h * 4 + fg) * 16;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(wreg[tap][h][n]) : "v"(ad));
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (wave == 0) dma16(rin, smem + 2 * slab_bytes, (int)0x80000000);  // out-of-range LDS-DMA deposits zeros
+    auto load_slab = [&](int sbuf, int m0) {
+        unsigned char* dst = smem + sbuf * slab_bytes;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // the row / chunk terms are recomputed here, not kept in registers across the K-loop
+        for (int jj = wave; jj < nins; jj += 4) {
+            const int sr = jj * 8 + (ln >> 3);
+            const int pix = m0 - (a.W + 1) + sr;
+            const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.in_pixels;
+            const int v = ok ? pix * 128 + (((ln & 7) ^ ((sr >> 1) & 7)) << 4) : (int)0x80000000;
+            dma16(rin, dst + jj * 1024, v);
+        }
+    };
+    auto load_masks = [&](int m0, unsigned (&fm)[4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int mm = m0 + wm * 64 + m * 16 + frow;
+            fm[m] = mm < a.M ? a.table[mm].mask : 0u;
+        }
+    };
+    const int prow0 = wm * 64 + frow + (a.W + 1);
+    // a masked (padding) tap reads zeros: any 16 bytes of the zero KiB will do, so the address is wave-uniform (a scalar
+    // operand of the select); pre-biased by the instruction offset 2048*m of fragment m
+    unsigned zb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) zb[m] = zrow - 2048u * m;
+    // epilogue mapping: thread -> 16-byte chunk ec of rows er0 + 32*p
+    const int ec = tid & 7, er0 = tid >> 3;
+    // BatchNorm statistics of the thread's 8 channels, accumulated across the block's tiles in LDS ([16][256] floats behind
+    // the zero row: 16 registers fewer in the K-loop, which sits at the 256-register limit of two waves per SIMD)
+    float* sacc = (float*)(smem + 2 * slab_bytes + 1024);
+    if (a.stats) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e * 256 + tid] = 0.f;
+    }
+    bf16* __restrict__ gout = (bf16*)a.out;
+    const bf16* __restrict__ gadd = (const bf16*)a.addend;
+
+    unsigned fmask[4] = {0u, 0u, 0u, 0u};
+    if (tile < t_end) {
+        load_slab(0, tile * BM);
+        load_masks(tile * BM, fmask);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // (a use the compiler can see: it places its own wait for the filter loads HERE, not in front of the first MFMA of
+    // every tile -- where it would also wait for the slab prefetch issued just before)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) asm volatile("" : "+v"(wreg[tap][h][n]));
+    asm volatile("" : "+v"(fmask[0]), "+v"(fmask[1]), "+v"(fmask[2]), "+v"(fmask[3]));
+#ifdef GDL_TIMING
+    unsigned long long tq_a, tq_b, tq[7] = {0, 0, 0, 0, 0, 0, 0};
+    int tq_n = 0;
+#define C64_SEG(i)                       \
+    tq_b = __builtin_amdgcn_s_memtime(); \
+    tq[i] += tq_b - tq_a;                \
+    tq_a = tq_b;
+    GDL_STAMP(1);
+#else
+#define C64_SEG(i)
+#endif
+    for (int it = 0; tile < t_end; ++it, tile += bpx) {
+#ifdef GDL_TIMING
+        tq_a = __builtin_amdgcn_s_memtime();
+        ++tq_n;
+#endif
+        const int m0 = tile * BM;
+        const bool more = tile + bpx < t_end;
+        if (more) {  // the other slab buffer is free: every wave is past its row reads of the tile before (barrier)
+            load_slab((it + 1) & 1, (tile + bpx) * BM);
+        }
+        C64_SEG(0)
+        const unsigned slab = smem_base + (it & 1) * slab_bytes;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // 18 half-steps (tap, 32-channel half); the pixel fragments of half-step s+1 are requested before the MFMAs of s
+        uint4 px[2][4];
+        unsigned pb[4];
+        auto tap_addr = [&](int tap) __attribute__((always_inline)) {
+            const int sr0 = prow0 + a.pshift[tap];
+            const unsigned ad0 = slab + sr0 * 128 + ((fg ^ ((sr0 >> 1) & 7)) << 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) pb[m] = ((fmask[m] >> tap) & 1u) ? ad0 : zb[m];
+        };
+        auto reads = [&](uint4 (&p)[4]) __attribute__((always_inline)) {
+            p[0] = lds_read16_asm_off<0>(pb[0]);
+            p[1] = lds_read16_asm_off<2048>(pb[1]);
+            p[2] = lds_read16_asm_off<4096>(pb[2]);
+            p[3] = lds_read16_asm_off<6144>(pb[3]);
+        };
+        tap_addr(0);
+        reads(px[0]);
+#pragma unroll
+        for (int hs = 0; hs < 18; ++hs) {
+            const int tap = hs >> 1, h = hs & 1;
+            if (hs + 1 < 18) {
+                if (h == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) pb[m] ^= 64u;  // the second 32-channel half: chunk ^ 4
+                } else {
+                    tap_addr(tap + 1);
+                }
+                reads(px[(hs + 1) & 1]);
+                lds_wait_n<4>();
+            } else {
+                lds_wait();
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[tap][h][n]),
+                                                                       __builtin_bit_cast(bf16x8_t, px[hs & 1][m]), acc[n][m], 0, 0, 0);
+        }
+        C64_SEG(1)
+        if (more) load_masks((tile + bpx) * BM, fmask);  // the next tile's tap masks (waited for with the slab below)
+        // the addend / ReLU-bit loads of the tile's four row passes: in flight while the tile is staged
+        uint4 gq[4];
+        unsigned mkq[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + er0 + p * 32;
+            const size_t goff = (size_t)m * 64 + ec * 8;
+            gq[p] = make_uint4(0u, 0u, 0u, 0u);
+            mkq[p] = 0xffu;
+            if (m < a.M) {
+                if (gadd) gq[p] = *(const uint4*)(gadd + goff);
+                if (a.relu_bits) mkq[p] = a.relu_bits[goff / 8];
+            }
+        }
+        // every wave is done with this slab: the tile is staged over it, [128][64] bf16 at a 144-byte pitch
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        C64_SEG(2)
+        unsigned char* Cs = smem + (it & 1) * slab_bytes;
+        {
+            // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15
+            // (stores the compiler cannot see: in front of a visible LDS store it would wait, vmcnt(0), for the slab prefetch
+            // AND for the addend loads issued just above)
+            const int px_row = wm * 64 + (lane & 15), ch = wn * 32 + (lane >> 4) * 4;
+            const unsigned cs0 = slab + px_row * PITCH + ch * 2;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint2 v = make_uint2(pack2bf(acc[n][m][0], acc[n][m][1]), pack2bf(acc[n][m][2], acc[n][m][3]));
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(cs0), "v"(v), "n"(m * 16 * PITCH + n * 32) : "memory");
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        C64_SEG(3)
+        // the prefetched slab and masks have landed (they had the whole K-loop); the stores of the tile before are done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C64_SEG(4)
+        // (tells the compiler the masks are here: it would otherwise wait for them -- and with them for the slab prefetch just
+        // issued -- at their first use in the next tile's K-loop)
+        asm volatile("" : "+v"(fmask[0]), "+v"(fmask[1]), "+v"(fmask[2]), "+v"(fmask[3]));
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+        uint4 vq[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = er0 + p * 32;
+            uint4 v = *(const uint4*)(Cs + row * PITCH + ec * 16);
+            if (gadd) {
+                float f[8], g[8];
+                unpack16<bf16>(v, f);
+                unpack16<bf16>(gq[p], g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += g[e];
+                v = pack16<bf16>(f);
+            }
+            if (a.relu_bits) {
+                const unsigned mk = mkq[p];
+                float f[8];
+                unpack16<bf16>(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
+                v = pack16<bf16>(f);
+            }
+            if (a.stats && m0 + row < a.M) {
+                float f[8];
+                unpack16<bf16>(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ssum[e] += f[e];
+                    ssq[e] += f[e] * f[e];
+                }
+            }
+            vq[p] = v;
+        }
+        // the four stores back to back (a load between two stores would wait for the first)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int m = m0 + er0 + p * 32;
+            if (m < a.M) *(uint4*)(gout + (size_t)m * 64 + ec * 8) = vq[p];
+        }
+        if (a.stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sacc[e * 256 + tid] += ssum[e];  // (read-modify-write: ds_add_f32 measured 5x slower here)
+                sacc[(8 + e) * 256 + tid] += ssq[e];
+            }
+        }
+        C64_SEG(5)
+        __syncthreads();  // the staged tile has been read: its buffer is the next prefetch's target
+        C64_SEG(6)
+    }
+#ifdef GDL_TIMING
+    GDL_STAMP(2);
+    if (a.dbg && threadIdx.x == 0) {
+        unsigned long long* d = a.dbg + ((size_t)(1 << 15) + blockIdx.x) * 8;
+        for (int i = 0; i < 7; ++i) d[i] = tq[i];
+        d[7] = tq_n;
+    }
+#endif
+    if (a.stats) {
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ssum[e] = sacc[e * 256 + tid];
+            ssq[e] = sacc[(8 + e) * 256 + tid];
+        }
+        // lanes with equal (lane & 7) hold the same 8 channels: fold them, then the 4 waves in fixed order
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            for (int msk = 8; msk < 64; msk <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], msk);
+                ssq[e] += __shfl_xor(ssq[e], msk);
+            }
+        float* red = (float*)smem;  // [4 waves][64][2]
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 64 + lane * 8 + e) * 2 + 0] = ssum[e];
+                red[(wave * 64 + lane * 8 + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid >> 1, w = tid & 1;
+            const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
+                             red[(3 * 64 + c) * 2 + w];
+            st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
+        }
+    }
+    GDL_STAMP(3);
+}
+
 static size_t slab_lds_bytes(int BM, int BN, int W, int IC, int dtype, bool single = false) {
     const int bke = dtype == GDL_BF16 ? 64 : 32, esz = dtype == GDL_BF16 ? 2 : 4;
     const int rows = BM + 2 * W + 2;
@@ -934,7 +1258,20 @@ struct ConvPlan {
     int bm, bn;
     size_t lds;
     int single;  // slab kernel: one slab buffer
+    int c64;     // 1: conv3x3_c64_kernel (persistent; BatchNorm partial rows = C64_GRID)
 };
+static size_t c64_lds_bytes(int W) {
+    const size_t b = 2 * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024 + 16 * 256 * 4;
+    return b > (size_t)72 * 1024 ? b : (size_t)72 * 1024;  // the prologue stages the 72 KiB filter through the same LDS
+}
+static bool c64_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_C64");  // tuning aid: 0 = the slab kernel for the 64 -> 64 channel layers too
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
 static int slab_cfg() {
     static int v = -1;
     if (v < 0) {
@@ -961,7 +1298,7 @@ static long slab_bn128_min() {
     }
     return v;
 }
-static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad) {
+static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_c64 = true) {
     ConvPlan p{};
     static int noslab = -1;
     if (noslab < 0) {
@@ -977,6 +1314,14 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     // Kinetics-Sounds shapes) still runs better on it with one block per CU than on the flat kernel (+0.7 % of that step)
     // tuning aid: GDL_PLAN="M:OC:BM:BN,..." forces the slab tile of the stride-1 3x3 layers with that many GEMM rows and
     // output channels (forward and data gradient share it); tools/plan_search.py walks it
+    // 64 -> 64 channels (layer 1): the persistent weights-in-registers kernel, two blocks per CU (80 KB of LDS each at most;
+    // the staged output tile, 128 x 144 bytes, has to fit into one slab buffer)
+    if (allow_c64 && !noslab && c64_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && IC == 64 && OC == 64 &&
+        c64_lds_bytes(W) <= (size_t)80 * 1024 && (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 >= (size_t)C64_BM * 144 &&
+        M >= 64 * C64_BM) {
+        p.slab = 1, p.c64 = 1, p.bm = C64_BM, p.bn = 64, p.lds = c64_lds_bytes(W);
+        return p;
+    }
     if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
         static const char* plan_env = tune_env("GDL_PLAN");
         for (const char* q = plan_env; q && *q;) {
@@ -1075,8 +1420,28 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     return p;
 }
 
+template <int MODE>
+static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
+    a.mtiles = ceil_div(a.M, C64_BM);
+    GDL_REQUIRE(!a.fold.ctr && !a.bias && !a.gelu_out && !a.orow, "conv: unsupported option for the 64-channel persistent kernel");
+    auto kfn = conv3x3_c64_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_c64)");
+        attr_set = true;
+    }
+    static char pname[64] = "";
+    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_c64_kernel<%d>", MODE);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
+    hipExtLaunchKernelGGL(kfn, dim3(C64_GRID), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
+    GDL_CHECK_LAUNCH("conv3x3_c64_kernel");
+    return GDL_OK;
+}
+
 template <typename T, int MODE>
 static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
+    if (pl.c64) return launch_c64<MODE>(a, pl.lds, st);
     if (pl.slab) {
         if constexpr (std::is_same<T, bf16>::value)
             if (pl.bn == 128 && pl.bm == 256) return launch_slab<T, 256, 128, MODE>(a, pl.lds, st);
@@ -1096,7 +1461,7 @@ static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
     const ConvPlan pl = plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad);
-    return ceil_div(N * P * Q, pl.bm);
+    return pl.c64 ? C64_GRID : ceil_div(N * P * Q, pl.bm);
 }
 
 // M-tile of a data gradient (the permuted stride-2 table is laid out for it)
@@ -1153,7 +1518,8 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     GDL_REQUIRE(a.OC % 64 == 0, "conv: output channels %d not a multiple of 64", a.OC);
     GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
     // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
-    const ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
+    ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
+    if (pl.c64 && fold && fold->ctr) pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad, false);  // (the fold wants one partial row per M-tile)
     a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction
     if (fold && fold->ctr) {
         GDL_REQUIRE(stats && bn && mode == GATHER_FWD && fold_fits(ceil_div(a.M, pl.bm), a.OC) && a.OC / pl.bn <= FOLD_NCG,

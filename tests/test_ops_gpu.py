@@ -502,7 +502,7 @@ def _fold_ws():
 FOLD_CONV = [
     # N, C, H, W, K, R, stride, pad -- rows (M-tiles) x column groups of the fold
     (2, 64, 17, 13, 64, 3, 1, 1),      # one group, one column group
-    (24, 64, 56, 56, 64, 3, 1, 1),     # 588 rows: 10 groups, ragged last group
+    (24, 64, 56, 56, 128, 3, 1, 1),    # several groups, ragged last group (64 -> 64 channels run the persistent kernel: no fold)
     (16, 128, 28, 28, 256, 3, 1, 1),   # 128-channel tiles: two column groups
     (16, 64, 65, 47, 128, 3, 2, 1),    # flat kernel, stride 2
     (48, 512, 7, 7, 512, 3, 1, 1),     # few rows, four column groups

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--shape", default="192,64,56,56,64,3,1,1")
     ap.add_argument("--op", default="fwd")
     ap.add_argument("--names", default="entry,issued,landed,kloop_end,kloop_end2,end")
+    ap.add_argument("--c64", action="store_true", help="the 64-channel persistent kernel's per-tile phases (use --names entry,loop,loop_end,end)")
     a = ap.parse_args()
     N, C, H, W, K, R, stride, pad = [int(v) for v in a.shape.split(",")]
     lib = L.load()
@@ -101,7 +102,13 @@ def main():
         print(f"  {names[i]:>10s} -> {names[i + 1]:<10s} mean {seg.mean():8.0f}  p10 {np.percentile(seg, 10):8.0f}  p90 "
               f"{np.percentile(seg, 90):8.0f}")
     seg = full[(1 << 15):][live]
-    if seg[:, 5].max() > 0:
+    if a.c64:  # conv3x3_c64_kernel: per-tile phase times of wave 0
+        nt = seg[:, 7].sum()
+        print(f"  tiles per block: mean {seg[:, 7].mean():.1f} max {seg[:, 7].max()}")
+        for i, nm in enumerate(("slab DMA issue", "K-loop", "barrier A", "staging + barrier B", "wait vmcnt(0)", "row loads / stores / stats",
+                                "barrier C")):
+            print(f"  per tile {nm:>28s}: {seg[:, i].sum() / max(nt, 1):7.0f}")
+    elif seg[:, 5].max() > 0:
         nk = seg[:, 5].mean()
         for i, nm in enumerate(("wait+barrier", "dma issue", "reads->1st data", "mfma0+2nd data", "mfma1")):
             print(f"  per K-step {nm:>16s}: {seg[:, i].mean() / nk:7.0f}")
