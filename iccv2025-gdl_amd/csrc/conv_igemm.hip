@@ -881,7 +881,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     u32x4_t wreg[9][2][2];
     {
         const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
-        for (int p = wave; p < 72; p += 4) dma16(rwt, smem + p * 1024, p * 1024 + lane * 16);
+        // (16-byte chunks of a 128-byte row XOR-swizzled by (row >> 1) & 7, as in the slabs: the operand reads below
+        // walk rows 9 apart)
+        for (int p = wave; p < 72; p += 4) {
+            const int row = p * 8 + (lane >> 3);
+            dma16(rwt, smem + p * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -891,7 +896,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const unsigned ad = smem_base + ((wn * 32 + n * 16 + frow) * 9 + tap) * 128 + (h * 4 + fg) * 16;
+                    const int row = (wn * 32 + n * 16 + frow) * 9 + tap;
+                    const unsigned ad = smem_base + row * 128 + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 4);
                     asm volatile("ds_read_b128 %0, %1" : "=v"(wreg[tap][h][n]) : "v"(ad));
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
