@@ -567,6 +567,196 @@ __global__ __launch_bounds__(256) void conv_stem_rows_kernel(ConvArgs a, int P, 
 }
 
 // =====================================================================================================
+// Persistent form of the row-slab stem forward (the one launched): same geometry and fragment addressing, but
+// * the whole 64 x (4 taps x 64) weight matrix lives in each wave's registers (32 MFMA operands, 128 VGPRs; staged through
+//   LDS once per block),
+// * a WAVE walks over stages on its own -- its two slab buffers, the staged output tile (over the slab just consumed) and its
+//   stores are private to it, so the loop has no barrier at all -- and the slab of its next stage is in flight (LDS-DMA)
+//   while it multiplies the current one,
+// * the BatchNorm statistics accumulate in registers across the wave's stages: ONE partial row per block
+//   (conv_stem_tiles_m() reports SRP_GRID rows).
+// The one-tile-per-block form spent ~85 % of a block's life outside its 128 MFMAs per wave (weights + slab from L2 / HBM,
+// eight exposed LDS round trips, a 256 x 64 epilogue): 6-9 % of the MFMA peak against an HBM floor (308 MB of output at
+// B = 64) three times lower than its run time.
+// LDS per wave: [slab 0][slab 1] of 9 KiB; the block's weight staging (32 KiB) uses the same bytes before the loop.
+// =====================================================================================================
+constexpr int SRP_GRID = 512;
+__global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int P, int Hp, int Wp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PITCH = 64 * 2 + 16;  // staged tile: [64 pixels][64 channels] bf16, 144-byte pitch = 9 216 B = one slab buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned smem_base = lds_addr(smem);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t wreg[4][2][4];  // [tap pair t4][filter row 2*t4 + kk][16-channel fragment]
+    {
+        const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
+        for (int p = wave; p < 32; p += 4) {  // rows (oc*4 + t4) of 128 B, chunk-swizzled
+            const int row = p * 8 + (lane >> 3);
+            dma16(rwt, smem + p * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) {
+                    const int row = (nn * 16 + frow) * 4 + t4;
+                    const unsigned ad = smem_base + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(wreg[t4][kk][nn]) : "v"(ad));
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // stages of this wave: XCD x owns a contiguous range, its 4 * gridDim/8 waves take every (that many)-th stage of it
+    const int xcd = blockIdx.x & 7, wj = (blockIdx.x >> 3) * 4 + wave, wpx = (gridDim.x >> 3) * 4;
+    const int st_per_xcd = (a.seg_stages + 7) >> 3;
+    const int s_end = min(a.seg_stages, (xcd + 1) * st_per_xcd);
+    int stg = xcd * st_per_xcd + wj;
+    unsigned char* Xw = smem + wave * (2 * SRF_SLAB);
+    const unsigned xw_base = smem_base + wave * (2 * SRF_SLAB);
+    auto load_slab = [&](int buf, int sg_all) {
+        const int R = sg_all / a.seg_nseg, sg = sg_all - R * a.seg_nseg;
+        const int n = R / P, oh = R - n * P;
+        const int ow0 = min(64 * sg, a.seg_Q - 64);
+        const int x_base = ((n * Hp + 2 * oh) * Wp + 2 * ow0) * 8;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // (recomputed per stage, not kept in registers)
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int off = 1024 * p + 16 * ln;
+            const int row = off / SRF_PITCH, col = off - row * SRF_PITCH;
+            const bool ok = row < 8 && col < 1072;
+            dma16(rin, Xw + buf * SRF_SLAB + p * 1024, ok ? x_base + row * Wp * 8 + col : (int)0x80000000);
+        }
+    };
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+    bf16* __restrict__ gout = (bf16*)a.out;
+    const int ec = lane & 7, er0 = lane >> 3;  // row pass p: tile row er0 + 8p, 16-byte chunk ec
+    if (stg < s_end) load_slab(0, stg);
+    if (stg + wpx < s_end) load_slab(1, stg + wpx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) asm volatile("" : "+v"(wreg[t4][kk][nn]));
+    for (int it = 0; stg < s_end; ++it, stg += wpx) {
+        const unsigned slab = xw_base + (it & 1) * SRF_SLAB;
+        const unsigned abase = slab + frow * 16 + fg * 16;
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[nn][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // eight half-steps (filter rows 0..7), one set of pixel fragments (the registers hold the filter: a second set would
+        // spill; the other wave of the SIMD multiplies while this one waits for its reads)
+        uint4 px[4];
+        auto half = [&](auto T4c, auto KKc) __attribute__((always_inline)) {
+            constexpr int T4 = decltype(T4c)::value, KK = decltype(KKc)::value;
+            px[0] = srf_a<T4, KK, 0>(abase);
+            px[1] = srf_a<T4, KK, 1>(abase);
+            px[2] = srf_a<T4, KK, 2>(abase);
+            px[3] = srf_a<T4, KK, 3>(abase);
+            lds_wait();
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[nn][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[T4][KK][nn]),
+                                                                        __builtin_bit_cast(bf16x8_t, px[m]), acc[nn][m], 0, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        half(I0{}, I0{});
+        half(I0{}, I1{});
+        half(I1{}, I0{});
+        half(I1{}, I1{});
+        half(I2{}, I0{});
+        half(I2{}, I1{});
+        half(I3{}, I0{});
+        half(I3{}, I1{});
+        // stage the 64 x 64 tile over the slab just consumed (this wave's own reads of it are complete).
+        // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15
+        {
+            const unsigned cs0 = slab + frow * PITCH + fg * 8;
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint2 v = make_uint2(pack2bf(acc[nn][m][0], acc[nn][m][1]), pack2bf(acc[nn][m][2], acc[nn][m][3]));
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(cs0), "v"(v), "n"(m * 16 * PITCH + nn * 32) : "memory");
+                }
+        }
+        // the tile is in LDS; the next stage's slab has landed (it had this stage's K-loop); the stores of the stage before
+        // are done
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int R = stg / a.seg_nseg, sg = stg - R * a.seg_nseg;
+        const int ow0 = min(64 * sg, a.seg_Q - 64);
+        const int skip = 64 * sg - ow0;  // rows below repeat the previous stage of the image row: neither stored nor counted
+        const unsigned char* Cs = smem + wave * (2 * SRF_SLAB) + (it & 1) * SRF_SLAB;
+        uint4 vq[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = er0 + 8 * p;
+            vq[p] = *(const uint4*)(Cs + row * PITCH + ec * 16);
+            if (a.stats && row >= skip) {
+                float f[8];
+                unpack16<bf16>(vq[p], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ssum[e] += f[e];
+                    ssq[e] += f[e] * f[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int row = er0 + 8 * p;
+            if (row >= skip) *(uint4*)(gout + ((size_t)R * a.seg_Q + ow0 + row) * 64 + ec * 8) = vq[p];
+        }
+        // this buffer is free (the row reads above have returned: their values are in the stores): the stage after next
+        if (stg + 2 * wpx < s_end) load_slab(it & 1, stg + 2 * wpx);
+    }
+    if (a.stats) {
+        // lanes with equal (lane & 7) hold the same 8 channels: fold them, then the 4 waves in fixed order
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            for (int msk = 8; msk < 64; msk <<= 1) {
+                ssum[e] += __shfl_xor(ssum[e], msk);
+                ssq[e] += __shfl_xor(ssq[e], msk);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave is out of its loop: the LDS is free
+        float* red = (float*)smem;  // [4 waves][64][2]
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 64 + lane * 8 + e) * 2 + 0] = ssum[e];
+                red[(wave * 64 + lane * 8 + e) * 2 + 1] = ssq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid >> 1, w = tid & 1;
+            const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
+                             red[(3 * 64 + c) * 2 + w];
+            st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
+        }
+    }
+}
+
+// =====================================================================================================
 // 3x3 stride-1 "slab" kernel (forward and data gradient).
 //
 // With NHWC storage the pixels [m0-(W+1), m0+BM+(W+1)) around a flat output tile [m0, m0+BM) are ONE
@@ -1578,9 +1768,18 @@ static bool stem_rows(int dtype, int W) {
     }
     return v != 0 && dtype == GDL_BF16 && (W - 1) / 2 + 1 >= 64;
 }
+static bool stem_pers() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_STEM_PERS");  // tuning aid: 0 = the one-tile-per-block row-slab kernel
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
 int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
     const int M = n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
-    if (stem_rows(dtype, W)) return ceil_div(n_img * ((H - 1) / 2 + 1) * ceil_div((W - 1) / 2 + 1, 64), 4);
+    if (stem_rows(dtype, W))
+        return stem_pers() ? SRP_GRID : ceil_div(n_img * ((H - 1) / 2 + 1) * ceil_div((W - 1) / 2 + 1, 64), 4);
     return ceil_div(M, pick_cfg(M, 64, dtype).bm);
 }
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
@@ -1616,6 +1815,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
     a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
     if (fold && fold->ctr) {
+        GDL_REQUIRE(!(stem_rows(dtype, W) && stem_pers()), "stem: the in-launch BatchNorm finalize needs GDL_STEM_PERS=0");
         GDL_REQUIRE(bn_partial && bn && fold_fits(conv_stem_tiles_m(dtype, n_img, H, W), 64), "stem: bad fold arguments");
         a.fold = *fold;
         a.fin = make_fin(*bn, 1e-5f, 0.1f);
@@ -1626,6 +1826,20 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
         a.seg_stages = n_img * P * a.seg_nseg;
         a.mtiles = ceil_div(a.seg_stages, 4);
         GDL_REQUIRE((size_t)a.seg_stages * 64 < (1UL << 31), "stem: too many rows");
+        if (stem_pers() && !a.fold.ctr) {
+            static bool attr_p = false;
+            if (!attr_p) {
+                hipError_t e = hipFuncSetAttribute((const void*)conv_stem_pers_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   8 * SRF_SLAB);
+                if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_stem_pers)");
+                attr_p = true;
+            }
+            ProfScope prof("gdl::conv_stem_pers_kernel", PROF_MFMA, st, a.flops, true);
+            hipExtLaunchKernelGGL(conv_stem_pers_kernel, dim3(SRP_GRID), dim3(256), 8 * SRF_SLAB, st, prof.e0(), prof.e1(), 0, a, P,
+                                  Hp, Wp);
+            GDL_CHECK_LAUNCH("conv_stem_pers_kernel");
+            return GDL_OK;
+        }
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)conv_stem_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
