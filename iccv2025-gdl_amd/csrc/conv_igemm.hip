@@ -1471,8 +1471,10 @@ static bool c64_enabled() {
 static int slab_cfg() {
     static int v = -1;
     if (v < 0) {
-        const char* e = tune_env("GDL_SLAB_CFG");  // tuning aid, bits: 1 = allow the 256 x 128 single-slab tile, 2 = the 192 x 128 one
-        v = e ? atoi(e) : 1;
+        // tuning aid, bits: 1 = allow the 256 x 128 single-slab tile, 2 = the 192 x 128 one.  Re-swept inside the step after the
+        // layer-1 / stem kernels became persistent (tools/ab_env.sh, 4 A/B rounds): 192-row tiles 5.85 ms, both 5.86, 256-row 5.91
+        const char* e = tune_env("GDL_SLAB_CFG");
+        v = e ? atoi(e) : 2;
     }
     return v;
 }
