@@ -203,6 +203,44 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
         ld_s += 1;
     };
 
+    // ---- stages >= 1, four-wave form: the same pieces with every per-lane term hoisted out of the loop.  Wave w issues dy
+    // pieces w and w+4, slab pieces w, w+4 (, ...), wave 0 the mask piece; a piece's swizzled source chunk depends on bits 1 and
+    // 3 of its row, which w and w+4 share, so ONE per-lane byte offset per operand advances by 64 pixels per stage and the
+    // other pieces are a scalar step away.  Bounds need no test: a pixel outside the tensor is outside the buffer descriptor
+    // (zeros), and a slice is a whole number of stages except at the tensor's end.  (The generic loop above spent about as
+    // long computing piece addresses as the DMA instructions themselves take.)
+    const int K2 = a.K * 2, C2 = a.C * 2;
+    int dyb, xb, mb;
+    {
+        const int row = wave * 8 + prow;
+        const int ch = (((pch >> 1) ^ w9_swz(row)) << 1) | (pch & 1);
+        dyb = (m_begin + W9_BP + row) * K2 + k0 * 2 + ch * 16;
+        xb = (m_begin + W9_BP + (RING ? a.W + 1 : -(a.W + 1)) + row) * C2 + c0 * 2 + ch * 16;
+        mb = (m_begin + W9_BP + lane) * (int)sizeof(GatherEntry) + 4;
+    }
+    auto load_fast = [&](int buf) {
+        unsigned char* Ks = smem + DY0 + buf * STAGE;
+        w9_dma16(rdy, Ks + wave * 1024, dyb);
+        w9_dma16(rdy, Ks + (wave + 4) * 1024, dyb + 32 * K2);
+        if (RING) {
+            const int rb = (ld_s + (ringT >> 6)) & (RING ? RING * 4 - 1 : 3);
+            unsigned char* dst = smem + rb * 8192;
+            w9_dma16(rx, dst + wave * 1024, xb);
+            w9_dma16(rx, dst + (wave + 4) * 1024, xb + 32 * C2);
+            if (rb == 0) w9_dma16(rx, smem + W9_RING + wave * 1024, xb);  // mirror of the ring's first 32 rows
+        } else {
+            unsigned char* Xs = Ks + W9_BP * 128;
+            int o = 0;
+            for (int jj = wave; jj < nins; jj += 4, o += 32 * C2) w9_dma16(rx, Xs + jj * 1024, xb + o);
+        }
+        if (wave == 0) w9_dma4(rtab, mask_st + buf * 256, mb);
+        dyb += W9_BP * K2;
+        xb += W9_BP * C2;
+        mb += W9_BP * (int)sizeof(GatherEntry);
+        ld_m += W9_BP;
+        ld_s += 1;
+    };
+
     // ---- per-lane LDS read addresses (stage buffer 0; the other buffer is +STAGE).
     // transpose read: lane supplies row (li>>2) of its 16-lane group's 4x16 block, 8 bytes at element
     // (li&3)*4 of the fragment's 16 channels; group g covers pixels g*8 + h*4 + 0..3 of the K-step.
@@ -255,7 +293,13 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, SPEC ? 1 : 2) void conv_wgrad9_ke
         t_b = __builtin_amdgcn_s_memtime();
         t_wait += t_b - t_a;
 #endif
-        if (loader && st + 1 < nst) load_stage((st + 1) & 1);
+        if (st + 1 < nst) {
+            if (SPEC) {
+                if (loader) load_stage((st + 1) & 1);
+            } else {
+                load_fast((st + 1) & 1);
+            }
+        }
 #ifdef GDL_TIMING
         t_a = __builtin_amdgcn_s_memtime();
         t_issue += t_a - t_b;
