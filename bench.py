@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--batches", type=int, default=8, help="distinct synthetic batches resident in HBM, fed round robin")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     ap.add_argument("--no-prof", action="store_true", help="do not tap per-kernel HIP events in the timed region")
+    ap.add_argument("--side-stream", choices=("auto", "on", "off"), default="auto",
+                    help="the visual weight gradients' own stream: auto = on without a process group, off with one")
     ap.add_argument("--phases", action="store_true", help="also report forward / head / backward / optimizer phase times")
     return ap.parse_args()
 
@@ -160,6 +162,12 @@ def main():
         else:
             dist.init_process_group(backend)
         pg = dist.group.WORLD
+    elif os.environ.get("GDL_BENCH_FORCE_PG") == "1":
+        # test plumbing: the data-parallel code path (bucketed RCCL all-reduce, its stream) with a one-rank group on one GPU
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+        pg = dist.group.WORLD
 
     from gdl import _lib as L
     from gdl.trainer import DGLTrainer
@@ -184,7 +192,7 @@ def main():
     model.to(dev)
     model.train()
     tr = DGLTrainer(model, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype,
-                    process_group=pg)
+                    process_group=pg, visual_side_stream={"auto": None, "on": True, "off": False}[a.side_stream])
     # synthetic CREMA-D batch, seed 1234 + rank, resident on the device
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B = a.batch

@@ -49,7 +49,7 @@ class _SwinAdapter:
 
 class DGLTrainer:
     def __init__(self, model, lr, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, mode="dgl", dtype=None,
-                 process_group=None, comm_backend="torch"):
+                 process_group=None, comm_backend="torch", visual_side_stream=None):
         """comm_backend: "torch" -- torch.distributed all_reduce on `process_group` (nccl = RCCL); "abi" -- the library's own
         RCCL communicator (gdl_comm_*), bootstrapped through `process_group`."""
         self.lib = L.load()
@@ -58,6 +58,12 @@ class DGLTrainer:
         self.lr, self.alpha, self.mu, self.wd, self.max_norm = float(lr), float(alpha), float(momentum), \
             float(weight_decay), float(max_norm)
         self.pg = process_group
+        # visual_side_stream: None = the visual encoder's weight gradients get a stream of their own unless a process group is
+        # given (the collective's stream is then the fourth); True / False force it.  Measured with a ONE-rank RCCL group on one
+        # MI355X (bench.py, GDL_BENCH_FORCE_PG=1): 6.05 ms without, 5.80 ms with it (5.78 ms without a group) -- but a one-rank
+        # all-reduce launches no kernel, so whether five streams hold up beside real RCCL traffic is for the first multi-GPU run
+        # to tell (bench.py --side-stream on).
+        self.visual_side_stream = visual_side_stream
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
         head = model.fusion_module
         # head kind: concat (fc_out [n,1024]; ConcatFusion / ConcatFusion_DGL) or sum (fc_x, fc_y [n,512]; SumFusion_DGL)
@@ -215,7 +221,8 @@ class DGLTrainer:
         side = os.environ.get("GDL_SIDE_STREAM") if os.environ.get("GDL_TUNING") == "1" else None
         if side == "1":
             self.eng_a.side_stream(True)
-        if (side == "1" or (side is None and self.reducer is None)) and not self.vis_swin:
+        want_v = self.visual_side_stream if self.visual_side_stream is not None else self.reducer is None
+        if (side in ("1", "2") or (side is None and want_v)) and not self.vis_swin:
             self.eng_v.side_stream(True)
         n, d = self.n_classes, self.device
         self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
