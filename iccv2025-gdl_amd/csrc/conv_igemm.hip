@@ -1455,6 +1455,7 @@ struct ConvPlan {
     size_t lds;
     int single;  // slab kernel: one slab buffer
     int c64;     // 1: conv3x3_c64_kernel (persistent; BatchNorm partial rows = C64_GRID)
+    int nwv8;    // slab kernel: the 128 x 128 tile on 512 threads (small layers: one block per CU at most)
 };
 static size_t c64_lds_bytes(int W) {
     const size_t b = 2 * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024 + 16 * 256 * 4;
@@ -1582,6 +1583,22 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
                 return p;
             }
         }
+        static int small8 = -1;
+        if (small8 < 0) {
+            // layers too small for 384 blocks of 128 x 128 (here: audio layer 4, M = 3 456) on the 8-wave form of that tile
+            // instead of 128 x 64 tiles: half the blocks, half the filter re-reads.  Alone it is SLOWER (46 -> 54 us), inside the
+            // step faster (5.73 -> 5.67 ms, three A/B rounds): tuning aid, 0 = off
+            const char* e = tune_env("GDL_SLAB_SMALL8");
+            small8 = e ? atoi(e) : 1;
+        }
+        if (small8 && !slab_bm && dtype == GDL_BF16 && OC % 128 == 0 && slab_cap == (size_t)80 * 1024) {
+            const size_t lds = slab_lds_bytes(128, 128, W, IC, dtype);
+            const long blocks = (long)((M + 127) / 128) * (OC / 128);
+            if (lds <= slab_cap && blocks < slab_bn128_min()) {
+                p.slab = 1, p.bm = 128, p.bn = 128, p.lds = lds, p.nwv8 = 1;
+                return p;
+            }
+        }
         if (!slab_bm && slab_bn != 64 && OC % 128 == 0) {
             const size_t lds = slab_lds_bytes(128, 128, W, IC, dtype);
             const long blocks = (long)((M + 127) / 128) * (OC / 128);
@@ -1645,6 +1662,8 @@ static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
             if (pl.bn == 128 && pl.bm == 256) return launch_slab<T, 256, 128, MODE>(a, pl.lds, st);
         if constexpr (std::is_same<T, bf16>::value)
             if (pl.bn == 128 && pl.bm == 192) return launch_slab<T, 192, 128, MODE>(a, pl.lds, st);
+        if constexpr (std::is_same<T, bf16>::value)
+            if (pl.bn == 128 && pl.nwv8) return launch_slab<T, 128, 128, MODE, 8>(a, pl.lds, st);
         if (pl.bn == 128) return launch_slab<T, 128, 128, MODE>(a, pl.lds, st);
         if (pl.bm == 256) return launch_slab<T, 256, 64, MODE>(a, pl.lds, st);
         return launch_slab<T, 128, 64, MODE>(a, pl.lds, st);

@@ -200,6 +200,12 @@ def test_stem_direct(case, dt):
     s = part.sum(0).cpu().numpy()
     gq = got.transpose(1, 0, 2, 3).reshape(64, -1).astype(np.float64)
     assert np.allclose(s[:, 0], gq.sum(1), rtol=1e-4, atol=1e-2) and np.allclose(s[:, 1], (gq * gq).sum(1), rtol=1e-4, atol=1e-2)
+    # run to run: outputs and partial rows bit-identical (the persistent kernel's waves walk their stages in a fixed order)
+    y2 = empty((n_img, P, Q, 64), dt)
+    part2 = torch.full((tiles, 64, 2), float("nan"), device=DEV)
+    L.call("gdl_stem_conv_fwd", dt, L.ptr(xp), L.ptr(wp), L.ptr(y2), L.ptr(part2), L.ptr(tab), n_img, H, W, Cin, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y2.view(torch.uint8), y.view(torch.uint8)) and torch.equal(part2.view(torch.int32), part.view(torch.int32))
     dy = quant(rng.standard_normal((n_img, 64, P, Q), dtype=np.float32), dt)
     refw = orc.conv2d_bwd_weight(dy, x4, (64, Cin, 7, 7), 2, 3)
     dyd = to_nhwc(dy, dt)
