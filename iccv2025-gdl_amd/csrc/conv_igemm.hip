@@ -753,6 +753,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
                              red[(3 * 64 + c) * 2 + w];
             st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
+        if (a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
     }
 }
 
@@ -1350,6 +1351,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                              red[(3 * 64 + c) * 2 + w];
             st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
+        // BatchNorm finalize inside the launch (fold.h): with ONE partial row per persistent block the ticket is paid once
+        // per block life (~40 us), not once per tile -- what made the fold lose on the one-tile-per-block kernels
+        if (a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
     }
     GDL_STAMP(3);
 }
@@ -1497,7 +1501,7 @@ static long slab_bn128_min() {
     }
     return v;
 }
-static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_c64 = true) {
+static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_nwv8 = true) {
     ConvPlan p{};
     static int noslab = -1;
     if (noslab < 0) {
@@ -1515,7 +1519,7 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     // output channels (forward and data gradient share it); tools/plan_search.py walks it
     // 64 -> 64 channels (layer 1): the persistent weights-in-registers kernel, two blocks per CU (80 KB of LDS each at most;
     // the staged output tile, 128 x 144 bytes, has to fit into one slab buffer)
-    if (allow_c64 && !noslab && c64_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && IC == 64 && OC == 64 &&
+    if (!noslab && c64_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && IC == 64 && OC == 64 &&
         c64_lds_bytes(W) <= (size_t)80 * 1024 && (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 >= (size_t)C64_BM * 144 &&
         M >= 64 * C64_BM) {
         p.slab = 1, p.c64 = 1, p.bm = C64_BM, p.bn = 64, p.lds = c64_lds_bytes(W);
@@ -1591,7 +1595,7 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
             const char* e = tune_env("GDL_SLAB_SMALL8");
             small8 = e ? atoi(e) : 1;
         }
-        if (small8 && !slab_bm && dtype == GDL_BF16 && OC % 128 == 0 && slab_cap == (size_t)80 * 1024) {
+        if (small8 && allow_nwv8 && !slab_bm && dtype == GDL_BF16 && OC % 128 == 0 && slab_cap == (size_t)80 * 1024) {
             const size_t lds = slab_lds_bytes(128, 128, W, IC, dtype);
             const long blocks = (long)((M + 127) / 128) * (OC / 128);
             if (lds <= slab_cap && blocks < slab_bn128_min()) {
@@ -1638,7 +1642,7 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
 template <int MODE>
 static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, C64_BM);
-    GDL_REQUIRE(!a.fold.ctr && !a.bias && !a.gelu_out && !a.orow, "conv: unsupported option for the 64-channel persistent kernel");
+    GDL_REQUIRE(!a.bias && !a.gelu_out && !a.orow, "conv: unsupported option for the 64-channel persistent kernel");
     auto kfn = conv3x3_c64_kernel<MODE>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1681,6 +1685,12 @@ int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int
     return pl.c64 ? C64_GRID : ceil_div(N * P * Q, pl.bm);
 }
 
+// true if the forward of this convolution runs on a persistent kernel (one BatchNorm partial row per block): the in-launch
+// finalize costs a ticket per block LIFE there and is used by default
+bool conv_fwd_persistent(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    return plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad).c64 != 0;
+}
 // M-tile of a data gradient (the permuted stride-2 table is laid out for it)
 int conv_dgrad_bm(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     return plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad).bm;
@@ -1736,10 +1746,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
     // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
     ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
-    if (pl.c64 && fold && fold->ctr) pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad, false);  // (the fold wants one partial row per M-tile)
+    if (pl.nwv8 && fold && fold->ctr) pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad, false);  // (the fold is written for 256 threads)
     a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction
     if (fold && fold->ctr) {
-        GDL_REQUIRE(stats && bn && mode == GATHER_FWD && fold_fits(ceil_div(a.M, pl.bm), a.OC) && a.OC / pl.bn <= FOLD_NCG,
+        GDL_REQUIRE(stats && bn && mode == GATHER_FWD && fold_fits(pl.c64 ? C64_GRID : ceil_div(a.M, pl.bm), a.OC) && a.OC / pl.bn <= FOLD_NCG,
                     "conv: bad fold arguments");
         a.fold = *fold;
         a.fin = make_fin(*bn, 1e-5f, 0.1f);
@@ -1797,6 +1807,7 @@ static bool stem_pers() {
     }
     return v != 0;
 }
+bool conv_stem_persistent(int dtype, int W) { return stem_rows(dtype, W) && stem_pers(); }
 int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
     const int M = n_img * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
     if (stem_rows(dtype, W))
@@ -1836,7 +1847,6 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
     a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
     if (fold && fold->ctr) {
-        GDL_REQUIRE(!(stem_rows(dtype, W) && stem_pers()), "stem: the in-launch BatchNorm finalize needs GDL_STEM_PERS=0");
         GDL_REQUIRE(bn_partial && bn && fold_fits(conv_stem_tiles_m(dtype, n_img, H, W), 64), "stem: bad fold arguments");
         a.fold = *fold;
         a.fin = make_fin(*bn, 1e-5f, 0.1f);
@@ -1847,7 +1857,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
         a.seg_stages = n_img * P * a.seg_nseg;
         a.mtiles = ceil_div(a.seg_stages, 4);
         GDL_REQUIRE((size_t)a.seg_stages * 64 < (1UL << 31), "stem: too many rows");
-        if (stem_pers() && !a.fold.ctr) {
+        if (stem_pers()) {
             static bool attr_p = false;
             if (!attr_p) {
                 hipError_t e = hipFuncSetAttribute((const void*)conv_stem_pers_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -436,6 +436,17 @@ static bool fold_on() {
 }
 
 // ReLU mask of a block output applied by the producing data gradient (default on; GDL_PREMASK=0: the block masks itself)
+// The persistent forward kernels (64 -> 64 channel layers, stem) pay the ticket once per block LIFE (512 long-lived blocks, one
+// partial row each) instead of once per tile, and there the fold costs nothing -- but it gains nothing either: 5.855 vs 5.841 ms
+// (three A/B rounds) with the ten finalize launches gone.  The step is throughput-bound, not launch-bound.  Off by default.
+static bool pers_fold_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = tune_env("GDL_PERS_FOLD");  // tuning aid: 1 = finalize inside the persistent kernels' launches
+        v = env ? atoi(env) : 0;
+    }
+    return v != 0;
+}
 static bool ds_fold_on() {
     static int v = -1;
     if (v < 0) {
@@ -478,7 +489,8 @@ static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int n
         return bn_finalize(e, n, training, bn_stats_tiles(M), (double)M, st);
     }
     const int tiles = conv_tiles_m(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad);
-    if (training && fold_on() && fold_fits(tiles, c.cout)) {  // statistics AND finalize inside the convolution's launch
+    const bool pers = pers_fold_on() && conv_fwd_persistent(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad);
+    if (training && (fold_on() || pers) && fold_fits(tiles, c.cout)) {  // statistics AND finalize inside the convolution's launch
         const BnFinTrain fin = fin_train_args(e, n, partial, tiles, (double)M);
         return conv_fwd(e->dtype, x, c.w_krsc, y, partial, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
                         &e->fold, &fin);
@@ -541,7 +553,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
     {
         const int tiles = conv_stem_tiles_m(dt, e->n_img, e->H, e->W);
-        if (training && fold_on() && fold_fits(tiles, 64)) {
+        if (training && (fold_on() || (pers_fold_on() && conv_stem_persistent(dt, e->W))) && fold_fits(tiles, 64)) {
             const BnFinTrain fin = fin_train_args(e, e->bn0, e->bn_partial, tiles, (double)e->m0);
             RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, e->bn_partial, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, &e->fold,
                              &fin));

@@ -49,6 +49,8 @@ int stem_ic(int dtype);
 int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st);
 int pack_stem_rows(int dtype, const float* w, void* wp, int cin, hipStream_t st);
 int conv_stem_tiles_m(int dtype, int n_img, int H, int W);
+bool conv_fwd_persistent(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+bool conv_stem_persistent(int dtype, int W);
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
                   int W, int Cin, hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr);
 size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W);

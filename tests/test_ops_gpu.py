@@ -508,7 +508,8 @@ def _fold_ws():
 FOLD_CONV = [
     # N, C, H, W, K, R, stride, pad -- rows (M-tiles) x column groups of the fold
     (2, 64, 17, 13, 64, 3, 1, 1),      # one group, one column group
-    (24, 64, 56, 56, 128, 3, 1, 1),    # several groups, ragged last group (64 -> 64 channels run the persistent kernel: no fold)
+    (24, 64, 56, 56, 128, 3, 1, 1),    # several groups, ragged last group
+    (24, 64, 56, 56, 64, 3, 1, 1),     # 64 -> 64 channels: the persistent kernel, 512 partial rows (one per block), 8 groups
     (16, 128, 28, 28, 256, 3, 1, 1),   # 128-channel tiles: two column groups
     (16, 64, 65, 47, 128, 3, 2, 1),    # flat kernel, stride 2
     (48, 512, 7, 7, 512, 3, 1, 1),     # few rows, four column groups
@@ -557,7 +558,12 @@ def test_conv_fwd_bn_fold(shape, dt):
         torch.cuda.synchronize()
         assert torch.equal(y.view(torch.int16 if dt == L.GDL_BF16 else torch.int32),
                            y0.view(torch.int16 if dt == L.GDL_BF16 else torch.int32))
-        assert torch.equal(part, part0)
+        if shape == (48, 512, 7, 7, 512, 3, 1, 1):
+            # this small layer runs the 8-wave 128 x 128 tile without the fold and 128 x 64 tiles with it (the fold is written
+            # for 256-thread blocks): same rows, same outputs, the row sums in another order
+            np.testing.assert_allclose(part.cpu().numpy(), part0.cpu().numpy(), rtol=2e-5, atol=1e-4)
+        else:
+            assert torch.equal(part, part0)
         assert int(nbt2.item()) == 1
         for a, b in zip(out + [rm2, rv2], ref + [rm, rv]):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=1e-7)
