@@ -220,24 +220,41 @@ __global__ __launch_bounds__(256) void maxpool_bwd_patch_kernel(const T* __restr
         const int n = row / PH, p = row - n * PH;
         for (int jj = threadIdx.x; jj < per_row; jj += blockDim.x) {
             const int q = jj / cpr, vc = jj - q * cpr;
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
             float a00[EPC], a01[EPC], a10[EPC], a11[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) a00[e] = a01[e] = a10[e] = a11[e] = 0.f;
-            auto window = [&](int pp, int qq, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
-                if (pp >= P || qq >= Q) return;
-                const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
+            // the gradient / arg-max vectors of the four windows that touch the patch: twelve loads in flight
+            // per thread instead of four dependent load -> decode round trips (an absent window reads as arg-max 255: no match)
+            uint4 dq[4];
+            uint2 iq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pp = p + (k >> 1), qq = q + (k & 1);
+                dq[k] = z;
+                iq[k] = make_uint2(0xffffffffu, 0xffffffffu);
+                if (pp < P && qq < Q) {
+                    const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
+                    dq[k] = *(const uint4*)(dout + o);
+                    if (EPC == 8)
+                        iq[k] = *(const uint2*)(idx + o);
+                    else
+                        iq[k].x = *(const uint32_t*)(idx + o);
+                }
+            }
+            auto window = [&](int k, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
                 float d[EPC];
-                unpack16<T>(*(const uint4*)(dout + o), d);
+                unpack16<T>(dq[k], d);
                 uint32_t ix[EPC];
                 if (EPC == 8) {
-                    const uint2 u = *(const uint2*)(idx + o);
+                    const uint2 u = iq[k];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         ix[e] = (u.x >> (8 * e)) & 0xff;
                         ix[(4 + e) % EPC] = (u.y >> (8 * e)) & 0xff;
                     }
                 } else {
-                    const uint32_t u = *(const uint32_t*)(idx + o);
+                    const uint32_t u = iq[k].x;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ix[e] = (u >> (8 * e)) & 0xff;
                 }
@@ -250,10 +267,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_patch_kernel(const T* __restr
                 }
             };
             // (the order of the additions into one position is that of maxpool_bwd_kernel: window rows, then columns)
-            window(p, q, 4, 5, 7, 8);
-            window(p, q + 1, -1, 3, -1, 6);
-            window(p + 1, q, -1, -1, 1, 2);
-            window(p + 1, q + 1, -1, -1, -1, 0);
+            window(0, 4, 5, 7, 8);
+            window(1, -1, 3, -1, 6);
+            window(2, -1, -1, 1, 2);
+            window(3, -1, -1, -1, 0);
             const int h = 2 * p, w = 2 * q;
             T* o0 = dx + (((size_t)n * H + h) * W + w) * C + vc * EPC;
             *(uint4*)o0 = pack16<T>(a00);
@@ -349,21 +366,37 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const T* __re
             float a00[EPC], a01[EPC], a10[EPC], a11[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) a00[e] = a01[e] = a10[e] = a11[e] = 0.f;
-            auto window = [&](int pp, int qq, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
-                if (pp >= P || qq >= Q) return;
-                const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
+            // ... and so are the gradient / arg-max vectors of the four windows that touch the patch: twelve loads in flight
+            // per thread instead of four dependent load -> decode round trips (an absent window reads as arg-max 255: no match)
+            uint4 dq[4];
+            uint2 iq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pp = p + (k >> 1), qq = q + (k & 1);
+                dq[k] = z;
+                iq[k] = make_uint2(0xffffffffu, 0xffffffffu);
+                if (pp < P && qq < Q) {
+                    const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
+                    dq[k] = *(const uint4*)(dout + o);
+                    if (EPC == 8)
+                        iq[k] = *(const uint2*)(idx + o);
+                    else
+                        iq[k].x = *(const uint32_t*)(idx + o);
+                }
+            }
+            auto window = [&](int k, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
                 float d[EPC];
-                unpack16<T>(*(const uint4*)(dout + o), d);
+                unpack16<T>(dq[k], d);
                 uint32_t ix[EPC];
                 if (EPC == 8) {
-                    const uint2 u = *(const uint2*)(idx + o);
+                    const uint2 u = iq[k];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         ix[e] = (u.x >> (8 * e)) & 0xff;
                         ix[(4 + e) % EPC] = (u.y >> (8 * e)) & 0xff;
                     }
                 } else {
-                    const uint32_t u = *(const uint32_t*)(idx + o);
+                    const uint32_t u = iq[k].x;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ix[e] = (u >> (8 * e)) & 0xff;
                 }
@@ -375,10 +408,10 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const T* __re
                     if (c11 >= 0 && ix[e] == (uint32_t)c11) a11[e] += d[e];
                 }
             };
-            window(p, q, 4, 5, 7, 8);
-            window(p, q + 1, -1, 3, -1, 6);
-            window(p + 1, q, -1, -1, 1, 2);
-            window(p + 1, q + 1, -1, -1, -1, 0);
+            window(0, 4, 5, 7, 8);
+            window(1, -1, 3, -1, 6);
+            window(2, -1, -1, 1, 2);
+            window(3, -1, -1, -1, 0);
             auto apply = [&](const uint4& yq, float (&g)[EPC]) __attribute__((always_inline)) {
                 float yv[EPC];
                 unpack16<T>(yq, yv);
