@@ -48,26 +48,35 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                 key[e] = 0u;
                 ym[e] = 0.f;
             }
+            // all nine window vectors are requested before the first is used (clamped address + validity flag instead of a
+            // branch around each load: nine loads in flight per thread)
+            uint4 v9[9];
+            bool ok9[9];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int ih = p * 2 - 1 + r;
-                if ((unsigned)ih >= (unsigned)H) continue;
+                const int ihc = min(max(ih, 0), H - 1);
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     const int iw = q * 2 - 1 + s;
-                    if ((unsigned)iw >= (unsigned)W) continue;
-                    float f[EPC];
-                    unpack16<T>(*(const uint4*)(y + (((size_t)n * H + ih) * W + iw) * C + vc * EPC), f);
-                    const uint32_t tag = 15u - (uint32_t)(r * 3 + s);
+                    const int iwc = min(max(iw, 0), W - 1);
+                    ok9[r * 3 + s] = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    v9[r * 3 + s] = *(const uint4*)(y + (((size_t)n * H + ihc) * W + iwc) * C + vc * EPC);
+                }
+            }
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        float v = f[e] * sc[e] + sf[e];
-                        v = v > 0.f ? v : 0.f;  // (+0 also for -0 and NaN: the key compare is unsigned)
-                        const uint32_t k = (__float_as_uint(v) & 0xfffffff0u) | tag;
-                        const bool gt = k > key[e];
-                        key[e] = gt ? k : key[e];
-                        if constexpr (YMAX) ym[e] = gt ? f[e] : ym[e];
-                    }
+            for (int t = 0; t < 9; ++t) {
+                float f[EPC];
+                unpack16<T>(v9[t], f);
+                const uint32_t tag = 15u - (uint32_t)t;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    float v = f[e] * sc[e] + sf[e];
+                    v = v > 0.f ? v : 0.f;  // (+0 also for -0 and NaN: the key compare is unsigned)
+                    const uint32_t k = (__float_as_uint(v) & 0xfffffff0u) | tag;
+                    const bool gt = ok9[t] && k > key[e];
+                    key[e] = gt ? k : key[e];
+                    if constexpr (YMAX) ym[e] = gt ? f[e] : ym[e];
                 }
             }
 #pragma unroll
