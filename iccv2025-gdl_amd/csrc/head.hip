@@ -311,6 +311,58 @@ __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logit
 //   out_x  = fc_out(sigmoid(hx) * hx),  out_y = fc_out(sigmoid(hy) * hy)       (the "gate" of each unimodal
 //   logit set is the modality's own hidden vector: h * sigmoid(h))
 // B x 512 x 512 products: tiny (33 MFLOP), latency bound, plain FMA kernels.
+// ---------------------------------------------------------------- one modality's auxiliary path on its own
+// u = f Wp^T + bp, d(u) = scale*(softmax(u) - onehot)/B, df = d(u) Wp  -- the unimodal logits, their cross-entropy gradient and
+// the feature gradient the encoder's backward starts from, for ONE modality of a DGL concat / sum head (Wp = that modality's
+// 512 columns of fc_out, or fc_x / fc_y).  In the DGL step an encoder learns from its own auxiliary loss only
+// (main_dgl.py:102-122), so its backward need not wait for the other encoder's forward: DGLTrainer launches this on the
+// encoder's own stream right behind its forward.  grid = B.  Every sum runs in the order head_fwd_kernel, softmax_ce_block and
+// head_bwd_feat_kernel use: df is bit-identical to the three-launch path.
+__global__ __launch_bounds__(256) void head_uni_dfeat_kernel(const float* __restrict__ f, const float* __restrict__ Wp, int ldw,
+                                                            const float* __restrict__ bp, const int64_t* __restrict__ labels,
+                                                            float scale, float* __restrict__ df, int B, int n) {
+    __shared__ float lg[512], dl[512];
+    __shared__ float lse_s;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float fv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fv[i] = f[(size_t)b * HD + lane + 64 * i];
+    for (int j = wave; j < n; j += 4) {
+        const float* w = Wp + (size_t)j * ldw;
+        float pa = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pa += w[lane + 64 * i] * fv[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o);
+        if (lane == 0) lg[j] = pa + bp[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mx = lg[0];
+        for (int j = 1; j < n; ++j) mx = fmaxf(mx, lg[j]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += expf(lg[j] - mx);
+        lse_s = mx + logf(se);
+    }
+    __syncthreads();
+    const long lab64 = (long)labels[b];
+    const int lab = (lab64 >= 0 && lab64 < n) ? (int)lab64 : -1;
+    for (int j = threadIdx.x; j < n; j += 256) dl[j] = scale * (expf(lg[j] - lse_s) - (j == lab ? 1.f : 0.f)) / (float)B;
+    __syncthreads();
+    for (int i = threadIdx.x; i < HD; i += 256) {
+        float s2 = 0.f;
+        for (int j = 0; j < n; ++j) s2 += dl[j] * Wp[(size_t)j * ldw + i];
+        df[(size_t)b * HD + i] = s2;
+    }
+}
+int head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale, float* df, int B,
+                   int n, hipStream_t st) {
+    GDL_REQUIRE(n <= 512, "head_uni_dfeat: at most 512 classes");
+    hipLaunchKernelGGL(head_uni_dfeat_kernel, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+    GDL_CHECK_LAUNCH("head_uni_dfeat_kernel");
+    return GDL_OK;
+}
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
 
 // grid = (B, 2): which = 0 -> hx = x W1^T + b1, 1 -> hy = y W2^T + b2.  Waves own outputs j = wave, wave+4, ..

@@ -49,7 +49,7 @@ class _SwinAdapter:
 
 class DGLTrainer:
     def __init__(self, model, lr, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, mode="dgl", dtype=None,
-                 process_group=None, comm_backend="torch", visual_side_stream=None):
+                 process_group=None, comm_backend="torch", visual_side_stream=None, early_backward=None):
         """comm_backend: "torch" -- torch.distributed all_reduce on `process_group` (nccl = RCCL); "abi" -- the library's own
         RCCL communicator (gdl_comm_*), bootstrapped through `process_group`."""
         self.lib = L.load()
@@ -64,6 +64,14 @@ class DGLTrainer:
         # all-reduce launches no kernel, so whether five streams hold up beside real RCCL traffic is for the first multi-GPU run
         # to tell (bench.py --side-stream on).
         self.visual_side_stream = visual_side_stream
+        # early_backward: None = on where it applies (DGL step with the concat (512 + 512) or sum head): each encoder's feature
+        # gradient comes from ITS auxiliary loss alone (main_dgl.py:110-122), so gdl_head_uni_dfeat computes it on the encoder's
+        # own stream right behind its forward and the backward starts without waiting for the other encoder; the fusion
+        # head (logits of all three sets, the losses, fc_out's gradient) follows on the audio stream behind the audio backward.
+        # Same numbers bit for bit (tests/test_step_gpu.py::test_early_backward_identical), no forward -> head -> backward junction.
+        self.early_backward = early_backward
+        if early_backward is None and os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_EARLY_BWD") == "0":
+            self.early_backward = False  # tuning aid (A/B)
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
         head = model.fusion_module
         # head kind: concat (fc_out [n,1024]; ConcatFusion / ConcatFusion_DGL) or sum (fc_x, fc_y [n,512]; SumFusion_DGL)
@@ -227,6 +235,7 @@ class DGLTrainer:
         n, d = self.n_classes, self.device
         self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
         self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
+        self.dscr_a, self.dscr_v = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
         if self.head == "film":
             if B > 64:
                 raise L.GdlError("DGLTrainer: the FiLM head handles at most 64 samples per step")
@@ -282,6 +291,66 @@ class DGLTrainer:
         self.s_v.wait_event(ev)
         # the visual encoder is the critical path (3x the audio work): enqueue it first so the single
         # host thread's ~100 launches per encoder pass do not delay it
+        dgl = self.mode == "dgl"
+        early = dgl and self.head in ("concat", "sum") and self.dv == 512 and not self.vis_swin and self.early_backward is not False
+        red = self.reducer
+        gv, ga = self.gviews[nf + 60:nf + 60 + self.nv], self.gviews[nf:nf + 60]
+        if early:
+            pv = self.pviews
+            if self.head == "concat":  # fc_out [n][1024] + one bias
+                wa, wv, ldw, ba, bv = L.ptr(pv[0]), pv[0].data_ptr() + 512 * 4, 1024, L.ptr(pv[1]), L.ptr(pv[1])
+            else:  # fc_x, fc_y [n][512] with their biases
+                wa, wv, ldw, ba, bv = L.ptr(pv[0]), L.ptr(pv[2]), 512, L.ptr(pv[1]), L.ptr(pv[3])
+            with torch.cuda.stream(self.s_v):
+                self.eng_v.forward(image, True, feat_out=self.fv)
+                L.call("gdl_head_uni_dfeat", L.ptr(self.fv), wv, ldw, bv, L.ptr(label), self.alpha, L.ptr(self.dfv), B, n,
+                       self.s_v.cuda_stream)
+                ev_v = self.s_v.record_event()
+            with torch.cuda.stream(self.s_a):
+                self.eng_a.forward(audio, True, feat_out=self.fa)
+                L.call("gdl_head_uni_dfeat", L.ptr(self.fa), wa, ldw, ba, L.ptr(label), self.alpha, L.ptr(self.dfa), B, n,
+                       self.s_a.cuda_stream)
+            # (host order: both forwards are enqueued before either backward, so neither chain waits for the host)
+            with torch.cuda.stream(self.s_v):
+                if red is None:
+                    self.eng_v.backward(gv, dfeat=self.dfv)
+                else:
+                    self.eng_v.backward(gv, dfeat=self.dfv, phase=1)
+            with torch.cuda.stream(self.s_a):
+                if red is None:
+                    self.eng_a.backward(ga, dfeat=self.dfa)
+                else:
+                    # collectives of one communicator run in issue order, identical on every rank
+                    self.eng_a.backward(ga, dfeat=self.dfa, phase=1)
+                    red.launch("audio_l4")
+            if red is not None:
+                with torch.cuda.stream(self.s_v):
+                    red.launch("visual_l4")
+                    self.eng_v.backward(gv, phase=2)
+                with torch.cuda.stream(self.s_a):
+                    self.eng_a.backward(ga, phase=2)
+                    red.launch("audio_rest")
+            # the fusion head on the audio stream (= main), behind the audio backward: all three logit sets, the losses, the
+            # gradient of fc_out (/ fc_x, fc_y) from loss_f alone; its feature gradients go to scratch (the encoders have theirs)
+            main.wait_event(ev_v)
+            st = main.cuda_stream
+            self._head_forward(True, st)
+            L.call("gdl_softmax_ce3", L.ptr(self.out), L.ptr(self.out_a), L.ptr(self.out_v), L.ptr(label), 1.0, self.alpha,
+                   self.alpha, self.losses.data_ptr(), L.ptr(self.g_f), L.ptr(self.g_a), L.ptr(self.g_v), B, n, st)
+            gvw = self.gviews
+            if self.head == "sum":
+                L.call("gdl_head_sum_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[2]), L.ptr(self.g_a),
+                       L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dscr_a), L.ptr(self.dscr_v), L.ptr(gvw[0]), L.ptr(gvw[1]),
+                       L.ptr(gvw[2]), L.ptr(gvw[3]), B, n, st)
+            else:
+                L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(self.g_a), L.ptr(self.g_v),
+                       L.ptr(self.g_f), 0, 0, L.ptr(self.dscr_a), L.ptr(self.dscr_v), L.ptr(gvw[0]), L.ptr(gvw[1]), B, n, st)
+            if red is not None:
+                red.launch("fusion")
+                with torch.cuda.stream(self.s_v):
+                    red.launch("visual_rest")
+            self._finish_step(main, st)
+            return
         with torch.cuda.stream(self.s_v):
             self.eng_v.forward(image, True, feat_out=self.fv)
         with torch.cuda.stream(self.s_a):
@@ -290,7 +359,6 @@ class DGLTrainer:
         main.wait_stream(self.s_v)
         self._mark(main, "fwd_done")
         st = main.cuda_stream
-        dgl = self.mode == "dgl"
         self._head_forward(dgl, st)
         lp = self.losses.data_ptr()
         if dgl:  # loss_f, alpha*loss_a, alpha*loss_v (main_dgl.py:102-108) in one launch
@@ -358,6 +426,11 @@ class DGLTrainer:
                 red.launch("audio_rest")
             with torch.cuda.stream(self.s_v):
                 red.launch("visual_rest")
+        self._finish_step(main, st)
+
+    def _finish_step(self, main, st):
+        """Joins the chains (and the collectives), then gradient statistics + clip + SGD on `main`."""
+        red = self.reducer
         main.wait_stream(self.s_a)
         main.wait_stream(self.s_v)
         if red is not None:

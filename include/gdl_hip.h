@@ -235,6 +235,14 @@ GDL_API int gdl_head_concat_fwd(const float* x, const float* y, const float* W, 
 GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out,
                                 const float* g_y_out, const float* g_out, int out_reaches_xy, int uni_in_dw, float* dx,
                                 float* dy, float* dW, float* db, int B, int n_classes, void* stream);
+/* One modality's auxiliary path of a DGL concat / sum head in ONE launch (main_dgl.py:102-122: an encoder learns from its own
+ * unimodal loss only, so its backward can start as soon as ITS forward is done):
+ *   u = f Wp^T + bp,  d(u) = scale*(softmax(u) - onehot(labels))/B,  df = d(u) Wp
+ * f [B][512], Wp = the modality's 512 columns (row stride ldw floats: W / W + 512 with ldw 1024 for ConcatFusion_DGL,
+ * fc_x / fc_y with ldw 512 for SumFusion_DGL), bp [n].  df is bit-identical to gdl_head_*_fwd + gdl_softmax_ce +
+ * gdl_head_*_bwd's dx / dy with the DGL flags. */
+GDL_API int gdl_head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale,
+                               float* df, int B, int n_classes, void* stream);
 /* The same head with unequal feature widths, W [n][x_dim + y_dim] (512 audio + 768 Swin features; the reference's
  * ConcatFusion_Swin, fusion_modules.py:79-88, in its DGL form :45-59): same contract as the two calls above. */
 GDL_API int gdl_head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out,

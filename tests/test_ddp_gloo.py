@@ -84,8 +84,9 @@ def test_bucket_allreduce_world2():
 
 
 def _worker5(rank, world, port, q):
-    """The five buckets of DGLTrainer in the issue order of its data-parallel step (trainer.py: fusion, audio_l4,
-    visual_l4, audio_rest, visual_rest), ranks seeded differently, replica state synchronised from rank 0 first."""
+    """The five buckets of DGLTrainer in the issue orders of its data-parallel step (trainer.py: audio_l4, visual_l4,
+    audio_rest, fusion, visual_rest with the early backward; fusion, audio_l4, visual_l4, audio_rest, visual_rest without),
+    ranks seeded differently, replica state synchronised from rank 0 first."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -110,7 +111,9 @@ def _worker5(rank, world, port, q):
     g0 = torch.Generator().manual_seed(7)
     ok = ok and torch.equal(params, torch.randn(o, generator=g0))
     for step in range(2):
-        for n in ("fusion", "audio_l4", "visual_l4", "audio_rest", "visual_rest"):
+        order = ("audio_l4", "visual_l4", "audio_rest", "fusion", "visual_rest") if step == 0 else \
+            ("fusion", "audio_l4", "visual_l4", "audio_rest", "visual_rest")
+        for n in order:
             red.launch(n)
         red.wait_all()
         gathered = [torch.empty_like(mine) for _ in range(world)]

@@ -806,3 +806,30 @@ def test_normalize_frames(golden_dir):
     got = gd.normalize_frames(torch.from_numpy(u8).to(DEV)).cpu().numpy()
     assert got.shape == (64, 3, 3, 224, 224)
     np.testing.assert_array_equal(got.reshape(-1, 3, 224, 224), orc.normalize_frames(u8.reshape(-1, 224, 224, 3)))
+
+
+@pytest.mark.parametrize("fusion", ["concat", "sum"])
+def test_early_backward_identical(fusion):
+    """DGLTrainer(early_backward=...): the per-modality head launch (gdl_head_uni_dfeat) + junction-free backward leaves the
+    SAME parameters, losses and statistics, bit for bit, as the forward -> head -> backward order (main_dgl.py:97-154)."""
+    from gdl.trainer import DGLTrainer
+
+    cfg = dict(_FULL_CFG["cremad"])
+    cfg["fusion"] = fusion
+    res = []
+    for early in (False, True):
+        torch.manual_seed(0)
+        model = _make_model(cfg, "bf16")
+        model.train()
+        tr = DGLTrainer(model, lr=2e-3, alpha=cfg["alpha"], early_backward=early)
+        for st in range(2):
+            spec, image, label = _batch(cfg, st)
+            tr.step(spec[:8], image[:8], label[:8])
+        torch.cuda.synchronize()
+        r = tr.read()
+        res.append((tr.params.clone(), tr.losses.clone(), r["total_norm"], tr.out_a.clone(), tr.out.clone()))
+    for a, b in zip(res[0], res[1]):
+        if torch.is_tensor(a):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        else:
+            assert a == b
