@@ -60,6 +60,42 @@ def test_head_dgl_golden(name, n):
     np.testing.assert_allclose(db.cpu().numpy(), g["db_f"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n", [6, 34, 309])
+def test_head_uni_dfeat(n):
+    """gdl_head_uni_dfeat (one modality's logits -> alpha * cross-entropy gradient -> feature gradient in one launch) against a
+    float64 restatement of main_dgl.py:102-110 for that modality, and bit for bit against the three-launch path it replaces
+    (gdl_head_concat_fwd, gdl_softmax_ce, gdl_head_concat_bwd)."""
+    B, alpha = 16, 4.0
+    rs = np.random.default_rng(5)
+    x, y = rs.standard_normal((B, 512), dtype=np.float32), rs.standard_normal((B, 512), dtype=np.float32)
+    W = (rs.standard_normal((n, 1024), dtype=np.float32) * 0.05).astype(np.float32)
+    b = (rs.standard_normal(n, dtype=np.float32) * 0.1).astype(np.float32)
+    lab = rs.integers(0, n, B)
+    xd, yd, Wd, bd, ld = dev(x), dev(y), dev(W), dev(b), torch.from_numpy(lab).to(DEV)
+    st = L.cur_stream()
+    out, xo, yo = (torch.empty((B, n), device=DEV) for _ in range(3))
+    gxo, gyo = torch.empty((B, n), device=DEV), torch.empty((B, n), device=DEV)
+    loss = torch.empty(1, device=DEV)
+    dx, dy, dW, db = torch.empty_like(xd), torch.empty_like(yd), torch.empty_like(Wd), torch.empty_like(bd)
+    L.call("gdl_head_concat_fwd", L.ptr(xd), L.ptr(yd), L.ptr(Wd), L.ptr(bd), L.ptr(out), L.ptr(xo), L.ptr(yo), B, n, st)
+    L.call("gdl_softmax_ce", L.ptr(xo), L.ptr(ld), alpha, L.ptr(loss), L.ptr(gxo), B, n, st)
+    L.call("gdl_softmax_ce", L.ptr(yo), L.ptr(ld), alpha, L.ptr(loss), L.ptr(gyo), B, n, st)
+    L.call("gdl_head_concat_bwd", L.ptr(xd), L.ptr(yd), L.ptr(Wd), L.ptr(gxo), L.ptr(gyo), None, 0, 0, L.ptr(dx), L.ptr(dy),
+           L.ptr(dW), L.ptr(db), B, n, st)
+    ux, uy = torch.full_like(xd, float("nan")), torch.full_like(yd, float("nan"))
+    L.call("gdl_head_uni_dfeat", L.ptr(xd), L.ptr(Wd), 1024, L.ptr(bd), L.ptr(ld), alpha, L.ptr(ux), B, n, st)
+    L.call("gdl_head_uni_dfeat", L.ptr(yd), Wd.data_ptr() + 512 * 4, 1024, L.ptr(bd), L.ptr(ld), alpha, L.ptr(uy), B, n, st)
+    torch.cuda.synchronize()
+    assert torch.equal(ux.view(torch.int32), dx.view(torch.int32)) and torch.equal(uy.view(torch.int32), dy.view(torch.int32))
+    for f, Wm, got in ((x, W[:, :512], ux), (y, W[:, 512:], uy)):
+        u = f.astype(np.float64) @ Wm.astype(np.float64).T + b
+        p = np.exp(u - u.max(1, keepdims=True))
+        p /= p.sum(1, keepdims=True)
+        p[np.arange(B), lab] -= 1.0
+        want = (alpha * p / B) @ Wm.astype(np.float64)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-6)
+
+
 def test_head_sum_dgl_golden():
     """SumFusion_DGL (fusion_modules.py:16-30) through the C ABI against the reference's golden (both backward phases)."""
     g = _gold("head_sum_dgl_c6")
