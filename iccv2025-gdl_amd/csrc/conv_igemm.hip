@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
 // slab | rows -> HBM (addend / ReLU bits / statistics as in conv_epilogue) | barrier.  The tile's stores are only waited
 // for one tile later.  BatchNorm statistics accumulate in registers ACROSS the block's tiles; the block leaves ONE
 // partial row (stats[blockIdx.x][64][2]): conv_tiles_m() reports C64_GRID rows for these layers.
-// LDS: [slab 0][slab 1][1 KiB of zeros][statistics accumulators, 16 KiB].
+// LDS: [slab 0][slab 1][1 KiB of zeros] (at least the 72 KiB the filter staging of the prologue needs).
 // =====================================================================================================
 constexpr int C64_BM = 128;
 constexpr int C64_GRID = 512;  // two blocks per CU of an MI355X; also the number of BatchNorm partial rows
@@ -1125,11 +1125,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     const int ec = tid & 7, er0 = tid >> 3;
     // BatchNorm statistics of the thread's 8 channels, accumulated across the block's tiles in LDS ([16][256] floats behind
     // the zero row: 16 registers fewer in the K-loop, which sits at the 256-register limit of two waves per SIMD)
-    float* sacc = (float*)(smem + 2 * slab_bytes + 1024);
-    if (a.stats) {
+    float tsum[8], tsq[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e * 256 + tid] = 0.f;
-    }
+    for (int e = 0; e < 8; ++e) tsum[e] = tsq[e] = 0.f;
     bf16* __restrict__ gout = (bf16*)a.out;
     const bf16* __restrict__ gadd = (const bf16*)a.addend;
 
@@ -1179,7 +1177,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // 18 half-steps (tap, 32-channel half); the pixel fragments of half-step s+1 are requested before the MFMAs of s
-        uint4 px[2][4];
+        constexpr int NPX = (MODE == MODE_FWD) ? 1 : 2;  // forward: one set (its statistics live in registers instead)
+        uint4 px[NPX][4];
         unsigned pb[4];
         auto tap_addr = [&](int tap) __attribute__((always_inline)) {
             const int sr0 = prow0 + a.pshift[tap];
@@ -1205,8 +1204,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                 } else {
                     tap_addr(tap + 1);
                 }
-                reads(px[(hs + 1) & 1]);
-                lds_wait_n<4>();
+                if constexpr (NPX == 2) {
+                    reads(px[(hs + 1) & 1]);
+                    lds_wait_n<4>();
+                } else {
+                    lds_wait();
+                }
             } else {
                 lds_wait();
             }
@@ -1215,7 +1218,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[tap][h][n]),
-                                                                       __builtin_bit_cast(bf16x8_t, px[hs & 1][m]), acc[n][m], 0, 0, 0);
+                                                                       __builtin_bit_cast(bf16x8_t, px[hs & (NPX - 1)][m]), acc[n][m], 0, 0, 0);
+            if constexpr (NPX == 1)
+                if (hs + 1 < 18) reads(px[0]);  // (behind the MFMAs that read the registers: they are issued in order)
         }
         C64_SEG(1)
         if (more) load_masks((tile + bpx) * BM, fmask);  // the next tile's tap masks (waited for with the slab below)
@@ -1286,7 +1291,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                 for (int e = 0; e < 8; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
                 v = pack16<bf16>(f);
             }
-            if (a.stats && m0 + row < a.M) {
+            if (MODE == MODE_FWD && a.stats && m0 + row < a.M) {
                 float f[8];
                 unpack16<bf16>(v, f);
 #pragma unroll
@@ -1303,11 +1308,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             const int m = m0 + er0 + p * 32;
             if (m < a.M) *(uint4*)(gout + (size_t)m * 64 + ec * 8) = vq[p];
         }
-        if (a.stats) {
+        if (MODE == MODE_FWD && a.stats) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sacc[e * 256 + tid] += ssum[e];  // (read-modify-write: ds_add_f32 measured 5x slower here)
-                sacc[(8 + e) * 256 + tid] += ssq[e];
+                tsum[e] += ssum[e];
+                tsq[e] += ssq[e];
             }
         }
         C64_SEG(5)
@@ -1322,12 +1327,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         d[7] = tq_n;
     }
 #endif
-    if (a.stats) {
+    if (MODE == MODE_FWD && a.stats) {
         float ssum[8], ssq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            ssum[e] = sacc[e * 256 + tid];
-            ssq[e] = sacc[(8 + e) * 256 + tid];
+            ssum[e] = tsum[e];
+            ssq[e] = tsq[e];
         }
         // lanes with equal (lane & 7) hold the same 8 channels: fold them, then the 4 waves in fixed order
 #pragma unroll
@@ -1462,7 +1467,7 @@ struct ConvPlan {
     int nwv8;    // slab kernel: the 128 x 128 tile on 512 threads (small layers: one block per CU at most)
 };
 static size_t c64_lds_bytes(int W) {
-    const size_t b = 2 * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024 + 16 * 256 * 4;
+    const size_t b = 2 * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024;
     return b > (size_t)72 * 1024 ? b : (size_t)72 * 1024;  // the prologue stages the 72 KiB filter through the same LDS
 }
 static bool c64_enabled() {
