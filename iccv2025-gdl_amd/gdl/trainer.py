@@ -292,7 +292,8 @@ class DGLTrainer:
         # the visual encoder is the critical path (3x the audio work): enqueue it first so the single
         # host thread's ~100 launches per encoder pass do not delay it
         dgl = self.mode == "dgl"
-        early = dgl and self.head in ("concat", "sum") and self.dv == 512 and not self.vis_swin and self.early_backward is not False
+        early = (dgl and self.head in ("concat", "sum") and self.dv == 512 and not self.vis_swin and n <= 512
+                 and self.early_backward is not False)
         red = self.reducer
         gv, ga = self.gviews[nf + 60:nf + 60 + self.nv], self.gviews[nf:nf + 60]
         if early:
