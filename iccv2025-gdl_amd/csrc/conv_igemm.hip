@@ -1060,7 +1060,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     const int nins = (a.slab_rows + 7) >> 3;
     const int slab_bytes = nins * 1024;
     const unsigned smem_base = lds_addr(smem);
-    const unsigned zrow = smem_base + 2 * slab_bytes;
+    const int nbuf = a.single_slab ? 1 : 2;  // wide images: ONE slab buffer (the next tile's slab is fetched behind the row pass, exposed)
+    const unsigned zrow = smem_base + nbuf * slab_bytes;
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
 
     // this wave's filter: operand (tap, 32-channel half h, 16-output-channel fragment n) = 8 input channels
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (wave == 0) dma16(rin, smem + 2 * slab_bytes, (int)0x80000000);  // out-of-range LDS-DMA deposits zeros
+    if (wave == 0) dma16(rin, smem + nbuf * slab_bytes, (int)0x80000000);  // out-of-range LDS-DMA deposits zeros
     auto load_slab = [&](int sbuf, int m0) {
         unsigned char* dst = smem + sbuf * slab_bytes;
         int ln = lane;
@@ -1166,11 +1167,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #endif
         const int m0 = tile * BM;
         const bool more = tile + bpx < t_end;
-        if (more) {  // the other slab buffer is free: every wave is past its row reads of the tile before (barrier)
-            load_slab((it + 1) & 1, (tile + bpx) * BM);
+        const int sb = nbuf == 2 ? (it & 1) : 0;
+        if (more && nbuf == 2) {  // the other slab buffer is free: every wave is past its row reads of the tile before (barrier)
+            load_slab(sb ^ 1, (tile + bpx) * BM);
         }
         C64_SEG(0)
-        const unsigned slab = smem_base + (it & 1) * slab_bytes;
+        const unsigned slab = smem_base + sb * slab_bytes;
         f32x4_t acc[2][4];
 #pragma unroll
         for (int n = 0; n < 2; ++n)
@@ -1242,7 +1244,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         C64_SEG(2)
-        unsigned char* Cs = smem + (it & 1) * slab_bytes;
+        unsigned char* Cs = smem + sb * slab_bytes;
         {
             // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15
             // (stores the compiler cannot see: in front of a visible LDS store it would wait, vmcnt(0), for the slab prefetch
@@ -1317,6 +1319,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         }
         C64_SEG(5)
         __syncthreads();  // the staged tile has been read: its buffer is the next prefetch's target
+        if (nbuf == 1 && more) {  // one buffer: the next tile's slab now, waited for at once (the CU's other block works meanwhile)
+            load_slab(0, (tile + bpx) * BM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         C64_SEG(6)
     }
 #ifdef GDL_TIMING
@@ -1466,8 +1474,8 @@ struct ConvPlan {
     int c64;     // 1: conv3x3_c64_kernel (persistent; BatchNorm partial rows = C64_GRID)
     int nwv8;    // slab kernel: the 128 x 128 tile on 512 threads (small layers: one block per CU at most)
 };
-static size_t c64_lds_bytes(int W) {
-    const size_t b = 2 * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024;
+static size_t c64_lds_bytes(int W, bool single = false) {
+    const size_t b = (single ? 1 : 2) * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024;
     return b > (size_t)72 * 1024 ? b : (size_t)72 * 1024;  // the prologue stages the 72 KiB filter through the same LDS
 }
 static bool c64_enabled() {
@@ -1525,11 +1533,24 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     // 64 -> 64 channels (layer 1): the persistent weights-in-registers kernel, two blocks per CU (80 KB of LDS each at most;
     // the staged output tile, 128 x 144 bytes, has to fit into one slab buffer)
     if (!noslab && c64_enabled() && dtype == GDL_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && IC == 64 && OC == 64 &&
-        c64_lds_bytes(W) <= (size_t)80 * 1024 && (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 >= (size_t)C64_BM * 144 &&
+        c64_lds_bytes(W, true) <= (size_t)80 * 1024 && (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 >= (size_t)C64_BM * 144 &&
         M >= 64 * C64_BM) {
-        p.slab = 1, p.c64 = 1, p.bm = C64_BM, p.bn = 64, p.lds = c64_lds_bytes(W);
+        // (images too wide for two slab buffers in 80 KB -- the 157-pixel audio layer 1 of the Kinetics-Sounds / VGGSound
+        // shapes -- run it with one)
+        p.single = c64_lds_bytes(W) > (size_t)80 * 1024;
+        static int wide = -1;
+        if (wide < 0) {
+            const char* e = tune_env("GDL_C64_WIDE");  // tuning aid: 0 = wide images stay on the slab kernel
+            wide = e ? atoi(e) : 1;
+        }
+        if (p.single && !wide) {
+            p.single = 0;
+            goto no_c64;
+        }
+        p.slab = 1, p.c64 = 1, p.bm = C64_BM, p.bn = 64, p.lds = c64_lds_bytes(W, p.single != 0);
         return p;
     }
+no_c64:
     if (!noslab && R == 3 && S == 3 && stride == 1 && pad == 1) {
         static const char* plan_env = tune_env("GDL_PLAN");
         for (const char* q = plan_env; q && *q;) {

@@ -35,6 +35,7 @@ CONV_SHAPES = [
     (2, 256, 14, 14, 512, 3, 2, 1),   # stride 2, C=256
     (4, 64, 56, 56, 64, 3, 1, 1),     # 64 -> 64 channels: the weights-stationary persistent kernel (bf16), 98 tiles
     (3, 64, 65, 47, 64, 3, 1, 1),     # the same with odd spatial dims and a ragged last tile (M = 9165)
+    (2, 64, 33, 157, 64, 3, 1, 1),    # the same on a wide image (Kinetics-Sounds audio layer 1): ONE slab buffer
 ]
 
 
