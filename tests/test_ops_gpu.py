@@ -33,6 +33,7 @@ CONV_SHAPES = [
     (3, 64, 120, 115, 64, 3, 1, 1),   # 256x64, ragged tail
     (4, 64, 112, 112, 128, 3, 1, 1),  # 256x64, two N-tiles
     (2, 256, 14, 14, 512, 3, 2, 1),   # stride 2, C=256
+    (2, 64, 65, 47, 128, 3, 2, 1),    # stride 2 at odd dims (the audio layer-2 geometry): the 9-tap stride-2 weight gradient's edges
     (4, 64, 56, 56, 64, 3, 1, 1),     # 64 -> 64 channels: the weights-stationary persistent kernel (bf16), 98 tiles
     (3, 64, 65, 47, 64, 3, 1, 1),     # the same with odd spatial dims and a ragged last tile (M = 9165)
     (2, 64, 33, 157, 64, 3, 1, 1),    # the same on a wide image (Kinetics-Sounds audio layer 1): ONE slab buffer
