@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     for (int m = 0; m < 4; ++m) zb[m] = zrow - 2048u * m;
     // epilogue mapping: thread -> 16-byte chunk ec of rows er0 + 32*p
     const int ec = tid & 7, er0 = tid >> 3;
-    // BatchNorm statistics of the thread's 8 channels, accumulated across the block's tiles in LDS ([16][256] floats behind
-    // the zero row: 16 registers fewer in the K-loop, which sits at the 256-register limit of two waves per SIMD)
+    // BatchNorm statistics of the thread's 8 channels, accumulated across the block's tiles (forward only; these 16 registers
+    // are why the forward keeps ONE set of pixel fragments: the K-loop sits at the 256-register limit of two waves per SIMD)
     float tsum[8], tsq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) tsum[e] = tsq[e] = 0.f;
