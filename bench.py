@@ -11,8 +11,12 @@ the gradient-truncated fusion head + three cross-entropies, both encoder backwar
 per-bucket gradient all-reduce (N > 1), global-norm clipping, the logged per-encoder gradient
 statistics and the SGD(momentum, weight decay) update -- nothing skipped, nothing cached.
 Rank 0 prints ONE JSON line (see the driver contract); `roofline` is measured live with HIP
-events around every launch of the dominant kernel inside the timed region, `cpu_baseline` times
-the CPU oracle (oracle/, a C port of the reference's arithmetic) on this machine's host cores.
+events around every launch of the dominant kernel inside the timed region; `cpu_baseline` times the
+PyTorch-CPU-operator restatement of the step (oracle/torch_step.py; the plain-C port of oracle/ rides
+along as `c_port`) on this machine's host cores; `comparators.torch_rocm` times that same restatement
+on the MI355X with stock PyTorch-ROCm operators (MIOpen, bf16 autocast, channels_last) -- a diagnostic,
+not the product path; `extra_workloads` are short legs of the Kinetics-Sounds shapes (configs[2]) and of
+the VGGSound shapes with the Swin-T visual branch (configs[4]) so that their numbers are driver-visible.
 """
 import argparse
 import json
@@ -65,7 +69,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE config 2: 64)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="cremad", choices=sorted(WORKLOADS),
-                    help="cremad = BASELINE configs[1] (the metric's configuration); ks = configs[2] shapes; vggsound = configs[4] shapes")
+                    help="cremad = BASELINE configs[1] (the metric's configuration); ks = configs[2] shapes; vggsound = configs[4]'s "
+                         "data shapes on the ResNet18 pair; vggsound_swin = configs[4] (Swin-T visual branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="samples in the C-port CPU step (about 10-20 s of CPU work)")
     ap.add_argument("--cpu-torch-batch", type=int, default=8, help="samples in the PyTorch-operator CPU step (3 warm-up + 5 timed)")
@@ -76,6 +81,8 @@ def parse():
     ap.add_argument("--side-stream", choices=("auto", "on", "off"), default="auto",
                     help="the visual weight gradients' own stream: auto = on without a process group, off with one")
     ap.add_argument("--phases", action="store_true", help="also report forward / head / backward / optimizer phase times")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short ks / vggsound_swin legs behind extra_workloads")
+    ap.add_argument("--no-comparator", action="store_true", help="skip comparators.torch_rocm (stock PyTorch-ROCm step)")
     return ap.parse_args()
 
 
@@ -134,6 +141,115 @@ def cpu_baseline(batch, torch_batch, threads, wl):
             "c_port": c_port}
 
 
+def torch_rocm_comparator(wl, B, dev):
+    """The SAME step with stock PyTorch-ROCm operators on this GPU (oracle/torch_step.py on `dev`: MIOpen convolutions /
+    batch norm, rocBLAS head, bf16 autocast, channels_last weights and inputs, fp32 master weights, foreach clip +
+    hand-written SGD as in the restatement).  Diagnostic only -- with no published number for the metric this is the
+    one figure that says what the reference's own arithmetic gets on an MI355X from the stock stack.  Returns a dict."""
+    from oracle import fixtures as fx
+    from oracle.torch_step import TorchStep
+
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True  # MIOpen find mode (its best kernel per shape)
+    try:
+        P, Bf = fx.model_state(wl["n_classes"], "concat_dgl")
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        data = [(torch.randn(B, *wl["spec"], generator=g).to(dev), torch.randn(B, 3, 3, 224, 224, generator=g).to(dev),
+                 torch.randint(0, wl["n_classes"], (B,), generator=g).to(dev)) for _ in range(4)]
+        out = {}
+        for tag, ac, cl in (("bf16_channels_last", torch.bfloat16, True), ("fp32_nchw", None, False)):
+            ts = TorchStep(P, Bf, device=dev, autocast=ac, channels_last=cl)
+            for i in range(8):
+                ts.train_step(*data[i % 4], wl["alpha"], 2e-3)
+            torch.cuda.synchronize()
+            n = 20
+            t0 = time.perf_counter()
+            for i in range(n):
+                ts.train_step(*data[i % 4], wl["alpha"], 2e-3)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out[tag] = {"ms_per_step": round(dt * 1e3, 3), "value": round(B / dt, 2), "unit": "samples/s", "steps": n}
+            del ts
+            torch.cuda.empty_cache()
+        best = out["bf16_channels_last"]
+        return {"value": best["value"], "unit": "samples/s", "ms_per_step": best["ms_per_step"], "batch": B,
+                "what": f"oracle/torch_step.py on the GPU: PyTorch {torch.__version__} eager operators (MIOpen find mode / rocBLAS), "
+                        "bf16 autocast + channels_last, fp32 master weights, 8 warm-up + 20 timed steps; diagnostic comparator, "
+                        "not the product path", "variants": out}
+    finally:
+        torch.backends.cudnn.benchmark = prev
+
+
+def build_model(wl, batch, dev):
+    """The model exactly as main_dgl.py:230-246 builds it (random init; identical on every rank via the seed)."""
+    from models.basic_model import AVClassifier_DGL
+    from utils.utils import setup_seed, weight_init
+
+    setup_seed(0)
+    args = argparse.Namespace(fusion_method="concat", dataset=wl["dataset"], modality="full", batch_size=batch, pe=0)
+    if wl.get("swin"):
+        from models.basic_model import AVClassifier_DGL_Swin
+
+        model = AVClassifier_DGL_Swin(args)  # (the Swin branch keeps its own initialisation, swin_transformer.py:568-576:
+        model.audio_net.apply(weight_init)   #  utils.weight_init would trip over PatchMerging's bias-free Linear)
+        model.fusion_module.apply(weight_init)
+    else:
+        model = AVClassifier_DGL(args)
+        model.apply(weight_init)
+    model.to(dev)
+    model.train()
+    return model, args
+
+
+def extra_leg(name, a, dev, lib, collect, steps=10, warmup=5):
+    """A short driver-visible leg of another BASELINE configuration (N = 1): its own ms_per_step and the in-step roofline
+    of its dominant kernel.  Same step, same trainer, same taps as the main measurement."""
+    from gdl.trainer import DGLTrainer
+
+    wl = WORKLOADS[name]
+    model, _ = build_model(wl, a.batch, dev)
+    tr = DGLTrainer(model, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    B = a.batch
+    data = [(torch.randn(B, *wl["spec"], generator=g).to(dev), torch.randn(B, 3, 3, 224, 224, generator=g).to(dev),
+             torch.randint(0, wl["n_classes"], (B,), generator=g).to(dev)) for _ in range(4)]
+    for i in range(warmup):
+        tr.step(*data[i % 4])
+    torch.cuda.synchronize()
+    lib.gdl_prof_set_filter(None)
+    lib.gdl_prof_enable(1)
+    for i in range(2):
+        tr.step(*data[i % 4])
+    torch.cuda.synchronize()
+    lib.gdl_prof_enable(0)
+    table = collect(2)
+    dom = table[0]["kernel"]
+    lib.gdl_prof_set_filter(dom.encode())
+    lib.gdl_prof_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(*data[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lib.gdl_prof_enable(0)
+    d = [k for k in collect(steps) if k["kernel"] == dom][0]
+    lib.gdl_prof_set_filter(None)
+    res = tr.read()
+    top = [{"kernel": k["kernel"], "ms_per_step": k["ms_per_step"], "frac": k["frac"], "bound": k["bound"]} for k in table[:6]]
+    del tr, model
+    torch.cuda.empty_cache()
+    return {"workload": wl["name"], "metric": wl["metric"], "value": round(B / dt, 2), "unit": "samples/s",
+            "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup + 2, "dtype": a.dtype, "batch": B,
+            "step_tflops": round(B / dt * wl["gflop"] / 1e3, 2),
+            "mfma_frac_end_to_end": round(B / dt * wl["gflop"] / 1e3 / MFMA_PEAK_TFLOPS[a.dtype], 4),
+            "loss_f": round(res["loss_f"], 5), "total_norm": round(res["total_norm"], 4),
+            "roofline": {"bound": d["bound"], "kernel": d["kernel"], "achieved": d["achieved"], "unit": d["unit"],
+                         "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma" else HBM_PEAK_GBS, "frac": d["frac"],
+                         "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]},
+            "top_kernels": top}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,22 +291,10 @@ def main():
     from utils.utils import setup_seed, weight_init
 
     lib = L.load()
-    # model exactly as main_dgl.py:230-246 builds it (random init; identical on every rank via the seed)
-    setup_seed(0)
     wl = WORKLOADS[a.workload]
-    args = argparse.Namespace(fusion_method="concat", dataset=wl["dataset"], modality="full", batch_size=a.batch, pe=0)
+    model, args = build_model(wl, a.batch, dev)
     if wl.get("swin"):
-        from models.basic_model import AVClassifier_DGL_Swin
-
-        model = AVClassifier_DGL_Swin(args)  # (the Swin branch keeps its own initialisation, swin_transformer.py:568-576:
-        model.audio_net.apply(weight_init)   #  utils.weight_init would trip over PatchMerging's bias-free Linear)
-        model.fusion_module.apply(weight_init)
-        a.no_f32 = a.no_cpu_baseline = True  # (both legs are written for the ResNet18 pair)
-    else:
-        model = AVClassifier_DGL(args)
-        model.apply(weight_init)
-    model.to(dev)
-    model.train()
+        a.no_f32 = a.no_cpu_baseline = a.no_comparator = True  # (those legs are written for the ResNet18 pair)
     tr = DGLTrainer(model, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=a.dtype,
                     process_group=pg, visual_side_stream={"auto": None, "on": True, "off": False}[a.side_stream])
     # synthetic CREMA-D batch, seed 1234 + rank, resident on the device
@@ -203,6 +307,9 @@ def main():
         data.append((torch.randn(B, *wl["spec"], generator=g).to(dev), torch.randn(B, 3, 3, 224, 224, generator=g).to(dev),
                      torch.randint(0, wl["n_classes"], (B,), generator=g).to(dev)))
     counter = [0]
+    # (total norm, clip coefficient) of every step of the timed region, copied device-to-device behind each step (8 bytes on
+    # the step's own stream: a measuring tap like the HIP events, read once after the region) -> clip_active_steps
+    tr.stats_log = torch.zeros((a.steps, 2), device=dev)
 
     def step():
         spec, image, label = data[counter[0] % len(data)]
@@ -262,6 +369,7 @@ def main():
     if prof:
         lib.gdl_prof_enable(1)
     torch.cuda.synchronize()
+    tr.stats_log_pos = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -269,6 +377,8 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    tr.stats_log_pos = None
+    clip_log = tr.stats_log.cpu().numpy()
     if world > 1:
         import torch.distributed as dist
 
@@ -302,6 +412,9 @@ def main():
         # The same kernels WITHOUT contention: each encoder's forward + backward on its own, weight gradients on the
         # chain's stream -- every launch has the device to itself.  The step's table says what a launch costs beside the
         # other streams (what the job pays); this one says what the kernel itself does (`roofline.alone`).
+        # (a measurement after the timed region: it advances the BatchNorm running statistics and overwrites the gradient
+        # arena; everything reported from the training run -- losses, norms, clip_log -- has been read above)
+        had_side = tr.eng_v.has_side_stream()
         tr.eng_v.side_stream(False)
         spec, image, _ = data[0]
         nf = tr.nf
@@ -315,7 +428,7 @@ def main():
         torch.cuda.synchronize()
         lib.gdl_prof_enable(0)
         alone = {k["kernel"]: k for k in collect(3)}
-        tr.eng_v.side_stream(True)
+        tr.eng_v.side_stream(had_side)  # exactly the configuration the timed region ran in
         for k in kernels:
             if k["kernel"] in alone:
                 k["alone_avg_us"], k["alone_frac"] = alone[k["kernel"]]["avg_us"], alone[k["kernel"]]["frac"]
@@ -333,11 +446,10 @@ def main():
         ev = tr.phase_events
         tr.phase_events = None
         acc = {}
-        for i in range(0, len(ev), 5):
-            names = [n for n, _ in ev[i:i + 5]]
-            es = [e for _, e in ev[i:i + 5]]
-            for k in range(4):
-                acc.setdefault(names[k] + "->" + names[k + 1], []).append(es[k].elapsed_time(es[k + 1]))
+        starts = [i for i, (n, _) in enumerate(ev) if n == "start"] + [len(ev)]
+        for lo, hi in zip(starts[:-1], starts[1:]):  # one group of marks per step, whatever marks the step's form records
+            for (n0, e0), (n1, e1) in zip(ev[lo:hi - 1], ev[lo + 1:hi]):
+                acc.setdefault(n0 + "->" + n1, []).append(e0.elapsed_time(e1))
         phases = {k: round(sum(v) / len(v), 3) for k, v in acc.items()}
     comm = None
     if world > 1:
@@ -367,6 +479,36 @@ def main():
         comm = {"allreduce_alone_ms": buckets_ms, "allreduce_alone_sum_ms": round(tot, 4), "step_ms_without_comm": round(t_nc, 3),
                 "exposed_ms": round(exposed, 3), "overlapped_frac": round(1.0 - min(1.0, exposed / tot), 4) if tot > 0 else None,
                 "bucket_mbytes": {k: round((hi - lo) * 4 / 1e6, 3) for k, (lo, hi) in tr.bucket.items()}}
+        # The two schedule choices that a one-GPU lease cannot decide, measured here on first contact with
+        # real RCCL traffic: the visual weight gradients' side stream (a fifth stream beside the collective's) and the
+        # early-backward form (another collective order).  Every rank runs every variant (they contain collectives); the
+        # headline `value` above is the default configuration's.
+        if not wl.get("swin"):
+            def timed(nsteps):
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                barrier()
+                t0_ = time.perf_counter()
+                for _ in range(nsteps):
+                    step()
+                torch.cuda.synchronize()
+                barrier()
+                t_ = torch.tensor([(time.perf_counter() - t0_) / nsteps * 1e3], device=dev, dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                return round(float(t_.item()), 3)
+
+            side0, early0 = tr.eng_v.has_side_stream(), tr.early_backward
+            variants = {}
+            for side in (False, True):
+                for early in (False, True):
+                    tr.eng_v.side_stream(side)
+                    tr.early_backward = early
+                    variants[f"side_stream_{'on' if side else 'off'}__early_backward_{'on' if early else 'off'}"] = timed(nn_)
+            tr.eng_v.side_stream(side0)
+            tr.early_backward = early0
+            comm["schedule_variants_ms"] = variants
+            comm["default_schedule"] = f"side_stream_{'on' if side0 else 'off'}__early_backward_{'on' if early0 is not False else 'off'}"
     f32_exact = None
     if a.dtype == "bf16" and not a.no_f32:
         # the exact-parity mode (f32 storage, f32-input MFMA == an fmaf chain) on the same workload: a short run
@@ -394,6 +536,28 @@ def main():
                      "steps": n32, "note": "f32 storage + f32-input MFMA (bit-for-bit an fp32 fmaf chain): the parity mode, "
                                            "not the benchmark configuration"}
         del tr32
+    extra = None
+    comparators = None
+    if world == 1 and pg is None:
+        try:
+            del tr
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        if a.workload == "cremad" and not a.no_extra and not a.no_prof:
+            extra = {}
+            for name in ("ks", "vggsound_swin"):
+                try:
+                    extra[name] = extra_leg(name, a, dev, lib, collect)
+                except Exception as e:  # a secondary leg must never take the headline line down
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                    lib.gdl_prof_enable(0)
+                    lib.gdl_prof_set_filter(None)
+        if not a.no_comparator and a.dtype == "bf16":
+            try:
+                comparators = {"torch_rocm": torch_rocm_comparator(wl, B, dev)}
+            except Exception as e:
+                comparators = {"torch_rocm": {"error": f"{type(e).__name__}: {e}"}}
     if world > 1:
         import torch.distributed as dist
 
@@ -405,7 +569,8 @@ def main():
     out = {
         "metric": wl["metric"],
         "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "timed_region_s": round(elapsed, 4),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": wl["name"],
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
@@ -417,8 +582,12 @@ def main():
         "loss_f": round(res["loss_f"], 5), "loss_a": round(res["loss_a"], 5), "loss_v": round(res["loss_v"], 5),
         "total_norm": round(res["total_norm"], 4),
         "clip_coef": round(res["clip_coef"], 4),
+        # steps of the timed region in which clip_grad_norm_ actually scaled the gradients (coefficient < 1; the kernels do
+        # the same work either way) and the range the global norm moved in
+        "clip_active_steps": int((clip_log[:, 1] < 1.0).sum()), "total_norm_range": [round(float(clip_log[:, 0].min()), 4),
+                                                                                    round(float(clip_log[:, 0].max()), 4)],
         "roofline": roof, "kernels": kernels, "phases_ms": phases, "f32_exact": f32_exact, "comm": comm,
-        "batches": len(data), "src_hash": src_hash(),
+        "batches": len(data), "src_hash": src_hash(), "extra_workloads": extra, "comparators": comparators,
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_torch_batch, a.cpu_threads, wl)

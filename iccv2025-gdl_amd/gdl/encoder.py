@@ -38,6 +38,10 @@ class EncoderEngine:
     def side_stream(self, enable=True):
         """Fork the weight gradients of backward() onto an engine-owned side stream (see include/gdl_hip.h)."""
         L.call("gdl_encoder_side_stream", self.h, 1 if enable else 0)
+        self._side = bool(enable)
+
+    def has_side_stream(self):
+        return bool(getattr(self, "_side", False))
 
     def __del__(self):
         try:

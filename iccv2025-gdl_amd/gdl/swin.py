@@ -123,7 +123,13 @@ class SwinEngine:
         self.tdtype = L.torch_dtype(self.dt)
         self.device = torch.device(device)
         self._tables, self._wg = {}, None
-        self._graphs, self.use_graph = {}, True
+        # HIP-graph replay of the forward / backward launch sequences (see _run); GDL_NOGRAPH=1 (with GDL_TUNING=1) keeps every
+        # pass eager -- the PMC scripts set it, so that counters are collected over ordinary launches
+        import os
+
+        self._graphs = {}
+        self.use_graph = not (os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_NOGRAPH") == "1")
+        self.serial = 0  # forward counter: a backward must follow the forward whose activations are in the buffers
         E, p = cfg["embed"], cfg["patch"]
         assert cfg["img"] % p == 0 and 3 * p * p <= 64
         res = cfg["img"] // p
@@ -298,6 +304,7 @@ class SwinEngine:
         key = ("f", out.data_ptr(), bool(pool_frames)) + tuple(p.data_ptr() for p in self._params)
         self._run(key, lambda: self._forward_body(out, pool_frames))
         self.have_fwd = True
+        self.serial += 1
         return out
 
     def _run(self, key, body):
@@ -318,16 +325,18 @@ class SwinEngine:
         ent["n"] += 1
         if ent["n"] <= 2:
             return body()
+        g = torch.cuda.CUDAGraph()
         try:
-            g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 body()
-            ent["g"] = g
-            g.replay()
-        except Exception:  # capture not possible on this stack: stay eager
+        except RuntimeError as e:  # capture not possible on this stack: stay eager from here on
             self.use_graph = False
             torch.cuda.synchronize(self.device)
-            body()
+            if torch.cuda.is_current_stream_capturing():
+                raise L.GdlError(f"SwinEngine: graph capture failed and the stream is still capturing: {e}") from e
+            return body()
+        ent["g"] = g
+        g.replay()
 
     def _forward_body(self, out, pool_frames):
         cfg, dt, N, st = self.cfg, self.dt, self.N, L.cur_stream()
@@ -363,11 +372,16 @@ class SwinEngine:
                self.L_out * (T if pool_frames else 1), self.C_out, last["ld"], st)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dfeat, grads):
+    def backward(self, dfeat, grads, serial=None):
         """dfeat float32 [B*T, C_last] (or [B, C_last] for a pool_frames forward); grads: float32 tensors of the
-        parameter shapes (overwritten)."""
+        parameter shapes (overwritten).  serial: the engine's `serial` right after the forward being differentiated -- if
+        another forward has run through the engine since (a validation pass of the same shape, two forwards before one
+        backward), its activations are gone and this raises instead of returning gradients of the wrong pass."""
         if not self.have_fwd:
             raise L.GdlError("SwinEngine.backward: no forward to differentiate")
+        if serial is not None and serial != self.serial:
+            raise L.GdlError("SwinEngine.backward: the engine has run another forward since the one being differentiated "
+                             f"(forward {serial}, now {self.serial}): its saved activations were overwritten")
         if len(grads) != len(self.names):
             raise L.GdlError("SwinEngine.backward: wrong number of gradient tensors")
         N = self.N

@@ -1,7 +1,15 @@
 """Native DGL training step: the whole body of /root/reference/main_dgl.py:97-154 as one
 sequence of gfx950 kernels on two HIP streams (+ a side stream for the visual weight gradients), without an autograd tape.
 
-Per step (all asynchronous, nothing is read back unless `read()` is called):
+Per step (all asynchronous, nothing is read back unless `read()` is called).  Default form for the concat / sum DGL heads
+without a process group ("early backward", bit-identical to the junction form below):
+  stream V: visual forward -> gdl_head_uni_dfeat (alpha * dCE(v_out)/d feature) -> visual backward
+  stream A: audio  forward -> gdl_head_uni_dfeat (alpha * dCE(a_out)/d feature) -> audio  backward
+            -> fusion head forward (all three logit sets), 3x cross-entropy, gradient of fc_out from loss_f alone
+  then on A: fused grad statistics (total norm -> clip coefficient, per-encoder sum mean|g|)  (main_dgl.py:129-143)
+             fused clip + SGD(momentum, weight decay) over the flat parameter arena            (:154)
+Junction form (other heads, the non-DGL step, and -- until a multi-GPU run has validated the early form's collective order --
+every data-parallel run):
   audio encoder forward  (stream A)  ||  visual encoder forward (stream V)
   fusion head forward, 3x cross-entropy, head backward with the DGL truncation   (stream A)
       - encoders receive only alpha * d(CE(a_out) + CE(v_out))      (main_dgl.py:108-110)
@@ -9,8 +17,7 @@ Per step (all asynchronous, nothing is read back unless `read()` is called):
       - fc_auxi never receives a gradient and is skipped by SGD      
   audio encoder backward (stream A)  ||  visual encoder backward (stream V)
       [+ per-bucket RCCL all-reduce as soon as a bucket is final]
-  fused grad statistics (total norm -> clip coefficient, per-encoder sum mean|g|)  (:129-143)
-  fused clip + SGD(momentum, weight decay) over the flat parameter arena               (:154)
+  grad statistics, clip + SGD as above
 
 The result is numerically the reference's two-phase backward: SURVEY section 0 shows the
 single-pass form is bit-identical in exact arithmetic, and tests/test_step_gpu.py checks it
@@ -69,7 +76,11 @@ class DGLTrainer:
         # own stream right behind its forward and the backward starts without waiting for the other encoder; the fusion
         # head (logits of all three sets, the losses, fc_out's gradient) follows on the audio stream behind the audio backward.
         # Same numbers bit for bit (tests/test_step_gpu.py::test_early_backward_identical), no forward -> head -> backward junction.
+        # With a process group None means OFF: the early form issues the collectives in a different order (audio_l4, visual_l4,
+        # audio_rest, fusion, visual_rest over two streams) that no multi-GPU run has exercised yet -- opt in with True.
         self.early_backward = early_backward
+        if early_backward is None and process_group is not None:
+            self.early_backward = False
         if early_backward is None and os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_EARLY_BWD") == "0":
             self.early_backward = False  # tuning aid (A/B)
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
@@ -166,6 +177,10 @@ class DGLTrainer:
         self.eng_a = self.eng_v = None
         self.steps = 0
         self.phase_events = None  # set to [] to record (name, event) marks on the main stream per step
+        # measuring tap (bench.py): a [n, 2] device tensor + a position; while the position is not None every step copies its
+        # (total norm, clip coefficient) into the next row, device to device on the step's stream
+        self.stats_log = None
+        self.stats_log_pos = None
 
     def _replica_buffers(self):
         """Every tensor of the replica that is not in the flat arenas: BatchNorm running statistics and counters of
@@ -197,11 +212,18 @@ class DGLTrainer:
         if self.reducer is not None:  # the model's parameters alias the arena: whatever rank 0 loaded is the truth
             self.reducer.sync_state([self.params, self.momentum] + self._replica_buffers())
 
+    def close(self):
+        """Releases what the trainer owns outside PyTorch's allocator: the optimizer descriptor and, for
+        comm_backend="abi", the RCCL communicator (ncclCommDestroy).  Idempotent; also run by __del__."""
+        if getattr(self, "reducer", None) is not None:
+            self.reducer.close()
+        if getattr(self, "opt", None):
+            self.lib.gdl_optim_destroy(self.opt)
+            self.opt = None
+
     def __del__(self):
         try:
-            if getattr(self, "opt", None):
-                self.lib.gdl_optim_destroy(self.opt)
-                self.opt = None
+            self.close()
         except Exception:
             pass
 
@@ -443,6 +465,9 @@ class DGLTrainer:
         L.call("gdl_optim_sgd_step", self.opt, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.momentum),
                L.ptr(self.stats), gs, self.lr, self.mu, self.wd, st)
         self._mark(main, "end")
+        if self.stats_log is not None and self.stats_log_pos is not None and self.stats_log_pos < self.stats_log.shape[0]:
+            self.stats_log[self.stats_log_pos].copy_(self.stats[:2], non_blocking=True)
+            self.stats_log_pos += 1
         self.steps += 1
 
     def _head_forward(self, dgl, st):

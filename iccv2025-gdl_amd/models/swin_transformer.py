@@ -110,6 +110,7 @@ class _SwinFn(torch.autograd.Function):
         eng.set_params([p.detach() for p in params])
         feat = eng.forward(x.float().contiguous(), pool_frames=pooled).clone()
         ctx.net, ctx.eng, ctx.n = net, eng, len(params)
+        ctx.serial = eng.serial  # the engine is shared by every forward of this shape (train and eval): see backward
         ctx.set_materialize_grads(False)
         return feat
 
@@ -118,7 +119,8 @@ class _SwinFn(torch.autograd.Function):
         if g is None:
             return (None, None, None) + (None,) * ctx.n
         grads = [torch.empty_like(p) for p in ctx.eng._params]
-        ctx.eng.backward(g.float().contiguous(), grads)
+        # raises if another forward went through the engine in between (as _ResNetFn does for the ResNet18 engine)
+        ctx.eng.backward(g.float().contiguous(), grads, serial=ctx.serial)
         return (None, None, None) + tuple(grads)
 
 

@@ -3,7 +3,8 @@
 Written from scratch on torch.nn.functional (none of the reference's files): it is the "PyTorch-op restatement" of
 BASELINE.md section 3 / SURVEY 8(d), timed by bench.py's `cpu_baseline` beside the C port (oracle/gdl_oracle.c) so that
 the reported CPU baseline is the arithmetic the reference actually runs on a CPU (ATen / oneDNN kernels), not only a
-naive port.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+naive port.  Only tests/, __graft_entry__.smoke() and bench.py's baseline legs (cpu_baseline, and the same restatement on the
+GPU as the diagnostic `comparators.torch_rocm`) may import it.
 
 What it follows: ResNet18 without pool / fc (/root/reference/models/backbone.py:75-201: 7x7/2 stem, BN, ReLU,
 MaxPool 3/2/1, four layers of two BasicBlocks with a 1x1/2 conv + BN shortcut on the first block of layers 2-4), the
@@ -41,19 +42,44 @@ def encoder(x, P, Bf, pre, training):
 
 
 class TorchStep:
-    def __init__(self, params, buffers, threads=None):
-        """params / buffers: name -> numpy array (oracle.fixtures.model_state)."""
+    def __init__(self, params, buffers, threads=None, device="cpu", autocast=None, channels_last=False):
+        """params / buffers: name -> numpy array (oracle.fixtures.model_state).
+        device / autocast / channels_last: the SAME restatement on another device -- bench.py's `comparators.torch_rocm`
+        runs it on the MI355X with stock PyTorch-ROCm operators (MIOpen / rocBLAS, bf16 autocast, channels_last weights):
+        a diagnostic number beside `cpu_baseline`, never the product path and never a parity reference."""
         if threads:
             torch.set_num_threads(int(threads))
-        self.P = {k: torch.from_numpy(np.array(v)).clone().requires_grad_(True) for k, v in params.items()}
-        self.Bf = {k: torch.from_numpy(np.array(v)).clone() for k, v in buffers.items()}
+        self.dev = torch.device(device)
+        self.autocast = autocast
+        self.cl = bool(channels_last)
+
+        def put(v, grad):
+            t = torch.from_numpy(np.array(v)).clone().to(self.dev)
+            if self.cl and t.dim() == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            return t.requires_grad_(True) if grad else t
+
+        self.P = {k: put(v, True) for k, v in params.items()}
+        self.Bf = {k: put(v, False) for k, v in buffers.items()}
         self.mom = {}
 
     def forward(self, spec, image, training=True):
+        if self.autocast is not None:
+            with torch.autocast(self.dev.type, dtype=self.autocast):
+                out, out_a, out_v = self._forward(spec, image, training)
+            return out.float(), out_a.float(), out_v.float()
+        return self._forward(spec, image, training)
+
+    def _forward(self, spec, image, training=True):
         P, Bf = self.P, self.Bf
         B, _, T, H, W = image.shape
-        a = encoder(spec.unsqueeze(1), P, Bf, "audio_net", training)
-        v = encoder(image.permute(0, 2, 1, 3, 4).reshape(B * T, 3, H, W), P, Bf, "visual_net", training)
+        xa = spec.unsqueeze(1)
+        xv = image.permute(0, 2, 1, 3, 4).reshape(B * T, 3, H, W)
+        if self.cl:
+            xa = xa.contiguous(memory_format=torch.channels_last)
+            xv = xv.contiguous(memory_format=torch.channels_last)
+        a = encoder(xa, P, Bf, "audio_net", training)
+        v = encoder(xv, P, Bf, "visual_net", training)
         v = v.view(B, T, 512, v.shape[-2], v.shape[-1]).permute(0, 2, 1, 3, 4)
         fa = torch.flatten(F.adaptive_avg_pool2d(a, 1), 1)
         fv = torch.flatten(F.adaptive_avg_pool3d(v, 1), 1)
@@ -65,8 +91,8 @@ class TorchStep:
         return out, out_a, out_v
 
     def train_step(self, spec, image, label, alpha, lr, momentum=0.9, wd=1e-4, max_norm=40.0):
-        spec, image = torch.as_tensor(spec), torch.as_tensor(image)
-        label = torch.as_tensor(label).long()
+        spec, image = torch.as_tensor(spec).to(self.dev), torch.as_tensor(image).to(self.dev)
+        label = torch.as_tensor(label).long().to(self.dev)
         P = self.P
         for p in P.values():
             p.grad = None
@@ -78,7 +104,9 @@ class TorchStep:
                 p.grad = None
         loss_f.backward()
         with_grad = [p for p in P.values() if p.grad is not None]
-        total = float(torch.nn.utils.clip_grad_norm_(with_grad, max_norm))
+        total = torch.nn.utils.clip_grad_norm_(with_grad, max_norm)
+        if self.dev.type == "cpu":
+            total = float(total)
         with torch.no_grad():
             for k, p in P.items():
                 if p.grad is None:
@@ -89,5 +117,8 @@ class TorchStep:
                 else:
                     self.mom[k].mul_(momentum).add_(g)
                 p.add_(self.mom[k], alpha=-lr)
+        if self.dev.type != "cpu":  # timing use: no host read-back per step
+            return {"out": out.detach(), "out_a": out_a.detach(), "out_v": out_v.detach(), "loss_f": loss_f.detach(),
+                    "loss_a": loss_a.detach(), "loss_v": loss_v.detach(), "total_norm": total}
         return {"out": out.detach().numpy(), "out_a": out_a.detach().numpy(), "out_v": out_v.detach().numpy(),
                 "loss_f": loss_f.item(), "loss_a": loss_a.item(), "loss_v": loss_v.item(), "total_norm": total}

@@ -244,3 +244,23 @@ def test_swin_trainer_graph_replay_equals_eager(golden_dir):
         np.testing.assert_array_equal(oa, ob)
         assert na == nb and la == lb
     np.testing.assert_array_equal(pa, pb)
+
+
+def test_swin_dropin_stale_forward_is_refused(golden_dir):
+    """The drop-in SwinTransformer shares one engine between every forward of a shape (train and eval): a backward through
+    an output whose activations a later forward has overwritten must raise (as the ResNet18 mirror does), never return the
+    gradients of the other pass."""
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+    net = _swin_dgl_model(cfg, "bf16").visual_net
+    net.train()
+    sc = cfg["swin"]
+    x = torch.randn(2, 3, 2, sc["img"], sc["img"], device=DEV)
+    y1 = net(x)
+    y1.sum().backward()  # the ordinary order works
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    y1 = net(x)
+    with torch.no_grad():
+        net(x + 1.0)  # e.g. a validation forward of the same shape in between
+    with pytest.raises(L.GdlError, match="another forward"):
+        y1.sum().backward()

@@ -41,13 +41,20 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--miopen", action="store_true",
+                    help="also time torch.nn.functional.conv2d (MIOpen, channels_last, the same dtype) forward / input gradient / "
+                         "weight gradient per shape: a comparator column, never the product path")
     a = ap.parse_args()
     dt = L.dtype_code(a.dtype)
     td = L.torch_dtype(dt)
     dev = "cuda:0"
     st = L.cur_stream()
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
-    print(f"{'shape':46s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
+    mtot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    if a.miopen:
+        torch.backends.cudnn.benchmark = True  # MIOpen find mode: the library's best kernel per shape
+    print(f"{'shape':46s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}"
+          + ("   || MIOpen fwd / dgrad / wgrad ms" if a.miopen else ""))
     for enc, mul, C, H, W, K, R, stride, pad, cnt in SHAPES:
         N = a.batch * mul
         P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
@@ -79,8 +86,25 @@ def main():
         tot["dgrad"] += t_d * cnt
         tot["wgrad"] += t_w * cnt
         name = f"{enc} {C}x{H}x{W}->{K} {R}x{R}/{stride} x{cnt}"
-        print(f"{name:46s} {gf:8.2f} | {t_f:8.3f} {gf / t_f:7.1f} | {t_d:8.3f} {gf / t_d:7.1f} | {t_w:8.3f} {gf / t_w:7.1f}")
+        line = f"{name:46s} {gf:8.2f} | {t_f:8.3f} {gf / t_f:7.1f} | {t_d:8.3f} {gf / t_d:7.1f} | {t_w:8.3f} {gf / t_w:7.1f}"
+        if a.miopen:
+            import torch.nn.functional as F
+            from torch.nn import grad as G
+
+            xm = x.permute(0, 3, 1, 2)   # NCHW view of the NHWC storage = channels_last
+            wm = wk.permute(0, 3, 1, 2)  # [K][C][R][S] view of [K][R][S][C] = channels_last
+            dym = dy.permute(0, 3, 1, 2)
+            m_f = timeit(lambda: F.conv2d(xm, wm, stride=stride, padding=pad), a.iters)
+            m_d = timeit(lambda: G.conv2d_input(xm.shape, wm, dym, stride=stride, padding=pad), a.iters)
+            m_w = timeit(lambda: G.conv2d_weight(xm, wm.shape, dym, stride=stride, padding=pad), a.iters)
+            mtot["fwd"] += m_f * cnt
+            mtot["dgrad"] += m_d * cnt
+            mtot["wgrad"] += m_w * cnt
+            line += f"   || {m_f:7.3f} {m_d:7.3f} {m_w:7.3f}"
+        print(line, flush=True)
     print("totals (ms, weighted by layer count):", {k: round(v, 3) for k, v in tot.items()}, "sum", round(sum(tot.values()), 3))
+    if a.miopen:
+        print("MIOpen totals (ms):", {k: round(v, 3) for k, v in mtot.items()}, "sum", round(sum(mtot.values()), 3))
 
 
 if __name__ == "__main__":
