@@ -14,7 +14,7 @@
 // (padding, stride-2 parity, M tail) comes from the buffer descriptor's bounds
 // check, the per-pixel offsets from a precomputed gather table (gather.h); one
 // barrier per K-step.  LDS rows are 128 B with a 16-byte
-// chunk XOR swizzle chunk ^= (row>>1)&7, conflict-free for the ds_read_b128
+// chunk XOR swizzle chunk ^= swz128(row) (below), conflict-free for the ds_read_b128
 // fragment reads.  Operands are swapped (weights = MFMA "A", pixels = MFMA "B")
 // so a lane ends up with 4 consecutive output channels of one pixel.  The
 // epilogue stages the tile through LDS, then streams full rows: optional addend
@@ -126,6 +126,17 @@ struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
     }
 };
+
+// 16-byte-chunk XOR swizzle of a 128-byte LDS row: logical chunk c of row r sits at chunk c ^ swz128(r).
+// ds_read_b128 serves a wave in four 16-lane groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32) and a group
+// is conflict-free when its 16 lanes hit 16 different 16-byte slots of the 256-byte bank row (= two LDS rows).  A fragment
+// read (lane -> row r0 + (lane & 15), chunk (lane >> 4) + 4 kk) therefore needs, among the 8 rows of one parity, distinct
+// physical chunks for a mix of logical chunks c (4 rows) and c + 1 (4 rows), c even.  The term below only flips chunk bits
+// 1-2 (values 0, 2, 4, 6, consecutive over consecutive same-parity rows), so c-rows stay on even and (c+1)-rows on odd chunks
+// and each set of four is distinct FOR EVERY r0 -- the tap-shifted slab reads of the 3x3 kernels start at arbitrary rows.
+// (Rounds 1-2 used (r >> 1) & 7: conflict-free only for r0 = 0 mod 4, 1.75x the LDS cycles averaged over the shifts; that
+// was the 42-44 % SQ_LDS_BANK_CONFLICT of the 64-channel kernel and the 22 % of the slab kernel.)
+__device__ __forceinline__ int swz128(int row) { return ((row >> 1) & 3) << 1; }
 
 // LDS fragment read hidden from the compiler: hipcc waits vmcnt(0) before any ds_read it can see
 // while an LDS-DMA is in flight (it cannot prove the ring slots disjoint), which would serialise
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // instruction fills 8 consecutive 128-byte rows, lane L -> row L>>3, physical chunk L&7, so the
     // XOR swizzle is applied to the SOURCE chunk each lane fetches.
     const int pchunk = tid & 7, row0 = tid >> 3;
-    const int schunk = pchunk ^ ((row0 >> 1) & 7);  // (row0 + 32*i)>>1 & 7 is the same for every i
+    const int schunk = pchunk ^ swz128(row0);  // (row0 + 32*i)>>1 & 7 is the same for every i
     int a_off[AROWS];
     unsigned a_mask[AROWS];
 #pragma unroll
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int m = 0; m < MI; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets: row = tilebase + (lane&15), logical chunk = kk*4 + (lane>>4)
-    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const int frow = lane & 15, fg = lane >> 4, fswz = swz128(frow);
     const int off_kk0 = frow * 128 + (((0 + fg) ^ fswz) << 4);
     const int off_kk1 = frow * 128 + (((4 + fg) ^ fswz) << 4);
 
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(256) void conv_stem_rows_kernel(ConvArgs a, int P, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = i * 8 + prow;
-            const int sch = pch ^ ((row >> 1) & 7);
+            const int sch = pch ^ swz128(row);
             dma16(rwt, Ws + wave * 8192 + i * 1024, (row * 4 + wave) * 128 + sch * 16);
         }
     }
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(256) void conv_stem_rows_kernel(ConvArgs a, int P, 
     for (int nn = 0; nn < 4; ++nn)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[nn][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fg = lane >> 4, fswz = (frow >> 1) & 7;
+    const int frow = lane & 15, fg = lane >> 4, fswz = swz128(frow);
     const unsigned abase = lds_addr(Xs) + frow * 16 + fg * 16;
     const unsigned wb0 = smem_base + frow * 128 + (((0 + fg) ^ fswz) << 4), wb1 = smem_base + frow * 128 + (((4 + fg) ^ fswz) << 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
         const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
         for (int p = wave; p < 32; p += 4) {  // rows (oc*4 + t4) of 128 B, chunk-swizzled
             const int row = p * 8 + (lane >> 3);
-            dma16(rwt, smem + p * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+            dma16(rwt, smem + p * 1024, row * 128 + (((lane & 7) ^ swz128(row)) << 4));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
 #pragma unroll
                 for (int nn = 0; nn < 4; ++nn) {
                     const int row = (nn * 16 + frow) * 4 + t4;
-                    const unsigned ad = smem_base + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4);
+                    const unsigned ad = smem_base + row * 128 + (((kk * 4 + fg) ^ swz128(row)) << 4);
                     asm volatile("ds_read_b128 %0, %1" : "=v"(wreg[t4][kk][nn]) : "v"(ad));
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -847,7 +858,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
         fmask[m] = mm < a.M ? a.table[mm].mask : 0u;
     }
     // weight tile DMA: lane -> row (tid>>3) + 8*NWV*i, physical chunk tid&7 (source chunk swizzled)
-    const int row0 = tid >> 3, schunk = (tid & 7) ^ ((row0 >> 1) & 7);
+    const int row0 = tid >> 3, schunk = (tid & 7) ^ swz128(row0);
     int b_off[BROWS];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) b_off[i] = (n0 + row0 + 8 * NWV * i) * a.ntaps * a.IC * esz + schunk * 16;
@@ -864,7 +875,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
             const int sr = jj * 8 + (lane >> 3);
             const int pix = m0 - (a.W + 1) + sr;
             const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.in_pixels;
-            const int v = ok ? pix * a.IC * esz + kc * 128 + (((lane & 7) ^ ((sr >> 1) & 7)) << 4) : (int)0x80000000;
+            const int v = ok ? pix * a.IC * esz + kc * 128 + (((lane & 7) ^ swz128(sr)) << 4) : (int)0x80000000;
             dma16(rin, dst + jj * 1024, v);
         }
     };
@@ -874,7 +885,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
     for (int n = 0; n < NI; ++n)
 #pragma unroll
         for (int m = 0; m < MI; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int fswz = (frow >> 1) & 7;
+    const int fswz = swz128(frow);
     // (this wave's weight fragments start WTN rows into the tile: 64 rows keep the swizzle term)
     const int woff0 = (wn * WTN + frow) * 128 + (((0 + fg) ^ fswz) << 4), woff1 = (wn * WTN + frow) * 128 + (((4 + fg) ^ fswz) << 4);
     int prow[MI];
@@ -929,7 +940,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
             // offset.  A masked (padding) tap reads the zero row: its base is pre-biased by -2048*m.
             // The second 32-channel half is chunk^4, i.e. address^64.
             const int sr0 = prow[0] + sh;
-            const unsigned ad0 = slab + sr0 * 128 + (((fg ^ ((sr0 >> 1) & 7))) << 4);
+            const unsigned ad0 = slab + sr0 * 128 + (((fg ^ swz128(sr0))) << 4);
             unsigned pb[MI];
 #pragma unroll
             for (int m = 0; m < MI; ++m) pb[m] = ((fmask[m] >> tap) & 1u) ? ad0 : zb[m];
@@ -1077,7 +1088,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         // walk rows 9 apart)
         for (int p = wave; p < 72; p += 4) {
             const int row = p * 8 + (lane >> 3);
-            dma16(rwt, smem + p * 1024, row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) << 4));
+            dma16(rwt, smem + p * 1024, row * 128 + (((lane & 7) ^ swz128(row)) << 4));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1089,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int row = (wn * 32 + n * 16 + frow) * 9 + tap;
-                    const unsigned ad = smem_base + row * 128 + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 4);
+                    const unsigned ad = smem_base + row * 128 + (((h * 4 + fg) ^ swz128(row)) << 4);
                     asm volatile("ds_read_b128 %0, %1" : "=v"(wreg[tap][h][n]) : "v"(ad));
                 }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1105,7 +1116,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             const int sr = jj * 8 + (ln >> 3);
             const int pix = m0 - (a.W + 1) + sr;
             const bool ok = sr < a.slab_rows && (unsigned)pix < (unsigned)a.in_pixels;
-            const int v = ok ? pix * 128 + (((ln & 7) ^ ((sr >> 1) & 7)) << 4) : (int)0x80000000;
+            const int v = ok ? pix * 128 + (((ln & 7) ^ swz128(sr)) << 4) : (int)0x80000000;
             dma16(rin, dst + jj * 1024, v);
         }
     };
@@ -1184,7 +1195,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         unsigned pb[4];
         auto tap_addr = [&](int tap) __attribute__((always_inline)) {
             const int sr0 = prow0 + a.pshift[tap];
-            const unsigned ad0 = slab + sr0 * 128 + ((fg ^ ((sr0 >> 1) & 7)) << 4);
+            const unsigned ad0 = slab + sr0 * 128 + ((fg ^ swz128(sr0)) << 4);
 #pragma unroll
             for (int m = 0; m < 4; ++m) pb[m] = ((fmask[m] >> tap) & 1u) ? ad0 : zb[m];
         };
