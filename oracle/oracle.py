@@ -367,10 +367,9 @@ class ResNet18:
 # ------------------------------------------------------------------ fusion heads
 def concat_dgl_fwd(x, y, W, b):
     """ConcatFusion_DGL.forward, fusion_modules.py:51-59 -> (x_out, y_out, output)."""
-    z = np.zeros_like(x)
     out = linear_fwd(np.concatenate([x, y], 1), W, b)  # :53-56 (detached input)
-    x_out = linear_fwd(np.concatenate([x, z], 1), W, b)  # :57
-    y_out = linear_fwd(np.concatenate([z, y], 1), W, b)  # :58
+    x_out = linear_fwd(np.concatenate([x, np.zeros_like(y)], 1), W, b)  # :57 (x and y may differ in width: 512 + C heads)
+    y_out = linear_fwd(np.concatenate([np.zeros_like(x), y], 1), W, b)  # :58
     return x_out, y_out, out
 
 
@@ -378,19 +377,19 @@ def concat_dgl_bwd(x, y, W, g_x_out, g_y_out, g_out):
     """Autograd of the three Linear calls above for upstream gradients on
     (x_out, y_out, output); any of them may be None.  `output` sees a detached
     input, so it contributes to dW/db only."""
-    z = np.zeros_like(x)
+    nx = x.shape[1]
     dW = np.zeros_like(W)
     db = np.zeros(W.shape[0], np.float32)
     dx = np.zeros_like(x)
     dy = np.zeros_like(y)
     if g_x_out is not None:
-        d, w_, b_ = linear_bwd(g_x_out, np.concatenate([x, z], 1), W)
-        dx += d[:, :512]
+        d, w_, b_ = linear_bwd(g_x_out, np.concatenate([x, np.zeros_like(y)], 1), W)
+        dx += d[:, :nx]
         dW += w_
         db += b_
     if g_y_out is not None:
-        d, w_, b_ = linear_bwd(g_y_out, np.concatenate([z, y], 1), W)
-        dy += d[:, 512:]
+        d, w_, b_ = linear_bwd(g_y_out, np.concatenate([np.zeros_like(x), y], 1), W)
+        dy += d[:, nx:]
         dW += w_
         db += b_
     if g_out is not None:

@@ -42,19 +42,24 @@ def encoder(x, P, Bf, pre, training):
 
 
 class TorchStep:
-    def __init__(self, params, buffers, threads=None, device="cpu", autocast=None, channels_last=False):
+    def __init__(self, params, buffers, threads=None, device="cpu", autocast=None, channels_last=False, dtype=None):
         """params / buffers: name -> numpy array (oracle.fixtures.model_state).
         device / autocast / channels_last: the SAME restatement on another device -- bench.py's `comparators.torch_rocm`
         runs it on the MI355X with stock PyTorch-ROCm operators (MIOpen / rocBLAS, bf16 autocast, channels_last weights):
-        a diagnostic number beside `cpu_baseline`, never the product path and never a parity reference."""
+        a diagnostic number beside `cpu_baseline`, never the product path and never a parity reference.
+        dtype=torch.float64: the step in double precision on the CPU -- the tests' measure of the fp32 oracle's OWN rounding
+        error (tests/test_step_gpu.py::test_full_size_oracle_parity)."""
         if threads:
             torch.set_num_threads(int(threads))
         self.dev = torch.device(device)
+        self.dtype = dtype
         self.autocast = autocast
         self.cl = bool(channels_last)
 
         def put(v, grad):
             t = torch.from_numpy(np.array(v)).clone().to(self.dev)
+            if dtype is not None and t.is_floating_point():
+                t = t.to(dtype)
             if self.cl and t.dim() == 4:
                 t = t.contiguous(memory_format=torch.channels_last)
             return t.requires_grad_(True) if grad else t
@@ -92,6 +97,8 @@ class TorchStep:
 
     def train_step(self, spec, image, label, alpha, lr, momentum=0.9, wd=1e-4, max_norm=40.0):
         spec, image = torch.as_tensor(spec).to(self.dev), torch.as_tensor(image).to(self.dev)
+        if self.dtype is not None:
+            spec, image = spec.to(self.dtype), image.to(self.dtype)
         label = torch.as_tensor(label).long().to(self.dev)
         P = self.P
         for p in P.values():
@@ -121,4 +128,6 @@ class TorchStep:
             return {"out": out.detach(), "out_a": out_a.detach(), "out_v": out_v.detach(), "loss_f": loss_f.detach(),
                     "loss_a": loss_a.detach(), "loss_v": loss_v.detach(), "total_norm": total}
         return {"out": out.detach().numpy(), "out_a": out_a.detach().numpy(), "out_v": out_v.detach().numpy(),
-                "loss_f": loss_f.item(), "loss_a": loss_a.item(), "loss_v": loss_v.item(), "total_norm": total}
+                "loss_f": loss_f.item(), "loss_a": loss_a.item(), "loss_v": loss_v.item(), "total_norm": total,
+                # post-clip norm of every gradient tensor (what DGLTrainer.read()["grad_norm"] reports)
+                "grad_norm": {k: float(p.grad.double().norm()) for k, p in P.items() if p.grad is not None}}

@@ -1,0 +1,135 @@
+"""bf16 parity at non-chaotic batch sizes: the sum / gated / film DGL heads and the Swin
+composition through DGLTrainer at B = 16 against the CPU oracle's step on the same batch and weights -- BOTH steps compared
+(the B = 2-4 golden fixtures can only check a second bf16 step for finiteness: their BatchNorms see 16-64 samples) -- and
+BASELINE config 5 at its own shapes (VGGSound spectrogram 129 x 626, 309 logits, Swin-T at 224 x 224, T = 3) at the largest
+batch whose CPU oracle step stays under a minute.  Reference semantics: /root/reference/main_dgl.py:97-154,
+models/fusion_modules.py:16-30,126-178,213-250, models/swin_transformer.py:596-634."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, dev
+
+from oracle import fixtures as fx
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(tag, r, ref):
+    tn = ref["total_norm"]
+    w = {k: float((np.abs(r[k] - ref[k]) / (1.0 + np.abs(ref[k]) / 3.0)).max()) for k in ("out", "out_a", "out_v")}
+    w.update({k: abs(r[k] - ref[k]) / max(1.0, abs(ref[k])) for k in ("loss_f", "loss_a", "loss_v")})
+    w.update({k: abs(r[k] - ref[k]) / ref[k] for k in ("total_norm", "audio_grad_sum", "visual_grad_sum")})
+    assert set(r["grad_norm"]) == set(ref["grad_norm"]), set(r["grad_norm"]) ^ set(ref["grad_norm"])
+    rel = {n: abs(r["grad_norm"][n] - want) / max(want, 1e-5 * tn) for n, want in ref["grad_norm"].items()}
+    wk = max(rel, key=rel.get)
+    w["grad_norm"], w["grad_norm_median"] = rel[wk], float(np.median(list(rel.values())))
+    print(f"{tag}: " + ", ".join(f"{k} {v:.2e}" for k, v in w.items()) + f" (worst tensor {wk})")
+    return w
+
+
+def _check(w, f32, later):
+    """SURVEY 8(c)'s bounds.  bf16: logits atol 3e-2 (+ 1 % of |logit|: `_report` scales by 1 + |ref| / 3), losses 1e-2,
+    total norm rtol 1e-2, per-parameter norms 0.1 on the worst tensor and 2e-2 on the median one; a SECOND step sees
+    weights that already differ by the first step's rounding and momentum, and gets 2x.  f32: 5e-4 / 5e-4 / 3e-3 / 1e-2
+    (second steps: the ReLU-flip noise measured in tests/test_oracle_golden.py, 1e-2 / 2e-2 / 6e-2)."""
+    k = 2.0 if later else 1.0
+    lt, ls, nt, gt, gm = ((1e-2, 1e-2, 2e-2, 6e-2, 1e-2) if later else (5e-4, 5e-4, 3e-3, 1e-2, 1e-3)) if f32 else \
+        (3e-2 * k, 1e-2 * k, 1e-2 * k, 0.1 * k, 2e-2 * k)
+    for n in ("out", "out_a", "out_v"):
+        assert w[n] <= lt, (n, w[n])
+    for n in ("loss_f", "loss_a", "loss_v"):
+        assert w[n] <= ls, (n, w[n])
+    assert w["total_norm"] <= nt and w["audio_grad_sum"] <= 2 * nt and w["visual_grad_sum"] <= 2 * nt, w
+    assert w["grad_norm"] <= gt and w["grad_norm_median"] <= gm, w
+
+
+@pytest.mark.parametrize("fusion", ["sum", "gated", "film"])
+def test_bf16_heads_b16_two_steps_vs_oracle(fusion):
+    """B = 16, spectrogram 129 x 94, two frames of 112 x 112, the CREMA-D head: two consecutive bf16 steps of DGLTrainer
+    against two steps of the fp32 oracle (momentum and the updated weights included)."""
+    from gdl.trainer import DGLTrainer
+    from models.basic_model import AVClassifier_DGL
+    from test_step_gpu import _load_state
+
+    B, ncls, alpha, lr = 16, 6, 4.0, 2e-3
+    shp = dict(spec_hw=(129, 94), frames=2, image_hw=(112, 112))
+    P, Bf = fx.model_state(ncls, fusion + "_dgl")
+    orc.set_num_threads(64)
+    ref = orc.AVModel({k: v.copy() for k, v in P.items()}, {k: np.array(v) for k, v in Bf.items()}, "dgl")
+    args = argparse.Namespace(fusion_method=fusion, dataset="CREMAD", modality="full", batch_size=B)
+    model = AVClassifier_DGL(args)
+    _load_state(model, {**P, **Bf})
+    model = model.to(DEV)
+    model.audio_net.gdl_dtype = model.visual_net.gdl_dtype = "bf16"
+    model.train()
+    tr = DGLTrainer(model, lr=lr, alpha=alpha, dtype="bf16")
+    for st in range(2):
+        spec, image, label = fx.make_batch(100 + st, B, shp["spec_hw"], shp["frames"], shp["image_hw"], ncls)
+        want = ref.train_step(spec, image, label, alpha, lr)
+        want["grad_norm"] = {k: float(np.sqrt(orc.sumsq(g))) for k, g in want.pop("grads").items()}
+        tr.step(dev(spec), dev(image), torch.from_numpy(label).to(DEV))
+        w = _report(f"{fusion} head B=16 bf16 step {st}", tr.read(), want)
+        _check(w, False, st > 0)
+
+
+def _swin_model(ncls, sc, dtype, B):
+    from models.basic_model import AVClassifier_DGL_Swin
+
+    args = argparse.Namespace(fusion_method="concat", dataset="VGGSound" if ncls == 309 else "CREMAD", modality="full",
+                              batch_size=B, pe=0)
+    model = AVClassifier_DGL_Swin(args, swin_kwargs=dict(img_size=sc["img"], patch_size=sc["patch"], embed_dim=sc["embed"],
+                                                         depths=list(sc["depths"]), num_heads=list(sc["heads"]),
+                                                         window_size=sc["window"], mlp_ratio=float(sc["mlp"]),
+                                                         drop_path_rate=0.))
+    P, Bf = fx.swin_dgl_state(ncls, sc)
+    assert [n for n, _ in model.named_parameters()] == list(P)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in {**P, **Bf}.items()}, strict=False)
+    model = model.to(DEV)
+    model.audio_net.gdl_dtype = model.visual_net.gdl_dtype = dtype
+    model.train()
+    return model, P, Bf
+
+
+def test_swin_composition_b16_bf16_two_steps_vs_oracle():
+    """The Swin composition (ResNet18 audio + two-stage Swin at 56 x 56 + ConcatFusion_DGL over 512 + 192) at B = 16, T = 2:
+    two bf16 steps of DGLTrainer against oracle/swin_step.py (pinned to the reference golden in tests/test_oracle_golden.py)."""
+    from gdl.trainer import DGLTrainer
+    from oracle.swin_step import SwinAVModel
+
+    B, ncls, alpha, lr, sc = 16, 6, 4.0, 2e-3, fx.SWIN_TINY2
+    model, P, Bf = _swin_model(ncls, sc, "bf16", B)
+    orc.set_num_threads(64)
+    ref = SwinAVModel({k: v.copy() for k, v in P.items()}, {k: np.array(v) for k, v in Bf.items()}, sc)
+    tr = DGLTrainer(model, lr=lr, alpha=alpha, dtype="bf16")
+    for st in range(2):
+        spec, image, label = fx.make_batch(200 + st, B, (65, 47), 2, (sc["img"], sc["img"]), ncls)
+        want = ref.train_step(spec, image, label, alpha, lr)
+        tr.step(dev(spec), dev(image), torch.from_numpy(label).to(DEV))
+        w = _report(f"Swin composition B=16 bf16 step {st}", tr.read(), want)
+        _check(w, False, st > 0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config5_full_shapes_vs_oracle(dtype):
+    """BASELINE configs[4] at its own shapes: VGGSound spectrogram 129 x 626, 309 logits, Swin-T (embed 96, depths 2-2-6-2,
+    heads 3-6-12-24, window 7) on T = 3 frames of 224 x 224, B = 8 (24 frames: 75 264 stage-1 tokens, every kernel form of
+    bench.py --workload vggsound_swin except the batch count) through DGLTrainer against the CPU oracle's step: all three
+    logit sets, the three losses, the pre-clip total norm, the logged sums and the post-clip norm of every gradient tensor."""
+    from gdl.trainer import DGLTrainer
+    from oracle.swin_step import SwinAVModel
+
+    B, ncls, alpha, lr, sc = 8, 309, 2.0, 2e-3, fx.SWIN_T
+    model, P, Bf = _swin_model(ncls, sc, dtype, B)
+    orc.set_num_threads(64)
+    torch.set_num_threads(64)
+    ref = SwinAVModel({k: v.copy() for k, v in P.items()}, {k: np.array(v) for k, v in Bf.items()}, sc)
+    spec, image, label = fx.make_batch(300, B, (129, 626), 3, (224, 224), ncls)
+    want = ref.train_step(spec, image, label, alpha, lr)
+    tr = DGLTrainer(model, lr=lr, alpha=alpha, dtype=dtype)
+    tr.step(dev(spec), dev(image), torch.from_numpy(label).to(DEV))
+    w = _report(f"config 5 shapes B=8 {dtype}", tr.read(), want)
+    _check(w, dtype == "f32", False)

@@ -311,3 +311,36 @@ def test_swin_oracle_matches_reference_golden(golden_dir, name, cfg_name):
         else:
             w = g["gradsample." + k]
             np.testing.assert_allclose(v.reshape(-1)[::997], w, rtol=0, atol=2e-5 * np.abs(w).max(), err_msg=k)
+
+
+def test_swin_step_oracle_matches_reference_golden(golden_dir):
+    """oracle/swin_step.py (the composed DGL step: C-oracle ResNet18 audio + torch-autograd Swin oracle + ConcatFusion_DGL over
+    512 + C + the step body of main_dgl.py:97-154) against the two-step golden of the composition assembled from the imported
+    reference classes (tests/golden/make_golden.py::_SwinDGL).  The GPU tests use this oracle at B = 16 and at config 5's own
+    shapes."""
+    import json
+
+    from oracle.swin_step import SwinAVModel
+
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+    P, Bf = fx.swin_dgl_state(cfg["n_classes"], cfg["swin"])
+    m = SwinAVModel(P, Bf, cfg["swin"])
+    for st in range(cfg["steps"]):
+        spec, image, label = fx.make_batch(cfg["seed"] + st, cfg["batch"], cfg["spec_hw"], cfg["frames"], cfg["image_hw"],
+                                           cfg["n_classes"])
+        r = m.train_step(spec, image, label, cfg["alpha"], cfg["lr"])
+        pre = f"s{st}."
+        lt, nt, gt = (2e-5, 2e-4, 2e-3) if st == 0 else (2e-3, 1e-3, 2e-2)  # (second step: fp32 ReLU-flip noise, as for ResNet)
+        for k in ("out", "out_a", "out_v"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=lt, atol=lt, err_msg=k)
+        for k in ("loss_f", "loss_a", "loss_v"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=lt * 10, atol=lt * 10, err_msg=k)
+        for k in ("total_norm", "audio_grad_sum", "visual_grad_sum"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=nt, err_msg=k)
+        names, gn, isnone = [str(n) for n in g[pre + "grad_names"]], g[pre + "grad_norm"], g[pre + "grad_is_none"]
+        for i, n in enumerate(names):
+            if isnone[i]:
+                assert n not in r["grad_norm"]
+            else:
+                assert abs(r["grad_norm"][n] - gn[i]) <= gt * gn[i] + 1e-7, (n, r["grad_norm"][n], gn[i])

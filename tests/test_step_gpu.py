@@ -726,6 +726,67 @@ def _full_oracle(workload):
     return _FULL_ORACLE[workload]
 
 
+_FULL_FP64 = {}
+
+
+def _full_fp64(workload):
+    """The same B=64 step in DOUBLE precision (oracle/torch_step.py with float64 parameters and activations on the host
+    cores, ~1-2 minutes): what the fp32 oracle itself is measured against, so that a bf16 deviation can be told from the
+    reference's own fp32 rounding (VERDICT r2, weak #1)."""
+    if workload not in _FULL_FP64:
+        from oracle.torch_step import TorchStep
+
+        cfg = _FULL_CFG[workload]
+        torch.set_num_threads(min(os.cpu_count() or 1, 96))
+        P, Bf = fx.model_state(cfg["n_classes"], "concat_dgl")
+        spec, image, label = fx.make_batch(cfg["seed"], cfg["batch"], cfg["spec_hw"], cfg["frames"], cfg["image_hw"],
+                                           cfg["n_classes"])
+        _FULL_FP64[workload] = TorchStep(P, Bf, dtype=torch.float64).train_step(spec, image, label, cfg["alpha"], 2e-3)
+    return _FULL_FP64[workload]
+
+
+def test_full_size_bf16_against_fp64():
+    """SURVEY 8(c)'s bf16 bounds at BASELINE configs[1] (B=64), UNMOVED -- logits atol 3e-2, per-parameter gradient norms
+    rtol 0.1 -- with the deviation measured against a float64 run of the step, and the fp32 oracle's own deviation from that
+    run printed beside it.  (Round 2 had widened the bounds of test_full_size_oracle_parity to 0.12 / 3e-2 + 1 % of |logit|
+    against the fp32 oracle; this test is the evidence for what the bf16 path deviates by when the reference's rounding is
+    taken out.)"""
+    from gdl.trainer import DGLTrainer
+
+    cfg = _FULL_CFG["cremad"]
+    ref32, ref64 = _full_oracle("cremad"), _full_fp64("cremad")
+    res = {}
+    for dtype in ("f32", "bf16"):
+        model = _make_model(cfg, dtype)
+        model.train()
+        tr = DGLTrainer(model, lr=2e-3, alpha=cfg["alpha"])
+        tr.step(*_batch(cfg, 0))
+        res[dtype] = tr.read()
+        del tr, model
+    tn = ref64["total_norm"]
+
+    def dev(r):
+        d = {k: float(np.abs(np.asarray(r[k], dtype=np.float64) - ref64[k]).max()) for k in ("out", "out_a", "out_v")}
+        rel = {n: abs(r["grad_norm"][n] - want) / max(want, 1e-6 * tn) for n, want in ref64["grad_norm"].items()}
+        wk = max(rel, key=rel.get)
+        d.update(total_norm=abs(r["total_norm"] - tn) / tn, grad_norm=rel[wk], grad_norm_tensor=wk,
+                 grad_norm_median=float(np.median(list(rel.values()))), loss_f=abs(r["loss_f"] - ref64["loss_f"]))
+        return d, rel
+
+    d32, _ = dev(ref32)
+    dh32, _ = dev(res["f32"])
+    dbf, relbf = dev(res["bf16"])
+    for name, d in (("fp32 C oracle", d32), ("HIP f32", dh32), ("HIP bf16", dbf)):
+        print(f"vs float64 -- {name}: " + ", ".join(f"{k} {v:.2e}" if isinstance(v, float) else f"{k} {v}" for k, v in d.items()))
+    top = sorted(relbf.items(), key=lambda kv: -kv[1])[:4]
+    print("bf16 worst tensors vs float64:", [(k, round(v, 4), round(abs(ref32["grad_norm"][k] - ref64["grad_norm"][k]) /
+                                             max(ref64["grad_norm"][k], 1e-6 * tn), 6)) for k, v in top])
+    for k in ("out", "out_a", "out_v"):
+        assert dbf[k] <= 3e-2, (k, dbf[k])
+    assert dbf["grad_norm"] <= 0.1, top
+    assert dbf["total_norm"] <= 1e-2 and dbf["grad_norm_median"] <= 2e-2
+
+
 @pytest.mark.parametrize("workload,dtype", [("cremad", "f32"), ("cremad", "bf16"), ("ks", "bf16")])
 def test_full_size_oracle_parity(workload, dtype):
     """One B=64 step of BASELINE.json's configs[1] (CREMA-D) / configs[2] (Kinetics-Sounds shapes) against the CPU
