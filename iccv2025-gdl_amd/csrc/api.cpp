@@ -75,6 +75,17 @@ int gdl_conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void*
     GDL_REQUIRE(dy && w_crsk && dy_ds && w_ds_ck && dx, "conv_dgrad_ds: null pointer");
     return conv_dgrad_ds(dtype, dy, w_crsk, dy_ds, w_ds_ck, dx, table, N, H, W, C, K, (hipStream_t)stream, relu_bits);
 }
+int gdl_conv_dgrad_bn_tiles(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    return conv_dgrad_tiles_m(dtype, N, H, W, C, K, R, S, stride, pad);
+}
+int gdl_conv_dgrad_bn(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const uint8_t* relu_bits,
+                      const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, const void* y,
+                      const float* mean, const float* rstd, float* partial, const void* y2, const float* mean2,
+                      const float* rstd2, float* partial2, void* stream) {
+    GDL_REQUIRE(dy && w_crsk && dx && y && mean && rstd && partial, "conv_dgrad_bn: null pointer");
+    const BwdStats bw{y, mean, rstd, partial, y2, mean2, rstd2, partial2};
+    return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits, &bw);
+}
 static FoldWs fold_ws_of(void* ws) {
     return FoldWs{(unsigned*)ws, (double*)((unsigned char*)ws + align_up(fold_ctr_bytes(), 256))};
 }

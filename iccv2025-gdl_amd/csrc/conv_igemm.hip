@@ -43,6 +43,13 @@ struct ConvArgs {
     void* gelu_out;            // optional, like out: out keeps the (biased) value u, gelu_out gets gelu(u) (Swin Mlp.fc1 + act)
     const uint8_t* relu_bits;  // optional: one byte per 16-byte vector of out; the stored value is zeroed where its bit is 0
     float* stats;              // optional [mtiles][OC][2]
+    // optional (data gradient): BatchNorm-backward sums of the stored rows against one or two partner tensors (ops.h BwdStats)
+    const void* bw_y;
+    const float *bw_mean, *bw_rstd;
+    float* bw_partial;
+    const void* bw_y2;
+    const float *bw_mean2, *bw_rstd2;
+    float* bw_partial2;
     const GatherEntry* table;  // [M]
     int M, OC, IC, ntaps;
     int mtiles;  // ceil(M/BM)
@@ -187,7 +194,7 @@ struct ConvSmem {
 // ---- epilogue shared by the kernels below: accumulators -> LDS tile [BM][BN] of T -> full rows.
 // Must be entered after every wave is done with the main-loop LDS contents (barrier) and with no
 // LDS-DMA in flight.
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool BWD = false>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], unsigned char* smem,
                                               const ConvArgs& a, int m0, int n0, int mtile, int ntile = 0) {
     constexpr int NT = WM * WN * 64;  // threads of the block (256 or 512)
@@ -215,6 +222,23 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             om[p] = m < a.M ? (a.orow ? a.orow[m] : m) : -1;
         }
     }
+    // BatchNorm-backward sums (ops.h BwdStats): the partner tensors' vectors of every pass are requested NOW, so that their
+    // latency (HBM: the partner is a forward activation last touched a whole backward ago) runs under the staging of the tile
+    // through LDS; loaded inside the store loop they cost the slab data gradients +19 us per launch (59 -> 78 us alone)
+    // (BWD: only the data-gradient instantiations carry this code and its registers)
+    const bool bw = BWD && a.bw_y != nullptr, bw2 = bw && a.bw_y2 != nullptr;
+    uint4 byq[BWD ? NPASS : 1], by2q[BWD ? NPASS : 1];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            byq[p] = by2q[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (bw && om[p] >= 0) {
+                const size_t goff = (size_t)om[p] * a.OC + n0 + ec * EPC;
+                byq[p] = *(const uint4*)((const T*)a.bw_y + goff);
+                if (bw2) by2q[p] = *(const uint4*)((const T*)a.bw_y2 + goff);
+            }
+        }
+    }
     // accumulators -> LDS tile [BM][BN] of T.
     // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
     unsigned char* Cs = smem;
@@ -237,6 +261,19 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     float ssum[EPC], ssq[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) ssum[e] = ssq[e] = 0.f;
+    // BatchNorm-backward sums of the stored rows against their partner tensor(s) (ops.h BwdStats): per-channel constants of this
+    // thread's EPC channels, three accumulators
+    float bmu[EPC], bmu2[EPC], bs1[EPC], bs2[EPC], bs3[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) bmu[e] = bmu2[e] = bs1[e] = bs2[e] = bs3[e] = 0.f;
+    if (bw) {
+        const int c0 = n0 + ec * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            bmu[e] = a.bw_mean[c0 + e];
+            if (bw2) bmu2[e] = a.bw_mean2[c0 + e];
+        }
+    }
     T* __restrict__ gout = (T*)a.out;
     const T* __restrict__ gadd = (const T*)a.addend;
 #pragma unroll
@@ -281,6 +318,22 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
                 ssq[e] += f[e] * f[e];
             }
         }
+        if (bw) {
+            float f[EPC], yv[EPC];
+            unpack16<T>(v, f);  // the value as it will be read back (a ReLU mask came through relu_bits above)
+            unpack16<T>(byq[BWD ? p : 0], yv);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                bs1[e] += f[e];
+                bs2[e] += f[e] * (yv[e] - bmu[e]);  // (x rstd once per channel, below)
+            }
+            if (bw2) {
+                float y2[EPC];
+                unpack16<T>(by2q[BWD ? p : 0], y2);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) bs3[e] += f[e] * (y2[e] - bmu2[e]);
+            }
+        }
         *(uint4*)(gout + goff) = v;
         if (a.gelu_out) {  // exact GELU of the value as stored
             float f[EPC];
@@ -290,13 +343,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             *(uint4*)((T*)a.gelu_out + goff) = pack16<T>(f);
         }
     }
-    if (a.stats) {
-        // lanes with equal (lane % CH) hold the same channels: fold them, then fold the 4 waves in fixed order
+    // per-channel sums of the block's rows -> one partial row [OC][2] per M-tile: lanes with equal (lane % CH) hold the same
+    // channels: fold them, then fold the waves in fixed order (deterministic)
+    auto tile_sums = [&](float (&s1)[EPC], float (&s2)[EPC], float* dst) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             for (int msk = CH; msk < 64; msk <<= 1) {
-                ssum[e] += __shfl_xor(ssum[e], msk);
-                ssq[e] += __shfl_xor(ssq[e], msk);
+                s1[e] += __shfl_xor(s1[e], msk);
+                s2[e] += __shfl_xor(s2[e], msk);
             }
         }
         float* red = (float*)(smem + SM::CS);  // [waves][BN][2]
@@ -305,8 +359,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             const int c = (lane % CH) * EPC;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                red[(wave * BN + c + e) * 2 + 0] = ssum[e];
-                red[(wave * BN + c + e) * 2 + 1] = ssq[e];
+                red[(wave * BN + c + e) * 2 + 0] = s1[e];
+                red[(wave * BN + c + e) * 2 + 1] = s2[e];
             }
         }
         __syncthreads();
@@ -317,10 +371,28 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             if constexpr (NT == 512)
                 s += ((red[(4 * BN + c) * 2 + w] + red[(5 * BN + c) * 2 + w]) + red[(6 * BN + c) * 2 + w]) +
                      red[(7 * BN + c) * 2 + w];
-            st_agent(a.stats + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
+            st_agent(dst + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
         }
+    };
+    if (a.stats) {
+        tile_sums(ssum, ssq, a.stats);
         if constexpr (NT == 256)  // (the fold's thread mapping is written for 256-thread blocks)
             if (a.fold.ctr) fold_finalize(a.stats, a.mtiles, a.OC, n0, BN, mtile, ntile, a.fold, smem, a.fin);
+    }
+    if (bw) {
+        float k1[EPC];
+        const int c0 = n0 + ec * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            k1[e] = bs1[e];  // (tile_sums folds its arguments in place: the second BatchNorm needs them again)
+            bs2[e] *= a.bw_rstd[c0 + e];
+            if (bw2) bs3[e] *= a.bw_rstd2[c0 + e];
+        }
+        tile_sums(bs1, bs2, a.bw_partial);
+        if (bw2) {
+            __syncthreads();  // the scratch rows are reused
+            tile_sums(k1, bs3, a.bw_partial2);
+        }
     }
 }
 
@@ -481,7 +553,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (empty) tail stages before LDS is reused
     __syncthreads();
 
-    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile, ntile);
+    conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD>(acc, smem, a, m0, n0, mtile, ntile);
 }
 
 // =====================================================================================================
@@ -1021,7 +1093,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
     GDL_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    conv_epilogue<T, BM, BN, WM, WN>(acc, smem, a, m0, n0, mtile, ntile);
+    conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD>(acc, smem, a, m0, n0, mtile, ntile);
     GDL_STAMP(5);
 #ifdef GDL_TIMING
     if (a.dbg && threadIdx.x == 0) {
@@ -1055,8 +1127,17 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
 // =====================================================================================================
 constexpr int C64_BM = 128;
 constexpr int C64_GRID = 512;  // two blocks per CU of an MI355X; also the number of BatchNorm partial rows
-template <int MODE>
+// BW (data gradient only): the BatchNorm-backward sums of the stored rows against the partner tensor a.bw_y (ops.h BwdStats,
+// one partner; optional ReLU mask), accumulated across the block's tiles like the forward's statistics -- and like the forward it
+// then keeps ONE set of pixel fragments (the accumulators take the registers of the second).
+template <int MODE, bool BW = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
+    static_assert(!BW || MODE == MODE_DGRAD, "BW: data gradient only");
+    constexpr bool STATS = MODE == MODE_FWD;  // per-channel sums accumulated in registers (tsum / tsq) across the tiles
+    // (BW accumulates in LDS instead -- per tile: fold the eight row-lanes of a wave that hold the same channels, then lanes 0-7
+    // add into the wave's row of [4 waves][64][2] floats -- so that no accumulator is live across the K-loop: with sixteen more
+    // registers there the compiler spilled per-tap addresses, and a spill reload inside the K-loop is a `s_waitcnt vmcnt(0)`,
+    // i.e. a wait for the slab prefetch just issued: 35 -> 90 us per launch)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = C64_BM, PITCH = 64 * 2 + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1106,6 +1187,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+    if constexpr (BW) {  // the partner BatchNorm's mean / rstd: 2 x 64 floats behind the zero KiB (the filter staging is over)
+        if (tid < 128) ((float*)(smem + nbuf * slab_bytes + 1024))[tid] = tid < 64 ? a.bw_mean[tid] : a.bw_rstd[tid - 64];
+        ((float*)(smem + nbuf * slab_bytes + 1536))[tid] = 0.f;  // the waves' accumulator rows [4][64][2]
+        ((float*)(smem + nbuf * slab_bytes + 1536))[tid + 256] = 0.f;
     }
     if (wave == 0) dma16(rin, smem + nbuf * slab_bytes, (int)0x80000000);  // out-of-range LDS-DMA deposits zeros
     auto load_slab = [&](int sbuf, int m0) {
@@ -1190,7 +1276,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         // 18 half-steps (tap, 32-channel half); the pixel fragments of half-step s+1 are requested before the MFMAs of s
-        constexpr int NPX = (MODE == MODE_FWD) ? 1 : 2;  // forward: one set (its statistics live in registers instead)
+        constexpr int NPX = STATS ? 1 : 2;  // forward / BW: one set (the statistics live in registers instead)
         uint4 px[NPX][4];
         unsigned pb[4];
         auto tap_addr = [&](int tap) __attribute__((always_inline)) {
@@ -1238,19 +1324,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         C64_SEG(1)
         if (more) load_masks((tile + bpx) * BM, fmask);  // the next tile's tap masks (waited for with the slab below)
         // the addend / ReLU-bit loads of the tile's four row passes: in flight while the tile is staged
-        uint4 gq[4];
+        uint4 gq[4], yq[4];
         unsigned mkq[4];
+
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int m = m0 + er0 + p * 32;
             const size_t goff = (size_t)m * 64 + ec * 8;
             gq[p] = make_uint4(0u, 0u, 0u, 0u);
+            yq[p] = make_uint4(0u, 0u, 0u, 0u);
             mkq[p] = 0xffu;
             if (m < a.M) {
                 if (gadd) gq[p] = *(const uint4*)(gadd + goff);
                 if (a.relu_bits) mkq[p] = a.relu_bits[goff / 8];
+                if constexpr (BW) yq[p] = *(const uint4*)((const bf16*)a.bw_y + goff);
             }
         }
+
         // every wave is done with this slab: the tile is staged over it, [128][64] bf16 at a 144-byte pitch
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1283,6 +1373,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         float ssum[8], ssq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+        float cm[16];  // BW: mean, rstd of this thread's 8 channels, from the constants' LDS rows (live only during the row pass)
+        if constexpr (BW) {
+            const float4* cn = (const float4*)(smem + nbuf * slab_bytes + 1024);
+            *(float4*)&cm[0] = cn[ec * 2], *(float4*)&cm[4] = cn[ec * 2 + 1];
+            *(float4*)&cm[8] = cn[16 + ec * 2], *(float4*)&cm[12] = cn[16 + ec * 2 + 1];
+        }
         uint4 vq[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -1313,7 +1409,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                     ssq[e] += f[e] * f[e];
                 }
             }
+            if constexpr (BW) {
+                if (m0 + row < a.M) {
+                    float f[8], yv[8];
+                    unpack16<bf16>(v, f);
+                    unpack16<bf16>(yq[p], yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        ssum[e] += f[e];
+                        ssq[e] += f[e] * (yv[e] - cm[e]);  // (a ReLU mask came through relu_bits; x rstd below)
+                    }
+                }
+            }
             vq[p] = v;
+        }
+        if constexpr (BW) {
+            // this tile's sums -> the wave's LDS row (before the stores: an LDS access behind pending stores waits for them)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ssq[e] *= cm[8 + e];
+                for (int msk = 8; msk < 64; msk <<= 1) {
+                    ssum[e] += __shfl_xor(ssum[e], msk);
+                    ssq[e] += __shfl_xor(ssq[e], msk);
+                }
+            }
+            if (lane < 8) {
+                float4* ar = (float4*)(smem + nbuf * slab_bytes + 1536) + (wave * 64 + lane * 8) / 2;  // [wave][64][2] floats
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    float4 t = ar[e2];
+                    t.x += ssum[2 * e2], t.y += ssq[2 * e2], t.z += ssum[2 * e2 + 1], t.w += ssq[2 * e2 + 1];
+                    ar[e2] = t;
+                }
+            }
         }
         // the four stores back to back (a load between two stores would wait for the first)
 #pragma unroll
@@ -1346,7 +1474,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         d[7] = tq_n;
     }
 #endif
+    if constexpr (BW) {
+        __syncthreads();
+        if (tid < 128) {  // the four waves' rows in fixed order
+            const float* ar = (const float*)(smem + nbuf * slab_bytes + 1536);
+            st_agent(a.bw_partial + (size_t)blockIdx.x * 128 + tid, ((ar[tid] + ar[128 + tid]) + ar[256 + tid]) + ar[384 + tid]);
+        }
+    }
     if (MODE == MODE_FWD && a.stats) {
+        float* const sdst = a.stats;
         float ssum[8], ssq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1373,7 +1509,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             const int c = tid >> 1, w = tid & 1;
             const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
                              red[(3 * 64 + c) * 2 + w];
-            st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
+            st_agent(sdst + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
         // BatchNorm finalize inside the launch (fold.h): with ONE partial row per persistent block the ticket is paid once
         // per block life (~40 us), not once per tile -- what made the fold lose on the one-tile-per-block kernels
@@ -1486,7 +1622,8 @@ struct ConvPlan {
     int nwv8;    // slab kernel: the 128 x 128 tile on 512 threads (small layers: one block per CU at most)
 };
 static size_t c64_lds_bytes(int W, bool single = false) {
-    const size_t b = (single ? 1 : 2) * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024;
+    // slabs, zero KiB, BW: constants (512 B) + accumulator rows (2 KiB)
+    const size_t b = (single ? 1 : 2) * (size_t)((C64_BM + 2 * W + 2 + 7) / 8) * 1024 + 1024 + 512 + 2048;
     return b > (size_t)72 * 1024 ? b : (size_t)72 * 1024;  // the prologue stages the 72 KiB filter through the same LDS
 }
 static bool c64_enabled() {
@@ -1676,11 +1813,13 @@ no_c64:
     return p;
 }
 
-template <int MODE>
+template <int MODE, bool BW = false>
 static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, C64_BM);
-    GDL_REQUIRE(!a.bias && !a.gelu_out && !a.orow, "conv: unsupported option for the 64-channel persistent kernel");
-    auto kfn = conv3x3_c64_kernel<MODE>;
+    GDL_REQUIRE(!a.bias && !a.gelu_out && !a.orow && !a.bw_y2, "conv: unsupported option for the 64-channel persistent kernel");
+    if constexpr (MODE == MODE_DGRAD && !BW)
+        if (a.bw_y) return launch_c64<MODE, true>(a, lds, st);
+    auto kfn = conv3x3_c64_kernel<MODE, BW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -1688,7 +1827,7 @@ static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
         attr_set = true;
     }
     static char pname[64] = "";
-    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_c64_kernel<%d>", MODE);
+    if (!pname[0]) snprintf(pname, sizeof(pname), BW ? "gdl::conv3x3_c64_kernel<%d, true>" : "gdl::conv3x3_c64_kernel<%d>", MODE);
     ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
     hipExtLaunchKernelGGL(kfn, dim3(C64_GRID), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_c64_kernel");
@@ -1728,6 +1867,13 @@ bool conv_fwd_persistent(int dtype, int N, int H, int W, int C, int K, int R, in
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
     return plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad).c64 != 0;
 }
+// partial rows a data gradient with BatchNorm-backward statistics (ops.h BwdStats) writes
+int conv_dgrad_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    const ConvPlan pl = plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad);
+    if (pl.c64) return C64_GRID;
+    const int rows = stride == 2 ? dgrad_perm_rows(N, H, W, pl.bm) : N * H * W;
+    return ceil_div(rows, pl.bm);
+}
 // M-tile of a data gradient (the permuted stride-2 table is laid out for it)
 int conv_dgrad_bm(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     return plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad).bm;
@@ -1743,7 +1889,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
                     const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
-                    const float* bias = nullptr, void* gelu_out = nullptr) {
+                    const float* bias = nullptr, void* gelu_out = nullptr, const BwdStats* bw = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1764,6 +1910,14 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     a.gelu_out = gelu_out;
     a.relu_bits = relu_bits;
     a.stats = stats;
+    if (bw && bw->y) {
+        GDL_REQUIRE(mode == GATHER_DGRAD && bw->mean && bw->rstd && bw->partial &&
+                        (!bw->y2 || (bw->mean2 && bw->rstd2 && bw->partial2)),
+                    "conv: bad BatchNorm-backward statistics arguments");
+        a.bw_y = bw->y, a.bw_mean = bw->mean, a.bw_rstd = bw->rstd;
+        a.bw_partial = bw->partial;
+        a.bw_y2 = bw->y2, a.bw_mean2 = bw->mean2, a.bw_rstd2 = bw->rstd2, a.bw_partial2 = bw->partial2;
+    }
     a.table = (const GatherEntry*)table;
     a.M = g.rows;
     a.ntaps = g.ntaps;
@@ -1931,9 +2085,10 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
 }
 
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
-               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits) {
+               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits,
+               const BwdStats* bw) {
     return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
-                    nullptr, relu_bits);
+                    nullptr, relu_bits, nullptr, nullptr, nullptr, nullptr, bw);
 }
 
 // forward with the epilogue's bias / residual: y = conv(x, w) + bias (+ addend), each optional (the Swin Linears)
@@ -1944,10 +2099,11 @@ int conv_fwd_bias(int dtype, const void* x, const void* w, void* y, const float*
 }
 
 int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
-                  const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits) {
+                  const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits,
+                  const BwdStats* bw) {
     GDL_REQUIRE(dy_ds && w_ds_ck, "conv_dgrad_ds: null pointer");
     return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, 3, 3, 2, 1, st, nullptr, nullptr,
-                    relu_bits, dy_ds, w_ds_ck);
+                    relu_bits, dy_ds, w_ds_ck, nullptr, nullptr, bw);
 }
 
 }  // namespace gdl

@@ -43,6 +43,7 @@ struct Block {
     void *y1 = nullptr, *a1 = nullptr, *y2 = nullptr, *yd = nullptr, *z = nullptr;
     uint8_t* zbits = nullptr;  // sign bits of z (one byte per 16-byte vector): the backward's ReLU mask, applied by the
                                // data gradient that produces the gradient of z (conv_dgrad's relu_bits)
+    uint8_t* abits = nullptr;  // the same for a1 = relu(bn1(y1)): conv2's data gradient stores the masked gradient
     const void* xin = nullptr;
 };
 
@@ -84,6 +85,10 @@ struct gdl_encoder {
     // gdl_encoder_backward_phase: state carried from phase 1 (layer4) to phase 2 (the rest)
     void *bw_dz = nullptr, *bw_spare = nullptr;
     bool bw_premasked = false;  // bw_dz already carries the ReLU mask of its block's output
+    int bw_b2_rows = 0;         // > 0: ... and the bn2 (downsample BatchNorm) sums of that block, in this many partial rows
+    // BatchNorm-backward sums written by the data gradients' epilogues (ops.h BwdStats): A = bn1 of the current block (from
+    // conv2's data gradient), B / B2 = bn2 / downsample BatchNorm of the block before (from conv1's data gradient)
+    float *bwA = nullptr, *bwB = nullptr, *bwB2 = nullptr;
     long bw_serial = -1;  // serial of the forward whose phase 1 ran
     ~gdl_encoder() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -170,6 +175,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
     size_t max_act = (size_t)n_img * h1 * w1 * 64;  // elements
     size_t max_tiles_c = (size_t)conv_stem_tiles_m(dtype, n_img, H, W) * 64;
     size_t max_bnb = (size_t)bn_bwd_blocks((size_t)m0, 64) * 64;
+    size_t max_bwt = 64;
     size_t wg = conv_stem_wgrad_ws_bytes(n_img, H, W);
     const void* prev = x1;
     for (Block& k : blocks) {
@@ -180,6 +186,7 @@ size_t gdl_encoder::plan(unsigned char* base) {
         k.y2 = b.take(out_el * e);
         k.z = b.take(out_el * e);
         k.zbits = (uint8_t*)b.take(out_el * e / 16);
+        k.abits = (uint8_t*)b.take(out_el * e / 16);
         conv_alloc(k.c1);
         conv_alloc(k.c2);
         for (Conv* c : {&k.c1, &k.c2}) {
@@ -207,6 +214,10 @@ size_t gdl_encoder::plan(unsigned char* base) {
         }
         const size_t bb = (size_t)bn_bwd_blocks((size_t)M, k.cout) * k.cout;
         if (bb > max_bnb) max_bnb = bb;
+        const size_t ta = (size_t)conv_dgrad_tiles_m(dtype, k.n, k.c2.h, k.c2.w, k.c2.cin, k.c2.cout, 3, 3, 1, 1) * k.cout;
+        const size_t tb = (size_t)conv_dgrad_tiles_m(dtype, k.n, k.c1.h, k.c1.w, k.c1.cin, k.c1.cout, 3, 3, k.c1.stride, 1) * k.cin;
+        if (ta > max_bwt) max_bwt = ta;
+        if (tb > max_bwt) max_bwt = tb;
         size_t w1 = conv_wgrad_ws_bytes(M, k.cin, k.cout, 9);
         size_t w2 = conv_wgrad_ws_bytes(M, k.cout, k.cout, 9);
         size_t w3 = k.has_ds ? conv_wgrad_ws_bytes(M, k.cin, k.cout, 1) : 0;
@@ -229,6 +240,9 @@ size_t gdl_encoder::plan(unsigned char* base) {
     bn_partial2 = (float*)b.take(bn_partial_floats * sizeof(float));
     bnb_partial = (float*)b.take(bnb_partial_floats * sizeof(float));
     bnb_partial2 = (float*)b.take(bnb_partial_floats * sizeof(float));
+    bwA = (float*)b.take(max_bwt * 2 * sizeof(float));
+    bwB = (float*)b.take(max_bwt * 2 * sizeof(float));
+    bwB2 = (float*)b.take(max_bwt * 2 * sizeof(float));
     wg_ws_bytes = wg;
     wg_ws = b.take(wg);
     fold.ctr = (unsigned*)b.take(fold_ctr_bytes());
@@ -464,6 +478,17 @@ static bool premask_on() {
     return v != 0;
 }
 
+// BatchNorm-backward reductions in the producing data gradient's epilogue (ops.h BwdStats; default on; GDL_BW_FUSE=0: the
+// separate bn_bwd_reduce / block_bwd_reduce passes over g and y)
+static bool bw_fuse_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = tune_env("GDL_BW_FUSE");
+        v = env ? atoi(env) : 1;
+    }
+    return v != 0;
+}
+
 static bool separate_stats() {
     static int sep = -1;
     if (sep < 0) {
@@ -569,7 +594,8 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     for (Block& k : e->blocks) {
         const size_t Mo = (size_t)k.n * k.p * k.q;
         RC(conv_bn(e, k.c1, k.b1, k.xin, k.y1, k.n, training, st));
-        RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st));
+        RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st,
+                  (training && bw_fuse_on()) ? k.abits : nullptr));
         if (k.has_ds && training && !separate_stats() && !fold_on()) {
             // bn2 and the downsample BatchNorm are independent: both convolutions first, ONE finalize launch for the two
             // (a finalize kernel costs the chain its whole ~6 us; 80 of them were 0.56 ms of the step)
@@ -667,6 +693,10 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
     // gradient that produced it applied the saved sign bits in its epilogue (every block but the last one): the block
     // then skips one read of z and one write of the masked gradient (two of its four tensor passes).
     bool premasked = phase == 2 ? e->bw_premasked : false;
+    // ... and with the bn2 / downsample-BatchNorm sums of this block in e->bwB / e->bwB2 (b2_rows partial rows) when the data
+    // gradient that produced dz computed them in its epilogue
+    int b2_rows = phase == 2 ? e->bw_b2_rows : 0;
+    const bool fuse = bw_fuse_on() && !fold_on();
     // weight gradients: forked onto the side stream (sw) once their dy exists on st
     hipStream_t sw = e->side ? e->side : st;
     auto fork = [&]() -> int {  // sw waits for everything enqueued on st so far
@@ -694,10 +724,20 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             const BnFinBwd fd{e->bnb_partial2, blocks, k.cout, (double)Mo, k.has_ds ? grads[k.bd.pidx] : nullptr,
                               k.has_ds ? grads[k.bd.pidx + 1] : nullptr, k.has_ds ? k.bd.coef : nullptr};
             const bool fold = fold_on() && fold_fits(blocks, k.cout);
+            if (b2_rows > 0) {
+                // the sums came with dz (conv1's data gradient of the block behind this one): only the finalize is left
+                const BnFinBwd g2{e->bwB, b2_rows, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef};
+                const BnFinBwd gd{e->bwB2, b2_rows, k.cout, (double)Mo, k.has_ds ? grads[k.bd.pidx] : nullptr,
+                                  k.has_ds ? grads[k.bd.pidx + 1] : nullptr, k.has_ds ? k.bd.coef : nullptr};
+                if (k.has_ds)
+                    RC(bn_bwd_finalize_pair(g2, gd, st));
+                else
+                    RC(bn_bwd_finalize(g2.partial, g2.blocks, k.cout, (double)Mo, g2.dgamma, g2.dbeta, g2.coef, st));
+            } else
             RC(block_bwd_reduce(dt, dz, k.z, k.y2, k.has_ds ? k.yd : nullptr, k.b2.mean, k.b2.rstd, k.has_ds ? k.bd.mean : nullptr,
                                 k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st,
                                 fold ? &e->fold : nullptr, &f2, &fd, premasked));
-            if (!fold) {
+            if (!fold && b2_rows == 0) {
                 if (k.has_ds)  // one finalize launch for bn2 and the downsample BatchNorm
                     RC(bn_bwd_finalize_pair(f2, fd, st));
                 else
@@ -724,11 +764,23 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         // beside the (HBM-bound) BatchNorm passes that follow rather than beside another MFMA-bound kernel
         const bool late = e->side && wgrad_late();
         if (!late) RC(wgrad2());
+        if (fuse) {
+            // gC = da1 * (a1 > 0) (sign bits of a1) with bn1's two sums from the epilogue; then finalize + apply
+            const BwdStats bwa{k.y1, k.b1.mean, k.b1.rstd, e->bwA, nullptr, nullptr, nullptr, nullptr};
+            RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, st,
+                          k.abits, &bwa));
+            if (late) RC(wgrad2());
+            const int rows = conv_dgrad_tiles_m(dt, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1);
+            RC(bn_bwd_finalize(e->bwA, rows, k.cout, (double)Mo, grads[k.b1.pidx], grads[k.b1.pidx + 1], k.b1.coef, st));
+            RC(bn_bwd_apply(dt, gC, k.y1, k.b1.scale, k.b1.shift, k.b1.mean, k.b1.rstd, e->params[k.b1.pidx], k.b1.coef, 0, gC, Mo,
+                            k.cout, st));  // gC = dy1 (in place; the gradient is masked already)
+        } else {
         RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
                       st));  // gC = da1
         if (late) RC(wgrad2());
         // relu + bn1 / conv1
         RC(bn_backward(e, k.b1, gC, k.y1, 1, gC, Mo, grads, st));  // gC = dy1 (in place)
+        }
         auto wgrad1 = [&]() -> int {  // weight gradient of conv1: needs dy1
             RC(fork());
             RC(conv_wgrad(dt, gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
@@ -745,27 +797,39 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         // the block's input is the previous block's output z (for block 0: the pooled stem output, whose mask the
         // stem's own backward applies): its sign bits turn dx into the masked gradient the previous block wants
         const uint8_t* inbits = (bi > 0 && premask_on()) ? e->blocks[bi - 1].zbits : nullptr;
+        // the gradient this launch stores is (masked by inbits) the gradient of the previous block's output: its epilogue also
+        // leaves the sums of that block's bn2 (and downsample BatchNorm) backward, so the block needs no pass of its own for them
+        BwdStats bwb{};
+        int next_rows = 0;
+        if (fuse && inbits) {
+            Block& pv = e->blocks[bi - 1];
+            bwb = BwdStats{pv.y2, pv.b2.mean, pv.b2.rstd, e->bwB, pv.has_ds ? pv.yd : nullptr,
+                           pv.has_ds ? pv.bd.mean : nullptr, pv.has_ds ? pv.bd.rstd : nullptr, pv.has_ds ? e->bwB2 : nullptr};
+            next_rows = conv_dgrad_tiles_m(dt, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1);
+        }
+        const BwdStats* bwp = next_rows ? &bwb : nullptr;
         if (k.has_ds && ds_fold_on() && k.c1.stride == 2) {
             // the shortcut's 1x1 stride-2 data gradient rides in the 3x3 one as a tenth tap of the (even, even) pixels:
             // one launch and one tensor write instead of two launches, two writes and a read
             RC(conv_dgrad_ds(dt, gC, k.c1.w_crsk, gD, k.cd.w_crsk, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, st,
-                             inbits));
+                             inbits, bwp));
             dxin = spare;
             spare = dz;
         } else if (k.has_ds) {
             RC(conv_dgrad(dt, gD, k.cd.w_crsk, spare, nullptr, k.cd.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 1, 1,
                           k.cd.stride, 0, st));
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, spare, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3,
-                          k.c1.stride, 1, st, inbits));
+                          k.c1.stride, 1, st, inbits, bwp));
             dxin = spare;
             spare = dz;  // the old dz buffer is free now
         } else {
             // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st,
-                          inbits));
+                          inbits, bwp));
             dxin = do2;
         }
         premasked = inbits != nullptr;
+        b2_rows = next_rows;
         if (late) RC(wgrad1());
         dz = dxin;
     }
@@ -773,6 +837,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         e->bw_dz = dz;
         e->bw_spare = spare;
         e->bw_premasked = premasked;
+        e->bw_b2_rows = b2_rows;
         e->bw_serial = (long)e->serial;
         if (e->side) {
             hipError_t he = hipEventRecord(e->ev_join, e->side);

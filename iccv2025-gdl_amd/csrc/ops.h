@@ -26,7 +26,24 @@ struct BnFinBwd {
     float *dgamma, *dbeta, *coef;
 };
 
+// BatchNorm-backward reductions produced by a data gradient's epilogue (round 3): the launch that writes a gradient tensor
+// g [rows][C] also leaves, per M-tile, the per-channel sums the BatchNorm backward of the layer(s) that tensor flows into needs
+//   partial[tile][C][2] = { sum g', sum g' * (y - mean) * rstd }      (what bn_bwd_reduce / block_bwd_reduce produce in a pass
+//   partial2[tile][C][2] = { sum g', sum g' * (y2 - mean2) * rstd2 }    of their own over g and y: two tensor reads each)
+// over the STORED values g' of the rows it stores (after the addend and the relu_bits mask -- the ReLU between a BatchNorm and
+// its consumer reaches the gradient through the sign bits bn_act leaves: relu(bn1(y1)) -> conv2, backbone.py:57-58).
+// y2 / partial2: a second BatchNorm fed by the same gradient (the downsample branch's, backbone.py:62-64).
+// tiles = conv_dgrad_tiles_m(...) rows.
+struct BwdStats {
+    const void* y;
+    const float *mean, *rstd;
+    float* partial;
+    const void* y2;
+    const float *mean2, *rstd2;
+    float* partial2;
+};
 // conv_igemm.hip
+int conv_dgrad_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 // (fold != nullptr: the BatchNorm finalize of `bn` runs inside the launch, fold.h; bn->partial / tiles are ignored)
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
@@ -36,11 +53,13 @@ int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const f
                   const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
-               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr);
+               int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr,
+               const BwdStats* bw = nullptr);
 // the 3x3 stride-2 pad-1 data gradient of a downsample block's conv1 with the 1x1 stride-2 data gradient of its shortcut
 // convolution folded in: dx = dgrad(dy, w_crsk) + dgrad_1x1s2(dy_ds, w_ds_ck) (+ relu_bits), one launch, no addend pass
 int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
-                  const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits = nullptr);
+                  const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits = nullptr,
+                  const BwdStats* bw = nullptr);
 // direct (implicit-GEMM) stem: layout.hip (padded NHWC4 input, row-wise weights), gather.hip (table),
 // conv_igemm.hip (forward), conv_wgrad.hip (weight gradient)
 size_t stem_pad_bytes(int dtype, int n_img, int H, int W);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "gdl_conv_dgrad_relu": ("i", "ipppppp" + "iiiiiiiii" + "p"),
     "gdl_conv_fwd_bias": ("i", "ippppppp" + "iiiiiiiii" + "p"),
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
+    "gdl_conv_dgrad_bn_tiles": ("i", "iiiiiiiiii"),
+    "gdl_conv_dgrad_bn": ("i", "ipppppp" + "iiiiiiiii" + "pppppppp" + "p"),
     "gdl_comm_unique_id": ("i", "p"),
     "gdl_comm_init": ("i", "piip"),
     "gdl_comm_world": ("i", "p"),

@@ -93,6 +93,18 @@ GDL_API int gdl_conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void
  * gdl_conv_dgrad_relu.  `table` = the GDL_GATHER_DGRAD table of the 3x3 stride-2 pad-1 geometry. */
 GDL_API int gdl_conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
                               const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, void* stream);
+/* BatchNorm-backward reductions in the producing data gradient's epilogue (round 3).  BasicBlock backward (backbone.py:52-66
+ * through autograd): the gradient dx a data gradient writes flows into a BatchNorm backward, which first needs per channel
+ *   sum g'  and  sum g' * (y - mean) * rstd,   g' = dx as stored (after the addend and the relu_bits mask),
+ * y = that BatchNorm's saved input.  gdl_conv_dgrad_bn = gdl_conv_dgrad(_relu) whose epilogue also leaves those sums per M-tile,
+ * partial[tile][C][2] (tile < gdl_conv_dgrad_bn_tiles(...)), ready for gdl_bn_bwd_finalize -- the separate reduce pass over
+ * g and y (gdl_bn_bwd_reduce: two tensor reads) disappears.  y2 / mean2 / rstd2 / partial2 (all or none): a second BatchNorm
+ * fed by the same gradient (the downsample branch's; not with the 64 -> 64 channel persistent kernel). */
+GDL_API int gdl_conv_dgrad_bn_tiles(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+GDL_API int gdl_conv_dgrad_bn(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
+                              const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
+                              int stride, int pad, const void* y, const float* mean, const float* rstd, float* partial,
+                              const void* y2, const float* mean2, const float* rstd2, float* partial2, void* stream);
 /* In-launch BatchNorm finalize ("the last block folds"): the kernel that produces the per-block partial sums also
  * reduces them -- the block that completes them, found by an arrival ticket, folds them in a fixed order and runs
  * the finalize arithmetic -- so no separate finalize launch sits on the chain (backbone.py:45-48,104: conv -> bn).

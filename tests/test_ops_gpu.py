@@ -660,3 +660,74 @@ def test_conv_run_to_run_determinism():
             else:
                 for a_, b_, nm in zip(first, cur, ("y", "bn partials", "dx", "dw")):
                     assert torch.equal(a_, b_), (nm, (N, C, H, W, K, R, stride))
+
+
+BW_SHAPES = [
+    # N, C, H, W, K, R, stride, pad, mask ("bits": ReLU through relu_bits, None), two partners
+    (2, 64, 17, 13, 64, 3, 1, 1, "bits", False),      # small slab / flat tile, ragged last tile
+    (24, 64, 56, 56, 64, 3, 1, 1, "bits", False),     # 64 -> 64 channels: the persistent kernel, one partial row per block
+    (24, 64, 56, 56, 64, 3, 1, 1, None, False),
+    (8, 128, 28, 28, 128, 3, 1, 1, "bits", True),     # 128-channel slab tiles, two BatchNorms fed by the same gradient
+    (16, 64, 33, 24, 128, 3, 2, 1, "bits", False),    # permuted stride-2 data gradient (rows scattered through orow)
+    (48, 512, 7, 7, 512, 3, 1, 1, "bits", True),      # the 8-wave 128 x 128 tile
+    (2, 64, 9, 6, 128, 1, 2, 0, None, False),         # 1x1 stride 2
+]
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape", BW_SHAPES)
+def test_conv_dgrad_bn_sums(shape, dt):
+    """gdl_conv_dgrad_bn: the data gradient whose epilogue also leaves the BatchNorm-backward sums of the stored gradient against
+    the partner tensor(s) -- the stored tensor against the oracle's data gradient (+ mask), the sums against a float64
+    restatement over the STORED values (what gdl_bn_bwd_reduce computes in its own pass, backbone.py:45-48,57 through autograd)."""
+    N, C, H, W, K, R, stride, pad, mask, two = shape
+    st = L.cur_stream()
+    lib = L.load()
+    _, w = _conv_case(N, C, H, W, K, R, stride, pad, dt)
+    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = quant(rng.standard_normal((N, K, P, Q), dtype=np.float32), dt)
+    ref = orc.conv2d_bwd_data(dy, w, (N, C, H, W), stride, pad)
+    y = quant(rng.standard_normal((N, C, H, W), dtype=np.float32) * 1.5 + 0.3, dt)
+    y2 = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    mean, rstd = (rng.standard_normal(C) * 0.3).astype(np.float32), (0.5 + rng.random(C)).astype(np.float32)
+    mean2, rstd2 = (rng.standard_normal(C) * 0.3).astype(np.float32), (0.5 + rng.random(C)).astype(np.float32)
+    sc, sh = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    bc = lambda v: v[None, :, None, None]
+    M = N * H * W
+    epc = 8 if dt == L.GDL_BF16 else 4
+    bits = None
+    if mask == "bits":  # sign bits of relu(y * sc + sh), as gdl_bn_act_bits leaves them
+        keep = (y * bc(sc) + bc(sh)) > 0
+        kb = np.transpose(keep, (0, 2, 3, 1)).reshape(-1, epc)
+        bits = torch.from_numpy((kb * (1 << np.arange(epc))[None, :]).sum(1).astype(np.uint8)).to(DEV)
+        ref = np.where(keep, ref, 0)
+    _, crsk = pack_weight(w, dt)
+    dyd, yd, y2d = to_nhwc(dy, dt), to_nhwc(y, dt), to_nhwc(y2, dt)
+    dx = empty((N, H, W, C), dt)
+    tab = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, R, R, stride, pad)
+    tiles = lib.gdl_conv_dgrad_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
+    part = torch.full((tiles, C, 2), float("nan"), device=DEV)
+    part2 = torch.full((tiles, C, 2), float("nan"), device=DEV)
+    md, rd, m2d, r2d = dev(mean), dev(rstd), dev(mean2), dev(rstd2)  # (kept alive across the launch)
+    L.call("gdl_conv_dgrad_bn", dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), None, L.ptr(bits) if bits is not None else None,
+           L.ptr(tab), N, H, W, C, K, R, R, stride, pad, L.ptr(yd), L.ptr(md), L.ptr(rd), L.ptr(part),
+           L.ptr(y2d) if two else None, L.ptr(m2d) if two else None, L.ptr(r2d) if two else None,
+           L.ptr(part2) if two else None, st)
+    torch.cuda.synchronize()
+    got = from_nhwc(dx)
+    assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
+    if mask:
+        assert np.all(got[ref == 0] == 0)
+    g64 = got.astype(np.float64)
+    s = part.double().sum(0).cpu().numpy()
+    assert np.isfinite(s).all()
+    want1 = g64.sum((0, 2, 3))
+    want2 = (g64 * (y.astype(np.float64) - bc(mean)) * bc(rstd)).sum((0, 2, 3))
+    scale_ = np.abs(g64).sum((0, 2, 3)).max()
+    np.testing.assert_allclose(s[:, 0], want1, rtol=1e-4, atol=2e-6 * scale_)
+    np.testing.assert_allclose(s[:, 1], want2, rtol=1e-4, atol=1e-5 * scale_)
+    if two:
+        s2 = part2.double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(s2[:, 0], want1, rtol=1e-4, atol=2e-6 * scale_)
+        np.testing.assert_allclose(s2[:, 1], (g64 * (y2.astype(np.float64) - bc(mean2)) * bc(rstd2)).sum((0, 2, 3)), rtol=1e-4,
+                                   atol=1e-5 * scale_)
