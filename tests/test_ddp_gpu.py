@@ -25,7 +25,8 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo", comm_backend="torch", early=None, side=None):
+    """backend "gloo": both ranks on cuda:0 (the one-GPU box); "nccl": one rank per GPU over RCCL (boxes with >= 2 GPUs)."""
     import torch.distributed as dist
 
     for p in (ROOT, os.path.join(ROOT, "iccv2025-gdl_amd")):
@@ -33,19 +34,25 @@ def _worker(rank, world, port, q):
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = "cuda:0" if backend == "gloo" else f"cuda:{rank}"
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from gdl.trainer import DGLTrainer
     from models.basic_model import AVClassifier_DGL
     from oracle import fixtures as fx
 
-    dev = "cuda:0"
     B, spec_hw, T, img_hw, ncls = 2, (65, 47), 2, (64, 64), 6
     P, Bf = fx.model_state(ncls, "concat_dgl")
     args = argparse.Namespace(fusion_method="concat", dataset="CREMAD", modality="full", batch_size=B)
     model = AVClassifier_DGL(args)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in {**P, **Bf}.items()})
     model = model.to(dev).train()
-    tr = DGLTrainer(model, lr=2e-3, alpha=4.0, dtype="f32", process_group=dist.group.WORLD)
+    tr = DGLTrainer(model, lr=2e-3, alpha=4.0, dtype="f32", process_group=dist.group.WORLD, comm_backend=comm_backend,
+                    early_backward=early, visual_side_stream=side)
     spec, image, label = fx.make_batch(100 + rank, B, spec_hw, T, img_hw, ncls)
     tr.step(torch.from_numpy(spec).to(dev), torch.from_numpy(image).to(dev), torch.from_numpy(label).to(dev))
     r = tr.read()
@@ -53,15 +60,16 @@ def _worker(rank, world, port, q):
     q.put((rank, r["total_norm"], r["loss_f"], {k: sd[k] for k in ("fusion_module.fc_out.weight", "audio_net.conv1.weight",
                                                                      "visual_net.layer4.1.conv2.weight",
                                                                      "audio_net.layer2.0.downsample.1.weight")}))
+    tr.close()
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_oracle():
+def _two_rank_vs_oracle(backend="gloo", comm_backend="torch", early=None, side=None):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend, comm_backend, early, side)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
@@ -98,6 +106,25 @@ def test_two_rank_step_matches_oracle():
         buf = np.zeros_like(p)
         orc.sgd_(p, g, buf, 2e-3, 0.9, 1e-4, True)
         np.testing.assert_allclose(got, p, rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("early,side", [(None, None), (True, True)])
+def test_two_rank_step_matches_oracle(early, side):
+    """(gloo, both ranks on cuda:0) the data-parallel default schedule, and the opt-in one: early backward (collectives issued as
+    audio_l4, visual_l4, audio_rest, fusion, visual_rest over two streams) with the visual weight gradients' side stream."""
+    _two_rank_vs_oracle("gloo", "torch", early, side)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device")
+@pytest.mark.parametrize("comm_backend", ["torch", "abi"])
+@pytest.mark.parametrize("early,side", [(None, None), (True, True)])
+def test_two_rank_rccl_step_matches_oracle(comm_backend, early, side):
+    """The same two-rank step over RCCL / xGMI, one rank per GPU, for both collective backends (torch.distributed's
+    all_reduce and the library's own communicator, gdl_comm_*) and for both schedules (the data-parallel default: junction
+    form, no side stream; and early backward + the visual weight gradients' side stream, whose collectives are issued in
+    another order over two streams).  Skipped on one-GPU boxes -- the first multi-GPU box runs it
+    (/root/reference/main_dgl.py:244 nn.DataParallel semantics)."""
+    _two_rank_vs_oracle("nccl", comm_backend, early, side)
 
 
 def test_bench_two_rank_control_flow():
