@@ -262,25 +262,35 @@ class SwinEngine:
         t, n, blk = self._pack_tab
         L.call("gdl_swin_pack_batched", L.ptr(t), n, blk, 0, st)
 
-    def _unpack_all(self, grads, st):
+    def _unpack_all(self, grads, st, part=None):
         key = tuple(g.data_ptr() for g in grads)
-        if getattr(self, "_unpack_key", None) != key:
-            recs = [r for o in self._linears_norms() for r in o.unpack_descs(grads)]
-            self._unpack_tab, self._unpack_key = self._desc_table(recs, True), key
-        t, n, blk = self._unpack_tab
+        cache = self.__dict__.setdefault("_unpack_tabs", {})
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+        if part not in cache:
+            recs = [r for o in self._linears_norms(part) for r in o.unpack_descs(grads)]
+            cache[part] = self._desc_table(recs, True)
+        t, n, blk = cache[part]
         L.call("gdl_swin_pack_batched", L.ptr(t), n, blk, 1, st)
 
-    def _linears_norms(self):
-        yield self.pe
-        yield self.pe_norm
-        for s in self.stages:
-            for b in s["blocks"]:
-                for k in ("norm1", "qkv", "proj", "norm2", "fc1", "fc2"):
-                    yield b[k]
-            if "red" in s:
+    def _linears_norms(self, part=None):
+        """part None: every Linear / LayerNorm; "last": the last stage's blocks and the final norm (the parameters whose
+        gradients backward phase 1 completes -- DGLTrainer's visual_l4 bucket); "rest": the others."""
+        last = len(self.stages) - 1
+        if part != "last":
+            yield self.pe
+            yield self.pe_norm
+        for si, s in enumerate(self.stages):
+            if part is None or (part == "last") == (si == last):
+                for b in s["blocks"]:
+                    for k in ("norm1", "qkv", "proj", "norm2", "fc1", "fc2"):
+                        yield b[k]
+            if "red" in s and part != "last":
                 yield s["red"]
                 yield s["mnorm"]
-        yield self.out_norm
+        if part != "rest":
+            yield self.out_norm
 
     def _v(self, flat, rows, cols):
         return flat[:rows * cols].view(rows, cols)
@@ -372,11 +382,15 @@ class SwinEngine:
                self.L_out * (T if pool_frames else 1), self.C_out, last["ld"], st)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dfeat, grads, serial=None):
+    def backward(self, dfeat, grads, serial=None, phase=0):
         """dfeat float32 [B*T, C_last] (or [B, C_last] for a pool_frames forward); grads: float32 tensors of the
         parameter shapes (overwritten).  serial: the engine's `serial` right after the forward being differentiated -- if
         another forward has run through the engine since (a validation pass of the same shape, two forwards before one
-        backward), its activations are gone and this raises instead of returning gradients of the wrong pass."""
+        backward), its activations are gone and this raises instead of returning gradients of the wrong pass.
+        phase 0: the whole backward.  phase 1: the upstream gradient, the final norm and the LAST stage -- afterwards the gradients
+        of `layers.<last>.*` and `norm.*` (half of Swin-T's parameters) are final on the stream, so a data-parallel caller
+        can start their all-reduce (DGLTrainer's visual_l4 bucket) while phase 2 (the other stages and the patch embedding;
+        same `dfeat` / `grads` arguments) runs -- the counterpart of gdl_encoder_backward_phase."""
         if not self.have_fwd:
             raise L.GdlError("SwinEngine.backward: no forward to differentiate")
         if serial is not None and serial != self.serial:
@@ -391,21 +405,36 @@ class SwinEngine:
         for gten, (n, shape) in zip(grads, self.names):
             if gten.dtype != torch.float32 or not gten.is_contiguous() or tuple(gten.shape) != shape:
                 raise L.GdlError(f"SwinEngine.backward: the gradient of {n} must be a contiguous float32 tensor of shape {shape}")
+        if phase not in (0, 1, 2):
+            raise L.GdlError("SwinEngine.backward: phase must be 0, 1 or 2")
+        if phase == 2 and getattr(self, "_bw_phase1_serial", None) != self.serial:
+            raise L.GdlError("SwinEngine.backward: phase 2 without phase 1 of the same forward")
+        if phase == 1:
+            self._bw_phase1_serial = self.serial
         grads = list(grads)
-        key = ("b", dfeat.data_ptr(), pooled) + tuple(t.data_ptr() for t in grads) + tuple(p.data_ptr() for p in self._params)
-        self._run(key, lambda: self._backward_body(dfeat, grads, pooled))
+        key = ("b", phase, dfeat.data_ptr(), pooled) + tuple(t.data_ptr() for t in grads) + tuple(p.data_ptr() for p in self._params)
+        self._run(key, lambda: self._backward_body(dfeat, grads, pooled, phase))
+        if phase == 2:
+            self._bw_phase1_serial = None
 
-    def _backward_body(self, dfeat, grads, pooled):
+    def _backward_body(self, dfeat, grads, pooled, phase=0):
         dt, N, st = self.dt, self.N, L.cur_stream()
         P = self._params
         last = self.stages[-1]
+        nst = len(self.stages)
         M, ld = last["M"], last["ld"]
         ga, gb = self._v(self.g_a, M, ld), self._v(self.g_b, M, ld)
-        L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), self.B if pooled else N,
-               self.L_out * (self.T if pooled else 1), self.C_out, ld, st)
-        self.out_norm.bwd(ga, self.x_last, self.out_stats, None, gb, M, st)
-        dx, spare = gb, ga  # dx: gradient of the current stage's output tokens
-        for si in range(len(self.stages) - 1, -1, -1):
+        if phase != 2:
+            L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), self.B if pooled else N,
+                   self.L_out * (self.T if pooled else 1), self.C_out, ld, st)
+            self.out_norm.bwd(ga, self.x_last, self.out_stats, None, gb, M, st)
+        # dx: gradient of the current stage's output tokens.  (Every block hands dx back in the buffer it got it in, so after
+        # the last stage it sits in g_b again: phase 2 picks it up there without any state from phase 1 -- both phases may
+        # be HIP-graph replays.)
+        dx, spare = gb, ga
+        first_si = nst - 2 if phase == 2 else nst - 1
+        last_si = nst - 1 if phase == 1 else 0
+        for si in range(first_si, last_si - 1, -1):
             s = self.stages[si]
             M, ld, r = s["M"], s["ld"], s["r"]
             if "red" in s:  # dx is the gradient of the merged tokens [M/4][ld(2C)]
@@ -442,10 +471,13 @@ class SwinEngine:
                 b["qkv"].wgrad(gq, b["h"], M, st)
                 b["qkv"].dgrad(gq, gtok, M, st)                                   # d h
                 b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st)    # dx = d x_in
+        if phase == 1:
+            self._unpack_all(grads, st, "last")  # the last stage's and the final norm's gradients -> the parameters' shapes
+            return
         # patch embedding: x0 = norm(conv(x) + b); no input gradient
         M0 = self.pe_rows.shape[0]
         g0 = self._v(spare.reshape(-1), M0, self.pe.np)
         self.pe_norm.bwd(dx, self.pe_out, self.pe_stats, None, g0, M0, st)
         L.call("gdl_swin_colsum", dt, L.ptr(g0), None, L.ptr(self.pe.db), L.ptr(self.partial), M0, self.pe.np, st)
         self.pe.wgrad(g0, self.pe_rows, M0, st)
-        self._unpack_all(grads, st)  # padded float32 gradients -> the parameters' shapes, one launch
+        self._unpack_all(grads, st, "rest" if phase == 2 else None)  # padded float32 gradients -> the parameters' shapes, one launch

@@ -34,7 +34,7 @@ from .encoder import EncoderEngine
 
 class _SwinAdapter:
     """gdl.swin.SwinEngine behind the EncoderEngine calls the trainer makes (features averaged over the T frames of a
-    sample; no BatchNorm state, no phases: phase 1 is the whole backward, phase 2 nothing)."""
+    sample; no BatchNorm state; phase 1 = upstream gradient + final norm + last stage, phase 2 = the rest)."""
 
     def __init__(self, cfg, dtype, B, T, device):
         from .swin import SwinEngine
@@ -51,7 +51,8 @@ class _SwinAdapter:
 
     def backward(self, grads, dfeat=None, phase=0):
         if phase != 2:
-            self.eng.backward(dfeat, list(grads))
+            self._dfeat = dfeat
+        self.eng.backward(self._dfeat, list(grads), phase=phase)
 
 
 class DGLTrainer:
@@ -145,8 +146,8 @@ class DGLTrainer:
         # of its 11.2 M parameters, is final right after the first two blocks of the backward: its own bucket lets
         # three quarters of the exchange overlap the rest of the backward.
         a0, v0 = nf, nf + 60
-        # (Swin: the last stage + final norm -- the tensors whose gradients the backward finishes first -- play layer4's
-        # part; its engine has no phases yet, so both visual buckets are launched behind the whole backward)
+        # (Swin: the last stage + final norm -- the tensors whose gradients the backward finishes first, SwinEngine.backward
+        # phase 1 -- play layer4's part)
         vsplit = v0 + 45 if not self.vis_swin else \
             v0 + next(i for i, (n, _) in enumerate(named[v0:]) if n.startswith("visual_net.layers.%d." % (model.visual_net.num_layers - 1)))
         self.bucket = {"fusion": (0, offs[nf]),

@@ -264,3 +264,42 @@ def test_swin_dropin_stale_forward_is_refused(golden_dir):
         net(x + 1.0)  # e.g. a validation forward of the same shape in between
     with pytest.raises(L.GdlError, match="another forward"):
         y1.sum().backward()
+
+
+@pytest.mark.parametrize("cfg_name", ["SWIN_TINY2", "SWIN_T"])
+def test_swin_backward_phases_equal_whole(cfg_name):
+    """SwinEngine.backward in two phases (1: upstream gradient + final norm + last stage, 2: the rest -- the data-parallel
+    schedule that lets the last stage's bucket travel while the rest is differentiated) leaves bit for bit the gradients of the
+    one-call backward, and the last stage's / final norm's are already final after phase 1."""
+    from gdl.swin import SwinEngine
+
+    cfg = getattr(fx, cfg_name)
+    B, T = 2, 2
+    eng = SwinEngine(cfg, "bf16", B, T, DEV)
+    eng.use_graph = False
+    P = fx.make_state(fx.swin_param_shapes(cfg))
+    params = [torch.from_numpy(v).to(DEV) for v in P.values()]
+    eng.set_params(params)
+    x = torch.from_numpy(fx.swin_input(cfg, B, T, 5)).to(DEV)
+    dy = torch.from_numpy(np.random.default_rng(3).standard_normal((B * T, eng.C_out), dtype=np.float32)).to(DEV)
+    eng.forward(x)
+    whole = [torch.full_like(p, float("nan")) for p in params]
+    eng.backward(dy, whole)
+    torch.cuda.synchronize()
+    eng.forward(x)
+    two = [torch.full_like(p, float("nan")) for p in params]
+    with pytest.raises(L.GdlError):
+        eng.backward(dy, two, phase=2)  # no phase 1 of this forward yet
+    eng.backward(dy, two, phase=1)
+    torch.cuda.synchronize()
+    last = f"layers.{len(cfg['depths']) - 1}."
+    names = list(P)
+    for n, a, b in zip(names, whole, two):
+        if n.startswith(last) or n.startswith("norm."):
+            assert torch.equal(a, b), n  # final after phase 1
+        else:
+            assert torch.isnan(b).all(), n  # untouched so far
+    eng.backward(dy, two, phase=2)
+    torch.cuda.synchronize()
+    for n, a, b in zip(names, whole, two):
+        assert torch.equal(a, b), n
