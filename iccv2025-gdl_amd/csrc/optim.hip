@@ -11,6 +11,8 @@
 #include "common.h"
 #include "prof.h"
 
+#include <string.h>
+
 #include <vector>
 
 struct gdl_optim {
@@ -19,10 +21,14 @@ struct gdl_optim {
     int nchunks = 0;
     std::vector<int64_t> offs;
     std::vector<int32_t> group;
-    // device tables (owned): chunk descriptors and per-segment chunk ranges
-    void* d_chunks = nullptr;    // ChunkDesc[nchunks]
-    void* d_segrange = nullptr;  // int32[nseg][4] = {first_chunk, n_chunks, group, 0}
-    void* d_segnumel = nullptr;  // double[nseg]
+    // The object owns NO device memory (the library never allocates or frees device memory).  Its descriptor
+    // tables -- chunk descriptors ChunkDesc[nchunks], per-segment chunk ranges int32[nseg][4] = {first_chunk, n_chunks, group, 0},
+    // per-segment element counts double[nseg] -- are kept on the host and uploaded into the head of the caller-provided
+    // workspace the first time gdl_optim_grad_stats sees that workspace (stream-ordered, once per workspace pointer):
+    //   ws = [chunk descriptors | segment ranges | element counts | per-chunk partials | per-segment sums]
+    std::vector<unsigned char> h_tables;  // the first three, concatenated as they sit in the workspace
+    size_t off_segrange = 0, off_segnumel = 0, off_partial = 0;
+    const void* bound_ws = nullptr;
 };
 
 namespace gdl {
@@ -218,31 +224,23 @@ int gdl_optim_create(gdl_optim_t** out, const int64_t* seg_offsets, const int32_
         numel[s] = (double)(e - b);
     }
     o->nchunks = (int)chunks.size();
-    hipError_t e1 = hipMalloc(&o->d_chunks, chunks.size() * sizeof(ChunkDesc));
-    hipError_t e2 = hipMalloc(&o->d_segrange, segrange.size() * sizeof(int32_t));
-    hipError_t e3 = hipMalloc(&o->d_segnumel, numel.size() * sizeof(double));
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-        gdl_optim_destroy(o);
-        return check_hip(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3), "optim_create: hipMalloc");
-    }
-    (void)hipMemcpy(o->d_chunks, chunks.data(), chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice);
-    (void)hipMemcpy(o->d_segrange, segrange.data(), segrange.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-    (void)hipMemcpy(o->d_segnumel, numel.data(), numel.size() * sizeof(double), hipMemcpyHostToDevice);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    o->off_segrange = up(chunks.size() * sizeof(ChunkDesc));
+    o->off_segnumel = up(o->off_segrange + segrange.size() * sizeof(int32_t));
+    o->off_partial = up(o->off_segnumel + numel.size() * sizeof(double));
+    o->h_tables.assign(o->off_partial, 0);
+    memcpy(o->h_tables.data(), chunks.data(), chunks.size() * sizeof(ChunkDesc));
+    memcpy(o->h_tables.data() + o->off_segrange, segrange.data(), segrange.size() * sizeof(int32_t));
+    memcpy(o->h_tables.data() + o->off_segnumel, numel.data(), numel.size() * sizeof(double));
     *out = o;
     return GDL_OK;
 }
 
-void gdl_optim_destroy(gdl_optim_t* o) {
-    if (!o) return;
-    if (o->d_chunks) (void)hipFree(o->d_chunks);
-    if (o->d_segrange) (void)hipFree(o->d_segrange);
-    if (o->d_segnumel) (void)hipFree(o->d_segnumel);
-    delete o;
-}
+void gdl_optim_destroy(gdl_optim_t* o) { delete o; }
 
 size_t gdl_optim_workspace_bytes(const gdl_optim_t* o) {
     if (!o) return 0;
-    return ((size_t)o->nchunks * 2 + (size_t)o->nseg * 2) * sizeof(double);
+    return o->off_partial + ((size_t)o->nchunks * 2 + (size_t)o->nseg * 2) * sizeof(double);
 }
 
 int gdl_optim_stats_len(const gdl_optim_t* o) { return o ? 4 + 2 * o->nseg : 0; }
@@ -254,17 +252,24 @@ int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, flo
         set_error("optim_grad_stats: workspace %zu < %zu", ws_bytes, gdl_optim_workspace_bytes(o));
         return GDL_ERR_WORKSPACE;
     }
+    GDL_REQUIRE(((uintptr_t)ws & 15) == 0, "optim_grad_stats: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    double* partial = (double*)ws;
+    unsigned char* w = (unsigned char*)ws;
+    if (o->bound_ws != ws) {  // descriptor tables -> the head of this workspace (once; ordered on `stream` like the kernels)
+        hipError_t he = hipMemcpyAsync(w, o->h_tables.data(), o->h_tables.size(), hipMemcpyHostToDevice, st);
+        if (he != hipSuccess) return check_hip(he, "optim_grad_stats: descriptor upload");
+        o->bound_ws = ws;
+    }
+    double* partial = (double*)(w + o->off_partial);
     double* segsum = partial + (size_t)o->nchunks * 2;
     {
         ProfScope prof("gdl::grad_stats_kernel", PROF_HBM, st, (double)o->total * 4.0);
-        hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)o->d_chunks, partial);
+        hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)w, partial);
     }
     GDL_CHECK_LAUNCH("grad_stats_kernel");
     hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial,
-                       (const int32_t*)o->d_segrange, (const double*)o->d_segnumel, o->nseg, max_norm, grad_scale, stats,
-                       segsum);
+                       (const int32_t*)(w + o->off_segrange), (const double*)(w + o->off_segnumel), o->nseg, max_norm, grad_scale,
+                       stats, segsum);
     GDL_CHECK_LAUNCH("grad_stats_final_kernel");
     return GDL_OK;
 }

@@ -132,8 +132,8 @@ GDL_API int gdl_pack_weight(int dtype, const float* w_kcrs, void* w_krsc, void* 
                             void* stream);
 
 
-/* Direct (implicit-GEMM) stem -- what the encoder engine runs; the im2col entry points above remain for
- * callers that want the matrix.  The reference's input tensor (same as gdl_stem_im2col) is copied once
+/* Direct (implicit-GEMM) stem, backbone.py:96-101,166 (7x7 stride 2 pad 3) -- what the encoder engine runs.  The reference's
+ * input tensor (float32 [B][Cin][T][H][W] visual / [B][1][H][W] audio, read in place through its strides) is copied once
  * into a zero-padded channels-last image with 4 channels per pixel,
  *     xp [B*T][H+6][W+8][4] dtype   (gdl_stem_pad_bytes bytes),
  * in which a filter row of an output pixel is 8 consecutive pixels (64 bytes bf16 / 128 bytes f32).
@@ -341,7 +341,11 @@ GDL_API int gdl_frames_normalize(const uint8_t* frames, int64_t n_img, int H, in
  *   audio_grad_sum, visual_grad_sum (both post-clip)} on the device.
  * gdl_optim_sgd_step: g *= clip_coef*grad_scale (written back); d = g + wd*p;
  *   m = mu*m + d; p -= lr*m  (momentum arena starts at zero, which reproduces
- *   torch's first-step `buf = d`). */
+ *   torch's first-step `buf = d`).
+ * The object owns no device memory: gdl_optim_create only builds host tables; `ws` (gdl_optim_workspace_bytes, 16-byte
+ * aligned, caller-owned) holds the descriptor tables in its head -- uploaded, ordered on `stream`, the first time
+ * gdl_optim_grad_stats is called with that pointer -- and the per-chunk partial sums behind them.  Keep the workspace intact
+ * between calls (or pass another pointer: the tables are uploaded again). */
 typedef struct gdl_optim gdl_optim_t;
 GDL_API int gdl_optim_create(gdl_optim_t** out, const int64_t* seg_offsets, const int32_t* seg_group, int nseg);
 GDL_API void gdl_optim_destroy(gdl_optim_t* o);
