@@ -412,14 +412,17 @@ def main():
         # sources this library was built from (hash stamp), for this workload / dtype / batch; otherwise null
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")))
+            import glob
+
+            # (the newest committed PMC table: profiles/rNN_pmc_kernels.json, tools/pmc_kernels.sh)
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")))[-1]))
             # the tap names a kernel without its template arguments: launch-weighted mean over its instantiations
             ks = [v for n, v in pm.get("kernels", {}).items() if n == d["kernel"] or n.startswith(d["kernel"] + "<")]
             if (ks and pm.get("src_hash") == src_hash() and pm.get("dtype") == a.dtype and pm.get("batch") == B and
                     pm.get("workload") == a.workload):
                 nl = sum(v["launches_per_step"] for v in ks)
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in ks) / nl)
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],

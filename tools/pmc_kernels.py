@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fold the rocprofv3 --pmc passes of tools/pmc_kernels.sh into profiles/r02_pmc_kernels.json + a readable table."""
+"""Fold the rocprofv3 --pmc passes of tools/pmc_kernels.sh into profiles/rNN_pmc_kernels.json (NN = $GDL_ROUND, default 03) + a readable table."""
 import collections
 import csv
 import glob
@@ -73,7 +73,7 @@ doc = {"src_hash": bench.src_hash(), "dtype": arg("--dtype", "bf16"), "batch": i
        "step_totals": {"hbm_read_GB": round(tot_r / 1e9, 3), "hbm_write_GB": round(tot_w / 1e9, 3)},
        "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_per_step"]))}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(doc, open(os.path.join(ROOT, "gpurun_out", "r02_pmc_kernels.json"), "w"), indent=1)
+json.dump(doc, open(os.path.join(ROOT, "gpurun_out", "r%s_pmc_kernels.json" % os.environ.get("GDL_ROUND", "03")), "w"), indent=1)
 print(f"steps seen {nsteps}; per step: read {tot_r / 1e9:.2f} GB, write {tot_w / 1e9:.2f} GB")
 for k, e in list(doc["kernels"].items())[:30]:
     print(f"  {k[:60]:60s} n/step {e['launches_per_step']:5.1f}  rd {e['hbm_read_bytes_per_launch'] / 1e6:8.1f} MB  wr "
