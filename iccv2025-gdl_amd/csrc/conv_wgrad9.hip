@@ -502,13 +502,14 @@ static W9Plan plan_w9(int M, int C, int K) {
     }
     // every block leaves 144 KB of fp32 partials that the reduce kernel reads back: at least `min_st` 64-pixel stages of work
     // per block.  Round 3 (tools/ab_env.sh, same box, three rounds, B = 64 step): 8 -> 5.72 ms, 36 -> 5.70, 48 -> 5.70,
-    // 72 -> 5.79, 110 -> 6.07.  With 48 the visual layers run 196 instead of 256 pixel slices and the audio layers (whose
-    // slices were 12 stages long) 64-128 instead of 256: 535 MB instead of 980 MB of partials written and read back per
-    // step at the same step time.
+    // 72 -> 5.79, 110 -> 6.07.  36 leaves the visual layers at their 256 slices of 37 stages and brings the audio layers
+    // (whose slices were 12 stages long) from 256 to 85-128 blocks: 680 MB instead of 980 MB of partials written and read back
+    // per step at the same step time.  (48 -- 196 visual slices, 535 MB -- is as fast in the step, but the kernel itself
+    // then runs on three quarters of the CUs: 94 instead of 84 us per launch in the step, 53 instead of 39 us alone.)
     static int min_st = -1;
     if (min_st < 0) {
         const char* e = tune_env("GDL_WGRAD9_MINST");  // tuning aid
-        min_st = e ? atoi(e) : 48;
+        min_st = e ? atoi(e) : 36;
     }
     int ns = (target + tiles - 1) / tiles;
     const int max_ns = (M + min_st * W9_BP - 1) / (min_st * W9_BP);
