@@ -339,7 +339,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             float f[EPC];
             unpack16<T>(v, f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = 0.5f * f[e] * (1.f + erff(f[e] * 0.70710678118654752f));
+            for (int e = 0; e < EPC; ++e) f[e] = gelu_val<T>(f[e]);
             *(uint4*)((T*)a.gelu_out + goff) = pack16<T>(f);
         }
     }

@@ -43,10 +43,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_df(float u) {
-    return 0.5f * (1.f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
-}
 
 // ------------------------------------------------------------------------------------------------ patch embedding rows
 template <typename T>
@@ -95,7 +91,7 @@ __global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, c
         if (MODE == 1) {
             ((uint4*)u)[i] = pack16<T>(f);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) f[e] = gelu_f(roundT<T>(f[e]));
+            for (int e = 0; e < EPC; ++e) f[e] = gelu_val<T>(roundT<T>(f[e]));
         }
         ((uint4*)y)[i] = pack16<T>(f);
     }
@@ -342,7 +338,7 @@ __global__ __launch_bounds__(256) void swin_colsum_kernel(T* __restrict__ g, con
                             float uu[EPC];
                             unpack16<T>(uv[q], uu);
 #pragma unroll
-                            for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_df(uu[e]));
+                            for (int e = 0; e < EPC; ++e) f[e] = roundT<T>(f[e] * gelu_grad<T>(uu[e]));
                             ((uint4*)g)[(base + q * stride) * vpr + vc] = pack16<T>(f);
                         }
 #pragma unroll
