@@ -575,8 +575,10 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
                                                              pack2bf(acc[jt][it][2] * inv, acc[jt][it][3] * inv));
     }
     __syncthreads();
-    // O = P V: tile (it, nt), K-steps of 32 keys
+    // O = P V, computed transposed (operands swapped, V^T rows taken in the order 8 q + r / 8 q + 4 + r: see sw_bwd_product):
+    // a lane owns eight consecutive channels of one query and stores them as one 16-byte vector
     f32x4_t o[4][2];
+    const int vrow = 8 * (l16 >> 2) + (l16 & 3);
 #pragma unroll
     for (int it = 0; it < 4; ++it)
 #pragma unroll
@@ -585,21 +587,19 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Ps[16 * it + l16][32 * ks + 8 * lq]);
-                const bf16x8_t vb = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Vt[16 * nt + l16][32 * ks + 8 * lq]);
-                o[it][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, vb, o[it][nt], 0, 0, 0);
+                const bf16x8_t vb = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Vt[vrow + 4 * nt][32 * ks + 8 * lq]);
+                o[it][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[it][nt], 0, 0, 0);
             }
         }
     if (!live) return;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * it + 4 * lq + r;
-            if (i >= Tn) continue;
-            bf16* ob = out + (img_row0 + S.tok[i]) * g.ld + h * SW_HD + l16;
-            ob[0].v = f2bf(o[it][0][r]);
-            ob[16].v = f2bf(o[it][1][r]);
-        }
+    for (int it = 0; it < 4; ++it) {
+        const int i = 16 * it + l16;
+        if (i >= Tn) continue;
+        const uint4 v = make_uint4(pack2bf(o[it][0][0], o[it][0][1]), pack2bf(o[it][0][2], o[it][0][3]),
+                                   pack2bf(o[it][1][0], o[it][1][1]), pack2bf(o[it][1][2], o[it][1][3]));
+        *(uint4*)(out + (img_row0 + S.tok[i]) * g.ld + h * SW_HD + 8 * lq) = v;
+    }
     if (h == 0 && lane < Tn)  // the row's padding columns stay zero
         for (int c = g.nh * SW_HD; c < g.ld; ++c) out[(img_row0 + S.tok[lane]) * g.ld + c].v = 0;
 }
@@ -613,13 +613,15 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
 // windows and is folded into d(table) at the end.  24 KB of LDS and <= 256 registers: six to eight waves per CU (the
 // first form kept three tiles and every accumulator live: 43 KB, 401 registers, three waves per CU).
 struct SwinMfmaBwdLds {
-    uint16_t Tl[SW_TP][SW_PP];                                       // dS [i][j], then dS^T [j][i], then P^T [j][i]
-    uint16_t Kt[SW_HD][SW_PP], Qt[SW_HD][SW_PP], Ot[SW_HD][SW_PP];  // K^T [d][j], Q^T [d][i], dO^T [d][i]
+    uint16_t Tl[SW_TP][SW_PP];  // dS [i][j], then dS^T [j][i], then P^T [j][i]
+    uint16_t Bt[SW_HD][SW_PP];  // the product's transposed B operand, in turn: K^T [d][j], Q^T [d][i], dO^T [d][i] -- scattered
+                                // from the fragment registers right before the product that reads it (round 3: ONE buffer instead
+                                // of three, 15 instead of 24 KB per wave: ten instead of six waves per CU)
     float tab[(2 * 7 - 1) * (2 * 7 - 1)];
     int tok[SW_TP];
     uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
 };
-static_assert(sizeof(((SwinMfmaBwdLds*)nullptr)->Tl) + 3 * sizeof(((SwinMfmaBwdLds*)nullptr)->Kt) >= SW_MAXT * (SW_MAXT + 1) * sizeof(float),
+static_assert(sizeof(((SwinMfmaBwdLds*)nullptr)->Tl) + sizeof(((SwinMfmaBwdLds*)nullptr)->Bt) >= SW_MAXT * (SW_MAXT + 1) * sizeof(float),
               "the fp32 d(bias) tile is folded in the operand area");
 // fragment of tile t (row = slot 16 t + l16, channels 8 lq ..) -> transposed LDS copy [channel][slot]
 __device__ __forceinline__ void sw_scatter_frag(uint16_t (*dst)[SW_PP], bf16x8_t f, int slot, int lq) {
@@ -631,28 +633,34 @@ __device__ __forceinline__ void sw_scatter_frag(uint16_t (*dst)[SW_PP], bf16x8_t
         dst[8 * lq + 2 * e2 + 1][slot] = (uint16_t)(w[e2] >> 16);
     }
 }
-// out rows (slot 16 t + 4 lq + r) x 32 channels = A (the LDS tile, rows = slots) . B (a transposed operand), written to
-// segment `seg` of dqkv
+// out[slot][32 channels] = A (the LDS tile, rows = slots) . B (a transposed operand), written to segment `seg` of dqkv.
+// The product is computed TRANSPOSED (operands swapped) with the channel rows of B taken in the order 8 q + r (first MFMA)
+// and 8 q + 4 + r (second): the accumulator row 4 lq + r of a lane then is channel 8 lq + r (+ 4), its column l16 the slot --
+// a lane owns EIGHT consecutive channels of one token and stores them as one 16-byte vector, four lanes cover the head's whole
+// 64-byte run of the row.  (Rounds 1-2 stored two bytes per lane and instruction, 32 instructions per product: 96 scattered
+// 2-byte store instructions per window against 12 now.)
 __device__ __forceinline__ void sw_bwd_product(const SwinMfmaBwdLds& S, const uint16_t (*Bm)[SW_PP], bf16* __restrict__ dqkv,
                                                size_t img_row0, const SwinAttnGeom& g, int h, int seg, float mul, int Tn, int l16,
                                                int lq) {
+    const int brow = 8 * (l16 >> 2) + (l16 & 3);  // channel of operand row l16 (first MFMA; + 4: second)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+        f32x4_t o0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, o1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Tl[16 * t + l16][32 * ks + 8 * lq]);
-                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[16 * nt + l16][32 * ks + 8 * lq]);
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, o, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int slot = 16 * t + 4 * lq + r;
-                if (slot < Tn) dqkv[(img_row0 + S.tok[slot]) * 3 * g.ld + seg * g.ld + h * SW_HD + 16 * nt + l16].v = f2bf(o[r] * mul);
-            }
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Tl[16 * t + l16][32 * ks + 8 * lq]);
+            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[brow][32 * ks + 8 * lq]);
+            const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[brow + 4][32 * ks + 8 * lq]);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a, o1, 0, 0, 0);
         }
+        const int slot = 16 * t + l16;
+        if (slot < Tn) {
+            const uint4 v = make_uint4(pack2bf(o0[0] * mul, o0[1] * mul), pack2bf(o0[2] * mul, o0[3] * mul),
+                                       pack2bf(o1[0] * mul, o1[1] * mul), pack2bf(o1[2] * mul, o1[3] * mul));
+            *(uint4*)(dqkv + (img_row0 + S.tok[slot]) * 3 * g.ld + seg * g.ld + h * SW_HD + 8 * lq) = v;
+        }
+    }
 }
 __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                                    const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
@@ -682,9 +690,9 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
             S.reg[lane] = (uint8_t)reg;
         }
         uint2 pkp[4][4], pkd[4][4];  // P and dS of tile (it, jt), rows 4 lq .. 4 lq + 3 of column 16 jt + l16, as bf16
+        // fragments straight from the rows (the token of slot 16 t + l16 is computed here: no LDS round trip before
+        // the loads); the transposed copies the second set of products needs are scattered from the same registers later
         {
-            // fragments straight from the rows (the token of slot 16 t + l16 is computed here: no LDS round trip before
-            // the loads); the transposed copies the second set of products needs are scattered from the same registers
             bf16x8_t qf[4], kf[4], of[4], vf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -699,12 +707,6 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                 } else {
                     qf[t] = kf[t] = vf[t] = of[t] = sw_zero_frag();
                 }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                sw_scatter_frag(S.Qt, qf[t], 16 * t + l16, lq);
-                sw_scatter_frag(S.Kt, kf[t], 16 * t + l16, lq);
-                sw_scatter_frag(S.Ot, of[t], 16 * t + l16, lq);
             }
             __syncthreads();  // (slot bookkeeping visible)
             int rj[4], cj[4], gj[4];
@@ -785,24 +787,39 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                 S.Tl[i0 + 2][j] = (uint16_t)(pkd[it][jt].y & 0xffffu);
                 S.Tl[i0 + 3][j] = (uint16_t)(pkd[it][jt].y >> 16);
             }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
+            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
+            sw_scatter_frag(S.Bt, tk >= 0 ? sw_ld_frag(qkv + (img_row0 + tk) * 3 * g.ld + g.ld + h * SW_HD + 8 * lq) : sw_zero_frag(), 16 * t + l16, lq);
+        }
         __syncthreads();
-        sw_bwd_product(S, S.Kt, dqkv, img_row0, g, h, 0, scale, Tn, l16, lq);
+        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 0, scale, Tn, l16, lq);
         __syncthreads();
         // ---- dK = scale dS^T Q: the tile holds dS^T [j][i]: one 8-byte store per (it, jt)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkd[it][jt];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
+            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
+            sw_scatter_frag(S.Bt, tk >= 0 ? sw_ld_frag(qkv + (img_row0 + tk) * 3 * g.ld + 0 + h * SW_HD + 8 * lq) : sw_zero_frag(), 16 * t + l16, lq);
+        }
         __syncthreads();
-        sw_bwd_product(S, S.Qt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
+        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
         __syncthreads();
         // ---- dV = P^T dO
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkp[it][jt];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
+            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
+            sw_scatter_frag(S.Bt, tk >= 0 ? sw_ld_frag(dout + (img_row0 + tk) * g.ld + h * SW_HD + 8 * lq) : sw_zero_frag(), 16 * t + l16, lq);
+        }
         __syncthreads();
-        sw_bwd_product(S, S.Ot, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
+        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
         if (h == 0 && lane < Tn)  // padding columns of the three segments stay zero
             for (int sgm = 0; sgm < 3; ++sgm)
                 for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
