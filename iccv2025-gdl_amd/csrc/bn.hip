@@ -214,23 +214,62 @@ __device__ __forceinline__ void ld_chan(const float* __restrict__ p, int c0, flo
 
 // ---------------------------------------------------------------- forward apply
 // out = [relu]( y*scale+shift + residual ),  RES: 0 none, 1 raw tensor, 2 tensor*res_scale+res_shift
-template <typename T, int RES, bool RELU>
+// ACC: the BatchNorm constants are not finalized yet -- every block derives them from the integer accumulators of the
+// producing convolution(s) (bnacc.h) into LDS, one channel per thread, and block 0 publishes them for the backward
+constexpr int BN_ACC_MAXC = 512;
+template <typename T, int RES, bool RELU, bool ACC>
 __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const T* __restrict__ res,
                                                             const float* __restrict__ rscale,
                                                             const float* __restrict__ rshift, T* __restrict__ out,
                                                             uint8_t* __restrict__ bits, size_t nvec, int C,
-                                                            size_t stride_vec) {
+                                                            size_t stride_vec, BnAccFin fa, BnAccFin fr) {
     constexpr int EPC = TT<T>::EPC;
+    __shared__ __attribute__((aligned(16))) float csm[ACC ? 4 : 1][ACC ? BN_ACC_MAXC : 4];
     size_t i = blockIdx.x * (size_t)BN_THREADS + threadIdx.x;
-    if (i >= nvec) return;
+    // ACC: the first trip's vectors are requested BEFORE the constants are derived (accumulator loads, double-precision
+    // arithmetic, a barrier): the prologue then hides behind the memory latency it would otherwise add to
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u), p1 = p0, q0 = p0, q1 = p0;
+    const bool live = i < nvec, pair = live && i + stride_vec < nvec;
+    if (ACC) {
+        if (live) {
+            p0 = *(const uint4*)(y + i * EPC);
+            if (RES) q0 = *(const uint4*)(res + i * EPC);
+        }
+        if (pair) {
+            p1 = *(const uint4*)(y + (i + stride_vec) * EPC);
+            if (RES) q1 = *(const uint4*)(res + (i + stride_vec) * EPC);
+        }
+        for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+            bn_acc_channel(fa, c, blockIdx.x == 0, csm[0][c], csm[1][c]);
+            if (RES == 2) {
+                if (fr.acc) {
+                    bn_acc_channel(fr, c, blockIdx.x == 0, csm[2][c], csm[3][c]);
+                } else {
+                    csm[2][c] = rscale[c];
+                    csm[3][c] = rshift[c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!live) return;
     const int c0 = (int)((i * EPC) % C);  // stride_vec*EPC is a multiple of C: channels are loop invariant
     float sc[EPC], sf[EPC], rsc[EPC], rsf[EPC];
-    ld_chan<EPC>(scale, c0, sc);
-    ld_chan<EPC>(shift, c0, sf);
-    if (RES == 2) {
-        ld_chan<EPC>(rscale, c0, rsc);
-        ld_chan<EPC>(rshift, c0, rsf);
+    if (ACC) {
+        ld_chan<EPC>(csm[0], c0, sc);
+        ld_chan<EPC>(csm[1], c0, sf);
+        if (RES == 2) {
+            ld_chan<EPC>(csm[2], c0, rsc);
+            ld_chan<EPC>(csm[3], c0, rsf);
+        }
+    } else {
+        ld_chan<EPC>(scale, c0, sc);
+        ld_chan<EPC>(shift, c0, sf);
+        if (RES == 2) {
+            ld_chan<EPC>(rscale, c0, rsc);
+            ld_chan<EPC>(rshift, c0, rsf);
+        }
     }
     auto one = [&](size_t j, const uint4& yv, const uint4& rv) {
         float f[EPC], g[EPC];
@@ -252,6 +291,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_act_kernel(const T* __restrict_
             bits[j] = (uint8_t)mk;
         }
     };
+    if (ACC) {  // the trip requested above
+        one(i, p0, q0);
+        if (!pair) return;
+        one(i + stride_vec, p1, q1);
+        i += 2 * stride_vec;
+    }
     // two vectors per trip: both loads are in flight before either is consumed
     for (; i + stride_vec < nvec; i += 2 * stride_vec) {
         const size_t j = i + stride_vec;
@@ -302,9 +347,16 @@ static inline void ew_grid(size_t nvec, int cpr, int& blocks, size_t& stride_vec
 
 template <typename T>
 static int bn_act_t(const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-                    const float* rshift, int relu, void* out, uint8_t* bits, size_t M, int C, hipStream_t st) {
+                    const float* rshift, int relu, void* out, uint8_t* bits, size_t M, int C, hipStream_t st,
+                    const BnAccFin* fa, const BnAccFin* fr) {
     constexpr int EPC = TT<T>::EPC;
     GDL_REQUIRE(C % EPC == 0, "bn_act: C=%d not a multiple of %d", C, EPC);
+    const bool acc = fa && fa->acc;
+    GDL_REQUIRE(acc || !(fr && fr->acc), "bn_act: accumulators for the residual BatchNorm only");
+    GDL_REQUIRE(!acc || C <= BN_ACC_MAXC, "bn_act: C=%d above %d with accumulators", C, BN_ACC_MAXC);
+    const BnAccFin none{};
+    const BnAccFin& a0 = acc ? *fa : none;
+    const BnAccFin& a1 = (acc && fr) ? *fr : none;
     const size_t nvec = M * (size_t)C / EPC;
     int blocks;
     size_t stride;
@@ -314,9 +366,15 @@ static int bn_act_t(const void* y, const float* scale, const float* shift, const
     char* pn = pname[resmode * 2 + (relu ? 1 : 0)];
     if (!pn[0]) snprintf(pn, 96, "gdl::bn_act_kernel<%s, %d, %s>", prof_tname<T>(), resmode, relu ? "true" : "false");
     ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * (resmode ? 3 : 2));
-#define BN_ACT_LAUNCH(RM, RL)                                                                                        \
-    hipLaunchKernelGGL((bn_act_kernel<T, RM, RL>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale, shift, \
-                       (const T*)res, rscale, rshift, (T*)out, bits, nvec, C, stride)
+#define BN_ACT_LAUNCH(RM, RL)                                                                                                  \
+    do {                                                                                                                      \
+        if (acc)                                                                                                              \
+            hipLaunchKernelGGL((bn_act_kernel<T, RM, RL, true>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale,   \
+                               shift, (const T*)res, rscale, rshift, (T*)out, bits, nvec, C, stride, a0, a1);                \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((bn_act_kernel<T, RM, RL, false>), dim3(blocks), dim3(BN_THREADS), 0, st, (const T*)y, scale,  \
+                               shift, (const T*)res, rscale, rshift, (T*)out, bits, nvec, C, stride, a0, a1);                \
+    } while (0)
     if (resmode == 0 && relu) BN_ACT_LAUNCH(0, true);
     if (resmode == 0 && !relu) BN_ACT_LAUNCH(0, false);
     if (resmode == 1 && relu) BN_ACT_LAUNCH(1, true);
@@ -328,10 +386,11 @@ static int bn_act_t(const void* y, const float* scale, const float* shift, const
     return GDL_OK;
 }
 int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st, uint8_t* relu_bits) {
+           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st, uint8_t* relu_bits, const BnAccFin* fa,
+           const BnAccFin* fr) {
     GDL_REQUIRE(!relu_bits || relu, "bn_act: relu_bits without relu");
-    if (dtype == GDL_BF16) return bn_act_t<bf16>(y, scale, shift, res, rscale, rshift, relu, out, relu_bits, M, C, st);
-    return bn_act_t<float>(y, scale, shift, res, rscale, rshift, relu, out, relu_bits, M, C, st);
+    if (dtype == GDL_BF16) return bn_act_t<bf16>(y, scale, shift, res, rscale, rshift, relu, out, relu_bits, M, C, st, fa, fr);
+    return bn_act_t<float>(y, scale, shift, res, rscale, rshift, relu, out, relu_bits, M, C, st, fa, fr);
 }
 
 // ---------------------------------------------------------------- backward

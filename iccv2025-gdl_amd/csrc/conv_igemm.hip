@@ -24,6 +24,7 @@
 
 #include <type_traits>
 
+#include "bnacc.h"
 #include "common.h"
 #include "fold.h"
 #include "gather.h"
@@ -43,6 +44,7 @@ struct ConvArgs {
     void* gelu_out;            // optional, like out: out keeps the (biased) value u, gelu_out gets gelu(u) (Swin Mlp.fc1 + act)
     const uint8_t* relu_bits;  // optional: one byte per 16-byte vector of out; the stored value is zeroed where its bit is 0
     float* stats;              // optional [mtiles][OC][2]
+    BnAcc sacc;                // optional (forward): the same two sums added to 64-bit integer accumulators instead (bnacc.h)
     // optional (data gradient): BatchNorm-backward sums of the stored rows against one or two partner tensors (ops.h BwdStats)
     const void* bw_y;
     const float *bw_mean, *bw_rstd;
@@ -309,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             for (int e = 0; e < EPC; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
             v = pack16<T>(f);
         }
-        if (a.stats) {
+        if (a.stats || a.sacc.acc) {
             float f[EPC];
             unpack16<T>(v, f);
 #pragma unroll
@@ -371,11 +373,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             if constexpr (NT == 512)
                 s += ((red[(4 * BN + c) * 2 + w] + red[(5 * BN + c) * 2 + w]) + red[(6 * BN + c) * 2 + w]) +
                      red[(7 * BN + c) * 2 + w];
-            st_agent(dst + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
+            if (dst)
+                st_agent(dst + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
+            else
+                bn_acc_add(a.sacc.acc, n0 + c, w, s, a.sacc.s1, a.sacc.s2);
         }
     };
-    if (a.stats) {
-        tile_sums(ssum, ssq, a.stats);
+    if (a.stats || a.sacc.acc) {
+        tile_sums(ssum, ssq, a.sacc.acc ? nullptr : a.stats);
         if constexpr (NT == 256)  // (the fold's thread mapping is written for 256-thread blocks)
             if (a.fold.ctr) fold_finalize(a.stats, a.mtiles, a.OC, n0, BN, mtile, ntile, a.fold, smem, a.fin);
     }
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
         for (int p = 0; p < 8; ++p) {
             const int row = er0 + 8 * p;
             vq[p] = *(const uint4*)(Cs + row * PITCH + ec * 16);
-            if (a.stats && row >= skip) {
+            if ((a.stats || a.sacc.acc) && row >= skip) {
                 float f[8];
                 unpack16<bf16>(vq[p], f);
 #pragma unroll
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
         // this buffer is free (the row reads above have returned: their values are in the stores): the stage after next
         if (stg + 2 * wpx < s_end) load_slab(it & 1, stg + 2 * wpx);
     }
-    if (a.stats) {
+    if (a.stats || a.sacc.acc) {
         // lanes with equal (lane & 7) hold the same 8 channels: fold them, then the 4 waves in fixed order
 #pragma unroll
         for (int e = 0; e < 8; ++e)
@@ -834,9 +839,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
             const int c = tid >> 1, w = tid & 1;
             const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
                              red[(3 * 64 + c) * 2 + w];
-            st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
+            if (a.sacc.acc)
+                bn_acc_add(a.sacc.acc, c, w, s2, a.sacc.s1, a.sacc.s2);
+            else
+                st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
-        if (a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
+        if (a.stats && a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
     }
 }
 
@@ -1400,7 +1408,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                 for (int e = 0; e < 8; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
                 v = pack16<bf16>(f);
             }
-            if (MODE == MODE_FWD && a.stats && m0 + row < a.M) {
+            if (MODE == MODE_FWD && (a.stats || a.sacc.acc) && m0 + row < a.M) {
                 float f[8];
                 unpack16<bf16>(v, f);
 #pragma unroll
@@ -1449,7 +1457,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             const int m = m0 + er0 + p * 32;
             if (m < a.M) *(uint4*)(gout + (size_t)m * 64 + ec * 8) = vq[p];
         }
-        if (MODE == MODE_FWD && a.stats) {
+        if (MODE == MODE_FWD && (a.stats || a.sacc.acc)) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 tsum[e] += ssum[e];
@@ -1481,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             st_agent(a.bw_partial + (size_t)blockIdx.x * 128 + tid, ((ar[tid] + ar[128 + tid]) + ar[256 + tid]) + ar[384 + tid]);
         }
     }
-    if (MODE == MODE_FWD && a.stats) {
+    if (MODE == MODE_FWD && (a.stats || a.sacc.acc)) {
         float* const sdst = a.stats;
         float ssum[8], ssq[8];
 #pragma unroll
@@ -1509,11 +1517,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             const int c = tid >> 1, w = tid & 1;
             const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
                              red[(3 * 64 + c) * 2 + w];
-            st_agent(sdst + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
+            if (a.sacc.acc)
+                bn_acc_add(a.sacc.acc, c, w, s2, a.sacc.s1, a.sacc.s2);
+            else
+                st_agent(sdst + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
         // BatchNorm finalize inside the launch (fold.h): with ONE partial row per persistent block the ticket is paid once
         // per block life (~40 us), not once per tile -- what made the fold lose on the one-tile-per-block kernels
-        if (a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
+        if (a.stats && a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
     }
     GDL_STAMP(3);
 }
@@ -1889,7 +1900,8 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
                     const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
-                    const float* bias = nullptr, void* gelu_out = nullptr, const BwdStats* bw = nullptr) {
+                    const float* bias = nullptr, void* gelu_out = nullptr, const BwdStats* bw = nullptr,
+                    const BnAcc* sacc = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1910,6 +1922,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     a.gelu_out = gelu_out;
     a.relu_bits = relu_bits;
     a.stats = stats;
+    if (sacc && sacc->acc) {
+        GDL_REQUIRE(mode == GATHER_FWD && !stats, "conv: integer statistics accumulators are a forward option (without partial rows)");
+        a.sacc = *sacc;
+    }
     if (bw && bw->y) {
         GDL_REQUIRE(mode == GATHER_DGRAD && bw->mean && bw->rstd && bw->partial &&
                         (!bw->y2 || (bw->mean2 && bw->rstd2 && bw->partial2)),
@@ -1974,8 +1990,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
 }
 
 int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,
-             int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn) {
-    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st, fold, bn);
+             int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn,
+             const BnAcc* sacc) {
+    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st, fold, bn, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, sacc);
 }
 
 // ---- direct stem forward (layout.hip / gather.h): implicit GEMM over the padded NHWC4 input
@@ -2006,7 +2024,7 @@ int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
     return ceil_div(M, pick_cfg(M, 64, dtype).bm);
 }
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
-                  int W, int Cin, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn) {
+                  int W, int Cin, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn, const BnAcc* sacc) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "stem: bad dtype %d", dtype);
     GDL_REQUIRE(xp && wp && y && table, "stem: null pointer");
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
@@ -2019,6 +2037,10 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     a.wt = wp;
     a.out = y;
     a.stats = bn_partial;
+    if (sacc && sacc->acc) {
+        GDL_REQUIRE(!bn_partial, "stem: integer statistics accumulators exclude partial rows");
+        a.sacc = *sacc;
+    }
     a.table = (const GatherEntry*)table;
     a.M = n_img * P * Q;
     a.OC = 64;

@@ -34,6 +34,7 @@ struct BN {
     int pidx;  // gamma index (beta = pidx + 1)
     int bidx;  // 0..19
     float *scale = nullptr, *shift = nullptr, *mean = nullptr, *rstd = nullptr, *coef = nullptr;
+    long long* acc = nullptr;  // [c][2] fixed-point forward statistics (bnacc.h), a slice of gdl_encoder::acc_arena
 };
 struct Block {
     Conv c1, c2, cd;
@@ -98,6 +99,8 @@ struct gdl_encoder {
         if (side) (void)hipStreamDestroy(side);
     }
     float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr;
+    long long* acc_arena = nullptr;  // the 20 BatchNorms' integer accumulators, contiguous: one memset per forward
+    size_t acc_bytes = 0;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
     FoldWs fold{nullptr, nullptr};  // in-launch BatchNorm finalize (fold.h): counters + group rows, used on the caller's stream
@@ -142,7 +145,14 @@ size_t gdl_encoder::plan(unsigned char* base) {
     idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
     ymax = b.take((size_t)n_img * h1 * w1 * 64 * e);  // raw stem output at each pooling window's argmax
     pack_dev = b.take(32 * sizeof(PackDescHost));
+    size_t acc_ch = 64;
+    for (const Block& k : blocks) acc_ch += (size_t)k.cout * (k.has_ds ? 3 : 2);
+    acc_bytes = acc_ch * 2 * sizeof(long long);
+    acc_arena = (long long*)b.take(acc_bytes);
+    size_t acc_used = 0;
     auto bn_alloc = [&](BN& n) {
+        n.acc = acc_arena ? acc_arena + acc_used : nullptr;
+        acc_used += 2 * (size_t)n.c;
         n.scale = (float*)b.take(sizeof(float) * n.c);
         n.shift = (float*)b.take(sizeof(float) * n.c);
         n.mean = (float*)b.take(sizeof(float) * n.c);
@@ -418,7 +428,28 @@ int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e) { return e ? e->seria
         if (rc__) return rc__; \
     } while (0)
 
+// Timing experiments only (a -DGDL_EXPERIMENT build, never the product library): GDL_SKIP is a bit mask of launches left out
+// -- the results are then WRONG; what is measured is the bound on what removing / fusing that pass could return
+// (tools/README.md: "skip bounds").  bits: 1 bn_act of a1 (all layers), 2 the same for 64-channel layers only, 4 bn1's backward
+// apply, 8 bn2's / the downsample BatchNorm's backward apply, 16 forward finalize, 32 backward finalize, 64 the stem's
+// maxpool_bn_bwd_apply, 128 the stem's bn_relu_maxpool, 256 the weight pack
+#ifdef GDL_EXPERIMENT
+static unsigned skip_mask() {
+    static long v = -1;
+    if (v < 0) {
+        const char* env = getenv("GDL_SKIP");
+        v = env ? atol(env) : 0;
+    }
+    return (unsigned)v;
+}
+static long g_skip_serial = 0;  // (skips start after a dozen complete steps, so that every buffer a skipped pass would have written holds sane -- stale -- values)
+#define GDL_SKIPPED(bit) (g_skip_serial > 12 && (skip_mask() & (bit)) != 0)
+#else
+#define GDL_SKIPPED(bit) false
+#endif
+
 static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double count, hipStream_t st) {
+    if (GDL_SKIPPED(16)) return GDL_OK;
     const float* gamma = e->params[n.pidx];
     const float* beta = e->params[n.pidx + 1];
     if (training)
@@ -498,6 +529,28 @@ static bool separate_stats() {
     return sep != 0;
 }
 
+// Forward BatchNorm statistics through integer accumulators (bnacc.h): no finalize launches in the forward; default on
+// (GDL_BN_ACC=0: fp32 partial rows + finalize kernels).  Excluded by the in-launch fold variants and the separate pass.
+static bool bn_acc_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* env = tune_env("GDL_BN_ACC");
+        v = env ? atoi(env) : 1;
+    }
+    return v != 0;
+}
+static BnAcc acc_producer(const BN& n, size_t rows) {
+    BnAcc a{n.acc, 0.0, 0.0};
+    bn_acc_scales(rows, &a.s1, &a.s2);
+    return a;
+}
+static BnAccFin acc_consumer(gdl_encoder* e, BN& n, size_t rows) {
+    double s1, s2;
+    bn_acc_scales(rows, &s1, &s2);
+    return BnAccFin{n.acc, 1.0 / s1, 1.0 / s2, (double)rows, e->params[n.pidx], e->params[n.pidx + 1], e->rmean[n.bidx],
+                    e->rvar[n.bidx], e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift, 1e-5f, 0.1f};
+}
+
 static BnFinTrain fin_train_args(gdl_encoder* e, BN& n, const float* partial, int tiles, double count) {
     return BnFinTrain{partial, tiles, n.c, count, e->params[n.pidx], e->params[n.pidx + 1], e->rmean[n.bidx], e->rvar[n.bidx],
                       e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift};
@@ -532,6 +585,9 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     GDL_REQUIRE(e->params_set, "encoder_forward: parameters not set");
     hipStream_t st = (hipStream_t)stream;
     const int dt = e->dtype;
+#ifdef GDL_EXPERIMENT
+    g_skip_serial = (long)e->serial;
+#endif
     if (!training) e->have_train_fwd = false;  // an eval pass overwrites the saved activations
     // weights -> kernel layouts (float32 master copies stay with the caller)
     RC(pack_stem_rows(dt, e->params[0], e->w0p, e->cin, st));
@@ -573,10 +629,34 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         if (he != hipSuccess) return check_hip(he, "encoder_forward: descriptor upload");
         e->pack_dirty = false;
     }
-    RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
+    // The layer1..4 weights are first needed by layer1's conv1, behind the whole stem (pad, 7x7 convolution, finalize, pooling:
+    // ~260 us): an engine with a side stream (idle during the forward) packs there, beside the stem, and joins in front of
+    // the first block.  Tuning aid GDL_PACK_SIDE=1 -- OFF by default: the skip bound of the pack is 0.12 ms, the overlap returned 0.4 % (5.661 -> 5.640 ms, three A/B rounds, one of them worse): inside the noise.
+    static int pack_side = -1;
+    if (pack_side < 0) {
+        const char* env = tune_env("GDL_PACK_SIDE");
+        pack_side = env ? atoi(env) : 0;
+    }
+    const bool pack_fork = e->side && pack_side;
+    if (pack_fork) {
+        hipError_t he = hipEventRecord(e->ev_fork, st);
+        if (he == hipSuccess) he = hipStreamWaitEvent(e->side, e->ev_fork, 0);
+        if (he != hipSuccess) return check_hip(he, "encoder_forward: pack fork");
+    }
+    if (!GDL_SKIPPED(256))
+        RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, pack_fork ? e->side : st));
+    if (pack_fork) {
+        hipError_t he = hipEventRecord(e->ev_join, e->side);
+        if (he != hipSuccess) return check_hip(he, "encoder_forward: pack event");
+    }
+    const bool acc = training && bn_acc_on() && !fold_on() && !pers_fold_on() && !separate_stats();
     // stem: conv1 (7x7/2) as a direct implicit GEMM over the padded input, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
-    RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st));
-    {
+    // (the padding launch also clears the BatchNorm accumulators of this forward)
+    RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st, acc ? e->acc_arena : nullptr, acc ? e->acc_bytes : 0));
+    if (acc) {
+        const BnAcc pa = acc_producer(e->bn0, e->m0);
+        RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, nullptr, nullptr, &pa));
+    } else {
         const int tiles = conv_stem_tiles_m(dt, e->n_img, e->H, e->W);
         if (training && (fold_on() || (pers_fold_on() && conv_stem_persistent(dt, e->W))) && fold_fits(tiles, 64)) {
             const BnFinTrain fin = fin_train_args(e, e->bn0, e->bn_partial, tiles, (double)e->m0);
@@ -588,14 +668,42 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
             RC(bn_finalize(e, e->bn0, training, tiles, (double)e->m0, st));
         }
     }
-    RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, training ? e->ymax : nullptr, e->n_img,
-                           e->h0, e->w0, 64, st));
+    if (!GDL_SKIPPED(128)) {
+        const BnAccFin f0 = acc ? acc_consumer(e, e->bn0, e->m0) : BnAccFin{};
+        RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, training ? e->ymax : nullptr, e->n_img,
+                               e->h0, e->w0, 64, st, &f0));
+    }
+    if (pack_fork) {  // the packed weights are needed from here on
+        hipError_t he = hipStreamWaitEvent(st, e->ev_join, 0);
+        if (he != hipSuccess) return check_hip(he, "encoder_forward: pack join");
+    }
     // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
     for (Block& k : e->blocks) {
         const size_t Mo = (size_t)k.n * k.p * k.q;
+        if (acc) {  // convolutions add their tiles' sums to the accumulators; the applies derive the constants themselves
+            auto conv = [&](const Conv& c, const BN& n, const void* x, void* y) {
+                const BnAcc pa = acc_producer(n, Mo);
+                return conv_fwd(dt, x, c.w_krsc, y, nullptr, c.tab_fwd, k.n, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
+                                nullptr, nullptr, &pa);
+            };
+            RC(conv(k.c1, k.b1, k.xin, k.y1));
+            const BnAccFin f1 = acc_consumer(e, k.b1, Mo), f2 = acc_consumer(e, k.b2, Mo);
+            RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st,
+                      bw_fuse_on() ? k.abits : nullptr, &f1));
+            RC(conv(k.c2, k.b2, k.a1, k.y2));
+            if (k.has_ds) {
+                RC(conv(k.cd, k.bd, k.xin, k.yd));
+                const BnAccFin fd = acc_consumer(e, k.bd, Mo);
+                RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st, k.zbits, &f2, &fd));
+            } else {
+                RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.xin, nullptr, nullptr, 1, k.z, Mo, k.cout, st, k.zbits, &f2));
+            }
+            continue;
+        }
         RC(conv_bn(e, k.c1, k.b1, k.xin, k.y1, k.n, training, st));
-        RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st,
-                  (training && bw_fuse_on()) ? k.abits : nullptr));
+        if (!(GDL_SKIPPED(1) || (GDL_SKIPPED(2) && k.cout == 64)))
+            RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st,
+                      (training && bw_fuse_on()) ? k.abits : nullptr));
         if (k.has_ds && training && !separate_stats() && !fold_on()) {
             // bn2 and the downsample BatchNorm are independent: both convolutions first, ONE finalize launch for the two
             // (a finalize kernel costs the chain its whole ~6 us; 80 of them were 0.56 ms of the step)
@@ -608,7 +716,8 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
                         k.c2.r, k.c2.s, k.c2.stride, k.c2.pad, st));
             RC(conv_fwd(dt, k.xin, k.cd.w_krsc, k.yd, e->bn_partial2, k.cd.tab_fwd, k.n, k.cd.h, k.cd.w, k.cd.cin, k.cd.cout,
                         k.cd.r, k.cd.s, k.cd.stride, k.cd.pad, st));
-            RC(bn_finalize_train_pair(fin(k.c2, k.b2, e->bn_partial), fin(k.cd, k.bd, e->bn_partial2), 1e-5f, 0.1f, st));
+            if (!GDL_SKIPPED(16))
+                RC(bn_finalize_train_pair(fin(k.c2, k.b2, e->bn_partial), fin(k.cd, k.bd, e->bn_partial2), 1e-5f, 0.1f, st));
             RC(bn_act(dt, k.y2, k.b2.scale, k.b2.shift, k.yd, k.bd.scale, k.bd.shift, 1, k.z, Mo, k.cout, st,
                       training ? k.zbits : nullptr));
             continue;
@@ -729,7 +838,8 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                 const BnFinBwd g2{e->bwB, b2_rows, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef};
                 const BnFinBwd gd{e->bwB2, b2_rows, k.cout, (double)Mo, k.has_ds ? grads[k.bd.pidx] : nullptr,
                                   k.has_ds ? grads[k.bd.pidx + 1] : nullptr, k.has_ds ? k.bd.coef : nullptr};
-                if (k.has_ds)
+                if (GDL_SKIPPED(32)) {
+                } else if (k.has_ds)
                     RC(bn_bwd_finalize_pair(g2, gd, st));
                 else
                     RC(bn_bwd_finalize(g2.partial, g2.blocks, k.cout, (double)Mo, g2.dgamma, g2.dbeta, g2.coef, st));
@@ -744,7 +854,8 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                     RC(bn_bwd_finalize(e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1],
                                        k.b2.coef, st));
             }
-            if (k.has_ds)  // gB = dy2 and gD = dyd from one pass over do2
+            if (GDL_SKIPPED(8)) {
+            } else if (k.has_ds)  // gB = dy2 and gD = dyd from one pass over do2
                 RC(bn_bwd_apply2(dt, do2, k.y2, k.b2.mean, k.b2.rstd, e->params[k.b2.pidx], k.b2.coef, gB, k.yd, k.bd.mean,
                                  k.bd.rstd, e->params[k.bd.pidx], k.bd.coef, gD, Mo, k.cout, st));
             else
@@ -771,7 +882,9 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                           k.abits, &bwa));
             if (late) RC(wgrad2());
             const int rows = conv_dgrad_tiles_m(dt, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1);
-            RC(bn_bwd_finalize(e->bwA, rows, k.cout, (double)Mo, grads[k.b1.pidx], grads[k.b1.pidx + 1], k.b1.coef, st));
+            if (!GDL_SKIPPED(32))
+                RC(bn_bwd_finalize(e->bwA, rows, k.cout, (double)Mo, grads[k.b1.pidx], grads[k.b1.pidx + 1], k.b1.coef, st));
+            if (!GDL_SKIPPED(4))
             RC(bn_bwd_apply(dt, gC, k.y1, k.b1.scale, k.b1.shift, k.b1.mean, k.b1.rstd, e->params[k.b1.pidx], k.b1.coef, 0, gC, Mo,
                             k.cout, st));  // gC = dy1 (in place; the gradient is masked already)
         } else {
@@ -855,6 +968,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         BN& n = e->bn0;
         const size_t Mp = (size_t)e->n_img * e->h1 * e->w1;
         RC(bn_backward_reduce(e, n, dz, e->ymax, 1, Mp, (double)e->m0, grads, st));
+        if (!GDL_SKIPPED(64))
         RC(maxpool_bn_bwd_apply(dt, dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->g0,
                                 e->n_img, e->h0, e->w0, 64, st));
     }

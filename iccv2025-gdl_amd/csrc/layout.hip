@@ -61,7 +61,10 @@ int stem_ic(int dtype) { return dtype == GDL_BF16 ? 64 : 32; }   // elements per
 // x float32 [B][Cin][T][H][W] (image n = b*T + t, backbone.py:162-164) -> xp.  One thread = one pixel.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_pad_kernel(const float* __restrict__ x, T* __restrict__ xp, int Cin, int Tn, int H,
-                                                       int W, int Hp, int Wp, size_t total) {
+                                                       int W, int Hp, int Wp, size_t total, uint4* __restrict__ zero,
+                                                       size_t zero_vec) {
+    // (the encoder's BatchNorm accumulators, bnacc.h, are zeroed here -- the first launch of a forward -- instead of by a memset of their own)
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < zero_vec; i += (size_t)gridDim.x * 256) zero[i] = make_uint4(0u, 0u, 0u, 0u);
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int wp = (int)(i % Wp);
         size_t t = i / Wp;
@@ -79,17 +82,20 @@ __global__ __launch_bounds__(256) void stem_pad_kernel(const float* __restrict__
             *(float4*)(xp + i * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
-int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st) {
+int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st, void* zero,
+             size_t zero_bytes) {
     GDL_REQUIRE(Cin >= 1 && Cin <= 4, "stem_pad: Cin=%d", Cin);
+    GDL_REQUIRE(zero_bytes % 16 == 0 && ((uintptr_t)zero & 15) == 0, "stem_pad: zero region not 16-byte aligned");
+    const size_t zv = zero ? zero_bytes / 16 : 0;
     const int Hp = stem_pad_hp(H), Wp = stem_pad_wp(W);
     const size_t total = (size_t)B * T * Hp * Wp;
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     ProfScope prof(dtype == GDL_BF16 ? "gdl::stem_pad_kernel<gdl::bf16>" : "gdl::stem_pad_kernel<float>", PROF_HBM, st,
                    (double)B * Cin * T * H * W * 4.0 + (double)total * 4 * (dtype == GDL_BF16 ? 2 : 4));
     if (dtype == GDL_BF16)
-        hipLaunchKernelGGL(stem_pad_kernel<bf16>, dim3(grid), dim3(256), 0, st, x, (bf16*)xp, Cin, T, H, W, Hp, Wp, total);
+        hipLaunchKernelGGL(stem_pad_kernel<bf16>, dim3(grid), dim3(256), 0, st, x, (bf16*)xp, Cin, T, H, W, Hp, Wp, total, (uint4*)zero, zv);
     else
-        hipLaunchKernelGGL(stem_pad_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)xp, Cin, T, H, W, Hp, Wp, total);
+        hipLaunchKernelGGL(stem_pad_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)xp, Cin, T, H, W, Hp, Wp, total, (uint4*)zero, zv);
     GDL_CHECK_LAUNCH("stem_pad_kernel");
     return GDL_OK;
 }

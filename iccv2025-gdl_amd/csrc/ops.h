@@ -1,6 +1,7 @@
 // ops.h -- internal (C++) launch interface of the kernels; the C ABI in api.cpp and the encoder
 // engine in encoder.cpp are thin layers over these.
 #pragma once
+#include "bnacc.h"
 #include "common.h"
 #include "fold.h"
 #include "gather.h"
@@ -48,7 +49,7 @@ int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int
 // (fold != nullptr: the BatchNorm finalize of `bn` runs inside the launch, fold.h; bn->partial / tiles are ignored)
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
              int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold = nullptr,
-             const BnFinTrain* bn = nullptr);
+             const BnFinTrain* bn = nullptr, const BnAcc* sacc = nullptr);
 int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend, void* gelu_out,
                   const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
@@ -65,13 +66,16 @@ int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_
 size_t stem_pad_bytes(int dtype, int n_img, int H, int W);
 int stem_taps(int dtype);
 int stem_ic(int dtype);
-int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st);
+// zero / zero_bytes (optional, 16-byte granular): a region the same launch clears (the encoder's BatchNorm accumulators)
+int stem_pad(int dtype, const float* x, void* xp, int B, int Cin, int T, int H, int W, hipStream_t st, void* zero = nullptr,
+             size_t zero_bytes = 0);
 int pack_stem_rows(int dtype, const float* w, void* wp, int cin, hipStream_t st);
 int conv_stem_tiles_m(int dtype, int n_img, int H, int W);
 bool conv_fwd_persistent(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 bool conv_stem_persistent(int dtype, int W);
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
-                  int W, int Cin, hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr);
+                  int W, int Cin, hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
+                  const BnAcc* sacc = nullptr);
 size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W);
 int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
                     void* ws, size_t ws_bytes, hipStream_t st);
@@ -104,8 +108,12 @@ int bn_finalize_train(const float* partial, int tiles, int C, double count, cons
 int bn_finalize_eval(int C, const float* gamma, const float* beta, float eps, const float* rm, const float* rv,
                      float* scale, float* shift, hipStream_t st);
 // relu_bits (optional, with relu): one byte per 16-byte vector of `out`, bit e = (out element e > 0)
+// fa / fr (optional): the BatchNorm of y / of the residual branch has no finalized constants yet -- they are derived from the
+// integer accumulators in the kernel's prologue and published by its first block (bnacc.h); scale / shift (rscale / rshift)
+// are then ignored
 int bn_act(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rscale,
-           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st, uint8_t* relu_bits = nullptr);
+           const float* rshift, int relu, void* out, size_t M, int C, hipStream_t st, uint8_t* relu_bits = nullptr,
+           const BnAccFin* fa = nullptr, const BnAccFin* fr = nullptr);
 int bn_bwd_blocks(size_t M, int C);
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
@@ -126,7 +134,7 @@ int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, co
 int relu_bwd(int dtype, const void* dy, const void* out, void* dx, size_t n, hipStream_t st);
 // pool.hip
 int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ymax,
-                        int N, int H, int W, int C, hipStream_t st);
+                        int N, int H, int W, int C, hipStream_t st, const BnAccFin* fa = nullptr);
 int maxpool_bn_bwd_apply(int dtype, const void* dout, const uint8_t* idx, const void* y0, const float* scale, const float* shift,
                          const float* mean, const float* rstd, const float* gamma, const float* coef, void* dy, int N, int H,
                          int W, int C, hipStream_t st);

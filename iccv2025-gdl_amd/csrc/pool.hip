@@ -3,6 +3,7 @@
 // nn.MaxPool2d(kernel_size=3, stride=2, padding=1): /root/reference/models/backbone.py:106,
 // applied to relu(bn1(conv1(x))) (:166-173).  F.adaptive_avg_pool2d(a,1) /
 // F.adaptive_avg_pool3d(v,1): /root/reference/models/basic_model.py:73-82.
+#include "bnacc.h"
 #include "common.h"
 #include "prof.h"
 
@@ -14,13 +15,23 @@ namespace gdl {
 // YMAX: also store the RAW (pre-BatchNorm) value at the chosen position, ymax[n,p,q,c] = y[argmax]: with it the stem's
 // BatchNorm-backward reduction runs over pooled-size tensors (sum_pos g0*xhat = sum_windows dout*xhat(ymax), see
 // maxpool_bn_bwd_apply_kernel) instead of over the stem output, the largest activation of the network.
-template <typename T, bool YMAX>
-__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, T* __restrict__ out,
+// ACC: scale / shift come from the stem convolution's integer accumulators (bnacc.h), derived per block into LDS; block 0
+// publishes them (and the saved / running statistics) for the backward.
+constexpr int POOL_ACC_MAXC = 256;
+template <typename T, bool YMAX, bool ACC>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale_g,
+                                                              const float* __restrict__ shift_g, T* __restrict__ out,
                                                               uint8_t* __restrict__ idx, T* __restrict__ ymax, int N, int H,
-                                                              int W, int C, int P, int Q) {
+                                                              int W, int C, int P, int Q, BnAccFin fa) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
+    __shared__ __attribute__((aligned(16))) float csm[ACC ? 2 : 1][ACC ? POOL_ACC_MAXC : 4];
+    if (ACC) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) bn_acc_channel(fa, c, blockIdx.x == 0, csm[0][c], csm[1][c]);
+        __syncthreads();
+    }
+    const float* const scale = ACC ? csm[0] : scale_g;  // (address space resolved at compile time: ACC is a template parameter)
+    const float* const shift = ACC ? csm[1] : shift_g;
     // a block walks whole output rows (n,p): one 32-bit division per row instead of three 64-bit ones per element
     const int rows = N * P, per_row = Q * cpr;
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -130,18 +141,27 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
     }
 }
 int bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* ymax,
-                        int N, int H, int W, int C, hipStream_t st) {
+                        int N, int H, int W, int C, hipStream_t st, const BnAccFin* fa) {
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     GDL_REQUIRE(C % epc == 0, "maxpool: C=%d", C);
+    const bool acc = fa && fa->acc;
+    GDL_REQUIRE(!acc || C <= POOL_ACC_MAXC, "maxpool: C=%d above %d with accumulators", C, POOL_ACC_MAXC);
+    const BnAccFin a0 = acc ? *fa : BnAccFin{};
     const size_t total = (size_t)N * P * Q * (C / epc);
     const int grid = N * P > 8192 ? 8192 : N * P;
     // read the stem output once, write pooled values + 1-byte indices
     ProfScope prof(dtype == GDL_BF16 ? "gdl::bn_relu_maxpool_kernel<gdl::bf16>" : "gdl::bn_relu_maxpool_kernel<float>", PROF_HBM, st,
                    (double)N * H * W * C * (16.0 / epc) + (double)total * ((ymax ? 32.0 : 16.0) + epc));
-#define GDL_POOL_LAUNCH(TT_, YM)                                                                                         \
-    hipLaunchKernelGGL((bn_relu_maxpool_kernel<TT_, YM>), dim3(grid), dim3(256), 0, st, (const TT_*)y, scale, shift, \
-                       (TT_*)out, idx, (TT_*)ymax, N, H, W, C, P, Q)
+#define GDL_POOL_LAUNCH(TT_, YM)                                                                                                 \
+    do {                                                                                                                         \
+        if (acc)                                                                                                                 \
+            hipLaunchKernelGGL((bn_relu_maxpool_kernel<TT_, YM, true>), dim3(grid), dim3(256), 0, st, (const TT_*)y, scale,      \
+                               shift, (TT_*)out, idx, (TT_*)ymax, N, H, W, C, P, Q, a0);                                         \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((bn_relu_maxpool_kernel<TT_, YM, false>), dim3(grid), dim3(256), 0, st, (const TT_*)y, scale,     \
+                               shift, (TT_*)out, idx, (TT_*)ymax, N, H, W, C, P, Q, a0);                                         \
+    } while (0)
     if (dtype == GDL_BF16) {
         if (ymax)
             GDL_POOL_LAUNCH(bf16, true);
