@@ -86,6 +86,16 @@ int gdl_conv_dgrad_bn(int dtype, const void* dy, const void* w_crsk, void* dx, c
     const BwdStats bw{y, mean, rstd, partial, y2, mean2, rstd2, partial2};
     return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits, &bw);
 }
+int gdl_conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, void* acc, double scale,
+                        const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && w_crsk && dx && u && acc && table && scale > 0.0, "conv_dgrad_gelu: bad arguments");
+    const BnAcc a{(long long*)acc, scale, 0.0};
+    return conv_dgrad_gelu(dtype, dy, w_crsk, dx, u, &a, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream);
+}
+int gdl_acc_to_float(const void* acc, int n, double inv_scale, float* out, void* stream) {
+    GDL_REQUIRE(acc && out && n > 0, "acc_to_float: bad arguments");
+    return acc_to_float((const long long*)acc, n, inv_scale, out, (hipStream_t)stream);
+}
 static FoldWs fold_ws_of(void* ws) {
     return FoldWs{(unsigned*)ws, (double*)((unsigned char*)ws + align_up(fold_ctr_bytes(), 256))};
 }
@@ -386,6 +396,11 @@ int gdl_swin_ln_bwd(int dtype, const void* dy, const void* x, const float* stats
                     float* dgamma_dbeta, void* partial, size_t M, int C, int ld, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx && dgamma_dbeta, "swin_ln_bwd: bad arguments");
     return swin_ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma_dbeta, (float*)partial, M, C, ld, (hipStream_t)stream);
+}
+int gdl_swin_ln_bwd_colsum(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
+                           void* dx, float* dgamma_dbeta_colsum, void* partial, size_t M, int C, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx && dgamma_dbeta_colsum, "swin_ln_bwd_colsum: bad arguments");
+    return swin_ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma_dbeta_colsum, (float*)partial, M, C, ld, (hipStream_t)stream, true);
 }
 int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && g && db, "swin_colsum: bad arguments");

@@ -181,6 +181,16 @@ int bn_finalize_train_pair(const BnFinTrain& a, const BnFinTrain& b, float eps, 
     return launch_fin_train(a, b, 2, eps, momentum, st);
 }
 
+__global__ void acc_to_float_kernel(const long long* __restrict__ acc, int n, double inv_scale, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) out[c] = (float)((double)acc[2 * c] * inv_scale);
+}
+int acc_to_float(const long long* acc, int n, double inv_scale, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(acc_to_float_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, acc, n, inv_scale, out);
+    GDL_CHECK_LAUNCH("acc_to_float_kernel");
+    return GDL_OK;
+}
+
 __global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                         const float* __restrict__ rm, const float* __restrict__ rv, float* scale,
                                         float* shift) {

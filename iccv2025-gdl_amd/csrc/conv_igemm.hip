@@ -42,6 +42,7 @@ struct ConvArgs {
     const void* addend;        // optional, like out
     const float* bias;         // optional [OC] float32, added with the addend (nn.Linear bias of the Swin GEMMs)
     void* gelu_out;            // optional, like out: out keeps the (biased) value u, gelu_out gets gelu(u) (Swin Mlp.fc1 + act)
+    const void* gelu_u;        // optional (data gradient): the stored value is out * gelu'(gelu_u[row][c]) (backward of Mlp.act)
     const uint8_t* relu_bits;  // optional: one byte per 16-byte vector of out; the stored value is zeroed where its bit is 0
     float* stats;              // optional [mtiles][OC][2]
     BnAcc sacc;                // optional (forward): the same two sums added to 64-bit integer accumulators instead (bnacc.h)
@@ -229,11 +230,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     // through LDS; loaded inside the store loop they cost the slab data gradients +19 us per launch (59 -> 78 us alone)
     // (BWD: only the data-gradient instantiations carry this code and its registers)
     const bool bw = BWD && a.bw_y != nullptr, bw2 = bw && a.bw_y2 != nullptr;
+    const bool gl = BWD && a.gelu_u != nullptr;  // (excludes bw: the host checks) -- the GELU input rides in the partner registers
     uint4 byq[BWD ? NPASS : 1], by2q[BWD ? NPASS : 1];
     if constexpr (BWD) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             byq[p] = by2q[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (gl && om[p] >= 0) byq[p] = *(const uint4*)((const T*)a.gelu_u + (size_t)om[p] * a.OC + n0 + ec * EPC);
             if (bw && om[p] >= 0) {
                 const size_t goff = (size_t)om[p] * a.OC + n0 + ec * EPC;
                 byq[p] = *(const uint4*)((const T*)a.bw_y + goff);
@@ -310,6 +313,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
 #pragma unroll
             for (int e = 0; e < EPC; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
             v = pack16<T>(f);
+        }
+        if constexpr (BWD) {
+            if (gl) {  // d gelu(u) / du times the gradient as a separate pass would have read it back (rounded to T once already)
+                float f[EPC], uu[EPC];
+                unpack16<T>(v, f);
+                unpack16<T>(byq[p], uu);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = f[e] * gelu_grad<T>(uu[e]);
+                v = pack16<T>(f);
+            }
         }
         if (a.stats || a.sacc.acc) {
             float f[EPC];
@@ -1901,7 +1914,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
                     const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
                     const float* bias = nullptr, void* gelu_out = nullptr, const BwdStats* bw = nullptr,
-                    const BnAcc* sacc = nullptr) {
+                    const BnAcc* sacc = nullptr, const void* gelu_u = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -1922,8 +1935,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     a.gelu_out = gelu_out;
     a.relu_bits = relu_bits;
     a.stats = stats;
+    a.gelu_u = gelu_u;
+    if (gelu_u) GDL_REQUIRE(mode == GATHER_DGRAD && !(bw && bw->y), "conv: the GELU derivative is a data-gradient option (without BatchNorm sums)");
     if (sacc && sacc->acc) {
-        GDL_REQUIRE(mode == GATHER_FWD && !stats, "conv: integer statistics accumulators are a forward option (without partial rows)");
+        GDL_REQUIRE((mode == GATHER_FWD || gelu_u) && !stats, "conv: integer accumulators belong to the forward statistics and to the GELU data gradient's column sums (without partial rows)");
         a.sacc = *sacc;
     }
     if (bw && bw->y) {
@@ -2111,6 +2126,18 @@ int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const vo
                const BwdStats* bw) {
     return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
                     nullptr, relu_bits, nullptr, nullptr, nullptr, nullptr, bw);
+}
+
+// dx = dgrad(dy) * gelu'(u), elementwise in the epilogue (u laid out like dx), and the column sums of dx as stored added to
+// the fixed-point accumulators acc (bnacc.h) -- Mlp.fc2's data gradient, the activation's backward and fc1's bias gradient
+// (/root/reference/models/swin_transformer.py:32-47) in one launch
+int conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, const BnAcc* acc, const void* table,
+                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
+    GDL_REQUIRE(u, "conv_dgrad_gelu: null pointer");
+    const ConvPlan pl = plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad);
+    GDL_REQUIRE(!pl.c64, "conv_dgrad_gelu: not available on the 64-channel persistent kernel");
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, acc, u);
 }
 
 // forward with the epilogue's bias / residual: y = conv(x, w) + bias (+ addend), each optional (the Swin Linears)

@@ -56,6 +56,11 @@ int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const f
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr,
                const BwdStats* bw = nullptr);
+// dx = dgrad(dy) * gelu'(u) with the column sums of dx (as stored) added to the fixed-point accumulators `acc` (bnacc.h)
+int conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, const BnAcc* acc, const void* table,
+                    int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
+// out[c] = acc[2c] * inv_scale
+int acc_to_float(const long long* acc, int n, double inv_scale, float* out, hipStream_t st);
 // the 3x3 stride-2 pad-1 data gradient of a downsample block's conv1 with the 1x1 stride-2 data gradient of its shortcut
 // convolution folded in: dx = dgrad(dy, w_crsk) + dgrad_1x1s2(dy_ds, w_ds_ck) (+ relu_bits), one launch, no addend pass
 int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_ds, const void* w_ds_ck, void* dx,
@@ -193,7 +198,7 @@ int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, vo
                 hipStream_t st);
 size_t swin_partial_bytes(int ld);
 int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
-                float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st);
+                float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st, bool colsum = false);
 int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st);
 int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_img, int H, int W, int ws, int shift, int nh, int ld,
                   hipStream_t st);

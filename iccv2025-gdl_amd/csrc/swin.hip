@@ -180,23 +180,27 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
 // dx = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial[blk][0][c] = sum dy*xhat,
 // partial[blk][1][c] = sum dy over the rows of the block: every lane sums its rows in ascending order, then the block's
 // 4 * (64 / lpr) row groups are folded through LDS in group order.
-template <typename T, int VPL, int U>
+// CS: a third partial row, partial[blk][2][c] = sum of dx AS STORED over the rows of the block -- the bias gradient of the
+// Linear whose output gradient dx is (x_out = x_mid + fc2(...) + b: d b = column sums of d x_out), instead of a pass of its own.
+template <typename T, int VPL, int U, bool CS>
 __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float2* __restrict__ stats, const float* __restrict__ gamma,
                                                           const T* __restrict__ add, T* __restrict__ dx,
                                                           float* __restrict__ partial, size_t M, int C, int ld, int lpr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ln_smem[];
-    float* red = (float*)ln_smem;  // [groups][2][ld]
+    float* red = (float*)ln_smem;  // [groups][NR][ld]
     constexpr int EPC = TT<T>::EPC;
+    constexpr int NR = CS ? 3 : 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & (lpr - 1), rpw = 64 / lpr;
     const int vpr = ld / EPC;
     const float invC = 1.f / (float)C;
-    float ag[VPL][EPC], ab[VPL][EPC], gm[VPL][EPC];
+    float ag[VPL][EPC], ab[VPL][EPC], gm[VPL][EPC], ac[CS ? VPL : 1][EPC];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c0 = (sub + lpr * i) * EPC;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
+            if (CS) ac[CS ? i : 0][e] = 0.f;
             ag[i][e] = ab[i][e] = 0.f;
             gm[i][e] = (sub + lpr * i < vpr && c0 + e < C) ? gamma[c0 + e] : 0.f;
         }
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
                     for (int e = 0; e < EPC; ++e) {
                         o[e] = c0 + e < C ? st[u].y * (d[u][i][e] - m1 - xv[u][i][e] * m2) : 0.f;
                         if (ar) o[e] += av[e];
+                        if (CS) ac[CS ? i : 0][e] += roundT<T>(o[e]);
                     }
                     outr[sub + lpr * i] = pack16<T>(o);
                 }
@@ -268,15 +273,16 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
             const int c0 = (sub + lpr * i) * EPC;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                red[((size_t)grp * 2 + 0) * ld + c0 + e] = ag[i][e];
-                red[((size_t)grp * 2 + 1) * ld + c0 + e] = ab[i][e];
+                red[((size_t)grp * NR + 0) * ld + c0 + e] = ag[i][e];
+                red[((size_t)grp * NR + 1) * ld + c0 + e] = ab[i][e];
+                if (CS) red[((size_t)grp * NR + 2) * ld + c0 + e] = ac[CS ? i : 0][e];
             }
         }
     __syncthreads();
-    float* outp = partial + (size_t)blockIdx.x * 2 * ld;
-    for (int c = threadIdx.x; c < 2 * ld; c += 256) {
+    float* outp = partial + (size_t)blockIdx.x * NR * ld;
+    for (int c = threadIdx.x; c < NR * ld; c += 256) {
         float sum = red[c];
-        for (int k = 1; k < ngrp; ++k) sum += red[(size_t)k * 2 * ld + c];
+        for (int k = 1; k < ngrp; ++k) sum += red[(size_t)k * NR * ld + c];
         outp[c] = sum;
     }
 }
@@ -1261,27 +1267,36 @@ static int partial_reduce(const float* partial, float* out, int nblk, int width,
     return GDL_OK;
 }
 
-// dgamma_dbeta: [2][ld] (padded layout)
+// dgamma_dbeta: [2][ld] (padded layout); colsum: [3][ld], row 2 = column sums of dx as stored
 int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
-                float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st) {
+                float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st, bool colsum) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld && partial, "swin_ln_bwd: width %d / %d", C, ld);
     const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr, vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
     const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
     const size_t gg = (M + (size_t)4 * rpw * uu - 1) / ((size_t)4 * rpw * uu);
     const int g = (int)(gg > (size_t)SW_PARTIAL_BLOCKS ? (size_t)SW_PARTIAL_BLOCKS : gg);
-    const size_t lds = (size_t)4 * rpw * 2 * ld * sizeof(float);
+    const int nr = colsum ? 3 : 2;
+    const size_t lds = (size_t)4 * rpw * nr * ld * sizeof(float);
+    GDL_REQUIRE(lds <= 64 * 1024, "swin_ln_bwd: width %d needs %zu bytes of LDS", ld, lds);
     {
         ProfScope prof("gdl::swin_ln_bwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (add ? 4 : 3));
-#define SW_LN_BWD(T, V, U_)                                                                                                         \
+#define SW_LN_BWD1(T, V, U_, CS_)                                                                                                   \
     do {                                                                                                                            \
         static bool attr = false;                                                                                                   \
         if (!attr) {                                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<T, V, U_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            hipError_t e = hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<T, V, U_, CS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
             if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_ln_bwd)");                                          \
             attr = true;                                                                                                            \
         }                                                                                                                           \
-        hipLaunchKernelGGL((swin_ln_bwd_kernel<T, V, U_>), dim3(g), dim3(256), lds, st, (const T*)dy, (const T*)x, (const float2*)stats, gamma, \
+        hipLaunchKernelGGL((swin_ln_bwd_kernel<T, V, U_, CS_>), dim3(g), dim3(256), lds, st, (const T*)dy, (const T*)x, (const float2*)stats, gamma, \
                            (const T*)add, (T*)dx, partial, M, C, ld, lpr);                                                          \
+    } while (0)
+#define SW_LN_BWD(T, V, U_)                \
+    do {                                   \
+        if (colsum)                        \
+            SW_LN_BWD1(T, V, U_, true);    \
+        else                               \
+            SW_LN_BWD1(T, V, U_, false);   \
     } while (0)
         if (dt == GDL_F32) {
             if (vpl == 1) SW_LN_BWD(float, 1, 4); else if (vpl == 2) SW_LN_BWD(float, 2, 2); else if (vpl == 3) SW_LN_BWD(float, 3, 1); else SW_LN_BWD(float, 6, 1);
@@ -1289,9 +1304,10 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
             if (vpl == 1) SW_LN_BWD(bf16, 1, 4); else if (vpl == 2) SW_LN_BWD(bf16, 2, 2); else SW_LN_BWD(bf16, 3, 1);
         }
 #undef SW_LN_BWD
+#undef SW_LN_BWD1
         GDL_CHECK_LAUNCH("swin_ln_bwd_kernel");
     }
-    return partial_reduce(partial, dgamma_dbeta, g, 2 * ld, st);
+    return partial_reduce(partial, dgamma_dbeta, g, nr * ld, st);
 }
 
 // db[ld] = column sums of g; gelu != 0: g <- g * gelu'(u) first

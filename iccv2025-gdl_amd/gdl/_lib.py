@@ -33,6 +33,8 @@ SIGNATURES = {
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
     "gdl_conv_dgrad_bn_tiles": ("i", "iiiiiiiiii"),
     "gdl_conv_dgrad_bn": ("i", "ipppppp" + "iiiiiiiii" + "pppppppp" + "p"),
+    "gdl_conv_dgrad_gelu": ("i", "ippppp" + "d" + "p" + "iiiiiiiii" + "p"),
+    "gdl_acc_to_float": ("i", "pidpp"),
     "gdl_comm_unique_id": ("i", "p"),
     "gdl_comm_init": ("i", "piip"),
     "gdl_comm_world": ("i", "p"),
@@ -45,6 +47,7 @@ SIGNATURES = {
     "gdl_swin_ln_fwd": ("i", "ippppp" + "zii" + "p"),
     "gdl_swin_partial_bytes": ("z", "i"),
     "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),
+    "gdl_swin_ln_bwd_colsum": ("i", "ipppppppp" + "zii" + "p"),
     "gdl_swin_colsum": ("i", "ipppp" + "zi" + "p"),
     "gdl_swin_attn_fwd": ("i", "ippp" + "iiiiiii" + "p"),
     "gdl_swin_attn_bwd_workspace_bytes": ("z", "iiiii"),

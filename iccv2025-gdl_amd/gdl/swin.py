@@ -79,6 +79,12 @@ class _Linear:
         L.call("gdl_conv_dgrad", e.dt, L.ptr(dy), L.ptr(self.wT), L.ptr(dx), None, L.ptr(e.table(L.GATHER_DGRAD, M, self.kp, self.np)),
                M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
 
+    # dx[M][kp] = (dy[M][np] . w) * gelu'(u), column sums of dx added to the fixed-point accumulators `acc` ([kp][2] int64)
+    def dgrad_gelu(self, dy, dx, u, acc, scale, M, st):
+        e = self.eng
+        L.call("gdl_conv_dgrad_gelu", e.dt, L.ptr(dy), L.ptr(self.wT), L.ptr(dx), L.ptr(u), L.ptr(acc), scale,
+               L.ptr(e.table(L.GATHER_DGRAD, M, self.kp, self.np)), M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
+
     # dw[np][kp] = dy^T . x
     def wgrad(self, dy, x, M, st):
         e = self.eng
@@ -93,7 +99,7 @@ class _Norm:
         dev = eng.device
         self.g = torch.zeros(self.ld, dtype=torch.float32, device=dev)
         self.b = torch.zeros(self.ld, dtype=torch.float32, device=dev)
-        self.dgb = torch.empty((2, self.ld), dtype=torch.float32, device=dev)
+        self.dgb = torch.empty((3, self.ld), dtype=torch.float32, device=dev)  # d gamma, d beta, (bwd(colsum=True)) column sums of dx
 
     def pack_descs(self, params):
         return [(params[src], dst, None, self.c, 1, self.c, self.ld, 1, 1, L.GDL_F32) for src, dst in ((self.w_idx, self.g), (self.b_idx, self.b))]
@@ -104,10 +110,11 @@ class _Norm:
     def fwd(self, x, y, stats, M, st):
         L.call("gdl_swin_ln_fwd", self.eng.dt, L.ptr(x), L.ptr(self.g), L.ptr(self.b), L.ptr(y), L.ptr(stats), M, self.c, self.ld, st)
 
-    def bwd(self, dy, x, stats, add, dx, M, st):
+    def bwd(self, dy, x, stats, add, dx, M, st, colsum=False):
+        """colsum: dgb[2] = column sums of dx -- the bias gradient of the Linear whose output gradient dx is"""
         e = self.eng
-        L.call("gdl_swin_ln_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(self.g), L.ptr(add) if add is not None else None,
-               L.ptr(dx), L.ptr(self.dgb), L.ptr(e.partial), M, self.c, self.ld, st)
+        L.call("gdl_swin_ln_bwd_colsum" if colsum else "gdl_swin_ln_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(self.g),
+               L.ptr(add) if add is not None else None, L.ptr(dx), L.ptr(self.dgb), L.ptr(e.partial), M, self.c, self.ld, st)
 
 
 class SwinEngine:
@@ -211,6 +218,43 @@ class SwinEngine:
         self.g_w = torch.empty(wide, dtype=td, device=dev)       # branch gradient at QKV / hidden width
         self.g_cat = torch.empty(max([s["M"] // 4 * 4 * s["C"] for s in self.stages[:-1]] + [1]), dtype=td, device=dev)
         self.g_cat2 = torch.empty_like(self.g_cat)
+        # fc1 bias gradients: fixed-point column-sum accumulators of the fused fc2 data gradient (gdl_conv_dgrad_gelu), one arena
+        # for all blocks (zeroed / converted once per backward phase); the float results ARE the Linears' db buffers (views)
+        self.fuse_gelu = not (os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_FUSE_GELU") == "0")
+        tot = 0
+        self.fc1_off = []
+        for s in self.stages:
+            for b in s["blocks"]:
+                b["fc1_off"] = tot
+                tot += b["fc1"].np
+            self.fc1_off.append(tot)  # end offset of the stage
+        self.fc1_acc = torch.zeros((tot, 2), dtype=torch.int64, device=dev)
+        self.fc1_db = torch.zeros(tot, dtype=torch.float32, device=dev)
+        if self.fuse_gelu:
+            for s in self.stages:
+                for b in s["blocks"]:
+                    b["fc1"].db = self.fc1_db[b["fc1_off"]:b["fc1_off"] + b["fc1"].np]
+        # Bias gradients of the Linears fed by the residual stream's gradient (fc2, proj, the patch embedding) = a third result
+        # row of the LayerNorm backward that produced that gradient; `cs_dx`: this block's fc2 gets it from the norm1 backward
+        # of the NEXT block (or the final norm's) -- not at a stage's last block below the last stage (patch merging in between)
+        self.fuse_ln = not (os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_FUSE_LN") == "0")
+        for si, s in enumerate(self.stages):
+            for j, b in enumerate(s["blocks"]):
+                b["cs_dx"] = None
+                if not self.fuse_ln:
+                    continue
+                b["proj"].db = b["norm2"].dgb[2]
+                if j + 1 < len(s["blocks"]):
+                    b["cs_dx"] = s["blocks"][j + 1]["norm1"]
+                    s["blocks"][j + 1]["cs_prev"] = True
+                elif si == len(self.stages) - 1:
+                    b["cs_dx"] = self.out_norm
+                if b["cs_dx"] is not None:
+                    b["fc2"].db = b["cs_dx"].dgb[2]
+        if self.fuse_ln:
+            self.pe.db = self.pe_norm.dgb[2]
+        # |mean over the rows| < 2^7 for every column of a hidden-width gradient; one scale for all stages (the widest M)
+        self.fc1_scale = 2.0 ** (62 - 7 - max(1, (M1 - 1).bit_length()))
         self._params = None
         self.have_fwd = False
 
@@ -427,13 +471,18 @@ class SwinEngine:
         if phase != 2:
             L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), self.B if pooled else N,
                    self.L_out * (self.T if pooled else 1), self.C_out, ld, st)
-            self.out_norm.bwd(ga, self.x_last, self.out_stats, None, gb, M, st)
+            self.out_norm.bwd(ga, self.x_last, self.out_stats, None, gb, M, st, colsum=self.fuse_ln)
         # dx: gradient of the current stage's output tokens.  (Every block hands dx back in the buffer it got it in, so after
         # the last stage it sits in g_b again: phase 2 picks it up there without any state from phase 1 -- both phases may
         # be HIP-graph replays.)
         dx, spare = gb, ga
         first_si = nst - 2 if phase == 2 else nst - 1
         last_si = nst - 1 if phase == 1 else 0
+        fuse = self.fuse_gelu
+        acc_lo = self.fc1_off[last_si - 1] if last_si > 0 else 0
+        acc_hi = self.fc1_off[first_si]
+        if fuse:
+            self.fc1_acc[acc_lo:acc_hi].zero_()
         for si in range(first_si, last_si - 1, -1):
             s = self.stages[si]
             M, ld, r = s["M"], s["ld"], s["r"]
@@ -453,15 +502,20 @@ class SwinEngine:
                 hid_ld = b["fc1"].np
                 gw = self._v(self.g_w, M, hid_ld)
                 # x_out = x_mid + fc2(gelu(fc1(norm2(x_mid)))) ; dx = d x_out
-                L.call("gdl_swin_colsum", dt, L.ptr(dx), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
+                if b["cs_dx"] is None:
+                    L.call("gdl_swin_colsum", dt, L.ptr(dx), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
                 b["fc2"].wgrad(dx, b["a"], M, st)
-                b["fc2"].dgrad(dx, gw, M, st)                                     # d a
-                L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
+                if fuse:  # d u = (dx . W2) * gelu'(u) and fc1's bias gradient in the GEMM's epilogue
+                    b["fc2"].dgrad_gelu(dx, gw, b["u"], self.fc1_acc[b["fc1_off"]:], self.fc1_scale, M, st)
+                else:
+                    b["fc2"].dgrad(dx, gw, M, st)                                 # d a
+                    L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
                 b["fc1"].wgrad(gw, b["m"], M, st)
                 b["fc1"].dgrad(gw, gtok, M, st)                                   # d m
-                b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st)   # spare = d x_mid
+                b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st, colsum=self.fuse_ln)   # spare = d x_mid
                 # x_mid = x_in + proj(attn(qkv(norm1(x_in))))
-                L.call("gdl_swin_colsum", dt, L.ptr(spare), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
+                if not self.fuse_ln:
+                    L.call("gdl_swin_colsum", dt, L.ptr(spare), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
                 b["proj"].wgrad(spare, b["attn"], M, st)
                 b["proj"].dgrad(spare, gtok, M, st)                               # d attention output
                 gq = self._v(self.g_w, M, 3 * ld)
@@ -470,14 +524,17 @@ class SwinEngine:
                 L.call("gdl_swin_colsum", dt, L.ptr(gq), None, L.ptr(b["qkv"].db), L.ptr(self.partial), M, 3 * ld, st)
                 b["qkv"].wgrad(gq, b["h"], M, st)
                 b["qkv"].dgrad(gq, gtok, M, st)                                   # d h
-                b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st)    # dx = d x_in
+                b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st, colsum=b.get("cs_prev", False))    # dx = d x_in
+        if fuse:
+            L.call("gdl_acc_to_float", L.ptr(self.fc1_acc[acc_lo:]), acc_hi - acc_lo, 1.0 / self.fc1_scale, L.ptr(self.fc1_db[acc_lo:]), st)
         if phase == 1:
             self._unpack_all(grads, st, "last")  # the last stage's and the final norm's gradients -> the parameters' shapes
             return
         # patch embedding: x0 = norm(conv(x) + b); no input gradient
         M0 = self.pe_rows.shape[0]
         g0 = self._v(spare.reshape(-1), M0, self.pe.np)
-        self.pe_norm.bwd(dx, self.pe_out, self.pe_stats, None, g0, M0, st)
-        L.call("gdl_swin_colsum", dt, L.ptr(g0), None, L.ptr(self.pe.db), L.ptr(self.partial), M0, self.pe.np, st)
+        self.pe_norm.bwd(dx, self.pe_out, self.pe_stats, None, g0, M0, st, colsum=self.fuse_ln)
+        if not self.fuse_ln:
+            L.call("gdl_swin_colsum", dt, L.ptr(g0), None, L.ptr(self.pe.db), L.ptr(self.partial), M0, self.pe.np, st)
         self.pe.wgrad(g0, self.pe_rows, M0, st)
         self._unpack_all(grads, st, "rest" if phase == 2 else None)  # padded float32 gradients -> the parameters' shapes, one launch

@@ -105,6 +105,17 @@ GDL_API int gdl_conv_dgrad_bn(int dtype, const void* dy, const void* w_crsk, voi
                               const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
                               int stride, int pad, const void* y, const float* mean, const float* rstd, float* partial,
                               const void* y2, const float* mean2, const float* rstd2, float* partial2, void* stream);
+/* Mlp backward in the data gradient's epilogue (round 3; /root/reference/models/swin_transformer.py:32-47, Mlp.forward
+ * fc1 -> act -> fc2 through autograd): gdl_conv_dgrad_gelu = gdl_conv_dgrad whose epilogue multiplies the stored value by
+ * gelu'(u[row][c]) (u laid out like dx: fc1's biased output, as gdl_conv_fwd_bias left it) and adds the column sums of dx AS
+ * STORED -- fc1's bias gradient -- to `acc`, int64 [C][2] fixed-point accumulators the caller zeroes: acc[2c] += round(sum *
+ * scale) per M-tile with device-scope integer atomics (associative: bit-identical from run to run; acc[2c + 1] is not used).  Choose scale = 2^(62 - h - ceil(log2(rows))) for |mean| < 2^h.
+ * gdl_acc_to_float: out[c] = acc[2c] * inv_scale.  Replaces gdl_swin_colsum(g, u): three passes over the widest tensor of a
+ * block. */
+GDL_API int gdl_conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, void* acc, double scale,
+                                const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                void* stream);
+GDL_API int gdl_acc_to_float(const void* acc, int n, double inv_scale, float* out, void* stream);
 /* In-launch BatchNorm finalize ("the last block folds"): the kernel that produces the per-block partial sums also
  * reduces them -- the block that completes them, found by an arrival ticket, folds them in a fixed order and runs
  * the finalize arithmetic -- so no separate finalize launch sits on the chain (backbone.py:45-48,104: conv -> bn).
@@ -451,6 +462,12 @@ GDL_API int gdl_swin_ln_fwd(int dtype, const void* x, const float* gamma, const 
 GDL_API size_t gdl_swin_partial_bytes(int ld);
 GDL_API int gdl_swin_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
                             void* dx, float* dgamma_dbeta, void* partial, size_t M, int C, int ld, void* stream);
+/* the same with a third result row: dgamma_dbeta_colsum [3][ld], row 2 = column sums of dx as stored -- the bias gradient of the
+ * Linear whose output gradient dx is (the residual stream's gradient feeds fc2 / proj / the patch embedding), instead of a
+ * gdl_swin_colsum pass over dx.  3 * ld <= the width `partial` was sized for. */
+GDL_API int gdl_swin_ln_bwd_colsum(int dtype, const void* dy, const void* x, const float* stats, const float* gamma,
+                                   const void* add, void* dx, float* dgamma_dbeta_colsum, void* partial, size_t M, int C, int ld,
+                                   void* stream);
 GDL_API int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream);
 GDL_API int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out, int n_img, int H, int W, int window,
                               int shift, int heads, int ld, void* stream);

@@ -78,6 +78,19 @@ def test_layernorm_fwd_bwd(dt, M, C, ld):
     sc = max(1.0, np.sqrt(M))
     np.testing.assert_allclose(_np(dgb)[0, :C], dgam, atol=3e-5 * sc * 10)
     np.testing.assert_allclose(_np(dgb)[1, :C], dbet, atol=3e-5 * sc * 10)
+    # the three-row form: same dx / d gamma / d beta bit for bit, row 2 = column sums of dx as stored
+    vpr, lpr = ld // (4 if dt == "f32" else 8), 16
+    while lpr < vpr and lpr < 64:
+        lpr *= 2
+    if 4 * (64 // lpr) * 3 * ld * 4 > 64 * 1024:
+        return  # (wider than the Swin residual stream ever is: the third LDS row does not fit, the library refuses)
+    dx3 = torch.full((M, ld), float("nan"), device=DEV, dtype=_td(dt))
+    dgb3 = torch.empty((3, ld), device=DEV)
+    part3 = torch.empty(L.load().gdl_swin_partial_bytes(2 * ld), dtype=torch.uint8, device=DEV)
+    L.call("gdl_swin_ln_bwd_colsum", dc, L.ptr(dyd), L.ptr(xd), L.ptr(stats), L.ptr(gd), L.ptr(addd), L.ptr(dx3), L.ptr(dgb3),
+           L.ptr(part3), M, C, ld, st)
+    assert torch.equal(dx3, dx) and torch.equal(dgb3[:2], dgb)
+    np.testing.assert_allclose(_np(dgb3)[2], _np(dx).sum(0), atol=3e-5 * sc * 10 * max(1.0, np.abs(want_dx).max()))
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -250,6 +263,49 @@ def test_linear_with_bias_and_residual(dt):
 
     yy = _np(y)
     assert np.abs(_np(ge) - 0.5 * yy * (1 + np.vectorize(math.erf)(yy / math.sqrt(2)))).max() < _tol(dt, 3e-6, 3e-2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,K,N", [(777, 384, 128), (5000, 768, 192), (300, 3072, 768)])
+def test_linear_dgrad_gelu_colsum(dt, M, K, N):
+    """gdl_conv_dgrad_gelu: dx = (dy . W) * gelu'(u) in the GEMM's epilogue, and the column sums of dx (fc1's bias gradient)
+    through the fixed-point accumulators + gdl_acc_to_float, against gdl_conv_dgrad followed by gdl_swin_colsum(g, u) (bit-identical
+    dx) and float64 (Mlp backward, swin_transformer.py:32-47: fc2 is [N <- K], hidden width K)."""
+    import math
+
+    from gpu_util import gather_table
+
+    dc = L.dtype_code(dt)
+    st = L.cur_stream()
+    dy, w = _q(rng.standard_normal((M, N)), dt), _q(rng.standard_normal((N, K)) * 0.1, dt)
+    u = _q(rng.standard_normal((M, K)) * 1.5, dt)
+    tab = gather_table(L.GATHER_DGRAD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    dyd, wT, ud = _dev(dy, dt), _dev(np.ascontiguousarray(w.T), dt), _dev(u, dt)  # w_crsk of a 1x1: [in = K][out = N]
+    dx = torch.full((M, K), float("nan"), device=DEV, dtype=_td(dt))
+    acc = torch.zeros((K, 2), dtype=torch.int64, device=DEV)
+    scale = 2.0 ** (62 - 7 - max(1, (M - 1).bit_length()))
+    L.call("gdl_conv_dgrad_gelu", dc, L.ptr(dyd), L.ptr(wT), L.ptr(dx), L.ptr(ud), L.ptr(acc), scale, L.ptr(tab), M, 1, 1, K, N, 1, 1,
+           1, 0, st)
+    db = torch.empty(K, device=DEV)
+    L.call("gdl_acc_to_float", L.ptr(acc), K, 1.0 / scale, L.ptr(db), st)
+    # the two-pass form
+    ref = torch.full((M, K), float("nan"), device=DEV, dtype=_td(dt))
+    L.call("gdl_conv_dgrad", dc, L.ptr(dyd), L.ptr(wT), L.ptr(ref), None, L.ptr(tab), M, 1, 1, K, N, 1, 1, 1, 0, st)
+    db2 = torch.empty(K, device=DEV)
+    part = torch.empty(L.load().gdl_swin_partial_bytes(K), dtype=torch.uint8, device=DEV)
+    L.call("gdl_swin_colsum", dc, L.ptr(ref), L.ptr(ud), L.ptr(db2), L.ptr(part), M, K, st)
+    assert torch.equal(dx, ref)
+    np.testing.assert_allclose(_np(db), _np(dx).sum(0), atol=2e-5 * np.sqrt(M))  # (exact up to 2^-35 per tile and the tiles' fp32 sums)
+    np.testing.assert_allclose(_np(db), _np(db2), atol=2e-4 * np.sqrt(M))
+    uu = u.astype(np.float64)
+    dgelu = 0.5 * (1 + np.vectorize(math.erf)(uu / math.sqrt(2))) + uu * np.exp(-0.5 * uu * uu) / math.sqrt(2 * math.pi)
+    want = (dy.astype(np.float64) @ w.astype(np.float64)) * dgelu
+    assert np.abs(_np(dx) - want).max() < _tol(dt, 3e-5, 6e-2) * max(1.0, np.abs(want).max())
+    # run to run: integer accumulation is order-independent
+    acc2 = torch.zeros_like(acc)
+    L.call("gdl_conv_dgrad_gelu", dc, L.ptr(dyd), L.ptr(wT), L.ptr(dx), L.ptr(ud), L.ptr(acc2), scale, L.ptr(tab), M, 1, 1, K, N, 1, 1,
+           1, 0, st)
+    assert torch.equal(acc[:, 0], acc2[:, 0])
 
 
 def test_head_concat_xy():
