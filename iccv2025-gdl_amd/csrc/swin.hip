@@ -103,8 +103,22 @@ __global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, c
 // 16 vectors: four rows per wave and one 16-byte load per lane instead of 2-byte loads.  stats[row] = (mean, rstd),
 // two-pass over the C real channels (padding columns hold zeros and are written as zeros).
 
+// all-reduce over the lpr (16, 32 or 64) lanes that share a row.  The 16 lanes of a DPP row through four rotate-and-add VALU
+// instructions (row_ror:8 / 4 / 2 / 1: the rotation butterfly gives every lane the same association tree, so the 16 results are
+// bit-identical) instead of four ds_bpermute round trips through the LDS crossbar -- a row's two dependent reductions were what
+// the LayerNorm kernels spent their time on (221 -> 144 us backward at stage 1 came from loads alone; the forward did not move until
+// this) -- then one or two cross-row exchanges.
+template <int CTRL>
+__device__ __forceinline__ float dpp_rot(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float group_sum(float v, int lpr) {
-    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += dpp_rot<0x128>(v);
+    v += dpp_rot<0x124>(v);
+    v += dpp_rot<0x122>(v);
+    v += dpp_rot<0x121>(v);
+    if (lpr > 16) v += __shfl_xor(v, 16, 64);
+    if (lpr > 32) v += __shfl_xor(v, 32, 64);
     return v;
 }
 // VPL: vectors per lane (compile-time bound of ceil(vectors per row / lpr)); U: row groups in flight per wave and
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
         }
     const size_t stride = (size_t)gridDim.x * 4 * rpw;
     for (size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr; base < M; base += stride * U) {
-        float v[U][VPL][EPC];
+        uint4 vq[U][VPL];  // (packed until a row group's turn: U x VPL x 4 registers in flight instead of U x VPL x EPC)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t row = base + u * stride;
@@ -138,19 +152,23 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
                 const uint4* xr = (const uint4*)(x + row * ld);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
-                    if (sub + lpr * i < vpr) unpack16<T>(xr[sub + lpr * i], v[u][i]);
+                    if (sub + lpr * i < vpr) vq[u][i] = xr[sub + lpr * i];
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t row = base + u * stride;
             if (row >= M) continue;  // (whole row groups drop out together: the shuffles below stay inside a group)
+            float v[1][VPL][EPC];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr) unpack16<T>(vq[u][i], v[0][i]);
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i)
                 if (sub + lpr * i < vpr)
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) s += v[u][i][e];  // padding columns are zero
+                    for (int e = 0; e < EPC; ++e) s += v[0][i][e];  // padding columns are zero
             const float mu = group_sum(s, lpr) * invC;
             float q = 0.f;
 #pragma unroll
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
                     const int c0 = (sub + lpr * i) * EPC;
 #pragma unroll
                     for (int e = 0; e < EPC; ++e)
-                        if (c0 + e < C) q += (v[u][i][e] - mu) * (v[u][i][e] - mu);
+                        if (c0 + e < C) q += (v[0][i][e] - mu) * (v[0][i][e] - mu);
                 }
             const float rstd = rsqrtf(group_sum(q, lpr) * invC + 1e-5f);
             if (sub == 0) stats[row] = make_float2(mu, rstd);
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
                     const int c0 = (sub + lpr * i) * EPC;
                     float o[EPC];
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[u][i][e] - mu) * rstd * gm[i][e] + bt[i][e] : 0.f;
+                    for (int e = 0; e < EPC; ++e) o[e] = c0 + e < C ? (v[0][i][e] - mu) * rstd * gm[i][e] + bt[i][e] : 0.f;
                     yr[sub + lpr * i] = pack16<T>(o);
                 }
         }
@@ -207,7 +225,10 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
     }
     const size_t stride = (size_t)gridDim.x * 4 * rpw;
     for (size_t base = ((size_t)blockIdx.x * 4 + wave) * rpw + lane / lpr; base < M; base += stride * U) {
-        float d[U][VPL][EPC], xv[U][VPL][EPC];
+        // every vector of the U row groups (dy, x and the addend) is requested before the first is used, and stays packed until
+        // its group's turn: 3 x U x VPL x 4 registers in flight (the unpacked form held 2 x U x VPL x EPC and fetched the
+        // addend behind the reductions)
+        uint4 dq[U][VPL], xq[U][VPL], aq[U][VPL];
         float2 st[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -218,15 +239,24 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
                     if (sub + lpr * i < vpr) {
-                        unpack16<T>(dr[sub + lpr * i], d[u][i]);
-                        unpack16<T>(xr[sub + lpr * i], xv[u][i]);
+                        dq[u][i] = dr[sub + lpr * i];
+                        xq[u][i] = xr[sub + lpr * i];
+                        if (add) aq[u][i] = ((const uint4*)(add + row * ld))[sub + lpr * i];
                     }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            __builtin_amdgcn_sched_barrier(0);  // one row group at a time: interleaved, the groups' unpacked values pile up in registers
             const size_t row = base + u * stride;
             if (row >= M) continue;
+            float d[1][VPL][EPC], xv[1][VPL][EPC];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (sub + lpr * i < vpr) {
+                    unpack16<T>(dq[u][i], d[0][i]);
+                    unpack16<T>(xq[u][i], xv[0][i]);
+                }
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; ++i)
@@ -235,11 +265,11 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         const bool real = c0 + e < C;
-                        const float dd = d[u][i][e];
-                        const float xh = real ? (xv[u][i][e] - st[u].x) * st[u].y : 0.f;
+                        const float dd = d[0][i][e];
+                        const float xh = real ? (xv[0][i][e] - st[u].x) * st[u].y : 0.f;
                         const float g = dd * gm[i][e];
-                        xv[u][i][e] = xh;  // (reuse: xhat)
-                        d[u][i][e] = g;    // (reuse: g)
+                        xv[0][i][e] = xh;  // (reuse: xhat)
+                        d[0][i][e] = g;    // (reuse: g)
                         s1 += g;
                         s2 += g * xh;
                         ag[i][e] += dd * xh;
@@ -248,17 +278,16 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
                 }
             const float m1 = group_sum(s1, lpr) * invC, m2 = group_sum(s2, lpr) * invC;
             uint4* outr = (uint4*)(dx + row * ld);
-            const uint4* ar = add ? (const uint4*)(add + row * ld) : nullptr;
 #pragma unroll
             for (int i = 0; i < VPL; ++i)
                 if (sub + lpr * i < vpr) {
                     const int c0 = (sub + lpr * i) * EPC;
                     float o[EPC], av[EPC];
-                    if (ar) unpack16<T>(ar[sub + lpr * i], av);
+                    if (add) unpack16<T>(aq[u][i], av);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
-                        o[e] = c0 + e < C ? st[u].y * (d[u][i][e] - m1 - xv[u][i][e] * m2) : 0.f;
-                        if (ar) o[e] += av[e];
+                        o[e] = c0 + e < C ? st[u].y * (d[0][i][e] - m1 - xv[0][i][e] * m2) : 0.f;
+                        if (add) o[e] += av[e];
                         if (CS) ac[CS ? i : 0][e] += roundT<T>(o[e]);
                     }
                     outr[sub + lpr * i] = pack16<T>(o);
@@ -1243,23 +1272,46 @@ int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, vo
                 hipStream_t st) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld, "swin_ln_fwd: width %d / %d", C, ld);
     const int lpr = ln_lpr(dt, ld), vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
-    const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
-    const int g = sw_grid(M, 4 * (64 / lpr) * uu, 256 * 32);
+    static int u2 = -1;
+    if (u2 < 0) {
+        const char* e = tune_env("GDL_SW_LN_U2");  // tuning aid: twice the row groups in flight per wave
+        u2 = e ? atoi(e) : 0;
+    }
+    const int uu = (vpl == 1 ? 4 : (vpl == 2 ? 2 : 1)) * (u2 && vpl <= 3 ? 2 : 1);
+    static int fcap = -1;
+    if (fcap < 0) {
+        const char* e = tune_env("GDL_SW_LN_CAP");  // tuning aid: block cap of the LayerNorm forward
+        fcap = e ? atoi(e) : 1024;  // (8192 -> 1024: 44 -> 37 us at stage 2, 65 -> 37 us at the second merge; tools/bench_swin_ln.py)
+    }
+    const int g = sw_grid(M, 4 * (64 / lpr) * uu, fcap);
     ProfScope prof("gdl::swin_ln_fwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 8 : 4));
 #define SW_LN_FWD(T, V, U_) \
     hipLaunchKernelGGL((swin_ln_fwd_kernel<T, V, U_>), dim3(g), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, (float2*)stats, M, C, ld, lpr)
     if (dt == GDL_F32) {
         if (vpl == 1) SW_LN_FWD(float, 1, 4); else if (vpl == 2) SW_LN_FWD(float, 2, 2); else if (vpl == 3) SW_LN_FWD(float, 3, 1); else SW_LN_FWD(float, 6, 1);
     } else {
-        if (vpl == 1) SW_LN_FWD(bf16, 1, 4); else if (vpl == 2) SW_LN_FWD(bf16, 2, 2); else SW_LN_FWD(bf16, 3, 1);
+        if (u2) {
+            if (vpl == 1) SW_LN_FWD(bf16, 1, 8); else if (vpl == 2) SW_LN_FWD(bf16, 2, 4); else SW_LN_FWD(bf16, 3, 2);
+        } else {
+            if (vpl == 1) SW_LN_FWD(bf16, 1, 4); else if (vpl == 2) SW_LN_FWD(bf16, 2, 2); else SW_LN_FWD(bf16, 3, 1);
+        }
     }
 #undef SW_LN_FWD
     GDL_CHECK_LAUNCH("swin_ln_fwd_kernel");
     return GDL_OK;
 }
 
-constexpr int SW_PARTIAL_BLOCKS = 512;  // blocks (= partial rows) of the LayerNorm backward and column-sum kernels
+constexpr int SW_PARTIAL_BLOCKS = 1024;  // most blocks (= partial rows) of the LayerNorm backward and column-sum kernels
 size_t swin_partial_bytes(int ld) { return (size_t)SW_PARTIAL_BLOCKS * 2 * ld * sizeof(float); }
+static int sw_pblocks() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_SW_PBLOCKS");  // tuning aid: blocks of the LayerNorm backward / column sums (<= 1024)
+        v = e ? atoi(e) : 512;
+        if (v < 1 || v > SW_PARTIAL_BLOCKS) v = 512;
+    }
+    return v;
+}
 
 static int partial_reduce(const float* partial, float* out, int nblk, int width, hipStream_t st) {
     hipLaunchKernelGGL(swin_partial_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, st, partial, out, nblk, width);
@@ -1274,7 +1326,10 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
     const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr, vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
     const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
     const size_t gg = (M + (size_t)4 * rpw * uu - 1) / ((size_t)4 * rpw * uu);
-    const int g = (int)(gg > (size_t)SW_PARTIAL_BLOCKS ? (size_t)SW_PARTIAL_BLOCKS : gg);
+    // three blocks per CU where there is work for them (the kernel holds ~140 registers: three waves per SIMD): 221 -> 175 us at
+    // stage 1; the small stages keep two (tools/bench_swin_ln.py)
+    const size_t cap = tune_env("GDL_SW_PBLOCKS") ? (size_t)sw_pblocks() : (M >= 30000 ? 768 : 512);
+    const int g = (int)(gg > cap ? cap : gg);
     const int nr = colsum ? 3 : 2;
     const size_t lds = (size_t)4 * rpw * nr * ld * sizeof(float);
     GDL_REQUIRE(lds <= 64 * 1024, "swin_ln_bwd: width %d needs %zu bytes of LDS", ld, lds);
@@ -1315,7 +1370,7 @@ int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_
     GDL_REQUIRE(ld % 64 == 0 && partial, "swin_colsum: bad arguments");
     const int vpr = ld / (dt == GDL_F32 ? 4 : 8), rpb = vpr <= 256 ? 256 / vpr : 1;
     const size_t passes = (M + rpb - 1) / rpb;
-    int nb = (int)(passes < (size_t)SW_PARTIAL_BLOCKS ? passes : (size_t)SW_PARTIAL_BLOCKS);
+    int nb = (int)(passes < (size_t)sw_pblocks() ? passes : (size_t)sw_pblocks());
     {
         ProfScope prof("gdl::swin_colsum_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (u ? 3 : 1));
         if (dt == GDL_F32) {

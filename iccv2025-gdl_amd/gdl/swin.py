@@ -221,6 +221,10 @@ class SwinEngine:
         # fc1 bias gradients: fixed-point column-sum accumulators of the fused fc2 data gradient (gdl_conv_dgrad_gelu), one arena
         # for all blocks (zeroed / converted once per backward phase); the float results ARE the Linears' db buffers (views)
         self.fuse_gelu = not (os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_FUSE_GELU") == "0")
+        # (tuning aid, OFF by default: measured 26.8 ms either way at 192 frames -- the Linears' three GEMMs are all HBM-bound, beside
+        # the weight gradients the data gradients slow down by what the weight gradients would have taken: 4.2 -> 6.4 ms)
+        self.side_wgrad = os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_SIDE_WGRAD") == "1"
+        self._side = None
         tot = 0
         self.fc1_off = []
         for s in self.stages:
@@ -255,6 +259,16 @@ class SwinEngine:
             self.pe.db = self.pe_norm.dgb[2]
         # |mean over the rows| < 2^7 for every column of a hidden-width gradient; one scale for all stages (the widest M)
         self.fc1_scale = 2.0 ** (62 - 7 - max(1, (M1 - 1).bit_length()))
+        # the weight gradients' split-K workspace at its final size (it is shared by launches on two streams: no regrowth later)
+        need = [self.pe_rows.shape[0], self.pe.kp, self.pe.np]
+        nb = self.lib.gdl_conv_wgrad_workspace_bytes(self.dt, *need[:1], 1, 1, *need[1:], 1, 1, 1, 0)
+        for s in self.stages:
+            for b in s["blocks"]:
+                for k in ("qkv", "proj", "fc1", "fc2"):
+                    nb = max(nb, self.lib.gdl_conv_wgrad_workspace_bytes(self.dt, s["M"], 1, 1, b[k].kp, b[k].np, 1, 1, 1, 0))
+            if "red" in s:
+                nb = max(nb, self.lib.gdl_conv_wgrad_workspace_bytes(self.dt, s["M"] // 4, 1, 1, s["red"].kp, s["red"].np, 1, 1, 1, 0))
+        self._wg = torch.empty(nb, dtype=torch.uint8, device=dev)
         self._params = None
         self.have_fwd = False
 
@@ -360,6 +374,11 @@ class SwinEngine:
         self.have_fwd = True
         self.serial += 1
         return out
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _run(self, key, body):
         """Run `body` (a fixed launch sequence over fixed buffers) -- eagerly the first two times and whenever the
@@ -479,6 +498,34 @@ class SwinEngine:
         first_si = nst - 2 if phase == 2 else nst - 1
         last_si = nst - 1 if phase == 1 else 0
         fuse = self.fuse_gelu
+        # Weight gradients on a side stream: nothing on the backward chain waits for them (they are only read when the gradients
+        # are unpacked), so the chain is the data gradients / attention / LayerNorm passes alone.  A weight gradient starts once
+        # its gradient operand exists (event from the chain) and the chain waits for it only in front of the launch that
+        # overwrites that operand's buffer: fc2's before norm1's backward rewrites dx, fc1's before the attention backward
+        # reuses g_w, proj's / qkv's before the NEXT block's norm2 backward / fc2 data gradient.  The side stream's launches are
+        # ordered among themselves (they share the split-K workspace).  Part of the captured graph like everything else.
+        cur = torch.cuda.current_stream(self.device)
+        side = self._side_stream() if self.side_wgrad else None
+        pend = {}
+
+        def wg(lin, dy, x, rows, tag):
+            if side is None:
+                return lin.wgrad(dy, x, rows, st)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                lin.wgrad(dy, x, rows, side.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(side)
+            pend[tag] = done
+
+        def need(tag=None):
+            for t in ([tag] if tag is not None else list(pend)):
+                done = pend.pop(t, None)
+                if done is not None:
+                    cur.wait_event(done)
+
         acc_lo = self.fc1_off[last_si - 1] if last_si > 0 else 0
         acc_hi = self.fc1_off[first_si]
         if fuse:
@@ -487,6 +534,7 @@ class SwinEngine:
             s = self.stages[si]
             M, ld, r = s["M"], s["ld"], s["r"]
             if "red" in s:  # dx is the gradient of the merged tokens [M/4][ld(2C)]
+                need()  # (the buffers change roles here: every pending weight gradient first)
                 M4, C4 = M // 4, 4 * s["C"]
                 gc, gc2 = self._v(self.g_cat, M4, C4), self._v(self.g_cat2, M4, C4)
                 s["red"].wgrad(dx, s["catn"], M4, st)
@@ -504,27 +552,32 @@ class SwinEngine:
                 # x_out = x_mid + fc2(gelu(fc1(norm2(x_mid)))) ; dx = d x_out
                 if b["cs_dx"] is None:
                     L.call("gdl_swin_colsum", dt, L.ptr(dx), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
-                b["fc2"].wgrad(dx, b["a"], M, st)
+                wg(b["fc2"], dx, b["a"], M, "fc2")
+                need("qkv")  # (the previous block's: it reads g_w)
                 if fuse:  # d u = (dx . W2) * gelu'(u) and fc1's bias gradient in the GEMM's epilogue
                     b["fc2"].dgrad_gelu(dx, gw, b["u"], self.fc1_acc[b["fc1_off"]:], self.fc1_scale, M, st)
                 else:
                     b["fc2"].dgrad(dx, gw, M, st)                                 # d a
                     L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
-                b["fc1"].wgrad(gw, b["m"], M, st)
+                wg(b["fc1"], gw, b["m"], M, "fc1")
                 b["fc1"].dgrad(gw, gtok, M, st)                                   # d m
+                need("proj")  # (the previous block's: it reads `spare`)
                 b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st, colsum=self.fuse_ln)   # spare = d x_mid
                 # x_mid = x_in + proj(attn(qkv(norm1(x_in))))
                 if not self.fuse_ln:
                     L.call("gdl_swin_colsum", dt, L.ptr(spare), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
-                b["proj"].wgrad(spare, b["attn"], M, st)
+                wg(b["proj"], spare, b["attn"], M, "proj")
                 b["proj"].dgrad(spare, gtok, M, st)                               # d attention output
                 gq = self._v(self.g_w, M, 3 * ld)
+                need("fc1")
                 L.call("gdl_swin_attn_bwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(gtok), L.ptr(gq),
                        L.ptr(grads[b["table_idx"]]), L.ptr(self.tpart), N, r, r, s["ws"], b["shift"], s["nh"], ld, st)
                 L.call("gdl_swin_colsum", dt, L.ptr(gq), None, L.ptr(b["qkv"].db), L.ptr(self.partial), M, 3 * ld, st)
-                b["qkv"].wgrad(gq, b["h"], M, st)
+                wg(b["qkv"], gq, b["h"], M, "qkv")
                 b["qkv"].dgrad(gq, gtok, M, st)                                   # d h
+                need("fc2")
                 b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st, colsum=b.get("cs_prev", False))    # dx = d x_in
+        need()
         if fuse:
             L.call("gdl_acc_to_float", L.ptr(self.fc1_acc[acc_lo:]), acc_hi - acc_lo, 1.0 / self.fc1_scale, L.ptr(self.fc1_db[acc_lo:]), st)
         if phase == 1:
