@@ -75,6 +75,9 @@ struct ConvArgs {
     // come from off0 + delta[tap], chunks 4..7 from off0 + delta_hi[tap]
     int split;
     int delta_hi[9];
+    // plain GEMM (1x1, stride 1, no padding: the Swin Linears): GEMM row m gathers source row m -- the flat kernel computes the
+    // offset instead of fetching table[m] (one dependent HBM round trip less at the head of a block whose K-loop is 2-6 steps)
+    int plain;
     // row-slab stem (conv_stem_rows_kernel): GEMM row g = stage*64 + i, stage = (image row R, segment sg): output pixel
     // R*seg_Q + ow0 + i with ow0 = min(64*sg, seg_Q - 64); rows i < 64*sg - ow0 repeat the previous stage: not stored
     int seg_Q, seg_nseg, seg_stages;
@@ -453,7 +456,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         GatherEntry e;
         e.off0 = 0;
         e.mask = 0;
-        if (m < a.M) e = a.table[m];
+        if (a.plain) {
+            if (m < a.M) e.off0 = m * a.IC * (int)sizeof(T), e.mask = 1u;
+        } else if (m < a.M) {
+            e = a.table[m];
+        }
         a_off[i] = e.off0 + (a.split ? (schunk & 3) : schunk) * 16;
         a_mask[i] = e.mask;
     }
@@ -537,6 +544,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int LPS = AROWS + BROWS;  // DMA instructions per stage per wave
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s) load_tile(s);
+    // a two-step K-loop (K = 128: the stage-1 Swin Linears) has both stages requested up front -- the ring has the room, and the
+    // second request would otherwise only go out once the first has landed: two HBM latencies in series per block
+    const bool pre2 = NST == 2 && nk == 2;
+    if (pre2) load_tile(1);
     int buf = 0, ldbuf = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 // the next stage's DMA is issued while the first half's fragment reads are in flight (issuing it
                 // blocks the wave for about as long as the reads take; see the slab kernel)
                 asm volatile("" ::: "memory");
-                if (NST > 2 || kt + 1 < nk) load_tile(ldbuf);  // deeper rings need the constant DMA count per K-step
+                if (!pre2 && (NST > 2 || kt + 1 < nk)) load_tile(ldbuf);  // deeper rings need the constant DMA count per K-step
                 asm volatile("" ::: "memory");
             }
             lds_wait();
@@ -1950,6 +1961,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
         a.bw_y2 = bw->y2, a.bw_mean2 = bw->mean2, a.bw_rstd2 = bw->rstd2, a.bw_partial2 = bw->partial2;
     }
     a.table = (const GatherEntry*)table;
+    a.plain = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 1 : 0;
     a.M = g.rows;
     a.ntaps = g.ntaps;
     for (int t = 0; t < 9; ++t) a.delta[t] = g.delta[t];

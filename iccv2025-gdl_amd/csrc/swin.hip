@@ -1119,6 +1119,32 @@ __global__ __launch_bounds__(256) void swin_merge_kernel(const T* __restrict__ s
     }
 }
 
+// the same by 16-byte vectors (C a multiple of the vector's element count: every Swin width): a thread moves one vector of the
+// un-merged tensor, row / column from 32-bit divisions of the pixel index -- the element-wise form ran at 1.45 TB/s
+template <typename T, int SCATTER>
+__global__ __launch_bounds__(256) void swin_merge_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W,
+                                                             int C, int ldx) {
+    constexpr int EPC = TT<T>::EPC;
+    const int H2 = H / 2, W2 = W / 2, vpr = ldx / EPC;
+    const size_t total = (size_t)N * H * W * vpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const unsigned pix = (unsigned)(i / vpr);
+        const int c0 = (int)(i - (size_t)pix * vpr) * EPC;
+        if (c0 >= C) {
+            if (SCATTER) ((uint4*)dst)[i] = make_uint4(0u, 0u, 0u, 0u);
+            continue;
+        }
+        const unsigned row = pix / (unsigned)W, w = pix - row * (unsigned)W;
+        const unsigned n = row / (unsigned)H, h = row - n * (unsigned)H;
+        const int q = (int)(h & 1u) + 2 * (int)(w & 1u);
+        const size_t m = (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * (4 * C) + q * C + c0;
+        if (SCATTER)
+            ((uint4*)dst)[i] = *(const uint4*)(src + m);
+        else
+            *(uint4*)(dst + m) = ((const uint4*)src)[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ token mean
 template <typename T>
 __global__ __launch_bounds__(256) void swin_token_mean_kernel(const T* __restrict__ x, float* __restrict__ y, int L, int C, int ld) {
@@ -1479,6 +1505,23 @@ int swin_merge(int dt, const void* src, void* dst, int N, int H, int W, int C, i
     GDL_REQUIRE(H % 2 == 0 && W % 2 == 0 && C <= ldx, "swin_merge: %dx%d tokens, %d / %d channels", H, W, C, ldx);
     const size_t total = (size_t)N * H * W * ldx;
     ProfScope prof("gdl::swin_merge_kernel", PROF_HBM, st, (double)total * (dt == GDL_F32 ? 8 : 4));
+    const int epc = dt == GDL_F32 ? 4 : 8;
+    if (C % epc == 0 && ldx % epc == 0 && (size_t)N * H * W < ((size_t)1 << 31)) {
+        const int g = sw_grid(total / epc, 256, 256 * 16);
+        if (dt == GDL_F32) {
+            if (scatter)
+                hipLaunchKernelGGL((swin_merge_vec_kernel<float, 1>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, ldx);
+            else
+                hipLaunchKernelGGL((swin_merge_vec_kernel<float, 0>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, ldx);
+        } else {
+            if (scatter)
+                hipLaunchKernelGGL((swin_merge_vec_kernel<bf16, 1>), dim3(g), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, N, H, W, C, ldx);
+            else
+                hipLaunchKernelGGL((swin_merge_vec_kernel<bf16, 0>), dim3(g), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, N, H, W, C, ldx);
+        }
+        GDL_CHECK_LAUNCH("swin_merge_vec_kernel");
+        return GDL_OK;
+    }
     if (dt == GDL_F32) {
         if (scatter)
             hipLaunchKernelGGL((swin_merge_kernel<float, 1>), dim3(sw_grid(total)), dim3(256), 0, st, (const float*)src, (float*)dst, N, H, W, C, ldx);
