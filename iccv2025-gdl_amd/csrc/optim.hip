@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
                                                   const float* __restrict__ stats, float grad_scale, float lr, float mu,
                                                   float wd, int64_t n) {
     const float k = (stats ? stats[1] : 1.f) * grad_scale;
+    const bool wb = k != 1.f;  // (clip inactive on one rank: g * 1 is g -- its 4 n bytes are not written back)
     const int64_t nv = n >> 2;
     for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         float4 pv = ((float4*)p)[i], gv = ((float4*)g)[i], mv = ((float4*)m)[i];
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
         pv.y -= lr * mv.y;
         pv.z -= lr * mv.z;
         pv.w -= lr * mv.w;
-        ((float4*)g)[i] = gv;
+        if (wb) ((float4*)g)[i] = gv;
         ((float4*)m)[i] = mv;
         ((float4*)p)[i] = pv;
     }
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
         for (int64_t i = (nv << 2) + threadIdx.x; i < n; i += 256) {
             const float gg = g[i] * k;
             const float mm = mu * m[i] + (gg + wd * p[i]);
-            g[i] = gg;
+            if (wb) g[i] = gg;
             m[i] = mm;
             p[i] -= lr * mm;
         }
