@@ -86,6 +86,26 @@ int gdl_conv_dgrad_bn(int dtype, const void* dy, const void* w_crsk, void* dx, c
     const BwdStats bw{y, mean, rstd, partial, y2, mean2, rstd2, partial2};
     return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits, &bw);
 }
+size_t gdl_conv_split_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad) {
+    return dt_ok(dtype) ? conv_split_ws_bytes(dtype, N, H, W, C, K, R, S, stride, pad, dgrad) : 0;
+}
+int gdl_conv_fwd_split(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
+                       int W, int C, int K, int R, int S, int stride, int pad, void* split_ws, size_t split_ws_bytes, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && x && w_krsc && y && table, "conv_fwd_split: null pointer");
+    const SplitWs sk{split_ws, split_ws_bytes};
+    return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, nullptr, nullptr,
+                    nullptr, &sk);
+}
+int gdl_conv_dgrad_bn_split(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const uint8_t* relu_bits,
+                            const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, const void* y,
+                            const float* mean, const float* rstd, float* partial, const void* y2, const float* mean2,
+                            const float* rstd2, float* partial2, void* split_ws, size_t split_ws_bytes, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype) && dy && w_crsk && dx && table, "conv_dgrad_bn_split: null pointer");
+    const BwdStats bw{y, mean, rstd, partial, y2, mean2, rstd2, partial2};
+    const SplitWs sk{split_ws, split_ws_bytes};
+    return conv_dgrad(dtype, dy, w_crsk, dx, addend, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, relu_bits,
+                      y ? &bw : nullptr, &sk);
+}
 int gdl_conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, void* acc, double scale,
                         const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && dy && w_crsk && dx && u && acc && table && scale > 0.0, "conv_dgrad_gelu: bad arguments");

@@ -78,6 +78,12 @@ struct ConvArgs {
     // plain GEMM (1x1, stride 1, no padding: the Swin Linears): GEMM row m gathers source row m -- the flat kernel computes the
     // offset instead of fetching table[m] (one dependent HBM round trip less at the head of a block whose K-loop is 2-6 steps)
     int plain;
+    // split-K of the slab kernel (round 3; the layers whose tile count leaves CUs idle -- layer 4 of both encoders, the audio
+    // layer 3): ksplit > 1 blocks share an output tile, block `split` multiplies channel chunks [split, split + 1) * kpt / ksplit
+    // and stores its fp32 accumulators to split_ws[split][M][OC]; splitk_finish_kernel folds them in fixed order and does what
+    // the epilogue would have done (rounding, addend, ReLU bits, statistics)
+    int ksplit;
+    float* split_ws;
     // row-slab stem (conv_stem_rows_kernel): GEMM row g = stage*64 + i, stage = (image row R, segment sg): output pixel
     // R*seg_Q + ow0 + i with ow0 = min(64*sg, seg_Q - 64); rows i < 64*sg - ow0 repeat the previous stage: not stored
     int seg_Q, seg_nseg, seg_stages;
@@ -925,10 +931,12 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
     const int ntn = a.OC / BN;
+    const int nsplit = a.ksplit > 1 ? a.ksplit : 1;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int mt_per_xcd = (a.mtiles + 7) >> 3;
-    const int mtile = xcd * mt_per_xcd + j / ntn;
-    const int ntile = j % ntn;
+    const int mtile = xcd * mt_per_xcd + j / (ntn * nsplit);
+    const int jr = j % (ntn * nsplit);
+    const int ntile = jr % ntn, split = jr / ntn;  // (the splits of a tile are neighbours on one XCD)
     if (mtile >= a.mtiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
     GDL_STAMP(0);
@@ -937,6 +945,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
 #endif
     const int esz = (int)sizeof(T);
     const int kpt = a.IC / BKE;  // channel chunks
+    const int kc0 = split * (kpt / nsplit), kc1 = kc0 + kpt / nsplit;  // this block's chunks
     const int nins = (a.slab_rows + 7) >> 3;
     const int slab_bytes = nins * 1024;
     const unsigned smem_base = lds_addr(smem);
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
     // zero row for masked (padding) taps: the rows of slab 0 past slab_rows (its last DMA piece is only partly
     // used; the out-of-range lanes deposit zeros) when there are any, else 1 KiB after the slabs
     const bool spare_row = (a.slab_rows & 7) != 0;
-    const int nslab = (kpt > 1 && !a.single_slab) ? 2 : 1;
+    const int nslab = (kc1 - kc0 > 1 && !a.single_slab) ? 2 : 1;
     const unsigned zrow = spare_row ? slab_base + a.slab_rows * 128 : slab_base + nslab * slab_bytes;
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
@@ -1000,8 +1009,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
         zb[m] = zrow + (fg << 4) - 2048u * m;
     }
 
-    load_slab(0, 0);
-    load_w(0, 0, 0);
+    load_slab(0, kc0);
+    load_w(0, kc0, 0);
     GDL_STAMP(1);
     // pixel shift of tap t without a scalar load per tap: +d1 inside a filter row, +d3 at a row change
     const int sh0 = a.pshift[0], d1 = a.pshift[1] - a.pshift[0], d3 = a.pshift[3] - a.pshift[2];
@@ -1015,8 +1024,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
 #else
 #define TSEG(accv)
 #endif
-    for (int kc = 0; kc < kpt; ++kc) {
-        const unsigned slab = slab_base + (nslab == 2 ? (kc & 1) * slab_bytes : 0);
+    for (int kc = kc0; kc < kc1; ++kc) {
+        const unsigned slab = slab_base + (nslab == 2 ? ((kc - kc0) & 1) * slab_bytes : 0);
         int sh = sh0, scol = 0;
         for (int tap = 0; tap < a.ntaps; ++tap) {
 #ifdef GDL_TIMING
@@ -1026,7 +1035,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (nslab == 1 && tap == 0 && kc > 0) {
+            if (nslab == 1 && tap == 0 && kc > kc0) {
                 // single slab buffer: every wave is past its last read of the previous chunk's slab (barrier above);
                 // fetch this chunk's slab now -- the wait is exposed once per chunk (9 K-steps), the other block of
                 // the CU works meanwhile, and the LDS it saves is what lets two 256-row blocks share a CU
@@ -1036,8 +1045,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
                 asm volatile("" ::: "memory");
             }
             TSEG(acc_wait)
-            if (kc == 0 && tap == 0) GDL_STAMP(2);
-            if (kc == 0 && tap == 1) GDL_STAMP(3);
+            if (kc == kc0 && tap == 0) GDL_STAMP(2);
+            if (kc == kc0 && tap == 1) GDL_STAMP(3);
             const unsigned Bs = smem_base + wbuf * WSTAGE;
             // Pixel fragment m sits 16 rows (2048 bytes) below fragment 0 and 16 rows do not change the
             // swizzle term, so ONE address is computed per tap; the per-fragment part is an instruction
@@ -1061,8 +1070,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
                     ntap = 0;
                     ++nkc;
                 }
-                if (nkc < kpt) load_w(wbuf ^ 1, nkc, ntap);
-                if (nslab == 2 && tap == 0 && kc + 1 < kpt) load_slab((kc + 1) & 1, kc + 1);
+                if (nkc < kc1) load_w(wbuf ^ 1, nkc, ntap);
+                if (nslab == 2 && tap == 0 && kc + 1 < kc1) load_slab((kc + 1 - kc0) & 1, kc + 1);
                 asm volatile("" ::: "memory");
             };
             if constexpr ((MI + NI) * 8 > 80) {
@@ -1124,6 +1133,22 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128
     }
     GDL_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsplit > 1) {
+        // split-K: the fp32 accumulators go out as they are (D[i][j]: channel (lane >> 4) * 4 + reg, pixel lane & 15 -- a lane's
+        // four values are 16 contiguous bytes of one row); splitk_finish_kernel does the rest
+        float* ws = a.split_ws + (size_t)split * a.M * a.OC;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+            const int row = m0 + wm * WTM + m * 16 + (lane & 15);
+            if (row < a.M) {
+#pragma unroll
+                for (int n = 0; n < NI; ++n)
+                    *(f32x4_t*)(ws + (size_t)row * a.OC + n0 + wn * WTN + n * 16 + (lane >> 4) * 4) = acc[n][m];
+            }
+        }
+        GDL_STAMP(5);
+        return;
+    }
     __syncthreads();
     conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD>(acc, smem, a, m0, n0, mtile, ntile);
     GDL_STAMP(5);
@@ -1637,7 +1662,7 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
         attr_set = true;
     }
     if (NWV != 4) GDL_REQUIRE(!a.fold.ctr, "conv: the in-launch BatchNorm finalize needs a 256-thread tile configuration");
-    const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / BN);
+    const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / BN) * (a.ksplit > 1 ? a.ksplit : 1);
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, MODE, NWV);
@@ -1920,12 +1945,162 @@ static FinTrain make_fin(const BnFinTrain& b, float eps, float momentum) {
                     eps, momentum};
 }
 
+// ---------------------------------------------------------------- split-K finish
+// One block per M-tile of the producing launch (so the per-tile statistics rows keep their count): out[row][c] = what
+// conv_epilogue would have stored from the sum of the `nsplit` fp32 partial tensors, folded in split order (deterministic):
+// rounded to T, + addend (rounded again, as the epilogue does), ReLU bits, then either the forward statistics (partial row or
+// integer accumulators) or the BatchNorm-backward sums against one or two partner tensors.  A thread owns one 16-byte channel
+// vector and every (256 / vectors-per-row)-th row of the tile; the row groups are folded through LDS in index order.
+struct SplitFinArgs {
+    const float* ws;
+    int nsplit, M, OC, BM;
+    void* out;
+    const void* addend;
+    const uint8_t* relu_bits;
+    float* stats;
+    BnAcc sacc;
+    const void* bw_y;
+    const float *bw_mean, *bw_rstd;
+    float* bw_partial;
+    const void* bw_y2;
+    const float *bw_mean2, *bw_rstd2;
+    float* bw_partial2;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(SplitFinArgs f) {
+    constexpr int EPC = TT<T>::EPC;
+    // grid (M-tiles, OC / 64): a block owns 64 channels of a tile's rows -- 8 vectors per row, 32 rows per trip; one block per
+    // M-tile (27 blocks for the audio layer 4) was latency-bound: 60 us for 7 MB
+    constexpr int FC = 64, cpr = FC / EPC, rpi = 256 / cpr;
+    __shared__ float red[rpi * FC * 3];  // [row group][channel][sum]
+    const int vc = threadIdx.x % cpr, rsub = threadIdx.x / cpr, c0 = blockIdx.y * FC + vc * EPC;
+    const int mtile = blockIdx.x, r0 = mtile * f.BM, r1 = min(f.M, r0 + f.BM);
+    const bool st = f.stats != nullptr || f.sacc.acc != nullptr, bw = f.bw_y != nullptr, bw2 = bw && f.bw_y2 != nullptr;
+    float s1[EPC], s2[EPC], s3[EPC], mu[EPC], mu2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        s1[e] = s2[e] = s3[e] = 0.f;
+        mu[e] = bw ? f.bw_mean[c0 + e] : 0.f;
+        mu2[e] = bw2 ? f.bw_mean2[c0 + e] : 0.f;
+    }
+    const size_t plane = (size_t)f.M * f.OC;
+    for (int row = r0 + rsub; row < r1; row += rpi) {
+        const size_t off = (size_t)row * f.OC + c0;
+        float v[EPC];
+#pragma unroll
+        for (int q = 0; q < EPC / 4; ++q) {
+            float4 a = *(const float4*)(f.ws + off + 4 * q);
+            for (int sp = 1; sp < f.nsplit; ++sp) {
+                const float4 b = *(const float4*)(f.ws + sp * plane + off + 4 * q);
+                a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+            }
+            v[4 * q] = a.x, v[4 * q + 1] = a.y, v[4 * q + 2] = a.z, v[4 * q + 3] = a.w;
+        }
+        uint4 pk = pack16<T>(v);  // (the epilogue stages the tile through LDS as T)
+        if (f.addend) {
+            float g[EPC];
+            unpack16<T>(pk, v);
+            unpack16<T>(*(const uint4*)((const T*)f.addend + off), g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] += g[e];
+            pk = pack16<T>(v);
+        }
+        unpack16<T>(pk, v);
+        if (f.relu_bits) {
+            const unsigned mk = f.relu_bits[off / EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = ((mk >> e) & 1u) ? v[e] : 0.f;
+            pk = pack16<T>(v);
+        }
+        if (st) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s1[e] += v[e];
+                s2[e] += v[e] * v[e];
+            }
+        }
+        if (bw) {
+            float y[EPC];
+            unpack16<T>(*(const uint4*)((const T*)f.bw_y + off), y);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                s1[e] += v[e];
+                s2[e] += v[e] * (y[e] - mu[e]);
+            }
+            if (bw2) {
+                unpack16<T>(*(const uint4*)((const T*)f.bw_y2 + off), y);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) s3[e] += v[e] * (y[e] - mu2[e]);
+            }
+        }
+        *(uint4*)((T*)f.out + off) = pk;
+    }
+    if (!st && !bw) return;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        float* d = red + (rsub * FC + vc * EPC + e) * 3;
+        d[0] = s1[e], d[1] = s2[e], d[2] = s3[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < FC) {
+        const int cl = threadIdx.x, c = blockIdx.y * FC + cl;
+        float t1 = red[cl * 3], t2 = red[cl * 3 + 1], t3 = red[cl * 3 + 2];
+        for (int r = 1; r < rpi; ++r) {
+            const float* d = red + (r * FC + cl) * 3;
+            t1 += d[0], t2 += d[1], t3 += d[2];
+        }
+        if (st) {
+            if (f.sacc.acc) {
+                bn_acc_add(f.sacc.acc, c, 0, t1, f.sacc.s1, f.sacc.s2);
+                bn_acc_add(f.sacc.acc, c, 1, t2, f.sacc.s1, f.sacc.s2);
+            } else {
+                f.stats[((size_t)mtile * f.OC + c) * 2 + 0] = t1;
+                f.stats[((size_t)mtile * f.OC + c) * 2 + 1] = t2;
+            }
+        }
+        if (bw) {
+            f.bw_partial[((size_t)mtile * f.OC + c) * 2 + 0] = t1;
+            f.bw_partial[((size_t)mtile * f.OC + c) * 2 + 1] = t2 * f.bw_rstd[c];
+            if (bw2) {
+                f.bw_partial2[((size_t)mtile * f.OC + c) * 2 + 0] = t1;
+                f.bw_partial2[((size_t)mtile * f.OC + c) * 2 + 1] = t3 * f.bw_rstd2[c];
+            }
+        }
+    }
+}
+// splits of a slab launch: only where the tiles leave CUs idle and the K-loop is long (bf16, 128 / 256 / 512 output channels)
+static int splitk_threshold() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_SPLITK_BLOCKS");  // tuning aid: the block count below which a slab launch splits K when it is given a workspace
+        v = e ? atoi(e) : 200;
+    }
+    return v;
+}
+static int plan_ksplit(const ConvPlan& pl, int dtype, int M, int OC, int IC) {
+    if (!pl.slab || pl.c64 || dtype != GDL_BF16 || splitk_threshold() <= 0) return 1;
+    if (OC != 128 && OC != 256 && OC != 512) return 1;
+    const long blocks = (long)ceil_div(M, pl.bm) * (OC / pl.bn);
+    if (blocks >= splitk_threshold()) return 1;
+    const int kpt = IC / 64;
+    int s = 1;
+    while (s < 4 && kpt % (2 * s) == 0 && kpt / (2 * s) >= 1 && blocks * (2 * s) <= 512) s *= 2;
+    return s;
+}
+size_t conv_split_ws_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad) {
+    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
+    const int M = dgrad ? N * H * W : N * P * Q, OC = dgrad ? C : K, IC = dgrad ? K : C;
+    const ConvPlan pl = plan_conv(dtype, M, OC, IC, W, R, S, stride, pad);
+    const int s = plan_ksplit(pl, dtype, M, OC, IC);
+    return s > 1 ? (size_t)s * M * OC * sizeof(float) : 0;
+}
+
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                     hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
                     const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
                     const float* bias = nullptr, void* gelu_out = nullptr, const BwdStats* bw = nullptr,
-                    const BnAcc* sacc = nullptr, const void* gelu_u = nullptr) {
+                    const BnAcc* sacc = nullptr, const void* gelu_u = nullptr, const SplitWs* split = nullptr) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "conv: bad dtype %d", dtype);
     GDL_REQUIRE(table, "conv: gather table is null (build it with gdl_conv_build_table)");
     const int bke = (dtype == GDL_BF16) ? 64 : 32;
@@ -2011,6 +2186,27 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
             for (int s2 = 0; s2 < 3; ++s2)
                 a.pshift[r * 3 + s2] = mode == GATHER_FWD ? (r - 1) * W + (s2 - 1) : (1 - r) * W + (1 - s2);
     }
+    const int ks = (split && split->ptr && !fold && !bias && !gelu_out && !gelu_u && !dy_ds) ? plan_ksplit(pl, dtype, a.M, a.OC, a.IC) : 1;
+    if (ks > 1) {
+        GDL_REQUIRE(split->bytes >= (size_t)ks * a.M * a.OC * sizeof(float), "conv: split-K workspace of %zu bytes, need %zu",
+                    split->bytes, (size_t)ks * a.M * a.OC * sizeof(float));
+        ConvArgs b = a;  // the producing launch leaves fp32 accumulators only
+        b.ksplit = ks;
+        b.split_ws = (float*)split->ptr;
+        b.addend = nullptr, b.relu_bits = nullptr, b.stats = nullptr, b.sacc = BnAcc{nullptr, 0.0, 0.0};
+        b.bw_y = b.bw_y2 = nullptr;
+        const int rc = mode == GATHER_FWD ? launch_mode<bf16, MODE_FWD>(b, pl, st) : launch_mode<bf16, MODE_DGRAD>(b, pl, st);
+        if (rc != GDL_OK) return rc;
+        SplitFinArgs f{};
+        f.ws = b.split_ws, f.nsplit = ks, f.M = a.M, f.OC = a.OC, f.BM = pl.bm;
+        f.out = a.out, f.addend = a.addend, f.relu_bits = a.relu_bits, f.stats = a.stats, f.sacc = a.sacc;
+        f.bw_y = a.bw_y, f.bw_mean = a.bw_mean, f.bw_rstd = a.bw_rstd, f.bw_partial = a.bw_partial;
+        f.bw_y2 = a.bw_y2, f.bw_mean2 = a.bw_mean2, f.bw_rstd2 = a.bw_rstd2, f.bw_partial2 = a.bw_partial2;
+        ProfScope prof("gdl::splitk_finish_kernel", PROF_HBM, st, (double)a.M * a.OC * (4.0 * ks + 2.0 * (1 + (a.addend ? 1 : 0) + (a.bw_y ? 1 : 0) + (a.bw_y2 ? 1 : 0))));
+        hipLaunchKernelGGL(splitk_finish_kernel<bf16>, dim3(ceil_div(a.M, pl.bm), a.OC / 64), dim3(256), 0, st, f);
+        GDL_CHECK_LAUNCH("splitk_finish_kernel");
+        return GDL_OK;
+    }
     if (dtype == GDL_BF16)
         return mode == GATHER_FWD ? launch_mode<bf16, MODE_FWD>(a, pl, st) : launch_mode<bf16, MODE_DGRAD>(a, pl, st);
     return mode == GATHER_FWD ? launch_mode<float, MODE_FWD>(a, pl, st) : launch_mode<float, MODE_DGRAD>(a, pl, st);
@@ -2018,9 +2214,9 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
 
 int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,
              int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn,
-             const BnAcc* sacc) {
+             const BnAcc* sacc, const SplitWs* split) {
     return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st, fold, bn, nullptr,
-                    nullptr, nullptr, nullptr, nullptr, nullptr, sacc);
+                    nullptr, nullptr, nullptr, nullptr, nullptr, sacc, nullptr, split);
 }
 
 // ---- direct stem forward (layout.hip / gather.h): implicit GEMM over the padded NHWC4 input
@@ -2135,9 +2331,9 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
 
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits,
-               const BwdStats* bw) {
+               const BwdStats* bw, const SplitWs* split) {
     return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
-                    nullptr, relu_bits, nullptr, nullptr, nullptr, nullptr, bw);
+                    nullptr, relu_bits, nullptr, nullptr, nullptr, nullptr, bw, nullptr, nullptr, split);
 }
 
 // dx = dgrad(dy) * gelu'(u), elementwise in the epilogue (u laid out like dx), and the column sums of dx as stored added to

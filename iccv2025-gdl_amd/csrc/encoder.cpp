@@ -99,6 +99,7 @@ struct gdl_encoder {
         if (side) (void)hipStreamDestroy(side);
     }
     float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr;
+    SplitWs sk{nullptr, 0};          // split-K workspace of the slab convolutions (ops.h): forward / data-gradient chain only
     long long* acc_arena = nullptr;  // the 20 BatchNorms' integer accumulators, contiguous: one memset per forward
     size_t acc_bytes = 0;
     void* wg_ws = nullptr;
@@ -255,6 +256,27 @@ size_t gdl_encoder::plan(unsigned char* base) {
     bwB2 = (float*)b.take(max_bwt * 2 * sizeof(float));
     wg_ws_bytes = wg;
     wg_ws = b.take(wg);
+    // Split-K of the under-filled slab convolutions (ops.h SplitWs), tuning aid GDL_SPLITK=1 -- OFF by default.  Measured (B = 64):
+    // alone the audio layer-4 convolutions go from 54-64 us to 26 us + a 15 us finish pass (their K-steps are latency-bound: 1 400
+    // clk per step of which 190 are MFMAs, one block on 108 of 256 CUs), inside the step nothing: 5.752 vs 5.752 ms with the audio
+    // layer 4 split four ways (four A/B rounds), 5.69 vs 5.64 ms with every layer below 200 tiles split (the visual layer 4 and its
+    // 38 MB of partials included) -- the CUs such a launch leaves idle are not idle in the step, the other streams' blocks run there.
+    static int splitk = -1;
+    if (splitk < 0) {
+        const char* env = tune_env("GDL_SPLITK");
+        splitk = env ? atoi(env) : 0;
+    }
+    if (splitk) {
+        size_t need = 0;
+        for (const Block& k : blocks)
+            for (const Conv* c : {&k.c1, &k.c2})
+                for (int dg = 0; dg < 2; ++dg) {
+                    const size_t nb = conv_split_ws_bytes(dtype, k.n, c->h, c->w, c->cin, c->cout, c->r, c->s, c->stride, c->pad, dg);
+                    need = nb > need ? nb : need;
+                }
+        sk.bytes = need;
+        sk.ptr = need ? b.take(need) : nullptr;
+    }
     fold.ctr = (unsigned*)b.take(fold_ctr_bytes());
     fold.gpart = (double*)b.take(fold_gpart_bytes());
     return align_up(b.off, 256);
@@ -574,7 +596,7 @@ static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int n
                         &e->fold, &fin);
     }
     RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s,
-                c.stride, c.pad, st));
+                c.stride, c.pad, st, nullptr, nullptr, nullptr, &e->sk));
     return bn_finalize(e, n, training, tiles, (double)M, st);
 }
 
@@ -684,7 +706,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
             auto conv = [&](const Conv& c, const BN& n, const void* x, void* y) {
                 const BnAcc pa = acc_producer(n, Mo);
                 return conv_fwd(dt, x, c.w_krsc, y, nullptr, c.tab_fwd, k.n, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
-                                nullptr, nullptr, &pa);
+                                nullptr, nullptr, &pa, &e->sk);
             };
             RC(conv(k.c1, k.b1, k.xin, k.y1));
             const BnAccFin f1 = acc_consumer(e, k.b1, Mo), f2 = acc_consumer(e, k.b2, Mo);
@@ -879,7 +901,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             // gC = da1 * (a1 > 0) (sign bits of a1) with bn1's two sums from the epilogue; then finalize + apply
             const BwdStats bwa{k.y1, k.b1.mean, k.b1.rstd, e->bwA, nullptr, nullptr, nullptr, nullptr};
             RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, st,
-                          k.abits, &bwa));
+                          k.abits, &bwa, &e->sk));
             if (late) RC(wgrad2());
             const int rows = conv_dgrad_tiles_m(dt, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1);
             if (!GDL_SKIPPED(32))
@@ -889,7 +911,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                             k.cout, st));  // gC = dy1 (in place; the gradient is masked already)
         } else {
         RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
-                      st));  // gC = da1
+                      st, nullptr, nullptr, &e->sk));  // gC = da1
         if (late) RC(wgrad2());
         // relu + bn1 / conv1
         RC(bn_backward(e, k.b1, gC, k.y1, 1, gC, Mo, grads, st));  // gC = dy1 (in place)
@@ -938,7 +960,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         } else {
             // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st,
-                          inbits, bwp));
+                          inbits, bwp, &e->sk));
             dxin = do2;
         }
         premasked = inbits != nullptr;

@@ -43,19 +43,29 @@ struct BwdStats {
     const float *mean2, *rstd2;
     float* partial2;
 };
+// split-K workspace of the slab convolutions (round 3): where plan_conv's tiles would leave CUs idle (layer 4 of both encoders,
+// the audio layer 3) `ksplit` blocks share an output tile, each multiplies a slice of the input channels and leaves fp32
+// accumulators in the workspace; a finish kernel folds them in fixed order and applies the epilogue (rounding, addend, ReLU
+// bits, statistics).  conv_split_ws_bytes: what a geometry needs (0: that convolution does not split); nullptr / too small a
+// buffer: no split.  bf16 only.
+struct SplitWs {
+    void* ptr;
+    size_t bytes;
+};
+size_t conv_split_ws_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad);
 // conv_igemm.hip
 int conv_dgrad_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 // (fold != nullptr: the BatchNorm finalize of `bn` runs inside the launch, fold.h; bn->partial / tiles are ignored)
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
              int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold = nullptr,
-             const BnFinTrain* bn = nullptr, const BnAcc* sacc = nullptr);
+             const BnFinTrain* bn = nullptr, const BnAcc* sacc = nullptr, const SplitWs* split = nullptr);
 int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend, void* gelu_out,
                   const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits = nullptr,
-               const BwdStats* bw = nullptr);
+               const BwdStats* bw = nullptr, const SplitWs* split = nullptr);
 // dx = dgrad(dy) * gelu'(u) with the column sums of dx (as stored) added to the fixed-point accumulators `acc` (bnacc.h)
 int conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, const BnAcc* acc, const void* table,
                     int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);

@@ -33,6 +33,9 @@ SIGNATURES = {
     "gdl_conv_dgrad_ds": ("i", "ippppppp" + "iiiii" + "p"),
     "gdl_conv_dgrad_bn_tiles": ("i", "iiiiiiiiii"),
     "gdl_conv_dgrad_bn": ("i", "ipppppp" + "iiiiiiiii" + "pppppppp" + "p"),
+    "gdl_conv_split_workspace_bytes": ("z", "iiiiiiiiiii"),
+    "gdl_conv_fwd_split": ("i", "ippppp" + "iiiiiiiii" + "pz" + "p"),
+    "gdl_conv_dgrad_bn_split": ("i", "ipppppp" + "iiiiiiiii" + "pppppppp" + "pz" + "p"),
     "gdl_conv_dgrad_gelu": ("i", "ippppp" + "d" + "p" + "iiiiiiiii" + "p"),
     "gdl_acc_to_float": ("i", "pidpp"),
     "gdl_comm_unique_id": ("i", "p"),

@@ -105,6 +105,23 @@ GDL_API int gdl_conv_dgrad_bn(int dtype, const void* dy, const void* w_crsk, voi
                               const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
                               int stride, int pad, const void* y, const float* mean, const float* rstd, float* partial,
                               const void* y2, const float* mean2, const float* rstd2, float* partial2, void* stream);
+/* Split-K of the 3x3 stride-1 "slab" convolutions (round 3).  Where a layer's output tiles would leave most CUs idle (layer 4
+ * of both encoders: 3 456 / 9 408 GEMM rows against a 4 608-deep reduction; the audio layer 3), 2 or 4 blocks share a tile, each
+ * multiplies a slice of the input channels and leaves fp32 accumulators in `split_ws`; a finish kernel folds them in fixed order
+ * (run-to-run identical) and applies the epilogue -- rounding, addend, ReLU bits, BatchNorm statistics / BatchNorm-backward sums,
+ * the same partial-row counts as the unsplit forms.  gdl_conv_split_workspace_bytes: bytes a geometry needs (0: it does not
+ * split; dgrad = 0 forward, 1 data gradient).  The _split entry points equal gdl_conv_fwd / gdl_conv_dgrad_bn with that workspace
+ * (NULL or too small: refused / unsplit).  bf16 only; results differ from the unsplit kernel by fp32 summation order. */
+GDL_API size_t gdl_conv_split_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                              int dgrad);
+GDL_API int gdl_conv_fwd_split(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N,
+                               int H, int W, int C, int K, int R, int S, int stride, int pad, void* split_ws,
+                               size_t split_ws_bytes, void* stream);
+GDL_API int gdl_conv_dgrad_bn_split(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend,
+                                    const uint8_t* relu_bits, const void* table, int N, int H, int W, int C, int K, int R, int S,
+                                    int stride, int pad, const void* y, const float* mean, const float* rstd, float* partial,
+                                    const void* y2, const float* mean2, const float* rstd2, float* partial2, void* split_ws,
+                                    size_t split_ws_bytes, void* stream);
 /* Mlp backward in the data gradient's epilogue (round 3; /root/reference/models/swin_transformer.py:32-47, Mlp.forward
  * fc1 -> act -> fc2 through autograd): gdl_conv_dgrad_gelu = gdl_conv_dgrad whose epilogue multiplies the stored value by
  * gelu'(u[row][c]) (u laid out like dx: fc1's biased output, as gdl_conv_fwd_bias left it) and adds the column sums of dx AS

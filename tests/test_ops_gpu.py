@@ -731,3 +731,94 @@ def test_conv_dgrad_bn_sums(shape, dt):
         np.testing.assert_allclose(s2[:, 0], want1, rtol=1e-4, atol=2e-6 * scale_)
         np.testing.assert_allclose(s2[:, 1], (g64 * (y2.astype(np.float64) - bc(mean2)) * bc(rstd2)).sum((0, 2, 3)), rtol=1e-4,
                                    atol=1e-5 * scale_)
+
+
+SPLIT_SHAPES = [
+    # N, C, H, W, K  (3x3 stride 1 pad 1; bf16): few output tiles against a deep reduction -> the slab kernel splits K
+    (64, 512, 9, 6, 512),     # audio layer 4 at B = 64: 27 x 4 tiles, 4-way
+    (48, 512, 7, 7, 512),     # a visual layer-4 shape at B = 16
+    (16, 256, 17, 12, 256),   # audio layer 3 at B = 16
+    (5, 512, 9, 6, 512),      # ragged last M-tile
+]
+
+
+@pytest.mark.parametrize("shape", SPLIT_SHAPES)
+def test_conv_split_k(shape):
+    """Split-K of the slab convolutions (gdl_conv_fwd_split / gdl_conv_dgrad_bn_split): the same results as the unsplit launches up
+    to fp32 summation order -- output tensor, BatchNorm statistics rows, BatchNorm-backward sums with addend (in place) + ReLU bits +
+    two partners -- the output also against the oracle, and bit-identical from run to run."""
+    N, C, H, W, K = shape
+    dt = L.GDL_BF16
+    st = L.cur_stream()
+    lib = L.load()
+    need_f = lib.gdl_conv_split_workspace_bytes(dt, N, H, W, C, K, 3, 3, 1, 1, 0)
+    need_d = lib.gdl_conv_split_workspace_bytes(dt, N, H, W, C, K, 3, 3, 1, 1, 1)
+    assert need_f > 0 and need_d > 0, "these shapes are expected to split"
+    assert lib.gdl_conv_split_workspace_bytes(dt, 192, 56, 56, 64, 64, 3, 3, 1, 1, 0) == 0  # a layer that fills the chip does not
+    ws = torch.empty(max(need_f, need_d), dtype=torch.uint8, device=DEV)
+    x, w = _conv_case(N, C, H, W, K, 3, 1, 1, dt)
+    krsc, crsk = pack_weight(w, dt)
+    xd = to_nhwc(x, dt)
+    tab = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, 3, 3, 1, 1)
+    tiles = lib.gdl_conv_bn_tiles(dt, N, H, W, C, K, 3, 3, 1, 1)
+    outs, parts = [], []
+    for split in (False, True, True):
+        y = empty((N, H, W, K), dt)
+        part = torch.full((tiles, K, 2), float("nan"), device=DEV)
+        if split:
+            L.call("gdl_conv_fwd_split", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), L.ptr(tab), N, H, W, C, K, 3, 3, 1, 1,
+                   L.ptr(ws), ws.numel(), st)
+        else:
+            L.call("gdl_conv_fwd", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), L.ptr(tab), N, H, W, C, K, 3, 3, 1, 1, st)
+        torch.cuda.synchronize()
+        outs.append(y)
+        parts.append(part)
+    ref = orc.conv2d_fwd(x, w, 1, 1)
+    assert relerr(from_nhwc(outs[1]), ref) < 4e-3
+    assert torch.equal(outs[1], outs[2]) and torch.equal(parts[1], parts[2])  # run to run
+    assert relerr(from_nhwc(outs[1]), from_nhwc(outs[0])) < 4e-3
+    s0, s1 = parts[0].double().sum(0).cpu().numpy(), parts[1].double().sum(0).cpu().numpy()
+    g = from_nhwc(outs[1]).astype(np.float64)
+    np.testing.assert_allclose(s1[:, 0], g.sum((0, 2, 3)), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s1[:, 1], (g * g).sum((0, 2, 3)), rtol=1e-4)
+    np.testing.assert_allclose(s1, s0, rtol=2e-2, atol=0.5)  # (different bf16 roundings of a few outputs)
+    # ---- data gradient: addend in place, ReLU bits, two BatchNorm partners
+    dy = quant(rng.standard_normal((N, K, H, W), dtype=np.float32), dt)
+    add = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    yb = quant(rng.standard_normal((N, C, H, W), dtype=np.float32) * 1.5 + 0.3, dt)
+    y2 = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    mean, rstd = (rng.standard_normal(C) * 0.3).astype(np.float32), (0.5 + rng.random(C)).astype(np.float32)
+    mean2, rstd2 = (rng.standard_normal(C) * 0.3).astype(np.float32), (0.5 + rng.random(C)).astype(np.float32)
+    bc = lambda v: v[None, :, None, None]
+    keep = yb > 0.3
+    kb = np.transpose(keep, (0, 2, 3, 1)).reshape(-1, 8)
+    bits = torch.from_numpy((kb * (1 << np.arange(8))[None, :]).sum(1).astype(np.uint8)).to(DEV)
+    dyd, yd, y2d = to_nhwc(dy, dt), to_nhwc(yb, dt), to_nhwc(y2, dt)
+    tabd = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, 3, 3, 1, 1)
+    tl = lib.gdl_conv_dgrad_bn_tiles(dt, N, H, W, C, K, 3, 3, 1, 1)
+    md, rd, m2d, r2d = dev(mean), dev(rstd), dev(mean2), dev(rstd2)
+    res = []
+    for split in (False, True, True):
+        dx = to_nhwc(add, dt)  # the addend is accumulated in place
+        p1 = torch.full((tl, C, 2), float("nan"), device=DEV)
+        p2 = torch.full((tl, C, 2), float("nan"), device=DEV)
+        args = [dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), L.ptr(dx), L.ptr(bits), L.ptr(tabd), N, H, W, C, K, 3, 3, 1, 1, L.ptr(yd),
+                L.ptr(md), L.ptr(rd), L.ptr(p1), L.ptr(y2d), L.ptr(m2d), L.ptr(r2d), L.ptr(p2)]
+        if split:
+            L.call("gdl_conv_dgrad_bn_split", *args, L.ptr(ws), ws.numel(), st)
+        else:
+            L.call("gdl_conv_dgrad_bn", *args, st)
+        torch.cuda.synchronize()
+        res.append((dx, p1, p2))
+    want = np.where(keep, orc.conv2d_bwd_data(dy, w, (N, C, H, W), 1, 1) + add, 0)
+    got = from_nhwc(res[1][0])
+    assert relerr(got, want) < 6e-3 and np.all(got[~keep] == 0)
+    assert all(torch.equal(a, b) for a, b in zip(res[1], res[2]))  # run to run
+    g64 = got.astype(np.float64)
+    sc_ = np.abs(g64).sum((0, 2, 3)).max()
+    a1, a2 = res[1][1].double().sum(0).cpu().numpy(), res[1][2].double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(a1[:, 0], g64.sum((0, 2, 3)), rtol=1e-4, atol=2e-6 * sc_)
+    np.testing.assert_allclose(a1[:, 1], (g64 * (yb.astype(np.float64) - bc(mean)) * bc(rstd)).sum((0, 2, 3)), rtol=1e-4, atol=1e-5 * sc_)
+    np.testing.assert_allclose(a2[:, 0], g64.sum((0, 2, 3)), rtol=1e-4, atol=2e-6 * sc_)
+    np.testing.assert_allclose(a2[:, 1], (g64 * (y2.astype(np.float64) - bc(mean2)) * bc(rstd2)).sum((0, 2, 3)), rtol=1e-4, atol=1e-5 * sc_)
+    assert relerr(got, from_nhwc(res[0][0])) < 6e-3

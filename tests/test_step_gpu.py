@@ -942,3 +942,18 @@ def test_early_backward_identical(fusion):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32))
         else:
             assert a == b
+
+
+@pytest.mark.parametrize("knobs", ["GDL_SPLITK=1", "GDL_BN_ACC=0", "GDL_BW_FUSE=0"])
+def test_alternate_paths_pass_the_goldens(knobs):
+    """The engine paths that are not the default (tuning knobs are read once per process, hence a child process): split-K of the
+    under-filled slab convolutions, forward BatchNorm statistics through partial rows + finalize launches instead of the integer
+    accumulators, separate BatchNorm-backward reduce passes -- each must pass the encoder and step goldens like the default."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GDL_TUNING="1", **dict(kv.split("=") for kv in knobs.split(",")))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "encoder_golden or step_golden", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout
