@@ -717,7 +717,9 @@ def test_conv_dgrad_bn_sums(shape, dt):
     got = from_nhwc(dx)
     assert relerr(got, ref) < tol(dt, 2e-6, 4e-3), relerr(got, ref)
     if mask:
-        assert np.all(got[ref == 0] == 0)
+        # (exactly where the bit is clear -- the reference itself can be an exact 0.0 elsewhere by cancellation)
+        bad = np.argwhere(~keep & (got != 0))
+        assert len(bad) == 0, (len(bad), bad[:6].tolist(), [float(got[tuple(b)]) for b in bad[:6]])
     g64 = got.astype(np.float64)
     s = part.double().sum(0).cpu().numpy()
     assert np.isfinite(s).all()
