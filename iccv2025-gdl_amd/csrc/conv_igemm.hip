@@ -206,7 +206,10 @@ struct ConvSmem {
 // ---- epilogue shared by the kernels below: accumulators -> LDS tile [BM][BN] of T -> full rows.
 // Must be entered after every wave is done with the main-loop LDS contents (barrier) and with no
 // LDS-DMA in flight.
-template <typename T, int BM, int BN, int WM, int WN, bool BWD = false>
+// PRE: the forward's bias and addend vectors are requested before the staging (the flat kernel's forward instantiations only --
+// the Swin Linears; in the slab / persistent forward kernels of the ResNets the prefetch registers cost more than they return:
+// 5.81 vs 5.69 ms when every instantiation had them)
+template <typename T, int BM, int BN, int WM, int WN, bool BWD = false, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], unsigned char* smem,
                                               const ConvArgs& a, int m0, int n0, int mtile, int ntile = 0) {
     constexpr int NT = WM * WN * 64;  // threads of the block (256 or 512)
@@ -240,17 +243,40 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     // (BWD: only the data-gradient instantiations carry this code and its registers)
     const bool bw = BWD && a.bw_y != nullptr, bw2 = bw && a.bw_y2 != nullptr;
     const bool gl = BWD && a.gelu_u != nullptr;  // (excludes bw: the host checks) -- the GELU input rides in the partner registers
-    uint4 byq[BWD ? NPASS : 1], by2q[BWD ? NPASS : 1];
+    // (the SECOND partner -- three launches per encoder -- is read inside the store loop: its NPASS vectors in registers on top
+    // of the first partner's made the 192-row data gradient spill 144 bytes per lane in every launch)
+    uint4 byq[BWD ? NPASS : 1];
     if constexpr (BWD) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
-            byq[p] = by2q[p] = make_uint4(0u, 0u, 0u, 0u);
+            byq[p] = make_uint4(0u, 0u, 0u, 0u);
             if (gl && om[p] >= 0) byq[p] = *(const uint4*)((const T*)a.gelu_u + (size_t)om[p] * a.OC + n0 + ec * EPC);
             if (bw && om[p] >= 0) {
                 const size_t goff = (size_t)om[p] * a.OC + n0 + ec * EPC;
                 byq[p] = *(const uint4*)((const T*)a.bw_y + goff);
-                if (bw2) by2q[p] = *(const uint4*)((const T*)a.bw_y2 + goff);
             }
+        }
+    }
+    // The forward's bias (the same EPC channels in every pass) and addend vectors are requested here as well: a load inside the
+    // store loop makes the compiler wait for vmcnt(0) before its first use -- loads and stores share the counter, so every pass
+    // then waits for the PREVIOUS pass's stores to be acknowledged (~1 000 clk each; tools/timing_probe.py: 8 200 clk of epilogue
+    // for the eight passes of a 128 x 128 tile of the Swin Linears)
+    T* __restrict__ gout = (T*)a.out;
+    const T* __restrict__ gadd = (const T*)a.addend;
+    float biasv[PRE ? EPC : 1];
+    uint4 gaq[PRE ? NPASS : 1];
+    if constexpr (PRE) {
+        if (a.bias) {
+#pragma unroll
+            for (int e4 = 0; e4 < EPC / 4; ++e4) {
+                const float4 b = *(const float4*)(a.bias + n0 + ec * EPC + 4 * e4);
+                biasv[4 * e4] = b.x, biasv[4 * e4 + 1] = b.y, biasv[4 * e4 + 2] = b.z, biasv[4 * e4 + 3] = b.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            gaq[p] = make_uint4(0u, 0u, 0u, 0u);
+            if (gadd && om[p] >= 0) gaq[p] = *(const uint4*)(gadd + (size_t)om[p] * a.OC + n0 + ec * EPC);
         }
     }
     // accumulators -> LDS tile [BM][BN] of T.
@@ -288,8 +314,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             if (bw2) bmu2[e] = a.bw_mean2[c0 + e];
         }
     }
-    T* __restrict__ gout = (T*)a.out;
-    const T* __restrict__ gadd = (const T*)a.addend;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         if (om[p] < 0) continue;
@@ -300,15 +324,24 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             float f[EPC];
             unpack16<T>(v, f);
             if (a.bias) {
+                if constexpr (PRE) {
 #pragma unroll
-                for (int e4 = 0; e4 < EPC / 4; ++e4) {
-                    const float4 b = *(const float4*)(a.bias + n0 + ec * EPC + 4 * e4);
-                    f[4 * e4] += b.x, f[4 * e4 + 1] += b.y, f[4 * e4 + 2] += b.z, f[4 * e4 + 3] += b.w;
+                    for (int e = 0; e < EPC; ++e) f[e] += biasv[e];
+                } else {
+#pragma unroll
+                    for (int e4 = 0; e4 < EPC / 4; ++e4) {
+                        const float4 b = *(const float4*)(a.bias + n0 + ec * EPC + 4 * e4);
+                        f[4 * e4] += b.x, f[4 * e4 + 1] += b.y, f[4 * e4 + 2] += b.z, f[4 * e4 + 3] += b.w;
+                    }
                 }
             }
             if (gadd) {
                 float g[EPC];
-                const uint4 w = *(const uint4*)(gadd + goff);
+                uint4 w;
+                if constexpr (PRE)
+                    w = gaq[p];
+                else
+                    w = *(const uint4*)(gadd + goff);
                 unpack16<T>(w, g);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) f[e] += g[e];
@@ -353,7 +386,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             }
             if (bw2) {
                 float y2[EPC];
-                unpack16<T>(by2q[BWD ? p : 0], y2);
+                unpack16<T>(*(const uint4*)((const T*)a.bw_y2 + goff), y2);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) bs3[e] += f[e] * (y2[e] - bmu2[e]);
             }
@@ -588,7 +621,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (empty) tail stages before LDS is reused
     __syncthreads();
 
-    conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD>(acc, smem, a, m0, n0, mtile, ntile);
+    conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD, MODE == MODE_FWD>(acc, smem, a, m0, n0, mtile, ntile);
 }
 
 // =====================================================================================================
@@ -918,8 +951,11 @@ __device__ __forceinline__ void slab_reads(uint4 (&px)[MI], uint4 (&wf)[NI], con
 // (NWV = 8 -- the same tile on 512 threads, 4 x 2 waves, four waves per SIMD with two blocks per CU -- was built and
 // measured: no faster than four waves (128 x 128 at 128 / 256 channels: 53 / 57 us forward either way; the step 6.45
 // against 6.48 ms).  Occupancy is not what bounds this kernel; the parameter stays for the record, only 4 is launched.)
+// (second bound = waves per SIMD the compiler must leave room for.  The 8-wave tile had 4 -- a 128-register cap that made its data
+// gradient spill 64-108 bytes per lane into the epilogue; it only runs where the launch has fewer blocks than CUs, so 2 -- one block
+// per CU, 256 registers -- costs no residency)
 template <typename T, int BM, int BN, int MODE, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 4 : ((BM >= 192 && BN == 128) ? 2 : 1)) void conv3x3_slab_kernel(ConvArgs a) {
+__global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 2 : ((BM >= 192 && BN == 128) ? 2 : 1)) void conv3x3_slab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WM = 4, WN = NWV / 4;
     constexpr int EPC = TT<T>::EPC;
@@ -1284,7 +1320,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) tsum[e] = tsq[e] = 0.f;
     bf16* __restrict__ gout = (bf16*)a.out;
-    const bf16* __restrict__ gadd = (const bf16*)a.addend;
+    // (addend and ReLU bits belong to data gradients: the forward instantiation carries neither their registers nor their branches)
+    const bf16* __restrict__ gadd = MODE == MODE_DGRAD ? (const bf16*)a.addend : nullptr;
+    const uint8_t* __restrict__ rbits = MODE == MODE_DGRAD ? a.relu_bits : nullptr;
 
     unsigned fmask[4] = {0u, 0u, 0u, 0u};
     if (tile < t_end) {
@@ -1393,7 +1431,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             mkq[p] = 0xffu;
             if (m < a.M) {
                 if (gadd) gq[p] = *(const uint4*)(gadd + goff);
-                if (a.relu_bits) mkq[p] = a.relu_bits[goff / 8];
+                if (rbits) mkq[p] = rbits[goff / 8];
                 if constexpr (BW) yq[p] = *(const uint4*)((const bf16*)a.bw_y + goff);
             }
         }
@@ -1449,7 +1487,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                 for (int e = 0; e < 8; ++e) f[e] += g[e];
                 v = pack16<bf16>(f);
             }
-            if (a.relu_bits) {
+            if (rbits) {
                 const unsigned mk = mkq[p];
                 float f[8];
                 unpack16<bf16>(v, f);

@@ -255,51 +255,40 @@ __global__ __launch_bounds__(256) void maxpool_bwd_patch_kernel(const T* __restr
             for (int e = 0; e < EPC; ++e) a00[e] = a01[e] = a10[e] = a11[e] = 0.f;
             // the gradient / arg-max vectors of the four windows that touch the patch: twelve loads in flight
             // per thread instead of four dependent load -> decode round trips (an absent window reads as arg-max 255: no match)
-            uint4 dq[4];
-            uint2 iq[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            // (named scalars, not arrays indexed by the window number: the index array ended up in scratch memory -- 32 bytes per
+            // lane read back inside the hottest loop of the stem's backward)
+            uint4 dq0 = z, dq1 = z, dq2 = z, dq3 = z;
+            uint2 iq0 = make_uint2(0xffffffffu, 0xffffffffu), iq1 = iq0, iq2 = iq0, iq3 = iq0;
+            auto fetch = [&](int k, uint4& dqk, uint2& iqk) __attribute__((always_inline)) {
                 const int pp = p + (k >> 1), qq = q + (k & 1);
-                dq[k] = z;
-                iq[k] = make_uint2(0xffffffffu, 0xffffffffu);
                 if (pp < P && qq < Q) {
                     const size_t o = (((size_t)n * P + pp) * Q + qq) * C + vc * EPC;
-                    dq[k] = *(const uint4*)(dout + o);
-                    if (EPC == 8)
-                        iq[k] = *(const uint2*)(idx + o);
+                    dqk = *(const uint4*)(dout + o);
+                    if constexpr (EPC == 8)
+                        iqk = *(const uint2*)(idx + o);
                     else
-                        iq[k].x = *(const uint32_t*)(idx + o);
+                        iqk.x = *(const uint32_t*)(idx + o);
                 }
-            }
-            auto window = [&](int k, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
+            };
+            fetch(0, dq0, iq0), fetch(1, dq1, iq1), fetch(2, dq2, iq2), fetch(3, dq3, iq3);
+            auto window = [&](const uint4& dqk, const uint2& u, int c00, int c01, int c10, int c11) __attribute__((always_inline)) {
                 float d[EPC];
-                unpack16<T>(dq[k], d);
-                uint32_t ix[EPC];
-                if (EPC == 8) {
-                    const uint2 u = iq[k];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ix[e] = (u.x >> (8 * e)) & 0xff;
-                        ix[(4 + e) % EPC] = (u.y >> (8 * e)) & 0xff;
-                    }
-                } else {
-                    const uint32_t u = iq[k].x;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ix[e] = (u >> (8 * e)) & 0xff;
-                }
+                unpack16<T>(dqk, d);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    if (c00 >= 0 && ix[e] == (uint32_t)c00) a00[e] += d[e];
-                    if (c01 >= 0 && ix[e] == (uint32_t)c01) a01[e] += d[e];
-                    if (c10 >= 0 && ix[e] == (uint32_t)c10) a10[e] += d[e];
-                    if (c11 >= 0 && ix[e] == (uint32_t)c11) a11[e] += d[e];
+                    // (the arg-max code of element e straight from the packed bytes: an ix[] array here lived in scratch memory)
+                    const uint32_t code = ((e < 4 ? u.x : u.y) >> (8 * (e & 3))) & 0xffu;
+                    if (c00 >= 0 && code == (uint32_t)c00) a00[e] += d[e];
+                    if (c01 >= 0 && code == (uint32_t)c01) a01[e] += d[e];
+                    if (c10 >= 0 && code == (uint32_t)c10) a10[e] += d[e];
+                    if (c11 >= 0 && code == (uint32_t)c11) a11[e] += d[e];
                 }
             };
             // (the order of the additions into one position is that of maxpool_bwd_kernel: window rows, then columns)
-            window(0, 4, 5, 7, 8);
-            window(1, -1, 3, -1, 6);
-            window(2, -1, -1, 1, 2);
-            window(3, -1, -1, -1, 0);
+            window(dq0, iq0, 4, 5, 7, 8);
+            window(dq1, iq1, -1, 3, -1, 6);
+            window(dq2, iq2, -1, -1, 1, 2);
+            window(dq3, iq3, -1, -1, -1, 0);
             const int h = 2 * p, w = 2 * q;
             T* o0 = dx + (((size_t)n * H + h) * W + w) * C + vc * EPC;
             *(uint4*)o0 = pack16<T>(a00);
@@ -389,9 +378,13 @@ __global__ __launch_bounds__(256) void maxpool_bn_bwd_apply_kernel(const T* __re
             // the four y0 vectors of the patch are requested before the windows are decoded
             const uint4 z = make_uint4(0u, 0u, 0u, 0u);
             const uint4 y00 = *(const uint4*)(y0 + o00);
-            const uint4 y01 = w1 ? *(const uint4*)(y0 + o00 + C) : z;
-            const uint4 y10 = h1 ? *(const uint4*)(y0 + o00 + (size_t)W * C) : z;
-            const uint4 y11 = (h1 && w1) ? *(const uint4*)(y0 + o00 + (size_t)W * C + C) : z;
+            // (clamped addresses instead of `cond ? *p : z`: the compiler turned that into a load through `cond ? p : &z` -- a
+            // FLAT load from a pointer select with z spilled to scratch memory every iteration; an absent neighbour's vector is
+            // read from the patch's own pixel and never stored)
+            const size_t ow = w1 ? (size_t)C : 0, oh = h1 ? (size_t)W * C : 0;
+            const uint4 y01 = *(const uint4*)(y0 + o00 + ow);
+            const uint4 y10 = *(const uint4*)(y0 + o00 + oh);
+            const uint4 y11 = *(const uint4*)(y0 + o00 + oh + ow);
             float a00[EPC], a01[EPC], a10[EPC], a11[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) a00[e] = a01[e] = a10[e] = a11[e] = 0.f;
