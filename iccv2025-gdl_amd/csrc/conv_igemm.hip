@@ -246,6 +246,14 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     // (the SECOND partner -- three launches per encoder -- is read inside the store loop: its NPASS vectors in registers on top
     // of the first partner's made the 192-row data gradient spill 144 bytes per lane in every launch)
     uint4 byq[BWD ? NPASS : 1];
+    unsigned mkq[BWD ? NPASS : 1];
+    if constexpr (BWD) {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            mkq[p] = 0xffu;
+            if (a.relu_bits && om[p] >= 0) mkq[p] = a.relu_bits[((size_t)om[p] * a.OC + n0 + ec * EPC) / EPC];
+        }
+    }
     if constexpr (BWD) {
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
@@ -349,7 +357,11 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             v = pack16<T>(f);
         }
         if (a.relu_bits) {  // ReLU backward of the tensor this is the gradient of, folded into the store
-            const unsigned mk = a.relu_bits[goff / EPC];
+            unsigned mk;
+            if constexpr (BWD)
+                mk = mkq[p];
+            else
+                mk = a.relu_bits[goff / EPC];
             float f[EPC];
             unpack16<T>(v, f);
 #pragma unroll
