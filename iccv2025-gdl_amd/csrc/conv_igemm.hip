@@ -1235,9 +1235,12 @@ constexpr int C64_GRID = 512;  // two blocks per CU of an MI355X; also the numbe
 // BW (data gradient only): the BatchNorm-backward sums of the stored rows against the partner tensor a.bw_y (ops.h BwdStats,
 // one partner; optional ReLU mask), accumulated across the block's tiles like the forward's statistics -- and like the forward it
 // then keeps ONE set of pixel fragments (the accumulators take the registers of the second).
-template <int MODE, bool BW = false>
+// ADD (data gradient only): the launch has an addend (the identity shortcut's gradient); the others carry no registers for it
+// (20 -> 8 bytes of scratch in the BatchNorm-sums form: step -0.2 %, four A/B rounds).
+template <int MODE, bool BW = false, bool ADD = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     static_assert(!BW || MODE == MODE_DGRAD, "BW: data gradient only");
+    static_assert(!ADD || MODE == MODE_DGRAD, "ADD: data gradient only");
     constexpr bool STATS = MODE == MODE_FWD;  // per-channel sums accumulated in registers (tsum / tsq) across the tiles
     // (BW accumulates in LDS instead -- per tile: fold the eight row-lanes of a wave that hold the same channels, then lanes 0-7
     // add into the wave's row of [4 waves][64][2] floats -- so that no accumulator is live across the K-loop: with sixteen more
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     for (int e = 0; e < 8; ++e) tsum[e] = tsq[e] = 0.f;
     bf16* __restrict__ gout = (bf16*)a.out;
     // (addend and ReLU bits belong to data gradients: the forward instantiation carries neither their registers nor their branches)
-    const bf16* __restrict__ gadd = MODE == MODE_DGRAD ? (const bf16*)a.addend : nullptr;
+    const bf16* __restrict__ gadd = ADD ? (const bf16*)a.addend : nullptr;
     const uint8_t* __restrict__ rbits = MODE == MODE_DGRAD ? a.relu_bits : nullptr;
 
     unsigned fmask[4] = {0u, 0u, 0u, 0u};
@@ -1923,13 +1926,16 @@ no_c64:
     return p;
 }
 
-template <int MODE, bool BW = false>
+template <int MODE, bool BW = false, bool ADD = false>
 static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, C64_BM);
     GDL_REQUIRE(!a.bias && !a.gelu_out && !a.orow && !a.bw_y2, "conv: unsupported option for the 64-channel persistent kernel");
+    GDL_REQUIRE(MODE == MODE_DGRAD || !a.addend, "conv: the 64-channel persistent forward kernel has no addend");
     if constexpr (MODE == MODE_DGRAD && !BW)
-        if (a.bw_y) return launch_c64<MODE, true>(a, lds, st);
-    auto kfn = conv3x3_c64_kernel<MODE, BW>;
+        if (a.bw_y) return launch_c64<MODE, true, ADD>(a, lds, st);
+    if constexpr (MODE == MODE_DGRAD && !ADD)
+        if (a.addend) return launch_c64<MODE, BW, true>(a, lds, st);
+    auto kfn = conv3x3_c64_kernel<MODE, BW, ADD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
