@@ -653,6 +653,7 @@ struct SwinMfmaBwdLds {
                                 // from the fragment registers right before the product that reads it (round 3: ONE buffer instead
                                 // of three, 15 instead of 24 KB per wave: ten instead of six waves per CU)
     float tab[(2 * 7 - 1) * (2 * 7 - 1)];
+    float tg[(2 * 7 - 1) * (2 * 7 - 1)];  // d(table) of this block's windows (LDS float adds, see the kernel)
     int tok[SW_TP];
     uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
 };
@@ -708,12 +709,14 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
     const int h = blockIdx.x % g.nh, grp = (blockIdx.x / g.nh) % ngrp;
     const size_t img_row0 = (size_t)(blockIdx.x / (g.nh * ngrp)) * L;
     const float scale = 0.17677669529663687f;
-    for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
-    f32x4_t da[4][4];  // d(bias) of this lane's (i, j) pairs, summed over the block's windows (fp32)
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) da[it][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int r = lane; r < tw * tw; r += 64) {
+        S.tab[r] = table[r * g.nh + h];
+        S.tg[r] = 0.f;
+    }
+    // d(bias): every dS_ij belongs to table entry (ri - rj, ci - cj) -- the index the forward bias lookup uses -- and is added
+    // there with an LDS float add.  (Round 2 kept the (i, j) pairs of a lane in 64 fp32 registers across the whole window loop
+    // and folded them at the end: with the fragments and the two packed tiles that was 256 registers + 296 bytes of scratch per
+    // lane.  One wave per block and program order make the LDS adds deterministic.)
     for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
         __syncthreads();  // (the previous window's operand tiles are no longer read)
         {
@@ -727,8 +730,9 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
         uint2 pkp[4][4], pkd[4][4];  // P and dS of tile (it, jt), rows 4 lq .. 4 lq + 3 of column 16 jt + l16, as bf16
         // fragments straight from the rows (the token of slot 16 t + l16 is computed here: no LDS round trip before
         // the loads); the transposed copies the second set of products needs are scattered from the same registers later
+        bf16x8_t qf[4], kf[4], of[4];  // (kept for the transposed operands of dQ / dK / dV below)
         {
-            bf16x8_t qf[4], kf[4], of[4], vf[4];
+            bf16x8_t vf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int slot = 16 * t + l16;
@@ -763,13 +767,15 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                     const int i = 16 * it + 4 * lq + r;
                     const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
                     float mx = -3.0e38f;
+                    int tix[4];
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
                         float a = acc[jt][r] * scale;
+                        tix[jt] = (ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1);
                         if (16 * jt + l16 >= Tn)
                             a = -3.0e38f;
                         else if (i < Tn) {
-                            a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
+                            a += S.tab[tix[jt]];
                             if (g.shift && gi != gj[jt]) a -= 100.f;
                         }
                         acc[jt][r] = a;
@@ -797,9 +803,10 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                     for (int o = 8; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
-                        const float p = (i < Tn && 16 * jt + l16 < Tn) ? acc[jt][r] : 0.f;
+                        const bool in = i < Tn && 16 * jt + l16 < Tn;
+                        const float p = in ? acc[jt][r] : 0.f;
                         const float ds = p * (dp[jt][r] - pd);
-                        da[it][jt][r] += ds;  // (zero outside the window: p is)
+                        if (in) atomicAdd(&S.tg[tix[jt]], ds);
                         acc[jt][r] = p;
                         dp[jt][r] = ds;
                     }
@@ -825,7 +832,8 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
 #pragma unroll
         for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
             const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            sw_scatter_frag(S.Bt, tk >= 0 ? sw_ld_frag(qkv + (img_row0 + tk) * 3 * g.ld + g.ld + h * SW_HD + 8 * lq) : sw_zero_frag(), 16 * t + l16, lq);
+            (void)tk;
+            sw_scatter_frag(S.Bt, kf[t], 16 * t + l16, lq);
         }
         __syncthreads();
         sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 0, scale, Tn, l16, lq);
@@ -838,7 +846,8 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
 #pragma unroll
         for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
             const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            sw_scatter_frag(S.Bt, tk >= 0 ? sw_ld_frag(qkv + (img_row0 + tk) * 3 * g.ld + 0 + h * SW_HD + 8 * lq) : sw_zero_frag(), 16 * t + l16, lq);
+            (void)tk;
+            sw_scatter_frag(S.Bt, qf[t], 16 * t + l16, lq);
         }
         __syncthreads();
         sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
@@ -851,7 +860,8 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
 #pragma unroll
         for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
             const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            sw_scatter_frag(S.Bt, tk >= 0 ? sw_ld_frag(dout + (img_row0 + tk) * g.ld + h * SW_HD + 8 * lq) : sw_zero_frag(), 16 * t + l16, lq);
+            (void)tk;
+            sw_scatter_frag(S.Bt, of[t], 16 * t + l16, lq);
         }
         __syncthreads();
         sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
@@ -860,32 +870,8 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                 for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
     }
     __syncthreads();
-    float(*Da)[SW_MAXT + 1] = (float(*)[SW_MAXT + 1]) & S.Tl[0][0];  // (the operand tiles are dead: reuse their space)
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * it + 4 * lq + r, j = 16 * jt + l16;
-                if (i < Tn && j < Tn) Da[i][j] = da[it][jt][r];
-            }
-    __syncthreads();
     float* tp = tpart + (size_t)blockIdx.x * tw * tw;
-    for (int r = lane; r < tw * tw; r += 64) {
-        const int dh = r / tw - (g.ws - 1), dw = r % tw - (g.ws - 1);
-        float a = 0.f;
-        for (int rj2 = 0; rj2 < g.ws; ++rj2) {
-            const int rr2 = rj2 + dh;
-            if (rr2 < 0 || rr2 >= g.ws) continue;
-            for (int cj2 = 0; cj2 < g.ws; ++cj2) {
-                const int cc2 = cj2 + dw;
-                if (cc2 < 0 || cc2 >= g.ws) continue;
-                a += Da[rr2 * g.ws + cc2][rj2 * g.ws + cj2];
-            }
-        }
-        tp[r] = a;
-    }
+    for (int r = lane; r < tw * tw; r += 64) tp[r] = S.tg[r];
 }
 
 // 32 consecutive channels of a token row -> LDS row (float)
