@@ -65,6 +65,7 @@ struct ConvArgs {
     // permuted stride-2 data gradient (gather.h): output pixel of each GEMM row (-1: padding row)
     const int* orow;
     const unsigned* tile_taps;  // per M-tile: OR of its rows' tap masks
+    const int* tile_order;      // launch slot -> M-tile (gather.hip: the classes of an image group meet in one XCD's L2)
     // ... with the 1x1 stride-2 data gradient of the block's downsample branch folded in (flat kernel): the (even, even)
     // input pixels -- the class whose tiles carry the centre tap -- get one more "tap" that gathers the SAME dy pixel as
     // the centre tap from a second gradient tensor (in2, [.][IC]) and multiplies it with a second matrix (wt2, [OC][IC])
@@ -486,9 +487,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int ntn = a.OC / BN;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int mt_per_xcd = (a.mtiles + 7) >> 3;
-    const int mtile = xcd * mt_per_xcd + j / ntn;
+    const int slot = xcd * mt_per_xcd + j / ntn;
     const int ntile = j % ntn;
-    if (mtile >= a.mtiles) return;
+    if (slot >= a.mtiles) return;
+    const int mtile = a.tile_order ? a.tile_order[slot] : slot;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
     // ---- per-thread gather bookkeeping: rows row0 + 32*i of the tile, one 16-byte chunk each.
@@ -2231,6 +2233,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     if (mode == GATHER_DGRAD && stride == 2) {
         a.orow = (const int*)((const GatherEntry*)table + dgrad_perm_cap(N, H, W));
         a.tile_taps = (const unsigned*)(a.orow + dgrad_perm_cap(N, H, W));
+        a.tile_order = (const int*)(a.tile_taps + (dgrad_perm_cap(N, H, W) / 64 + 1));
         a.M = dgrad_perm_rows(N, H, W, pl.bm);
     }
     if (pl.slab) {
