@@ -36,8 +36,9 @@ enum { GATHER_FWD = 0, GATHER_DGRAD = 1 };
 // kernel and none at all for three of the four classes of a 1x1 -- each class padded to a multiple of
 // the M-tile `bm`, so that every tile is class-pure and its K-loop runs over the taps that can be valid
 // only (4x fewer MFMAs than masking all 9).  Layout: GatherEntry[cap], int32 orow[cap] (output pixel of
-// the GEMM row, -1 for padding rows), uint32 tile_taps[cap/64] (OR of the row masks of every M-tile),
-// cap = N*H*W + 4*256.
+// the GEMM row, -1 for padding rows), uint32 tile_taps[cap/64 + 1] (OR of the row masks of every M-tile),
+// int32 tile_order[cap/64 + 1] (launch slot -> M-tile: every XCD works through its eighth of all four
+// classes in turn, gather.hip), cap = N*H*W + 4*256.
 inline size_t dgrad_perm_cap(int N, int H, int W) { return (size_t)N * H * W + 4 * 256; }
 // number of GEMM rows of the permuted table for M-tile bm
 int dgrad_perm_rows(int N, int H, int W, int bm);
