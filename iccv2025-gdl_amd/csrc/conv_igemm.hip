@@ -1922,6 +1922,12 @@ no_c64:
     // a second MFMA-bound stream beside them
     if (R == 1 && S == 1 && stride == 1 && forced_cfg() == 0 && OC % 128 == 0 && (long)((M + 127) / 128) * (OC / 128) >= 256)
         c = {128, 128};
+    static int n64bm = -1;
+    if (n64bm < 0) {
+        const char* e = tune_env("GDL_PLAIN_N64_BM");  // tuning aid: M-tile of plain GEMMs whose width is not a multiple of 128
+        n64bm = e ? atoi(e) : 0;
+    }
+    if (R == 1 && S == 1 && stride == 1 && forced_cfg() == 0 && OC % 128 != 0 && n64bm == 128 && c.bm == 256) c = {128, 64};
     p.slab = 0;
     p.bm = c.bm;
     p.bn = c.bn;
