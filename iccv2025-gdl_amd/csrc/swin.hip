@@ -121,6 +121,21 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
     if (lpr > 32) v += __shfl_xor(v, 32, 64);
     return v;
 }
+// the same rotation butterfly over one DPP row of 16 lanes (every lane gets the result)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_rot<0x128>(v);
+    v += dpp_rot<0x124>(v);
+    v += dpp_rot<0x122>(v);
+    v += dpp_rot<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_rot<0x128>(v));
+    v = fmaxf(v, dpp_rot<0x124>(v));
+    v = fmaxf(v, dpp_rot<0x122>(v));
+    v = fmaxf(v, dpp_rot<0x121>(v));
+    return v;
+}
 // VPL: vectors per lane (compile-time bound of ceil(vectors per row / lpr)); U: row groups in flight per wave and
 // iteration -- all their loads are issued before the first reduction, so a lane keeps U x VPL 16-byte loads in flight
 // instead of one (the one-row form ran at ~1 TB/s).
@@ -781,8 +796,7 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                         acc[jt][r] = a;
                         mx = fmaxf(mx, a);
                     }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    mx = row16_max(mx);  // (DPP rotations within the 16 lanes that share a query row, not ds_bpermute round trips)
                     float den = 0.f;
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
@@ -790,8 +804,7 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                         acc[jt][r] = e;
                         den += e;
                     }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+                    den = row16_sum(den);
                     const float inv = 1.f / den;
                     float pd = 0.f;
 #pragma unroll
@@ -799,8 +812,7 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                         acc[jt][r] *= inv;  // P
                         pd += acc[jt][r] * dp[jt][r];
                     }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
+                    pd = row16_sum(pd);
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
                         const bool in = i < Tn && 16 * jt + l16 < Tn;
