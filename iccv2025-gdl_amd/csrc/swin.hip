@@ -524,6 +524,13 @@ struct SwinMfmaLds {              // per wave
     int tok[SW_TP];               // slot -> token row of the image (-1: padding slot)
     uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];  // slot -> window row, column, mask region
 };
+// ordering of one wave's LDS writes against its own later reads (other lanes' data): the LDS unit executes a wave's instructions
+// in order; the compiler must not reorder them either
+__device__ __forceinline__ void sw_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ bf16x8_t sw_ld_frag(const bf16* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
 __device__ __forceinline__ bf16x8_t sw_zero_frag() { return __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u)); }
 
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
             S.Vt[2 * d2 + 1][lane] = (uint16_t)(vw[d2] >> 16);
         }
     }
-    __syncthreads();
+    sw_wave_sync();  // (the LDS tiles are this wave's own: no block barrier -- four independent waves would wait for each other)
     // Q / K fragments: tile t covers slots 16 t + l16; this lane's 8 channels start at 8 lq
     bf16x8_t qf[4], kf[4];
 #pragma unroll
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
             *(uint2*)&S.Ps[i][16 * jt + 4 * lq] = make_uint2(pack2bf(acc[jt][it][0] * inv, acc[jt][it][1] * inv),
                                                              pack2bf(acc[jt][it][2] * inv, acc[jt][it][3] * inv));
     }
-    __syncthreads();
+    sw_wave_sync();  // (the LDS tiles are this wave's own: no block barrier -- four independent waves would wait for each other)
     // O = P V, computed transposed (operands swapped, V^T rows taken in the order 8 q + r / 8 q + 4 + r: see sw_bwd_product):
     // a lane owns eight consecutive channels of one query and stores them as one 16-byte vector
     f32x4_t o[4][2];
