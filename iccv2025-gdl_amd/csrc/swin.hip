@@ -675,7 +675,6 @@ struct SwinMfmaBwdLds {
                                 // from the fragment registers right before the product that reads it (round 3: ONE buffer instead
                                 // of three, 15 instead of 24 KB per wave: ten instead of six waves per CU)
     float tab[(2 * 7 - 1) * (2 * 7 - 1)];
-    float tg[(2 * 7 - 1) * (2 * 7 - 1)];  // d(table) of this block's windows (LDS float adds, see the kernel)
     int tok[SW_TP];
     uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
 };
@@ -731,14 +730,13 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
     const int h = blockIdx.x % g.nh, grp = (blockIdx.x / g.nh) % ngrp;
     const size_t img_row0 = (size_t)(blockIdx.x / (g.nh * ngrp)) * L;
     const float scale = 0.17677669529663687f;
-    for (int r = lane; r < tw * tw; r += 64) {
-        S.tab[r] = table[r * g.nh + h];
-        S.tg[r] = 0.f;
-    }
-    // d(bias): every dS_ij belongs to table entry (ri - rj, ci - cj) -- the index the forward bias lookup uses -- and is added
-    // there with an LDS float add.  (Round 2 kept the (i, j) pairs of a lane in 64 fp32 registers across the whole window loop
-    // and folded them at the end: with the fragments and the two packed tiles that was 256 registers + 296 bytes of scratch per
-    // lane.  One wave per block and program order make the LDS adds deterministic.)
+    for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
+    // d(bias): table entry (dh, dw) collects dS_ij over the pairs with (ri - rj, ci - cj) = (dh, dw).  A lane owns the entries
+    // lane, lane + 64, lane + 128 and gathers their pairs from the dS^T tile of every window (bf16, the values dK is computed
+    // from) into three fp32 registers.  (Round 2 kept all (i, j) pairs of a lane in 64 fp32 registers across the window loop --
+    // 256 registers + 296 bytes of scratch; LDS float adds at the lookup index, `ds_add_f32`, cost 500 clk per instruction:
+    // 43 % of the kernel, tools/probe_attn_bwd.py.)
+    float tga[3] = {0.f, 0.f, 0.f};
     for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
         __syncthreads();  // (the previous window's operand tiles are no longer read)
         {
@@ -789,15 +787,13 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                     const int i = 16 * it + 4 * lq + r;
                     const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
                     float mx = -3.0e38f;
-                    int tix[4];
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) {
                         float a = acc[jt][r] * scale;
-                        tix[jt] = (ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1);
                         if (16 * jt + l16 >= Tn)
                             a = -3.0e38f;
                         else if (i < Tn) {
-                            a += S.tab[tix[jt]];
+                            a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
                             if (g.shift && gi != gj[jt]) a -= 100.f;
                         }
                         acc[jt][r] = a;
@@ -825,7 +821,6 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                         const bool in = i < Tn && 16 * jt + l16 < Tn;
                         const float p = in ? acc[jt][r] : 0.f;
                         const float ds = p * (dp[jt][r] - pd);
-                        if (in) atomicAdd(&S.tg[tix[jt]], ds);
                         acc[jt][r] = p;
                         dp[jt][r] = ds;
                     }
@@ -837,6 +832,20 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                 }
             }
         }
+        // ---- dV = P^T dO  (first: P^T and dO are dead afterwards -- the order dV, dQ, dK, d(table) keeps the fewest registers live)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkp[it][jt];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
+            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
+            (void)tk;
+            sw_scatter_frag(S.Bt, of[t], 16 * t + l16, lq);
+        }
+        __syncthreads();
+        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
+        __syncthreads();
         // ---- dQ = scale dS K: the tile holds dS row-major [i][j] (2-byte stores: a lane's four values are four rows)
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -871,26 +880,30 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
         __syncthreads();
         sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
         __syncthreads();
-        // ---- dV = P^T dO
+        // the tile still holds dS^T [j][i]: this window's share of d(table)
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkp[it][jt];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
-            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            (void)tk;
-            sw_scatter_frag(S.Bt, of[t], 16 * t + l16, lq);
+        for (int q = 0; q < 3; ++q) {
+            int e = lane + 64 * q;
+            asm volatile("" : "+v"(e));  // (recomputed per window: hoisted out of the window loop, the entry's bounds would live across the strip loop)
+            if (e < tw * tw) {
+                const int dh = e / tw - (g.ws - 1), dw = e % tw - (g.ws - 1);
+                const int r0 = max(0, -dh), r1 = min(g.ws, g.ws - dh), c0 = max(0, -dw), c1 = min(g.ws, g.ws - dw);
+                float acc_e = 0.f;
+                for (int rj2 = r0; rj2 < r1; ++rj2)
+                    for (int cj2 = c0; cj2 < c1; ++cj2)
+                        acc_e += __uint_as_float((uint32_t)S.Tl[rj2 * g.ws + cj2][(rj2 + dh) * g.ws + cj2 + dw] << 16);
+                tga[q] += acc_e;
+            }
         }
-        __syncthreads();
-        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
         if (h == 0 && lane < Tn)  // padding columns of the three segments stay zero
             for (int sgm = 0; sgm < 3; ++sgm)
                 for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
     }
     __syncthreads();
     float* tp = tpart + (size_t)blockIdx.x * tw * tw;
-    for (int r = lane; r < tw * tw; r += 64) tp[r] = S.tg[r];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (lane + 64 * q < tw * tw) tp[lane + 64 * q] = tga[q];
 }
 
 // 32 consecutive channels of a token row -> LDS row (float)
