@@ -731,12 +731,11 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
     const size_t img_row0 = (size_t)(blockIdx.x / (g.nh * ngrp)) * L;
     const float scale = 0.17677669529663687f;
     for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
-    // d(bias): table entry (dh, dw) collects dS_ij over the pairs with (ri - rj, ci - cj) = (dh, dw).  A lane owns the entries
-    // lane, lane + 64, lane + 128 and gathers their pairs from the dS^T tile of every window (bf16, the values dK is computed
-    // from) into three fp32 registers.  (Round 2 kept all (i, j) pairs of a lane in 64 fp32 registers across the window loop --
+    // d(bias): table entry (dh, dw) collects dS_ij over the pairs with (ri - rj, ci - cj) = (dh, dw), gathered from the dS^T tile
+    // of every window (bf16, the values dK is computed from) into four fp32 registers per lane (see the fold below).  (Round 2 kept all (i, j) pairs of a lane in 64 fp32 registers across the window loop --
     // 256 registers + 296 bytes of scratch; LDS float adds at the lookup index, `ds_add_f32`, cost 500 clk per instruction:
     // 43 % of the kernel, tools/probe_attn_bwd.py.)
-    float tga[3] = {0.f, 0.f, 0.f};
+    float tga[4] = {0.f, 0.f, 0.f, 0.f};
     for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
         __syncthreads();  // (the previous window's operand tiles are no longer read)
         {
@@ -880,20 +879,29 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
         __syncthreads();
         sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
         __syncthreads();
-        // the tile still holds dS^T [j][i]: this window's share of d(table)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            int e = lane + 64 * q;
-            asm volatile("" : "+v"(e));  // (recomputed per window: hoisted out of the window loop, the entry's bounds would live across the strip loop)
-            if (e < tw * tw) {
-                const int dh = e / tw - (g.ws - 1), dw = e % tw - (g.ws - 1);
-                const int r0 = max(0, -dh), r1 = min(g.ws, g.ws - dh), c0 = max(0, -dw), c1 = min(g.ws, g.ws - dw);
-                float acc_e = 0.f;
-                for (int rj2 = r0; rj2 < r1; ++rj2)
-                    for (int cj2 = c0; cj2 < c1; ++cj2)
-                        acc_e += __uint_as_float((uint32_t)S.Tl[rj2 * g.ws + cj2][(rj2 + dh) * g.ws + cj2 + dw] << 16);
-                tga[q] += acc_e;
+        // the tile still holds dS^T [j][i]: this window's share of d(table).  Lane u < ws^2 owns the offsets (dh0, dw0) =
+        // (u / ws - (ws - 1), u % ws - (ws - 1)) <= 0 and their +ws partners: for EVERY key (rj, cj) exactly one of the four entries
+        // (dh0 [+ ws], dw0 [+ ws]) has its query (rj + dh, cj + dw) inside the window -- the wrapped one -- so each lane reads
+        // ws^2 elements per window, no more, no less (a lane per entry walked 1 .. ws^2 pairs: the wave paid for the longest)
+        int u = lane;
+        asm volatile("" : "+v"(u));  // (per window: hoisted out of the window loop, the offsets and bounds would live across the strip loop)
+        if (u < Tn) {
+            const int dh0 = u / g.ws - (g.ws - 1), dw0 = u % g.ws - (g.ws - 1);
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+            for (int rj2 = 0; rj2 < g.ws; ++rj2) {
+                const bool wr = rj2 + dh0 < 0;
+                const int ri2 = rj2 + dh0 + (wr ? g.ws : 0);
+                for (int cj2 = 0; cj2 < g.ws; ++cj2) {
+                    const bool wc = cj2 + dw0 < 0;
+                    const int ci2 = cj2 + dw0 + (wc ? g.ws : 0);
+                    const float v = __uint_as_float((uint32_t)S.Tl[rj2 * g.ws + cj2][ri2 * g.ws + ci2] << 16);
+                    a00 += (!wr && !wc) ? v : 0.f;
+                    a01 += (!wr && wc) ? v : 0.f;
+                    a10 += (wr && !wc) ? v : 0.f;
+                    a11 += (wr && wc) ? v : 0.f;
+                }
             }
+            tga[0] += a00, tga[1] += a01, tga[2] += a10, tga[3] += a11;
         }
         if (h == 0 && lane < Tn)  // padding columns of the three segments stay zero
             for (int sgm = 0; sgm < 3; ++sgm)
@@ -901,9 +909,14 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
     }
     __syncthreads();
     float* tp = tpart + (size_t)blockIdx.x * tw * tw;
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        if (lane + 64 * q < tw * tw) tp[lane + 64 * q] = tga[q];
+    if (lane < Tn) {  // entries (dh0 [+ ws], dw0 [+ ws]); the partners past the table's edge (dh0 = 0 or dw0 = 0) do not exist
+        const int dh0 = lane / g.ws - (g.ws - 1), dw0 = lane % g.ws - (g.ws - 1);
+        const int e0 = (dh0 + g.ws - 1) * tw + (dw0 + g.ws - 1);
+        tp[e0] = tga[0];
+        if (dw0 < 0) tp[e0 + g.ws] = tga[1];
+        if (dh0 < 0) tp[e0 + g.ws * tw] = tga[2];
+        if (dh0 < 0 && dw0 < 0) tp[e0 + g.ws * tw + g.ws] = tga[3];
+    }
 }
 
 // 32 consecutive channels of a token row -> LDS row (float)

@@ -44,6 +44,6 @@ d = dbg.cpu().numpy()
 d = d[d[:, 0] > 0]
 tot = d[:, :5].sum(1)
 print(f"{e0.elapsed_time(e1) * 1e3:.0f} us; {len(d)} blocks stamped; per block (all its windows), mean clk: total {tot.mean():.0f}")
-for k, nm in enumerate(("bookkeeping + Q/K/V/dO loads", "S, softmax, dS (strip loop)", "dS tile + K^T + dQ product", "dS^T + Q^T + dK product",
-                        "P^T + dO^T + dV product")):
+for k, nm in enumerate(("bookkeeping + Q/K/V/dO loads", "S, softmax, dS (strip loop)", "P^T + dO^T + dV product", "dS tile + K^T + dQ product",
+                        "dS^T + Q^T + dK product + d(table)")):
     print(f"  {nm:32s} {d[:, k].mean():9.0f}  {100 * d[:, k].sum() / tot.sum():5.1f} %")
