@@ -546,6 +546,22 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
     const int w = live ? (int)((unit / g.nh) % g.nwin) : 0;
     const size_t img_row0 = live ? (size_t)(unit / ((long)g.nh * g.nwin)) * L : 0;
     const int l16 = lane & 15, lq = lane >> 4;
+    // Q / K fragments: tile t covers slots 16 t + l16; this lane's 8 channels start at 8 lq.  The slot's token is computed here
+    // (not read back from the bookkeeping in LDS), so these loads go out together with the V rows below: one round trip to
+    // memory per window instead of two in series
+    bf16x8_t qf[4], kf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int slot = 16 * t + l16;
+        const int tokq = (live && slot < Tn) ? sw_token(g, w, slot, nullptr) : -1;
+        if (tokq >= 0) {
+            const bf16* base = qkv + (img_row0 + tokq) * 3 * g.ld + h * SW_HD + 8 * lq;
+            qf[t] = sw_ld_frag(base);
+            kf[t] = sw_ld_frag(base + g.ld);
+        } else {
+            qf[t] = kf[t] = sw_zero_frag();
+        }
+    }
     // slot bookkeeping + the head's bias column + V transposed
     {
         int reg = 0;
@@ -569,19 +585,6 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __r
         }
     }
     sw_wave_sync();  // (the LDS tiles are this wave's own: no block barrier -- four independent waves would wait for each other)
-    // Q / K fragments: tile t covers slots 16 t + l16; this lane's 8 channels start at 8 lq
-    bf16x8_t qf[4], kf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int tok = S.tok[16 * t + l16];
-        if (live && tok >= 0) {
-            const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
-            qf[t] = sw_ld_frag(base);
-            kf[t] = sw_ld_frag(base + g.ld);
-        } else {
-            qf[t] = kf[t] = sw_zero_frag();
-        }
-    }
     // scores, TRANSPOSED tiles: acc[jt][it][r] = S[i = 16 it + l16][j = 16 jt + 4 lq + r] -- a lane owns four consecutive keys
     // of one query, so P goes to LDS (row-major [query][key], the A operand of P V) in 8-byte stores; a query's 64 keys
     // live in 4 lanes (lq) x 4 tiles x 4 registers: the row reductions are xor-shuffles over lanes 16 and 32
