@@ -154,6 +154,12 @@ def load():
     if not os.path.exists(SO_PATH):
         raise GdlError(f"libgdl_hip.so not found at {SO_PATH}: build it with `make -C iccv2025-gdl_amd/csrc` "
                        "(or __graft_entry__.build()); there is no fallback path")
+    # ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and the device memory / streams this binding passes
+    # around are PyTorch's.  Imported first, the library's dependency resolves to that copy; loaded the other way round (the
+    # library before torch, e.g. __graft_entry__.build() followed by smoke() in one process) the library's first HIP call
+    # fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(SO_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
