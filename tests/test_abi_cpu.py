@@ -206,3 +206,17 @@ def test_swin_mirror_matches_reference_layout():
     P, _ = fx.swin_dgl_state(309, fx.SWIN_T)
     assert [n for n, _ in m.named_parameters()] == list(P)
     assert m.fusion_module.fc_out.weight.shape == (309, 512 + 768)
+
+
+def test_isa_screen_no_cross_half_packed_add():
+    """tools/check_isa.sh on the in-tree build: no object of libgdl_hip.so may contain `v_pk_add_f32 .. op_sel:[0,1] op_sel_hi:[1,0]`,
+    the packed-f32 form the SLP vectoriser makes of the epilogues' statistics and that gives run-to-run different BatchNorm sums on
+    MI355X (csrc/Makefile; the GPU side is tests/test_ops_gpu.py::test_bn_sums_determinism_full_size)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = os.path.join(root, "iccv2025-gdl_amd", "csrc", "build")
+    if not any(f.endswith(".o") for f in os.listdir(build)):
+        pytest.skip("objects not kept next to the library")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "check_isa.sh"), build], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "check_isa: 0 cross-half" in r.stdout

@@ -662,6 +662,63 @@ def test_conv_run_to_run_determinism():
                     assert torch.equal(a_, b_), (nm, (N, C, H, W, K, R, stride))
 
 
+@pytest.mark.parametrize("shape", [(192, 128, 28, 28, 256, 3, 2, 1), (192, 128, 28, 28, 128, 3, 1, 1),
+                                   (192, 256, 14, 14, 256, 3, 1, 1), (192, 64, 56, 56, 128, 1, 2, 0)])
+def test_bn_sums_determinism_full_size(shape):
+    """The statistics of the convolution epilogues at the FULL visual shapes of the B = 64 step (192 images), six runs each:
+    the forward's BatchNorm partial rows and the data gradient's BatchNorm-backward sums (ReLU bits, two partners where the tile
+    has them) must be bit-identical.  These are the shapes (two convolution waves per SIMD) where a library built WITH the SLP
+    vectoriser differs from run to run -- whole waves off by a few elements' worth -- because of one packed-f32 instruction form
+    (csrc/Makefile, tools/check_isa.sh); the small shapes of test_conv_run_to_run_determinism do not show it.  The engine's
+    int64-accumulator path adds these same per-tile sums and is covered by test_step_gpu.py::test_full_size_properties."""
+    N, C, H, W, K, R, stride, pad = shape
+    dt = L.GDL_BF16
+    st = L.cur_stream()
+    lib = L.load()
+    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(N, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+    dy = torch.randn(N, P, Q, K, device=DEV, generator=g).to(torch.bfloat16)
+    wk = torch.randn(K, R, R, C, device=DEV, generator=g).to(torch.bfloat16)
+    wc = torch.randn(C, R, R, K, device=DEV, generator=g).to(torch.bfloat16)
+    y1 = torch.randn(N, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+    y2 = torch.randn(N, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+    bits = torch.randint(0, 256, (N * H * W * C // 8,), device=DEV, generator=g, dtype=torch.int32).to(torch.uint8)
+    mean, rstd = torch.randn(C, device=DEV, generator=g) * 0.3, torch.rand(C, device=DEV, generator=g) + 0.5
+    tiles = lib.gdl_conv_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
+    btiles = lib.gdl_conv_dgrad_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
+    tf = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
+    tdg = gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, R, R, stride, pad)
+    two = R == 3 and stride == 1
+    first = None
+    for rep in range(6):
+        y = torch.full((N, P, Q, K), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dx = torch.full((N, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+        part = torch.full((tiles, K, 2), float("nan"), device=DEV)
+        bp1 = torch.full((btiles, C, 2), float("nan"), device=DEV)
+        bp2 = torch.full((btiles, C, 2), float("nan"), device=DEV)
+        L.call("gdl_conv_fwd", dt, L.ptr(x), L.ptr(wk), L.ptr(y), L.ptr(part), L.ptr(tf), N, H, W, C, K, R, R, stride, pad, st)
+        L.call("gdl_conv_dgrad_bn", dt, L.ptr(dy), L.ptr(wc), L.ptr(dx), None, L.ptr(bits), L.ptr(tdg), N, H, W, C, K, R, R, stride,
+               pad, L.ptr(y1), L.ptr(mean), L.ptr(rstd), L.ptr(bp1), L.ptr(y2) if two else None, L.ptr(mean) if two else None,
+               L.ptr(rstd) if two else None, L.ptr(bp2) if two else None, st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(part).any() and not torch.isnan(bp1).any() and (not two or not torch.isnan(bp2).any())
+        cur = (y.view(torch.int16).clone(), part.view(torch.int32).clone(), dx.view(torch.int16).clone(),
+               bp1.view(torch.int32).clone(), bp2.view(torch.int32).clone())
+        if first is None:
+            first = cur
+            # and the forward partials are the sums of the stored outputs
+            yf = y.double().view(-1, K)
+            ps = part.double().sum(0)
+            assert torch.allclose(ps[:, 0], yf.sum(0), rtol=1e-5, atol=0.5)
+            assert torch.allclose(ps[:, 1], (yf * yf).sum(0), rtol=1e-5)
+        else:
+            for a_, b_, nm in zip(first, cur, ("y", "bn partials", "dx", "bn-backward sums", "bn-backward sums (second partner)")):
+                if nm.endswith("(second partner)") and not two:
+                    continue
+                assert torch.equal(a_, b_), (nm, shape, int((a_ != b_).sum()))
+
+
 BW_SHAPES = [
     # N, C, H, W, K, R, stride, pad, mask ("bits": ReLU through relu_bits, None), two partners
     (2, 64, 17, 13, 64, 3, 1, 1, "bits", False),      # small slab / flat tile, ragged last tile

@@ -1,0 +1,26 @@
+#!/bin/bash
+# ISA screen of a built library: no kernel may contain the packed-f32 add with the halves of its SECOND source crossed,
+#     v_pk_add_f32 D, A, B op_sel:[0,1] op_sel_hi:[1,0]
+# That form is what clang's SLP vectoriser makes of `ssum[e] += f[e]` next to `ssq[e] += f[e] * f[e]` in the convolution
+# epilogues, and on MI355X it gives run-to-run different BatchNorm sums at the full-size visual shapes (round 4, DESIGN.md
+# "Toolchain note": re-assembling the compiler's own output with that one instruction replaced by two v_add_f32 -- or by the same
+# packed add with the operands commuted, op_sel:[1,0] op_sel_hi:[0,1] -- is bit-stable; wait states in front of / behind it are not).
+# The library is built with -fno-slp-vectorize, so the count must be 0; a toolchain or flag change that brings it back fails here.
+# usage: tools/check_isa.sh <build dir with the .o files>     (exit 1 if the form is present)
+set -e
+B=${1:-iccv2025-gdl_amd/csrc/build}
+LLVM=/opt/rocm/lib/llvm/bin
+T=$(mktemp -d)
+bad=0; pk=0
+for o in "$B"/*.o; do
+  $LLVM/llvm-objcopy --dump-section .hip_fatbin=$T/fb.bin "$o" 2>/dev/null || continue
+  $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fb.bin --output=$T/dev.co --unbundle 2>/dev/null || continue
+  $LLVM/llvm-objdump -d $T/dev.co > $T/dev.s
+  n=$(grep -c 'v_pk_add_f32.*op_sel:\[0,1\] op_sel_hi:\[1,0\]' $T/dev.s || true)
+  p=$(grep -c 'v_pk_\(add\|mul\|fma\)_f32' $T/dev.s || true)
+  [ "$n" != "0" ] && echo "$(basename $o): $n cross-half v_pk_add_f32"
+  bad=$((bad + n)); pk=$((pk + p))
+done
+rm -rf $T
+echo "check_isa: $bad cross-half v_pk_add_f32 (second source), $pk packed-f32 VALU instructions in $B"
+[ "$bad" = "0" ]

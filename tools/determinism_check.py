@@ -52,6 +52,21 @@ def main():
             res["stats"].append(part.view(torch.int32).clone())
             res["dgrad"].append(dx.view(torch.int16).clone())
             res["wgrad"].append(dw.view(torch.int32).clone())
+        if os.environ.get("DETAIL") and any(int((res["stats"][0] != t).sum()) for t in res["stats"][1:]):
+            # where do the statistics differ?  rows = M-tiles, columns = (channel, sum | sum of squares)
+            a = res["stats"][0].view(torch.float32)
+            for i, t in enumerate(res["stats"][1:], 1):
+                b = t.view(torch.float32)
+                d = (res["stats"][0] != t).nonzero()
+                if len(d) == 0:
+                    continue
+                tl, ch, w = d[:, 0], d[:, 1], d[:, 2]
+                print(f"   run {i} vs 0: {len(d)} words differ of {a.numel()}; tiles {tl.min().item()}..{tl.max().item()} "
+                      f"({len(tl.unique())} of {a.shape[0]}), channels {sorted(ch.unique().tolist())[:24]}, "
+                      f"which {sorted(w.unique().tolist())}, nan a/b {int(torch.isnan(a).sum())}/{int(torch.isnan(b).sum())}")
+                for j in range(min(6, len(d))):
+                    x, y_ = a[tl[j], ch[j], w[j]].item(), b[tl[j], ch[j], w[j]].item()
+                    print(f"      tile {tl[j].item()} ch {ch[j].item()} {'sum' if w[j] == 0 else 'sq '}: {x!r} vs {y_!r}  rel {abs(x - y_) / max(abs(x), 1e-30):.2e}")
         line = f"{enc} {C}x{H}x{W}->{K} {R}x{R}/{stride}:"
         for k, v in res.items():
             nd = sum(int((v[0] != t).sum()) for t in v[1:])

@@ -48,9 +48,11 @@ for shape in sys.argv[1:]:
     print(f"wgrad {shape}: {e0.elapsed_time(e1) * 1e3:.1f} us (kernel+reduce)")
     for gname, d in groups:
         d = d[d[:, 0] != 0]
+        if len(d) == 0:  # (the four-wave form has no loader waves)
+            continue
         nst = d[:, 6].mean()
-        span = (d[:, 0].max() - d[:, 0].min()) / 100.0  # s_memtime ticks at 100 MHz
-        print(f"  {gname}: {len(d)} records, {nst:.1f} stages each, entry spread {span:.1f} us")
+        span = float(d[:, 0].max() - d[:, 0].min())  # s_memtime ticks = shader cycles
+        print(f"  {gname}: {len(d)} records, {nst:.1f} stages each, entry spread {span:.0f} clk")
         for i, nm in ((1, "prologue"), (2, "wait+barrier"), (3, "issue"), (7, "masks"), (4, "compute"), (5, "epilogue")):
             v = d[:, i]
             per = f" ({v.mean() / nst:7.1f} / stage)" if i in (2, 3, 4, 7) else ""
