@@ -217,9 +217,10 @@ def build_model(wl, batch, dev):
     return model, args
 
 
-def extra_leg(name, a, dev, lib, collect, steps=10, warmup=5):
+def extra_leg(name, a, dev, lib, collect, steps=30, warmup=15):
     """A short driver-visible leg of another BASELINE configuration (N = 1): its own ms_per_step and the in-step roofline
-    of its dominant kernel.  Same step, same trainer, same taps as the main measurement."""
+    of its dominant kernel.  Same step, same trainer, same taps as the main measurement.  15 + 2 warm-up and 30 timed steps
+    (round 3's 5 + 2 / 10 read 15 % above the 100-step runs: clocks and the allocator had not settled)."""
     from gdl.trainer import DGLTrainer
 
     wl = WORKLOADS[name]
@@ -347,6 +348,9 @@ def main():
         n_ms = (ctypes.c_double * max(ns, 1))()
         n_w = (ctypes.c_double * max(ns, 1))()
         L.call("gdl_prof_collect", n_l, n_ms, n_w)
+        n_fl = (ctypes.c_double * max(ns, 1))()
+        n_by = (ctypes.c_double * max(ns, 1))()
+        L.call("gdl_prof_collect_floor", n_fl, n_by)
         table = []
         for s in range(ns):
             if n_l[s] == 0:
@@ -355,13 +359,22 @@ def main():
             rate = n_w[s] / (n_ms[s] * 1e-3)  # flop/s or byte/s
             peak = MFMA_PEAK_TFLOPS[a.dtype] if bound == "mfma" else HBM_PEAK_GBS
             ach = rate / 1e12 if bound == "mfma" else rate / 1e9
-            table.append({"kernel": lib.gdl_prof_slot_name(s).decode(), "bound": bound,
-                          "launches_per_step": n_l[s] / nsteps, "avg_us": round(n_ms[s] / n_l[s] * 1e3, 2),
-                          "ms_per_step": round(n_ms[s] / nsteps, 4), "achieved": round(ach, 2),
-                          "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(ach / peak, 4)})
+            row = {"kernel": lib.gdl_prof_slot_name(s).decode(), "bound": bound,
+                   "launches_per_step": n_l[s] / nsteps, "avg_us": round(n_ms[s] / n_l[s] * 1e3, 2),
+                   "ms_per_step": round(n_ms[s] / nsteps, 4), "achieved": round(ach, 2),
+                   "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(ach / peak, 4),
+                   # what `frac` is a fraction of: the MFMA peak (flops) or the HBM peak (bytes)
+                   "frac_of": bound}
+            if bound == "mfma" and n_by[s] > 0:
+                # combined roofline: every launch priced against the roof that binds IT, max(flop / MFMA peak, algorithmic
+                # bytes / HBM peak) -- the layer-1 launches of the convolutions sit at the HBM ridge
+                row["frac_combined"] = round(n_fl[s] / n_ms[s], 4)
+                row["algorithmic_mbytes_per_launch"] = round(n_by[s] / n_l[s] / 1e6, 2)
+            table.append(row)
         table.sort(key=lambda k: -k["ms_per_step"])
         return table
 
+    L.call("gdl_prof_set_peaks", MFMA_PEAK_TFLOPS[a.dtype] * 1e12, HBM_PEAK_GBS * 1e9)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -426,7 +439,10 @@ def main():
             pass
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
-                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"]}
+                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"], "frac_of": d["frac_of"]}
+        if "frac_combined" in d:
+            roof["combined"] = {"frac": d["frac_combined"], "algorithmic_mbytes_per_launch": d["algorithmic_mbytes_per_launch"],
+                                "note": "sum over the launches of max(flop / MFMA peak, algorithmic bytes / HBM peak) / measured time"}
     if prof and world == 1 and kernels and not wl.get("swin"):
         # The same kernels WITHOUT contention: each encoder's forward + backward on its own, weight gradients on the
         # chain's stream -- every launch has the device to itself.  The step's table says what a launch costs beside the
@@ -451,9 +467,12 @@ def main():
         for k in kernels:
             if k["kernel"] in alone:
                 k["alone_avg_us"], k["alone_frac"] = alone[k["kernel"]]["avg_us"], alone[k["kernel"]]["frac"]
+                if "frac_combined" in alone[k["kernel"]]:
+                    k["alone_frac_combined"] = alone[k["kernel"]]["frac_combined"]
         if roof and roof["kernel"] in alone:
             al = alone[roof["kernel"]]
             roof["alone"] = {"avg_launch_us": al["avg_us"], "achieved": al["achieved"], "frac": al["frac"],
+                             "frac_combined": al.get("frac_combined"),
                              "note": "same launches with nothing else on the device (encoders run one after the other, "
                                      "no side stream)"}
     phases = None
@@ -528,6 +547,20 @@ def main():
             tr.early_backward = early0
             comm["schedule_variants_ms"] = variants
             comm["default_schedule"] = f"side_stream_{'on' if side0 else 'off'}__early_backward_{'on' if early0 is not False else 'off'}"
+    if rank == 0:
+        # the headline measurement is complete here: leave it on stderr (and in gpurun_out/ when that exists) BEFORE the secondary
+        # legs below -- a hard fault in one of them (graph capture, MIOpen, an OOM kill) must not take it along
+        head = {"metric": wl["metric"], "value": round(world * B * a.steps / elapsed, 2), "unit": "samples/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "dtype": a.dtype,
+                "roofline": roof, "provisional": "headline only; the full line follows on stdout"}
+        sys.stderr.write("bench.py headline: " + json.dumps(head) + "\n")
+        sys.stderr.flush()
+        try:
+            if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                with open(os.path.join(ROOT, "gpurun_out", "bench_headline.json"), "w") as f:
+                    f.write(json.dumps(head) + "\n")
+        except OSError:
+            pass
     f32_exact = None
     if a.dtype == "bf16" and not a.no_f32:
         # the exact-parity mode (f32 storage, f32-input MFMA == an fmaf chain) on the same workload: a short run
@@ -577,6 +610,11 @@ def main():
                 comparators = {"torch_rocm": torch_rocm_comparator(wl, B, dev, find=a.comparator_find)}
             except Exception as e:
                 comparators = {"torch_rocm": {"error": f"{type(e).__name__}: {e}"}}
+    if kernels:
+        for k in kernels:
+            if k["kernel"] == "gdl::sgd_kernel":
+                k["bytes_note"] = ("20 n bytes charged: p, g, m read, p, m written; the 4 n-byte write-back of the clipped gradient "
+                                   "happens only in steps whose clip is active (config.clip_regime)")
     if world > 1:
         import torch.distributed as dist
 
@@ -593,6 +631,10 @@ def main():
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": wl["name"],
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   # which regime of clip_grad_norm_(40) the timed steps ran in (the kernels are the same; an inactive clip
+                   # skips the 4 n-byte write-back of the scaled gradients in sgd_kernel)
+                   "clip_regime": f"clip active in {int((clip_log[:, 1] < 1.0).sum())} of {a.steps} timed steps "
+                                  f"({len(data)} distinct batches cycled, {a.warmup} warm-up steps)",
                    "buckets": "fusion head | audio layer4 | audio rest | visual layer4 | visual rest, RCCL all-reduce, layer4 "
                               "buckets overlapped with the rest of the backward" if world > 1 else "none"},
         "samples_per_sec_per_gpu": round(value / world, 2),

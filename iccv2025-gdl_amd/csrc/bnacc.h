@@ -12,6 +12,11 @@
 // Fixed point: sum * 2^sh1, sum of squares * 2^sh2 with sh1 = 62 - 13 - L, sh2 = 62 - 26 - L, L = ceil(log2(rows)): exact
 // headroom for |y| < 8192 (bf16 / f32 activations of this network are O(1-100)); resolution at rows = 602 112: 3e-8 / 1.5e-5
 // per tile sum.  The accumulators of an encoder are zeroed by ONE hipMemsetAsync at the start of its forward.
+// Guard (round 4): the headroom is finite and integer wrap-around is silent, where the fp32 partial rows gave inf / NaN.  A block
+// whose sum does not fit its share of the range -- |sum * 2^sh| >= 2^62 / gridDim.x, i.e. mean |y| of the block's rows beyond
+// 8192 / (channel tiles), or a NaN / inf -- does not add it: it sets the BatchNorm's flag word (acc[2 C], cleared with the
+// accumulators) and the consumer turns the statistics of that BatchNorm into NaN, so a diverged activation is as loud as it
+// was with floats (tests/test_step_gpu.py::test_bn_accumulator_guard).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -24,6 +29,7 @@ namespace gdl {
 struct BnAcc {  // producer side (convolution epilogue)
     long long* acc;   // [C][2], zeroed; nullptr: off
     double s1, s2;    // 2^sh1, 2^sh2
+    long long* flag;  // optional: set to non-zero when a sum exceeds the headroom (see "Guard")
 };
 struct BnAccFin {  // consumer side
     const long long* acc;  // nullptr: the constants come from the scale / shift arrays (a finalize kernel wrote them)
@@ -33,6 +39,7 @@ struct BnAccFin {  // consumer side
     int64_t* nbt;
     float *save_mean, *save_rstd, *scale, *shift;
     float eps, momentum;
+    const long long* flag;  // optional: non-zero = a producer exceeded the headroom -> statistics = NaN
 };
 
 static inline void bn_acc_scales(size_t rows, double* s1, double* s2) {
@@ -46,7 +53,9 @@ static inline void bn_acc_scales(size_t rows, double* s1, double* s2) {
 // scale / shift of channel c from the totals; `publish`: also write the saved statistics and update the running ones (exactly
 // one thread per channel and launch does)
 __device__ __forceinline__ void bn_acc_channel(const BnAccFin& a, int c, bool publish, float& sc, float& sf) {
-    const double s = (double)a.acc[2 * c] * a.inv_s1, q = (double)a.acc[2 * c + 1] * a.inv_s2;
+    double s = (double)a.acc[2 * c] * a.inv_s1;
+    const double q = (double)a.acc[2 * c + 1] * a.inv_s2;
+    if (a.flag && *a.flag != 0) s = __builtin_nan("");  // (headroom exceeded somewhere in this BatchNorm: be loud)
     const double mean = s / a.count;
     double var = q / a.count - mean * mean;  // biased
     if (var < 0.0) var = 0.0;
@@ -68,9 +77,14 @@ __device__ __forceinline__ void bn_acc_channel(const BnAccFin& a, int c, bool pu
     }
 }
 // one tile's (or one persistent block's) sum -> the accumulator
-__device__ __forceinline__ void bn_acc_add(long long* acc, int c, int w, float s, double s1, double s2) {
-    const long long q = __double2ll_rn((double)s * (w ? s2 : s1));
-    (void)__hip_atomic_fetch_add((unsigned long long*)acc + 2 * c + w, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void bn_acc_add(const BnAcc& a, int c, int w, float s) {
+    const double v = (double)s * (w ? a.s2 : a.s1);
+    if (!(fabs(v) < 4.6e18 / (double)gridDim.x)) {  // (also NaN / inf) the block's share of 2^62
+        if (a.flag) (void)__hip_atomic_fetch_or((unsigned long long*)a.flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const long long q = __double2ll_rn(v);
+    (void)__hip_atomic_fetch_add((unsigned long long*)a.acc + 2 * c + w, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 

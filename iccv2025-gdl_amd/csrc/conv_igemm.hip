@@ -89,6 +89,7 @@ struct ConvArgs {
     // R*seg_Q + ow0 + i with ow0 = min(64*sg, seg_Q - 64); rows i < 64*sg - ow0 repeat the previous stage: not stored
     int seg_Q, seg_nseg, seg_stages;
     double flops;  // algorithmic work of the launch (measurement tap)
+    double hbm_bytes;  // its algorithmic HBM bytes: both activation tensors once + the filter (combined roofline, prof.h)
     // BatchNorm finalize folded into the launch (fold.h): the block that completes the statistics computes
     // mean / rstd / scale / shift and the running statistics (fold.ctr == nullptr: the caller launches bn_finalize_train)
     FoldWs fold;
@@ -210,7 +211,13 @@ struct ConvSmem {
 // PRE: the forward's bias and addend vectors are requested before the staging (the flat kernel's forward instantiations only --
 // the Swin Linears; in the slab / persistent forward kernels of the ResNets the prefetch registers cost more than they return:
 // 5.81 vs 5.69 ms when every instantiation had them)
-template <typename T, int BM, int BN, int WM, int WN, bool BWD = false, bool PRE = false>
+// F32ST (round 4; flat data-gradient kernels whose LDS holds a whole fp32 tile: the BN = 64 tiles, i.e. every gradient of a
+// 64-channel tensor): when the launch carries BatchNorm-backward sums, the accumulators are staged as fp32 and the sums are
+// taken from the values BEFORE their rounding to bf16.  A BatchNorm parameter gradient of layer 1 is the sum of 602 112 signed
+// gradients per channel that nearly cancel; summed from the stored bf16 values, the rounding errors' random walk alone was
+// ~0.1 of it (tests/test_step_gpu.py::test_full_size_bf16_against_fp64).  The stored tensor is rounded once (accumulator +
+// addend -> bf16) instead of twice.
+template <typename T, int BM, int BN, int WM, int WN, bool BWD = false, bool PRE = false, bool F32ST = false>
 __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / WM / 16], unsigned char* smem,
                                               const ConvArgs& a, int m0, int n0, int mtile, int ntile = 0) {
     constexpr int NT = WM * WN * 64;  // threads of the block (256 or 512)
@@ -291,7 +298,19 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     // accumulators -> LDS tile [BM][BN] of T.
     // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15.
     unsigned char* Cs = smem;
-    {
+    constexpr int PITCH32 = BN * 4 + 16;  // F32ST: rows of BN floats
+    static_assert(!F32ST || (BWD && sizeof(T) == 2 && BM * PITCH32 + SM::RED <= SM::BYTES), "F32ST: the fp32 tile must fit");
+    const bool f32st = F32ST && bw;
+    if (f32st) {
+        const int px_row = wm * WTM + (lane & 15);
+        const int ch = wn * WTN + (lane >> 4) * 4;
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+            for (int m = 0; m < MI; ++m)
+                *(float4*)(Cs + (px_row + m * 16) * PITCH32 + (ch + n * 16) * 4) =
+                    make_float4(acc[n][m][0], acc[n][m][1], acc[n][m][2], acc[n][m][3]);
+    } else {
         const int px_row = wm * WTM + (lane & 15);
         const int ch = wn * WTN + (lane >> 4) * 4;
 #pragma unroll
@@ -327,8 +346,40 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     for (int p = 0; p < NPASS; ++p) {
         if (om[p] < 0) continue;
         const int row = er0 + p * RPI;
-        uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
         const size_t goff = (size_t)om[p] * a.OC + n0 + ec * EPC;
+        if constexpr (F32ST) {
+            if (f32st) {  // fp32 row: addend, ReLU mask and the sums on the unrounded values, one rounding at the store
+                float f[EPC], yv[EPC];
+                *(float4*)&f[0] = *(const float4*)(Cs + row * PITCH32 + ec * 32);
+                *(float4*)&f[4] = *(const float4*)(Cs + row * PITCH32 + ec * 32 + 16);
+                if (gadd) {
+                    float g[EPC];
+                    unpack16<T>(*(const uint4*)(gadd + goff), g);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] += g[e];
+                }
+                if (a.relu_bits) {
+                    const unsigned mk = mkq[p];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
+                }
+                unpack16<T>(byq[p], yv);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    bs1[e] += f[e];
+                    bs2[e] += f[e] * (yv[e] - bmu[e]);
+                }
+                if (bw2) {
+                    float y2[EPC];
+                    unpack16<T>(*(const uint4*)((const T*)a.bw_y2 + goff), y2);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) bs3[e] += f[e] * (y2[e] - bmu2[e]);
+                }
+                *(uint4*)(gout + goff) = pack16<T>(f);
+                continue;
+            }
+        }
+        uint4 v = *(const uint4*)(Cs + row * SM::PITCH + ec * 16);
         if (gadd || a.bias) {
             float f[EPC];
             unpack16<T>(v, f);
@@ -423,7 +474,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
                 s2[e] += __shfl_xor(s2[e], msk);
             }
         }
-        float* red = (float*)(smem + SM::CS);  // [waves][BN][2]
+        float* red = (float*)(smem + (f32st ? BM * PITCH32 : SM::CS));  // [waves][BN][2]
         if (CH >= 64 || lane < CH) {
             // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
             const int c = (lane % CH) * EPC;
@@ -444,7 +495,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
             if (dst)
                 st_agent(dst + ((size_t)mtile * a.OC + n0 + c) * 2 + w, s);
             else
-                bn_acc_add(a.sacc.acc, n0 + c, w, s, a.sacc.s1, a.sacc.s2);
+                bn_acc_add(a.sacc, n0 + c, w, s);
         }
     };
     if (a.stats || a.sacc.acc) {
@@ -635,7 +686,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the (empty) tail stages before LDS is reused
     __syncthreads();
 
-    conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD, MODE == MODE_FWD>(acc, smem, a, m0, n0, mtile, ntile);
+    // (fp32 staging of the data gradient where the whole fp32 tile fits the main loop's LDS: the 64-channel-wide tiles)
+    constexpr bool F32ST = MODE == MODE_DGRAD && sizeof(T) == 2 && BM * (BN * 4 + 16) + SM::RED <= SM::BYTES;
+    conv_epilogue<T, BM, BN, WM, WN, MODE == MODE_DGRAD, MODE == MODE_FWD, F32ST>(acc, smem, a, m0, n0, mtile, ntile);
 }
 
 // =====================================================================================================
@@ -917,7 +970,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
             const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
                              red[(3 * 64 + c) * 2 + w];
             if (a.sacc.acc)
-                bn_acc_add(a.sacc.acc, c, w, s2, a.sacc.s1, a.sacc.s2);
+                bn_acc_add(a.sacc, c, w, s2);
             else
                 st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
@@ -1234,6 +1287,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 2 : ((BM >= 192 && BN == 128
 // =====================================================================================================
 constexpr int C64_BM = 128;
 constexpr int C64_GRID = 512;  // two blocks per CU of an MI355X; also the number of BatchNorm partial rows
+constexpr int C64_F32_TILE = 35 * 1024;  // BW: a slab buffer also holds the staged tile as [128][64] floats at a 272-byte pitch
 // BW (data gradient only): the BatchNorm-backward sums of the stored rows against the partner tensor a.bw_y (ops.h BwdStats,
 // one partner; optional ReLU mask), accumulated across the block's tiles like the forward's statistics -- and like the forward it
 // then keeps ONE set of pixel fragments (the accumulators take the registers of the second).
@@ -1260,7 +1314,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
     const int t_end = min(a.mtiles, (xcd + 1) * mt_per_xcd);
     int tile = xcd * mt_per_xcd + bj;
     const int nins = (a.slab_rows + 7) >> 3;
-    const int slab_bytes = nins * 1024;
+    const int slab_bytes = BW ? max(nins * 1024, C64_F32_TILE) : nins * 1024;
     const unsigned smem_base = lds_addr(smem);
     const int nbuf = a.single_slab ? 1 : 2;  // wide images: ONE slab buffer (the next tile's slab is fetched behind the row pass, exposed)
     const unsigned zrow = smem_base + nbuf * slab_bytes;
@@ -1453,11 +1507,77 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             }
         }
 
+        uint4 vq[4];
+        float ssum[8], ssq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+        float cm[8];  // BW: means of this thread's 8 channels, from the constants' LDS rows (live only during the row pass)
+        unsigned char* Cs = smem + sb * slab_bytes;
+        if constexpr (BW) {
+            // Round 4: the BatchNorm-backward sums are taken from the fp32 accumulators (+ addend, masked) BEFORE the rounding to
+            // bf16 (see conv_epilogue's F32ST): the tile is staged as [128][64] floats at a 272-byte pitch (34 KiB; the BW
+            // instantiations size their slab buffers for it, C64_F32_TILE) and rounded once, at the store.
+            constexpr int P32 = 64 * 4 + 16;
+            static_assert(C64_BM * P32 <= C64_F32_TILE, "fp32 tile");
+            // every wave is done with this slab
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            C64_SEG(2)
+            {
+                // (stores the compiler cannot see: in front of a visible LDS store it would wait, vmcnt(0), for the slab
+                // prefetch AND for the addend loads issued just above)
+                const unsigned cs0 = slab + (wm * 64 + (lane & 15)) * P32 + (wn * 32 + (lane >> 4) * 4) * 4;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(cs0), "v"(acc[n][m]), "n"(m * 16 * P32 + n * 64) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            C64_SEG(3)
+            // the prefetched slab and masks have landed (they had the whole K-loop); the stores of the tile before are done
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            C64_SEG(4)
+            asm volatile("" : "+v"(fmask[0]), "+v"(fmask[1]), "+v"(fmask[2]), "+v"(fmask[3]));
+            {  // (the means now, the rstd behind the row pass: eight registers less across it)
+                const float4* cn = (const float4*)(smem + nbuf * slab_bytes + 1024);
+                *(float4*)&cm[0] = cn[ec * 2], *(float4*)&cm[4] = cn[ec * 2 + 1];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = er0 + p * 32;
+                float f[8];
+                *(float4*)&f[0] = *(const float4*)(Cs + row * P32 + ec * 32);
+                *(float4*)&f[4] = *(const float4*)(Cs + row * P32 + ec * 32 + 16);
+                if (gadd) {
+                    float g[8];
+                    unpack16<bf16>(gq[p], g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                }
+                if (rbits) {
+                    const unsigned mk = mkq[p];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = ((mk >> e) & 1u) ? f[e] : 0.f;
+                }
+                if (m0 + row < a.M) {
+                    float yv[8];
+                    unpack16<bf16>(yq[p], yv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        ssum[e] += f[e];
+                        ssq[e] += f[e] * (yv[e] - cm[e]);  // (x rstd below)
+                    }
+                }
+                vq[p] = pack16<bf16>(f);
+            }
+        } else {
         // every wave is done with this slab: the tile is staged over it, [128][64] bf16 at a 144-byte pitch
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         C64_SEG(2)
-        unsigned char* Cs = smem + sb * slab_bytes;
         {
             // D[i][j]: i = channel = (lane>>4)*4 + reg, j = pixel = lane&15
             // (stores the compiler cannot see: in front of a visible LDS store it would wait, vmcnt(0), for the slab prefetch
@@ -1482,16 +1602,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
         // (tells the compiler the masks are here: it would otherwise wait for them -- and with them for the slab prefetch just
         // issued -- at their first use in the next tile's K-loop)
         asm volatile("" : "+v"(fmask[0]), "+v"(fmask[1]), "+v"(fmask[2]), "+v"(fmask[3]));
-        float ssum[8], ssq[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
-        float cm[16];  // BW: mean, rstd of this thread's 8 channels, from the constants' LDS rows (live only during the row pass)
-        if constexpr (BW) {
-            const float4* cn = (const float4*)(smem + nbuf * slab_bytes + 1024);
-            *(float4*)&cm[0] = cn[ec * 2], *(float4*)&cm[4] = cn[ec * 2 + 1];
-            *(float4*)&cm[8] = cn[16 + ec * 2], *(float4*)&cm[12] = cn[16 + ec * 2 + 1];
-        }
-        uint4 vq[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = er0 + p * 32;
@@ -1521,25 +1631,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                     ssq[e] += f[e] * f[e];
                 }
             }
-            if constexpr (BW) {
-                if (m0 + row < a.M) {
-                    float f[8], yv[8];
-                    unpack16<bf16>(v, f);
-                    unpack16<bf16>(yq[p], yv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        ssum[e] += f[e];
-                        ssq[e] += f[e] * (yv[e] - cm[e]);  // (a ReLU mask came through relu_bits; x rstd below)
-                    }
-                }
-            }
             vq[p] = v;
+        }
         }
         if constexpr (BW) {
             // this tile's sums -> the wave's LDS row (before the stores: an LDS access behind pending stores waits for them)
+            float rs[8];
+            {
+                const float4* cn = (const float4*)(smem + nbuf * slab_bytes + 1024);
+                *(float4*)&rs[0] = cn[16 + ec * 2], *(float4*)&rs[4] = cn[16 + ec * 2 + 1];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                ssq[e] *= cm[8 + e];
+                ssq[e] *= rs[e];
                 for (int msk = 8; msk < 64; msk <<= 1) {
                     ssum[e] += __shfl_xor(ssum[e], msk);
                     ssq[e] += __shfl_xor(ssq[e], msk);
@@ -1622,7 +1726,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             const float s2 = ((red[(0 * 64 + c) * 2 + w] + red[(1 * 64 + c) * 2 + w]) + red[(2 * 64 + c) * 2 + w]) +
                              red[(3 * 64 + c) * 2 + w];
             if (a.sacc.acc)
-                bn_acc_add(a.sacc.acc, c, w, s2, a.sacc.s1, a.sacc.s2);
+                bn_acc_add(a.sacc, c, w, s2);
             else
                 st_agent(sdst + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
@@ -1700,7 +1804,7 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, WM, WN, MODE);
-    ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true, a.hbm_bytes);
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), SM::BYTES, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv_igemm_kernel");
     return GDL_OK;
@@ -1721,7 +1825,7 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, MODE, NWV);
-    ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true, a.hbm_bytes);
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(NWV * 64), lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_slab_kernel");
     return GDL_OK;
@@ -1943,6 +2047,12 @@ static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
         if (a.bw_y) return launch_c64<MODE, true, ADD>(a, lds, st);
     if constexpr (MODE == MODE_DGRAD && !ADD)
         if (a.addend) return launch_c64<MODE, BW, true>(a, lds, st);
+    if constexpr (BW) {  // (slab buffers of at least C64_F32_TILE bytes: see the kernel)
+        const size_t sl = (size_t)((a.slab_rows + 7) / 8) * 1024;
+        const size_t need = (a.single_slab ? 1 : 2) * (sl > (size_t)C64_F32_TILE ? sl : (size_t)C64_F32_TILE) + 1024 + 512 + 2048;
+        if (need > lds) lds = need;
+        GDL_REQUIRE(lds <= (size_t)80 * 1024, "conv: LDS of the 64-channel data gradient with BatchNorm sums");
+    }
     auto kfn = conv3x3_c64_kernel<MODE, BW, ADD>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1952,7 +2062,7 @@ static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
     }
     static char pname[64] = "";
     if (!pname[0]) snprintf(pname, sizeof(pname), BW ? "gdl::conv3x3_c64_kernel<%d, true>" : "gdl::conv3x3_c64_kernel<%d>", MODE);
-    ProfScope prof(pname, PROF_MFMA, st, a.flops, true);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true, a.hbm_bytes);
     hipExtLaunchKernelGGL(kfn, dim3(C64_GRID), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_c64_kernel");
     return GDL_OK;
@@ -2115,8 +2225,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(SplitFinArgs f) {
         }
         if (st) {
             if (f.sacc.acc) {
-                bn_acc_add(f.sacc.acc, c, 0, t1, f.sacc.s1, f.sacc.s2);
-                bn_acc_add(f.sacc.acc, c, 1, t2, f.sacc.s1, f.sacc.s2);
+                bn_acc_add(f.sacc, c, 0, t1);
+                bn_acc_add(f.sacc, c, 1, t2);
             } else {
                 f.stats[((size_t)mtile * f.OC + c) * 2 + 0] = t1;
                 f.stats[((size_t)mtile * f.OC + c) * 2 + 1] = t2;
@@ -2221,6 +2331,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
     if (pl.nwv8 && fold && fold->ctr) pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad, false);  // (the fold is written for 256 threads)
     a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction
+    {
+        const double esz = dtype == GDL_BF16 ? 2.0 : 4.0;
+        a.hbm_bytes = esz * ((double)N * H * W * C + (double)N * P * Q * K + (double)K * C * R * S);
+    }
     if (fold && fold->ctr) {
         GDL_REQUIRE(stats && bn && mode == GATHER_FWD && fold_fits(pl.c64 ? C64_GRID : ceil_div(a.M, pl.bm), a.OC) && a.OC / pl.bn <= FOLD_NCG,
                     "conv: bad fold arguments");
@@ -2258,7 +2372,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
         ConvArgs b = a;  // the producing launch leaves fp32 accumulators only
         b.ksplit = ks;
         b.split_ws = (float*)split->ptr;
-        b.addend = nullptr, b.relu_bits = nullptr, b.stats = nullptr, b.sacc = BnAcc{nullptr, 0.0, 0.0};
+        b.addend = nullptr, b.relu_bits = nullptr, b.stats = nullptr, b.sacc = BnAcc{nullptr, 0.0, 0.0, nullptr};
         b.bw_y = b.bw_y2 = nullptr;
         const int rc = mode == GATHER_FWD ? launch_mode<bf16, MODE_FWD>(b, pl, st) : launch_mode<bf16, MODE_DGRAD>(b, pl, st);
         if (rc != GDL_OK) return rc;
@@ -2347,6 +2461,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     }
     GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
     a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
+    a.hbm_bytes = (dtype == GDL_BF16 ? 2.0 : 4.0) * ((double)a.M * 64 + (double)n_img * H * W * Cin + 64.0 * 49 * Cin);
     if (fold && fold->ctr) {
         GDL_REQUIRE(bn_partial && bn && fold_fits(conv_stem_tiles_m(dtype, n_img, H, W), 64), "stem: bad fold arguments");
         a.fold = *fold;
@@ -2366,7 +2481,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
                 if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_stem_pers)");
                 attr_p = true;
             }
-            ProfScope prof("gdl::conv_stem_pers_kernel", PROF_MFMA, st, a.flops, true);
+            ProfScope prof("gdl::conv_stem_pers_kernel", PROF_MFMA, st, a.flops, true, a.hbm_bytes);
             hipExtLaunchKernelGGL(conv_stem_pers_kernel, dim3(SRP_GRID), dim3(256), 8 * SRF_SLAB, st, prof.e0(), prof.e1(), 0, a, P,
                                   Hp, Wp);
             GDL_CHECK_LAUNCH("conv_stem_pers_kernel");
@@ -2379,7 +2494,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
             if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_stem_rows)");
             attr_set = true;
         }
-        ProfScope prof("gdl::conv_stem_rows_kernel", PROF_MFMA, st, a.flops, true);
+        ProfScope prof("gdl::conv_stem_rows_kernel", PROF_MFMA, st, a.flops, true, a.hbm_bytes);
         hipExtLaunchKernelGGL(conv_stem_rows_kernel, dim3((a.mtiles + 7) / 8 * 8), dim3(256), SRF_W + 4 * SRF_SLAB, st, prof.e0(),
                               prof.e1(), 0, a, P, Hp, Wp);
         GDL_CHECK_LAUNCH("conv_stem_rows_kernel");

@@ -422,7 +422,8 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     static char pname[96] = "";
     if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv_wgrad_kernel<%s, %d, %d>", prof_tname<T>(), TK, TC);
-    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.K * a.C * a.RS, true);
+    ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.K * a.C * a.RS, true,
+                   (double)a.dy_bytes + (double)a.x_bytes + 4.0 * (double)a.K * a.C * a.RS);
     hipExtLaunchKernelGGL(kfn, dim3(grid), dim3(256), BYTES, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv_wgrad_kernel");
     return GDL_OK;

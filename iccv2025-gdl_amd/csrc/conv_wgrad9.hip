@@ -607,7 +607,9 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     const int per_slice = a.tiles_k * a.tiles_c;
     const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
     {
-        ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true);
+        // (algorithmic bytes: dy and x once + the fp32 result; the partials and their fold are overhead, not algorithm)
+        ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true,
+                       2.0 * (double)a.M * (K + C) + 4.0 * (double)K * C * 9);
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
     }

@@ -115,6 +115,7 @@ struct gdl_encoder {
     bool params_set = false;
     int64_t serial = 0;
     bool have_train_fwd = false;
+    bool acc_last = false;  // the last forward ran its statistics through the integer accumulators (their flag words are valid)
     int64_t numel[GDL_ENC_NPARAMS];
     // gather tables: geometry -> workspace slot; built lazily on the first forward's stream
     struct TabJob {
@@ -146,14 +147,15 @@ size_t gdl_encoder::plan(unsigned char* base) {
     idx = (uint8_t*)b.take((size_t)n_img * h1 * w1 * 64);
     ymax = b.take((size_t)n_img * h1 * w1 * 64 * e);  // raw stem output at each pooling window's argmax
     pack_dev = b.take(32 * sizeof(PackDescHost));
-    size_t acc_ch = 64;
-    for (const Block& k : blocks) acc_ch += (size_t)k.cout * (k.has_ds ? 3 : 2);
+    // (per BatchNorm [c][2] sums + its overflow flag word, padded to 16 bytes: bnacc.h)
+    size_t acc_ch = 64 + 1;
+    for (const Block& k : blocks) acc_ch += (size_t)(k.cout + 1) * (k.has_ds ? 3 : 2);
     acc_bytes = acc_ch * 2 * sizeof(long long);
     acc_arena = (long long*)b.take(acc_bytes);
     size_t acc_used = 0;
     auto bn_alloc = [&](BN& n) {
         n.acc = acc_arena ? acc_arena + acc_used : nullptr;
-        acc_used += 2 * (size_t)n.c;
+        acc_used += 2 * (size_t)n.c + 2;
         n.scale = (float*)b.take(sizeof(float) * n.c);
         n.shift = (float*)b.take(sizeof(float) * n.c);
         n.mean = (float*)b.take(sizeof(float) * n.c);
@@ -444,6 +446,29 @@ int gdl_encoder_set_params(gdl_encoder_t* e, const float* const* params, float* 
 
 int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e) { return e ? e->serial : -1; }
 
+// Number of BatchNorms of the LAST training forward whose fixed-point statistics exceeded their headroom (bnacc.h "Guard"; their
+// statistics were turned into NaN).  ReLU swallows NaN (max(NaN, 0) = 0), so the activations alone would not show it: callers
+// that read results back (DGLTrainer.read) ask here.  Synchronises `stream`.  < 0: error code.
+int gdl_encoder_bn_overflow(gdl_encoder_t* e, void* stream) {
+    GDL_REQUIRE(e, "encoder_bn_overflow: null encoder");
+    if (!e->acc_arena || !e->acc_last) return 0;
+    std::vector<long long> host(e->acc_bytes / sizeof(long long));
+    hipError_t he = hipMemcpyAsync(host.data(), e->acc_arena, e->acc_bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+    if (he != hipSuccess) return -check_hip(he, "encoder_bn_overflow: read-back");
+    int n = 0;
+    auto flagged = [&](const BN& b) {
+        if (b.acc && host[(size_t)(b.acc - e->acc_arena) + 2 * (size_t)b.c] != 0) ++n;
+    };
+    flagged(e->bn0);
+    for (const Block& k : e->blocks) {
+        flagged(k.b1);
+        flagged(k.b2);
+        if (k.has_ds) flagged(k.bd);
+    }
+    return n;
+}
+
 #define RC(x)                 \
     do {                      \
         int rc__ = (x);       \
@@ -562,7 +587,7 @@ static bool bn_acc_on() {
     return v != 0;
 }
 static BnAcc acc_producer(const BN& n, size_t rows) {
-    BnAcc a{n.acc, 0.0, 0.0};
+    BnAcc a{n.acc, 0.0, 0.0, n.acc ? n.acc + 2 * (size_t)n.c : nullptr};
     bn_acc_scales(rows, &a.s1, &a.s2);
     return a;
 }
@@ -570,7 +595,8 @@ static BnAccFin acc_consumer(gdl_encoder* e, BN& n, size_t rows) {
     double s1, s2;
     bn_acc_scales(rows, &s1, &s2);
     return BnAccFin{n.acc, 1.0 / s1, 1.0 / s2, (double)rows, e->params[n.pidx], e->params[n.pidx + 1], e->rmean[n.bidx],
-                    e->rvar[n.bidx], e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift, 1e-5f, 0.1f};
+                    e->rvar[n.bidx], e->nbt[n.bidx], n.mean, n.rstd, n.scale, n.shift, 1e-5f, 0.1f,
+                    n.acc ? n.acc + 2 * (size_t)n.c : nullptr};
 }
 
 static BnFinTrain fin_train_args(gdl_encoder* e, BN& n, const float* partial, int tiles, double count) {
@@ -672,6 +698,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         if (he != hipSuccess) return check_hip(he, "encoder_forward: pack event");
     }
     const bool acc = training && bn_acc_on() && !fold_on() && !pers_fold_on() && !separate_stats();
+    e->acc_last = acc;
     // stem: conv1 (7x7/2) as a direct implicit GEMM over the padded input, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     // (the padding launch also clears the BatchNorm accumulators of this forward)
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st, acc ? e->acc_arena : nullptr, acc ? e->acc_bytes : 0));

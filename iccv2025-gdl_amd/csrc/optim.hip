@@ -246,6 +246,19 @@ size_t gdl_optim_workspace_bytes(const gdl_optim_t* o) {
 
 int gdl_optim_stats_len(const gdl_optim_t* o) { return o ? 4 + 2 * o->nseg : 0; }
 
+int gdl_optim_bind_workspace(gdl_optim_t* o, void* ws, size_t ws_bytes, void* stream) {
+    GDL_REQUIRE(o && ws, "optim_bind_workspace: null argument");
+    if (ws_bytes < gdl_optim_workspace_bytes(o)) {
+        set_error("optim_bind_workspace: workspace %zu < %zu", ws_bytes, gdl_optim_workspace_bytes(o));
+        return GDL_ERR_WORKSPACE;
+    }
+    GDL_REQUIRE(((uintptr_t)ws & 15) == 0, "optim_bind_workspace: workspace must be 16-byte aligned");
+    hipError_t he = hipMemcpyAsync(ws, o->h_tables.data(), o->h_tables.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (he != hipSuccess) return check_hip(he, "optim_bind_workspace: descriptor upload");
+    o->bound_ws = ws;
+    return GDL_OK;
+}
+
 int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, float grad_scale, float* stats, void* ws,
                          size_t ws_bytes, void* stream) {
     GDL_REQUIRE(o && grads && stats && ws, "optim_grad_stats: null argument");
@@ -284,7 +297,9 @@ int gdl_optim_sgd_step(gdl_optim_t* o, float* params, float* grads, float* momen
     int64_t blocks = (nv + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    ProfScope prof("gdl::sgd_kernel", PROF_HBM, (hipStream_t)stream, (double)o->total * 4.0 * 6);
+    // (p, g, m read + p, m written = 20 n bytes; the clipped gradient's 4 n-byte write-back only happens when the clip is active --
+    // decided on the device, stats[1] -- and is not charged: round 3's 24 n overstated the kernel at 0.96 of the HBM peak)
+    ProfScope prof("gdl::sgd_kernel", PROF_HBM, (hipStream_t)stream, (double)o->total * 4.0 * 5);
     hipLaunchKernelGGL(sgd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum, stats,
                        grad_scale, lr, mu, wd, o->total);
     GDL_CHECK_LAUNCH("sgd_kernel");

@@ -15,12 +15,15 @@ struct Rec {
     int slot;
     hipEvent_t e0, e1;
     double work;
+    double bytes;  // MFMA-bound launches: algorithmic HBM bytes (0 = not stated)
 };
 static std::mutex g_mu;
 static bool g_on = false;
 static std::string g_filter;  // when non-empty only launches of this kernel name are recorded
 static std::vector<Slot> g_slots;
 static std::vector<Rec> g_recs;
+static std::vector<double> g_floor_ms, g_bytes;  // per slot, filled by the last gdl_prof_collect (gdl_prof_collect_floor)
+static double g_peak_flops = 2.5e15, g_peak_bytes = 8.0e12;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 
 bool prof_enabled() { return g_on; }
@@ -49,6 +52,7 @@ int prof_begin(const char* name, int bound, hipStream_t st, bool ext) {
     Rec r;
     r.slot = slot;
     r.work = 0;
+    r.bytes = 0;
     if (!g_pool.empty()) {
         r.e0 = g_pool.back().first;
         r.e1 = g_pool.back().second;
@@ -61,11 +65,12 @@ int prof_begin(const char* name, int bound, hipStream_t st, bool ext) {
     return (int)g_recs.size() - 1;
 }
 
-void prof_end(int token, hipStream_t st, double work, bool ext) {
+void prof_end(int token, hipStream_t st, double work, bool ext, double bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (token < 0 || token >= (int)g_recs.size()) return;
     if (!ext) (void)hipEventRecord(g_recs[token].e1, st);
     g_recs[token].work = work;
+    g_recs[token].bytes = bytes;
 }
 
 }  // namespace gdl
@@ -113,6 +118,8 @@ int gdl_prof_collect(int64_t* launches, double* ms, double* work) {
     if (e != hipSuccess) return check_hip(e, "prof_collect: hipDeviceSynchronize");
     std::lock_guard<std::mutex> lk(g_mu);
     const int ns = (int)g_slots.size();
+    g_floor_ms.assign(ns, 0.0);
+    g_bytes.assign(ns, 0.0);
     for (int s = 0; s < ns; ++s) {
         launches[s] = 0;
         ms[s] = 0.0;
@@ -124,10 +131,37 @@ int gdl_prof_collect(int64_t* launches, double* ms, double* work) {
             launches[r.slot] += 1;
             ms[r.slot] += (double)t;
             work[r.slot] += r.work;
+            // per-launch floor of the combined roofline: the slower of its arithmetic and its bytes at the peaks
+            const bool mfma = g_slots[r.slot].bound == PROF_MFMA;
+            const double tf = mfma ? r.work / g_peak_flops : 0.0;
+            const double by = mfma ? r.bytes : r.work;
+            const double tb = by / g_peak_bytes;
+            g_floor_ms[r.slot] += (tf > tb ? tf : tb) * 1e3;
+            g_bytes[r.slot] += by;
         }
         g_pool.push_back({r.e0, r.e1});
     }
     g_recs.clear();
+    return GDL_OK;
+}
+
+// Combined roofline of the launches folded by the LAST gdl_prof_collect: floor_ms[s] = sum over the slot's launches of
+// max(flop / peak_flops, bytes / peak_bytes) (the peaks given to gdl_prof_set_peaks; defaults 2.5e15 / 8e12), bytes[s] = their
+// algorithmic HBM bytes (0 where a launcher states none: the floor is then the arithmetic's).  No device work.
+int gdl_prof_set_peaks(double peak_flops, double peak_bytes) {
+    GDL_REQUIRE(peak_flops > 0 && peak_bytes > 0, "prof_set_peaks: peaks must be positive");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_peak_flops = peak_flops;
+    g_peak_bytes = peak_bytes;
+    return GDL_OK;
+}
+
+int gdl_prof_collect_floor(double* floor_ms, double* bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t s = 0; s < g_floor_ms.size(); ++s) {
+        if (floor_ms) floor_ms[s] = g_floor_ms[s];
+        if (bytes) bytes[s] = g_bytes[s];
+    }
     return GDL_OK;
 }
 

@@ -28,7 +28,9 @@ bool prof_enabled();
 // launch, which on a device shared by several streams also counts the wait for free CUs.
 int prof_begin(const char* name, int bound, hipStream_t st, bool ext = false);
 // work: algorithmic flops (MFMA-bound kernels) or algorithmic bytes (HBM-bound kernels)
-void prof_end(int token, hipStream_t st, double work, bool ext = false);
+// bytes: for an MFMA-bound kernel additionally its algorithmic HBM bytes (operands once + result), so that the launch can be
+// priced against the COMBINED roofline max(flop / MFMA peak, bytes / HBM peak) -- gdl_prof_collect_floor (0: not stated)
+void prof_end(int token, hipStream_t st, double work, bool ext = false, double bytes = 0.0);
 void prof_events(int token, hipEvent_t* e0, hipEvent_t* e1);
 
 struct ProfScope {
@@ -36,10 +38,11 @@ struct ProfScope {
     hipStream_t st;
     double work;
     bool ext;
-    ProfScope(const char* name, int bound, hipStream_t s, double w, bool ext_launch = false)
-        : tok(prof_begin(name, bound, s, ext_launch)), st(s), work(w), ext(ext_launch) {}
+    double bytes;
+    ProfScope(const char* name, int bound, hipStream_t s, double w, bool ext_launch = false, double hbm_bytes = 0.0)
+        : tok(prof_begin(name, bound, s, ext_launch)), st(s), work(w), ext(ext_launch), bytes(hbm_bytes) {}
     ~ProfScope() {
-        if (tok >= 0) prof_end(tok, st, work, ext);
+        if (tok >= 0) prof_end(tok, st, work, ext, bytes);
     }
     // events for hipExtLaunchKernelGGL (null when the tap is off: a plain launch)
     hipEvent_t e0() const {

@@ -115,6 +115,7 @@ SIGNATURES = {
     "gdl_optim_destroy": (None, "p"),
     "gdl_optim_workspace_bytes": ("z", "p"),
     "gdl_optim_stats_len": ("i", "p"),
+    "gdl_optim_bind_workspace": ("i", "ppzp"),
     "gdl_optim_grad_stats": ("i", "ppffp" + "pzp"),
     "gdl_optim_sgd_step": ("i", "ppppp" + "ffff" + "p"),
     "gdl_encoder_create": ("i", "piiiiii"),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "gdl_encoder_forward": ("i", "ppippp"),
     "gdl_encoder_backward": ("i", "ppppp"),
     "gdl_encoder_forward_serial": ("l", "p"),
+    "gdl_encoder_bn_overflow": ("i", "pp"),
     "gdl_prof_enable": ("i", "i"),
     "gdl_prof_enabled": ("i", ""),
     "gdl_prof_set_filter": ("i", "s"),
@@ -137,6 +139,8 @@ SIGNATURES = {
     "gdl_prof_slot_name": ("s", "i"),
     "gdl_prof_slot_bound": ("i", "i"),
     "gdl_prof_collect": ("i", "ppp"),
+    "gdl_prof_set_peaks": ("i", "dd"),
+    "gdl_prof_collect_floor": ("i", "pp"),
 }
 
 _lib = None

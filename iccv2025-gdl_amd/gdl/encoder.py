@@ -90,6 +90,13 @@ class EncoderEngine:
     def serial(self):
         return self.lib.gdl_encoder_forward_serial(self.h)
 
+    def bn_overflow(self):
+        """BatchNorms of the last training forward whose fixed-point statistics exceeded their headroom (0 = fine).  Synchronises."""
+        n = self.lib.gdl_encoder_bn_overflow(self.h, L.cur_stream())
+        if n < 0:
+            raise L.GdlError(f"gdl_encoder_bn_overflow: error {-n}")
+        return n
+
     def backward(self, grads, dfeat=None, dfmap=None, phase=0):
         """grads: 60 float32 CUDA tensors (overwritten).  phase 0 = everything; 1 = upstream gradient + layer4 (the last
         15 gradient tensors are then final: their all-reduce can start), 2 = the rest (no dfeat / dfmap)."""

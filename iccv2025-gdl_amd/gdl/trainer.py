@@ -171,6 +171,8 @@ class DGLTrainer:
         self.opt = h
         self.opt_ws_bytes = self.lib.gdl_optim_workspace_bytes(h)
         self.opt_ws = torch.empty(max(self.opt_ws_bytes, 8), dtype=torch.uint8, device=self.device)
+        # (explicit: a caching allocator may hand out a block at the address of an earlier trainer's workspace)
+        L.call("gdl_optim_bind_workspace", self.opt, L.ptr(self.opt_ws), self.opt_ws_bytes, L.cur_stream())
         self.stats = torch.zeros(self.lib.gdl_optim_stats_len(h), device=self.device)
         self.losses = torch.zeros(3, device=self.device)  # loss_f, loss_a, loss_v
         self.s_a = torch.cuda.Stream(device=self.device)
@@ -553,6 +555,12 @@ class DGLTrainer:
         if self.mode == "dgl":
             r["out_a"] = self.out_a.cpu().numpy()
             r["out_v"] = self.out_v.cpu().numpy()
+        # a diverged BatchNorm (statistics beyond the fixed-point headroom, csrc/bnacc.h) must be as loud as the reference's
+        # inf / NaN: ReLU turns the NaN statistics' outputs into zeros, so the logits alone may look sane
+        bad = sum(e.bn_overflow() for e in (self.eng_a, self.eng_v) if e is not None and hasattr(e, "bn_overflow"))
+        if bad:
+            raise FloatingPointError(f"gdl: the statistics of {bad} BatchNorm layer(s) overflowed in the last training forward "
+                                     "(activations of mean magnitude beyond 8192: the run has diverged)")
         return r
 
     def grad(self, name):

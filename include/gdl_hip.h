@@ -373,13 +373,17 @@ GDL_API int gdl_frames_normalize(const uint8_t* frames, int64_t n_img, int H, in
  * The object owns no device memory: gdl_optim_create only builds host tables; `ws` (gdl_optim_workspace_bytes, 16-byte
  * aligned, caller-owned) holds the descriptor tables in its head -- uploaded, ordered on `stream`, the first time
  * gdl_optim_grad_stats is called with that pointer -- and the per-chunk partial sums behind them.  Keep the workspace intact
- * between calls (or pass another pointer: the tables are uploaded again). */
+ * between calls (or pass another pointer: the tables are uploaded again).  gdl_optim_bind_workspace (round 4) uploads the tables
+ * unconditionally: call it whenever the workspace memory may have changed hands without its ADDRESS changing (a caching
+ * allocator returns a freed block at the same address; another kernel scribbled over it), and before capturing
+ * gdl_optim_grad_stats into a HIP graph -- the implicit first-use upload is a pageable-memory copy, which a capture refuses. */
 typedef struct gdl_optim gdl_optim_t;
 GDL_API int gdl_optim_create(gdl_optim_t** out, const int64_t* seg_offsets, const int32_t* seg_group, int nseg);
 GDL_API void gdl_optim_destroy(gdl_optim_t* o);
 GDL_API size_t gdl_optim_workspace_bytes(const gdl_optim_t* o);
 GDL_API int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, float grad_scale, float* stats,
                                  void* ws, size_t ws_bytes, void* stream);
+GDL_API int gdl_optim_bind_workspace(gdl_optim_t* o, void* ws, size_t ws_bytes, void* stream);
 GDL_API int gdl_optim_stats_len(const gdl_optim_t* o); /* 4 + 2*nseg floats */
 GDL_API int gdl_optim_sgd_step(gdl_optim_t* o, float* params, float* grads, float* momentum, const float* stats,
                                float grad_scale, float lr, float mu, float wd, void* stream);
@@ -431,6 +435,12 @@ GDL_API int gdl_encoder_backward_phase(gdl_encoder_t* e, int phase, const float*
                                        float* const* grads, void* stream);
 /* serial number of the last training forward (to detect stale activations) */
 GDL_API int64_t gdl_encoder_forward_serial(const gdl_encoder_t* e);
+/* Round 4: the training forward's BatchNorm statistics travel through 64-bit fixed-point accumulators with finite headroom
+ * (mean |y| of a block's rows < 8192 / channel tiles).  A BatchNorm whose sums exceeded it -- or were NaN / inf -- gets NaN
+ * statistics instead of wrapped integers; since ReLU turns NaN into 0 the activations may not show it, so this returns the number
+ * of such BatchNorms in the last training forward (0 = fine; < 0 = -error code).  Synchronises `stream`.  A diverged
+ * nn.BatchNorm2d of the reference shows as inf / NaN in its outputs (backbone.py:45-48,104,144); here ask this. */
+GDL_API int gdl_encoder_bn_overflow(gdl_encoder_t* e, void* stream);
 
 /* ------------------------------------------------------------------ measurement tap
  * Optional HIP-event timing of every kernel launch (off by default).  While enabled, each
@@ -449,6 +459,12 @@ GDL_API int gdl_prof_nslots(void);
 GDL_API const char* gdl_prof_slot_name(int slot);
 GDL_API int gdl_prof_slot_bound(int slot);
 GDL_API int gdl_prof_collect(int64_t* launches, double* ms, double* work);
+/* Combined roofline (round 4; measurement only): the convolution launchers also state their algorithmic HBM bytes (operands once
+ * + result).  After gdl_prof_collect, floor_ms[s] = the sum over slot s's launches of max(flop / peak_flops, bytes / peak_bytes)
+ * -- what the launches would take at the peaks, each priced against the roof that binds it -- and bytes[s] their algorithmic
+ * bytes (either pointer may be NULL).  gdl_prof_set_peaks: the two peaks (defaults: 2.5e15 flop/s bf16 MFMA, 8e12 B/s HBM3E). */
+GDL_API int gdl_prof_set_peaks(double peak_flops, double peak_bytes);
+GDL_API int gdl_prof_collect_floor(double* floor_ms, double* bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Swin visual encoder (/root/reference/models/swin_transformer.py, which the DGL script does not

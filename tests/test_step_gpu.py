@@ -400,6 +400,45 @@ def test_encoder_golden(name, modality, dtype):
     assert relerr(ye.cpu().numpy(), g["y_eval"]) < (2e-4 if f32 else 4e-2)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bn_accumulator_guard(dtype):
+    """The forward BatchNorm statistics travel through 64-bit fixed-point accumulators (csrc/bnacc.h; the f32 parity mode too).
+    (i) Resolution: an input scaled by 2^-10 / 2^6 (stem outputs of mean magnitude ~1e-3 / ~60 instead of ~1; variances around
+    and below eps at the small scale) must still match the fp32 torch restatement -- the fixed-point sums of squares do not
+    quantise small variances away.  (ii) The headroom is finite (mean |y| of a block < 8192 / channel tiles): an input
+    scaled by 2^22 must NOT give finite garbage from wrapped integers -- the producers flag the BatchNorm, the consumer turns
+    its statistics into NaN (as float partial sums would have), and gdl_encoder_bn_overflow reports it."""
+    from models.backbone import resnet18
+
+    g = _gold("enc_audio_tiny")
+    net = resnet18(modality="audio", args=None)
+    P = fx.make_state(fx.resnet18_param_shapes("", 1))
+    Bf = fx.make_state(fx.resnet18_buffer_shapes(""))
+    _load_state(net, {**P, **Bf})
+    net = net.to(DEV)
+    net.gdl_dtype = dtype
+    net.train()
+    x = dev(g["x"])
+    from oracle.torch_step import encoder as torch_encoder
+
+    Pt = {"n." + k: torch.from_numpy(np.array(v)) for k, v in P.items()}
+    with torch.no_grad():
+        for sc in (2.0 ** -10, 1.0, 2.0 ** 6):
+            ys = net(x * sc).cpu().numpy()
+            Bt = {"n." + k: torch.from_numpy(np.array(v)).clone() for k, v in Bf.items()}
+            want = torch_encoder(torch.from_numpy(g["x"]) * sc, Pt, Bt, "n", True).numpy()
+            r = relerr(ys, want)
+            assert np.isfinite(ys).all() and r < (2e-3 if dtype == "f32" else 6e-2), (sc, r)
+        eng = net._engine(x)
+        assert eng.bn_overflow() == 0
+        net(x * 2.0 ** 22)
+        # (ReLU turns the NaN statistics' outputs into zeros, so the features may be finite: the engine is asked)
+        assert eng.bn_overflow() >= 1, "overflowing statistics must be reported, not wrapped silently"
+        assert not np.isfinite(net.bn1.running_mean.cpu().numpy()).all(), "... and the running statistics show it"
+        net(x)
+        assert eng.bn_overflow() == 0  # (per forward: the flags are cleared with the accumulators)
+
+
 @pytest.mark.parametrize("modality,shape", [("audio", (2, 1, 65, 47)), ("visual", (2, 3, 2, 64, 64))])
 def test_encoder_backward_phases(modality, shape):
     """gdl_encoder_backward_phase 1 + 2 == gdl_encoder_backward, bit for bit (same kernels, same order), with and
