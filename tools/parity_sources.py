@@ -82,7 +82,7 @@ def encoder(x, P, Bf, pre):
     return x
 
 
-def step(P0, Bf0, spec, image, label, alpha):
+def step(P0, Bf0, spec, image, label, alpha, want_grads=False):
     P = {k: torch.from_numpy(np.array(v)).double().requires_grad_(True) for k, v in P0.items()}
     Bf = {k: torch.from_numpy(np.array(v)).double() if np.array(v).dtype.kind == "f" else torch.from_numpy(np.array(v)) for k, v in Bf0.items()}
     B, _, T, H, W = image.shape
@@ -99,7 +99,28 @@ def step(P0, Bf0, spec, image, label, alpha):
     loss = (F.cross_entropy(out_a, label) + F.cross_entropy(out_v, label)) * alpha
     loss.backward()
     g = {k: float(p.grad.norm()) for k, p in P.items() if p.grad is not None and not k.startswith("fusion_module.")}
-    return torch.cat((out, out_a, out_v), 1).detach().numpy(), g
+    lo = torch.cat((out, out_a, out_v), 1).detach().numpy()
+    if want_grads:
+        return lo, g, {k: p.grad.numpy() for k, p in P.items() if p.grad is not None and not k.startswith("fusion_module.")}
+    return lo, g
+
+
+def two_steps(P0, Bf0, batches, alpha, lr=2e-3, mom=0.9, wd=1e-4, max_norm=40.0):
+    """two consecutive steps (encoder parameters only: SGD with momentum + weight decay + clip, main_dgl.py:129,154,249);
+    BatchNorm running statistics do not enter a training forward"""
+    P = {k: np.array(v, dtype=np.float64) for k, v in P0.items()}
+    res = []
+    buf = {}
+    for spec, image, label in batches:
+        lo, g, grads = step(P, Bf0, spec, image, label, alpha, want_grads=True)
+        res.append((lo, g))
+        total = float(np.sqrt(sum(float((v * v).sum()) for v in grads.values())))
+        clip = min(1.0, max_norm / (total + 1e-6))
+        for k, gv in grads.items():
+            d = gv * clip + wd * P[k]
+            buf[k] = d if k not in buf else mom * buf[k] + d
+            P[k] = P[k] - lr * buf[k]
+    return res
 
 
 def main():
@@ -107,11 +128,27 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 1, 64))
     ap.add_argument("--sources", default="w,in,y,a,dy,dx,all")
+    ap.add_argument("--two-steps", action="store_true", help="two consecutive steps with every source on: the deviation of the SECOND step")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     P0, Bf0 = fx.model_state(6, "concat_dgl")
     spec, image, label = fx.make_batch(0, args.batch, [257, 188], 3, [224, 224], 6)
     spec, image, label = torch.from_numpy(spec).double(), torch.from_numpy(image).double(), torch.from_numpy(label).long()
+    if args.two_steps:
+        b = [(spec, image, label)]
+        s2, i2, l2 = fx.make_batch(1, args.batch, [257, 188], 3, [224, 224], 6)
+        b.append((torch.from_numpy(s2).double(), torch.from_numpy(i2).double(), torch.from_numpy(l2).long()))
+        ON.clear()
+        ref = two_steps(P0, Bf0, b, 4.0)
+        ON.update(["w", "in", "y", "a", "dy", "dx"])
+        got = two_steps(P0, Bf0, b, 4.0)
+        for st, ((lo0, g0), (lo, g)) in enumerate(zip(ref, got)):
+            rel = {k: abs(g[k] - g0[k]) / g0[k] for k in g0}
+            wk = max(rel, key=rel.get)
+            tn0, tn = np.sqrt(sum(v * v for v in g0.values())), np.sqrt(sum(v * v for v in g.values()))
+            print(f"B = {args.batch} step {st}, all bf16 storage points on vs none: logits {np.abs(lo - lo0).max():.2e}, total norm "
+                  f"{abs(tn - tn0) / tn0:.2e}, per-tensor norms worst {rel[wk]:.4f} ({wk}), median {np.median(list(rel.values())):.4f}", flush=True)
+        return
     ON.clear()
     lo0, g0 = step(P0, Bf0, spec, image, label, 4.0)
     watch = ["visual_net.layer1.1.bn1.bias", "audio_net.layer1.1.bn2.bias", "visual_net.layer1.1.bn1.weight", "visual_net.layer1.0.bn2.bias",
