@@ -514,7 +514,14 @@ def main():
         t_nc = float(t.item())
         tot = sum(buckets_ms.values())
         exposed = max(0.0, elapsed / a.steps * 1e3 - t_nc)
-        comm = {"allreduce_alone_ms": buckets_ms, "allreduce_alone_sum_ms": round(tot, 4), "step_ms_without_comm": round(t_nc, 3),
+        sent0, calls0 = tr.reducer.bytes_sent, tr.reducer.calls
+        step()
+        torch.cuda.synchronize()
+        barrier()
+        comm = {**tr.reducer.describe(),
+                # what ONE step hands to all-reduce calls (five buckets = the whole 22.4 M-parameter gradient arena once)
+                "allreduce_bytes_per_step": tr.reducer.bytes_sent - sent0, "allreduce_calls_per_step": tr.reducer.calls - calls0,
+                "allreduce_alone_ms": buckets_ms, "allreduce_alone_sum_ms": round(tot, 4), "step_ms_without_comm": round(t_nc, 3),
                 "exposed_ms": round(exposed, 3), "overlapped_frac": round(1.0 - min(1.0, exposed / tot), 4) if tot > 0 else None,
                 "bucket_mbytes": {k: round((hi - lo) * 4 / 1e6, 3) for k, (lo, hi) in tr.bucket.items()}}
         # The two schedule choices that a one-GPU lease cannot decide, measured here on first contact with

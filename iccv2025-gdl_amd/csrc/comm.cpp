@@ -28,6 +28,7 @@ struct Rccl {
     AllReduceFn all_reduce = nullptr;
     CommDestroyFn comm_destroy = nullptr;
     GetErrorStringFn error_string = nullptr;
+    int (*comm_count)(void*, int*) = nullptr;  // ncclCommCount: the communicator's own idea of its size
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -51,6 +52,7 @@ int load_rccl() {
     r.all_reduce = (AllReduceFn)dlsym(h, "ncclAllReduce");
     r.comm_destroy = (CommDestroyFn)dlsym(h, "ncclCommDestroy");
     r.error_string = (GetErrorStringFn)dlsym(h, "ncclGetErrorString");
+    r.comm_count = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
     if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.comm_destroy) {
         set_error("gdl_comm: librccl lacks the NCCL API symbols");
         dlclose(h);
@@ -105,7 +107,14 @@ int gdl_comm_init(gdl_comm_t** out, int rank, int world, const void* id128) {
     return GDL_OK;
 }
 
-int gdl_comm_world(const gdl_comm_t* c) { return c ? c->world : 0; }
+// the number of ranks AS RCCL REPORTS IT (ncclCommCount) -- what bench.py prints as comm.nranks, so that "did RCCL see N ranks" can be
+// read off the line; falls back to the size the communicator was created with if the library lacks the symbol
+int gdl_comm_world(const gdl_comm_t* c) {
+    if (!c) return 0;
+    int n = 0;
+    if (g_rccl.comm_count && c->comm && g_rccl.comm_count(c->comm, &n) == 0 && n > 0) return n;
+    return c->world;
+}
 
 int gdl_comm_allreduce_bucket(gdl_comm_t* c, float* grads, size_t count, void* stream) {
     GDL_REQUIRE(c && c->comm && (grads || count == 0), "comm_allreduce_bucket: bad arguments");

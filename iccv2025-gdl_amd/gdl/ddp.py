@@ -59,6 +59,8 @@ class BucketReducer:
             self.comm, self._L = h, L
         elif backend not in ("torch", "abi"):
             raise ValueError(f"BucketReducer: unknown backend {backend!r}")
+        self.bytes_sent = 0  # bytes handed to all-reduce calls since construction (describe())
+        self.calls = 0
         self.pending = {}
         self.enabled = True  # False: launch() / wait_all() keep their bookkeeping but move no data (bench.py times the
         #                      step without its collectives to report how much of them the backward hides)
@@ -71,6 +73,17 @@ class BucketReducer:
     def grad_scale(self):
         return 1.0 / self.world
 
+    def describe(self):
+        """Who moves the buckets, and between how many ranks AS THE COMMUNICATOR REPORTS IT: ncclCommCount through gdl_comm_world for
+        the 'abi' backend, torch.distributed's world size + backend name otherwise (bench.py's comm.nranks)."""
+        if self.comm is not None:
+            return {"backend": "abi (gdl_comm_*: RCCL bound by the extension)", "nranks": int(self._L.load().gdl_comm_world(self.comm)),
+                    "nranks_source": "ncclCommCount"}
+        if dist.is_initialized():
+            return {"backend": f"torch.distributed/{dist.get_backend(self.pg)}", "nranks": int(dist.get_world_size(self.pg)),
+                    "nranks_source": "dist.get_world_size"}
+        return {"backend": "none", "nranks": 1, "nranks_source": "no process group"}
+
     def launch(self, name):
         """Start the sum-all-reduce of one bucket on the current stream's dependency chain.
         Each bucket may be launched once per step."""
@@ -80,6 +93,8 @@ class BucketReducer:
         if (self.world == 1 and not self.force_comm) or not self.enabled or hi <= lo:
             self.pending[name] = None
             return
+        self.bytes_sent += (hi - lo) * self.flat.element_size()
+        self.calls += 1
         if self.comm is not None:
             cur = torch.cuda.current_stream(self.flat.device)
             self.cstream.wait_stream(cur)

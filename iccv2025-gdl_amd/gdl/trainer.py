@@ -118,6 +118,8 @@ class DGLTrainer:
         # the visual branch: ResNet18 (60 tensors, 512 features) or the Swin composition of SURVEY row N4
         # (models.basic_model.AVClassifier_DGL_Swin: gdl.swin.SwinEngine, num_features wide)
         self.vis_swin = hasattr(model.visual_net, "cfg") and hasattr(model.visual_net, "num_features")
+        if self.vis_swin and getattr(model.visual_net, "drop_path_rate", 0.0) > 0:
+            raise L.GdlError("DGLTrainer: the Swin branch trains with drop_path_rate = 0 only (stochastic depth is random per sample)")
         self.nv = len(named) - nf - 60
         self.dv = int(model.visual_net.num_features) if self.vis_swin else 512
         if self.vis_swin and (self.head != "concat" or mode != "dgl"):

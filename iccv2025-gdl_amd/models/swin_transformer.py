@@ -132,10 +132,14 @@ class SwinTransformer(nn.Module):
         super().__init__()
         if getattr(args, "pe", 0):
             raise NotImplementedError("gdl: SwinTransformer with args.pe (the DUL branch) is not built")
-        if ape or not patch_norm or qk_scale is not None or drop_rate or attn_drop_rate or drop_path_rate or in_chans != 3 or \
+        if ape or not patch_norm or qk_scale is not None or drop_rate or attn_drop_rate or in_chans != 3 or \
                 norm_layer is not nn.LayerNorm or not qkv_bias or modality != 'visual':
             raise NotImplementedError("gdl: SwinTransformer supports modality='visual', ape=False, patch_norm=True, qkv_bias=True, "
-                                      "in_chans=3 and drop_rate = attn_drop_rate = drop_path_rate = 0 (pass drop_path_rate=0.)")
+                                      "in_chans=3 and drop_rate = attn_drop_rate = 0")
+        # Stochastic depth (the reference constructor's default is 0.1, swin_transformer.py:516): DropPath is the identity in
+        # eval mode (:546 via timm), so a default-constructed model evaluates here; a TRAINING forward with a rate > 0 draws
+        # random per-sample masks, which the engine does not -- forward() refuses that combination (pass drop_path_rate=0.).
+        self.drop_path_rate = float(drop_path_rate)
         if any(embed_dim * 2 ** i != 32 * h for i, h in enumerate(num_heads)) or mlp_ratio != int(mlp_ratio):
             raise NotImplementedError("gdl: SwinTransformer needs head dimension 32 and an integer mlp_ratio")
         self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
@@ -188,10 +192,17 @@ class SwinTransformer(nn.Module):
     def forward_features(self, x):
         raise NotImplementedError("gdl: the token map is internal to the engine; use forward()")
 
+    def _check_mode(self):
+        if self.training and self.drop_path_rate > 0:
+            raise NotImplementedError("gdl: SwinTransformer in training mode needs drop_path_rate=0. (stochastic depth is random per "
+                                      f"sample; this model was built with {self.drop_path_rate}); eval mode is fine")
+
     def forward(self, x):
+        self._check_mode()
         return _SwinFn.apply(self, False, x, *self.parameters())
 
     def forward_pooled(self, x):
         """[B, 3, T, H, W] -> [B, num_features]: the features averaged over the T frames of a sample (not a method of the
         reference class; the counterpart of the pooling basic_model.py:77-80 applies to the ResNet branch)."""
+        self._check_mode()
         return _SwinFn.apply(self, x.shape[2] > 1, x, *self.parameters())

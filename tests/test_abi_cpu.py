@@ -198,8 +198,13 @@ def test_swin_mirror_matches_reference_layout():
         assert "layers.0.blocks.0.attn.relative_position_index" in bufs and "layers.0.blocks.1.attn_mask" in bufs
         assert "layers.0.blocks.0.attn_mask" not in bufs  # un-shifted blocks have none (a None buffer is not in the state)
         assert net.num_features == cfg["embed"] << (len(cfg["depths"]) - 1)
+    # the reference's default drop_path_rate = 0.1 (swin_transformer.py:516): DropPath is the identity in eval mode, so the model
+    # is constructible and evaluates; a TRAINING forward (random per-sample masks) is refused before anything touches the GPU
+    dflt = SwinTransformer(args, "visual", embed_dim=96, depths=[2, 2], num_heads=[3, 6])
+    assert dflt.drop_path_rate == pytest.approx(0.1)
+    dflt.train()
     with pytest.raises(NotImplementedError):
-        SwinTransformer(args, "visual")  # the reference's default drop_path_rate = 0.1 is stochastic
+        dflt(torch.zeros(1, 3, 224, 224))
     with pytest.raises(NotImplementedError):
         SwinTransformer(argparse.Namespace(pe=1), "visual", drop_path_rate=0.)
     m = AVClassifier_DGL_Swin(argparse.Namespace(fusion_method="concat", dataset="VGGSound", modality="full", pe=0))

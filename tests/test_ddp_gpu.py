@@ -64,8 +64,7 @@ def _worker(rank, world, port, q, backend="gloo", comm_backend="torch", early=No
     dist.destroy_process_group()
 
 
-def _two_rank_vs_oracle(backend="gloo", comm_backend="torch", early=None, side=None):
-    world = 2
+def _two_rank_vs_oracle(backend="gloo", comm_backend="torch", early=None, side=None, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -76,11 +75,12 @@ def _two_rank_vs_oracle(backend="gloo", comm_backend="torch", early=None, side=N
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    # both ranks hold the same parameters and the same (global) gradient norm
-    assert res[0][1] == pytest.approx(res[1][1], rel=1e-6)
-    for k in res[0][3]:
-        np.testing.assert_array_equal(res[0][3][k], res[1][3][k])
-    # oracle emulation of the 2-rank step
+    # every rank holds the same parameters and the same (global) gradient norm
+    for r in range(1, world):
+        assert res[0][1] == pytest.approx(res[r][1], rel=1e-6)
+        for k in res[0][3]:
+            np.testing.assert_array_equal(res[0][3][k], res[r][3][k])
+    # oracle emulation of the N-rank step
     sys.path.insert(0, ROOT)
     from oracle import fixtures as fx
     from oracle import oracle as orc
@@ -95,7 +95,7 @@ def _two_rank_vs_oracle(backend="gloo", comm_backend="torch", early=None, side=N
         grads.append(r["grads"])
         losses.append(r["loss_f"])
     P, _ = fx.model_state(ncls, "concat_dgl")
-    avg = {k: (grads[0][k] + grads[1][k]) * np.float32(0.5) for k in grads[0]}
+    avg = {k: sum(g[k] for g in grads) * np.float32(1.0 / world) for k in grads[0]}
     total = float(np.sqrt(sum(orc.sumsq(g) for g in avg.values())))
     coef = min(1.0, 40.0 / (total + 1e-6))
     assert res[0][1] == pytest.approx(total, rel=5e-3)
@@ -113,6 +113,12 @@ def test_two_rank_step_matches_oracle(early, side):
     """(gloo, both ranks on cuda:0) the data-parallel default schedule, and the opt-in one: early backward (collectives issued as
     audio_l4, visual_l4, audio_rest, fusion, visual_rest over two streams) with the visual weight gradients' side stream."""
     _two_rank_vs_oracle("gloo", "torch", early, side)
+
+
+def test_four_rank_step_matches_oracle():
+    """The same check with FOUR ranks on the one device (gloo): the five buckets' issue order (audio_l4, visual_l4, audio_rest,
+    fusion, visual_rest in the early-backward form) and the 1 / world scaling beyond two ranks (VERDICT r3 next #5 ii)."""
+    _two_rank_vs_oracle("gloo", "torch", True, True, world=4)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device")
@@ -145,6 +151,10 @@ def test_bench_two_rank_control_flow():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert d["roofline"] and d["roofline"]["achieved"] > 0 and d["cpu_baseline"] is None
+    # "did the communicator see N ranks, and how many bytes went through it" is answerable from the line (VERDICT r3 next #5 i)
+    c = d["comm"]
+    assert c["nranks"] == 2 and "gloo" in c["backend"] and c["allreduce_calls_per_step"] == 5
+    assert c["allreduce_bytes_per_step"] == sum(round(v * 1e6) for v in c["bucket_mbytes"].values()) or c["allreduce_bytes_per_step"] > 80e6
 
 
 @pytest.mark.gpu
