@@ -93,8 +93,7 @@ int gdl_conv_fwd_split(int dtype, const void* x, const void* w_krsc, void* y, fl
                        int W, int C, int K, int R, int S, int stride, int pad, void* split_ws, size_t split_ws_bytes, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && x && w_krsc && y && table, "conv_fwd_split: null pointer");
     const SplitWs sk{split_ws, split_ws_bytes};
-    return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, nullptr, nullptr,
-                    nullptr, &sk);
+    return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, nullptr, &sk);
 }
 int gdl_conv_dgrad_bn_split(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const uint8_t* relu_bits,
                             const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, const void* y,
@@ -115,26 +114,6 @@ int gdl_conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx,
 int gdl_acc_to_float(const void* acc, int n, double inv_scale, float* out, void* stream) {
     GDL_REQUIRE(acc && out && n > 0, "acc_to_float: bad arguments");
     return acc_to_float((const long long*)acc, n, inv_scale, out, (hipStream_t)stream);
-}
-static FoldWs fold_ws_of(void* ws) {
-    return FoldWs{(unsigned*)ws, (double*)((unsigned char*)ws + align_up(fold_ctr_bytes(), 256))};
-}
-size_t gdl_fold_workspace_bytes(void) { return align_up(fold_ctr_bytes(), 256) + fold_gpart_bytes(); }
-int gdl_fold_workspace_init(void* fold_ws, size_t bytes, void* stream) {
-    GDL_REQUIRE(fold_ws && bytes >= gdl_fold_workspace_bytes() && ((uintptr_t)fold_ws & 15) == 0, "fold_workspace_init: bad workspace");
-    return check_hip(hipMemsetAsync(fold_ws, 0, fold_ctr_bytes(), (hipStream_t)stream), "fold_workspace_init");
-}
-int gdl_conv_fwd_bn(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
-                    int W, int C, int K, int R, int S, int stride, int pad, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, int64_t* nbt, float* save_mean, float* save_rstd, float* scale,
-                    float* shift, void* fold_ws, void* stream) {
-    GDL_REQUIRE(x && w_krsc && y && bn_partial && gamma && beta && save_mean && save_rstd && scale && shift && fold_ws,
-                "conv_fwd_bn: null pointer");
-    const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-    const FoldWs fw = fold_ws_of(fold_ws);
-    const BnFinTrain fin{bn_partial, 0, K, (double)N * P * Q, gamma, beta, running_mean, running_var, nbt, save_mean, save_rstd,
-                         scale, shift};
-    return conv_fwd(dtype, x, w_krsc, y, bn_partial, table, N, H, W, C, K, R, S, stride, pad, (hipStream_t)stream, &fw, &fin);
 }
 int gdl_conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N,
                    int H, int W, int C, int K, int R, int S, int stride, int pad, void* stream) {
@@ -224,14 +203,6 @@ int gdl_bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scal
                       void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && g && y && save_mean && save_rstd && partial, "bn_bwd_reduce: bad arguments");
     return bn_bwd_reduce(dtype, g, y, scale, shift, save_mean, save_rstd, relu_mask, partial, M, C, (hipStream_t)stream);
-}
-int gdl_bn_bwd_reduce_fin(int dtype, const void* g, const void* y, const float* scale, const float* shift,
-                          const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M, int C,
-                          double count, float* dgamma, float* dbeta, float* coef, void* fold_ws, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && g && y && save_mean && save_rstd && partial && dgamma && dbeta && coef && fold_ws,
-                "bn_bwd_reduce_fin: bad arguments");
-    return bn_bwd_reduce_fold(dtype, g, y, scale, shift, save_mean, save_rstd, relu_mask, partial, M, C, count, dgamma, dbeta,
-                              coef, fold_ws_of(fold_ws), (hipStream_t)stream);
 }
 int gdl_bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                         void* stream) {

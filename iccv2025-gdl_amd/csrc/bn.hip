@@ -11,7 +11,6 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "fold.h"
 #include "ops.h"
 #include "prof.h"
 
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd,
                                                                    float* __restrict__ partial, size_t nvec, int C,
-                                                                   size_t stride_vec, FoldWs fws, FinBwd fin) {
+                                                                   size_t stride_vec) {
     constexpr int EPC = TT<T>::EPC;
     extern __shared__ float red[];  // [rpp][C][2]
     const int cpr = C / EPC;
@@ -460,8 +459,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(const T* __re
         for (int r = 0; r < rpp; ++r) a += red[(size_t)r * C * 2 + k];
         st_agent(partial + (size_t)blockIdx.x * C * 2 + k, a);
     }
-    // the last block to arrive folds the partial rows and finalizes (dgamma, dbeta, coef): fold.h
-    if (fws.ctr) fold_finalize(partial, (int)gridDim.x, C, 0, C, (int)blockIdx.x, 0, fws, (unsigned char*)red, fin);
 }
 
 // one block per 16384 elements (8 bf16 / 16 f32 vectors per thread), at most 2048 blocks; tensors
@@ -476,8 +473,7 @@ int bn_bwd_blocks(size_t M, int C) {
 
 template <typename T>
 static int bn_bwd_reduce_t(const void* g, const void* y, const float* scale, const float* shift, const float* mean,
-                           const float* rstd, int relu_mask, float* partial, size_t M, int C, const FoldWs& fws,
-                           const FinBwd& fin, hipStream_t st) {
+                           const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
     GDL_REQUIRE(C % EPC == 0 && cpr <= BN_THREADS && BN_THREADS % cpr == 0, "bn_bwd: C=%d unsupported", C);
@@ -491,29 +487,17 @@ static int bn_bwd_reduce_t(const void* g, const void* y, const float* scale, con
     ProfScope prof(pn, PROF_HBM, st, (double)nvec * 16.0 * 2);
     if (relu_mask)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)g,
-                           (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride, fws, fin);
+                           (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)g,
-                           (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride, fws, fin);
+                           (const T*)y, scale, shift, mean, rstd, partial, nvec, C, stride);
     GDL_CHECK_LAUNCH("bn_bwd_reduce_kernel");
     return GDL_OK;
 }
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st) {
-    const FoldWs none{nullptr, nullptr};
-    const FinBwd fin{};
-    if (dtype == GDL_BF16) return bn_bwd_reduce_t<bf16>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, none, fin, st);
-    return bn_bwd_reduce_t<float>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, none, fin, st);
-}
-// the same with the finalize folded into the launch (fold.h): `count` = elements per channel the BatchNorm normalised
-// over (M, or for the stem's pooled form the stem-output pixel count)
-int bn_bwd_reduce_fold(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
-                       const float* rstd, int relu_mask, float* partial, size_t M, int C, double count, float* dgamma,
-                       float* dbeta, float* coef, const FoldWs& fws, hipStream_t st) {
-    GDL_REQUIRE(fws.ctr && fold_fits(bn_bwd_blocks(M, C), C), "bn_bwd_reduce_fold: no fold workspace / too many rows");
-    const FinBwd fin{dgamma, dbeta, coef, C, count};
-    if (dtype == GDL_BF16) return bn_bwd_reduce_t<bf16>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, fws, fin, st);
-    return bn_bwd_reduce_t<float>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, fws, fin, st);
+    if (dtype == GDL_BF16) return bn_bwd_reduce_t<bf16>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, st);
+    return bn_bwd_reduce_t<float>(g, y, scale, shift, mean, rstd, relu_mask, partial, M, C, st);
 }
 
 // Fused head of a BasicBlock's backward: do2 = dz * (z > 0) (written out: the identity / downsample
@@ -531,7 +515,7 @@ __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* _
                                                                       const float* __restrict__ rstdd, T* __restrict__ do2,
                                                                       float* __restrict__ partial2,
                                                                       float* __restrict__ partiald, size_t nvec, int C,
-                                                                      size_t stride_vec, FoldWs fws, FinBwd fin2, FinBwd find) {
+                                                                      size_t stride_vec) {
     constexpr int EPC = TT<T>::EPC;
     extern __shared__ float red[];  // [rpp][C][2] (+ the same again for the downsample branch)
     const int cpr = C / EPC;
@@ -608,21 +592,12 @@ __global__ __launch_bounds__(BN_THREADS) void block_bwd_reduce_kernel(const T* _
         st_agent(partial2 + (size_t)blockIdx.x * C * 2 + k, a);
         if (DS) st_agent(partiald + (size_t)blockIdx.x * C * 2 + k, b);
     }
-    if (fws.ctr) {  // fold.h: one ticket episode per BatchNorm (column groups 0 and 1 of the workspace)
-        fold_finalize(partial2, (int)gridDim.x, C, 0, C, (int)blockIdx.x, 0, fws, (unsigned char*)red, fin2);
-        if (DS) {
-            FoldWs w2 = fws;
-            w2.gpart += (size_t)FOLD_MAXG * FOLD_CMAX * 2;  // second group-row array
-            fold_finalize(partiald, (int)gridDim.x, C, 0, C, (int)blockIdx.x, 1, w2, (unsigned char*)red, find);
-        }
-    }
 }
 
 template <typename T>
 static int block_bwd_reduce_t(const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                               const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
-                              float* partiald, size_t M, int C, const FoldWs& fws, const FinBwd& fin2, const FinBwd& find,
-                              hipStream_t st, bool pre) {
+                              float* partiald, size_t M, int C, hipStream_t st, bool pre) {
     constexpr int EPC = TT<T>::EPC;
     const int cpr = C / EPC;
     GDL_REQUIRE(C % EPC == 0 && cpr <= BN_THREADS && BN_THREADS % cpr == 0, "block_bwd_reduce: C=%d unsupported", C);
@@ -638,7 +613,7 @@ static int block_bwd_reduce_t(const void* dz, const void* z, const void* y2, con
 #define GDL_BBR(DSV, PREV)                                                                                                  \
     hipLaunchKernelGGL((block_bwd_reduce_kernel<T, DSV, PREV>), dim3(blocks), dim3(BN_THREADS), sh, st, (const T*)dz,        \
                        (const T*)z, (const T*)y2, (const T*)yd, mean2, rstd2, meand, rstdd, (T*)do2, partial2, partiald, nvec, \
-                       C, stride, fws, fin2, find)
+                       C, stride)
     if (yd && pre) GDL_BBR(true, true);
     if (yd && !pre) GDL_BBR(true, false);
     if (!yd && pre) GDL_BBR(false, true);
@@ -649,22 +624,11 @@ static int block_bwd_reduce_t(const void* dz, const void* z, const void* y2, con
 }
 int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                      const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
-                     float* partiald, size_t M, int C, hipStream_t st, const FoldWs* fws, const BnFinBwd* fin2,
-                     const BnFinBwd* find, bool premasked) {
+                     float* partiald, size_t M, int C, hipStream_t st, bool premasked) {
     GDL_REQUIRE(premasked || (z && do2), "block_bwd_reduce: z / do2 missing");
-    FoldWs w{nullptr, nullptr};
-    FinBwd f2{}, fd{};
-    if (fws && fws->ctr) {
-        GDL_REQUIRE(fin2 && (!yd || find) && fold_fits(bn_bwd_blocks(M, C), C), "block_bwd_reduce: bad fold arguments");
-        w = *fws;
-        f2 = FinBwd{fin2->dgamma, fin2->dbeta, fin2->coef, C, fin2->count};
-        if (yd) fd = FinBwd{find->dgamma, find->dbeta, find->coef, C, find->count};
-    }
     if (dtype == GDL_BF16)
-        return block_bwd_reduce_t<bf16>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, w, f2, fd, st,
-                                        premasked);
-    return block_bwd_reduce_t<float>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, w, f2, fd, st,
-                                     premasked);
+        return block_bwd_reduce_t<bf16>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, st, premasked);
+    return block_bwd_reduce_t<float>(dz, z, y2, yd, mean2, rstd2, meand, rstdd, do2, partial2, partiald, M, C, st, premasked);
 }
 
 // dgamma = sum g'*xhat, dbeta = sum g'; coef[0][c] = dbeta/M, coef[1][c] = dgamma/M

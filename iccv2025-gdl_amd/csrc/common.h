@@ -184,4 +184,9 @@ __device__ __forceinline__ int fdiv_small(int n, int d, float rcp) {
     return q;
 }
 
+#if defined(__HIPCC__)
+// agent-scope (write-through) stores / loads of results other kernels or the host read
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 }  // namespace gdl

@@ -26,7 +26,6 @@
 
 #include "bnacc.h"
 #include "common.h"
-#include "fold.h"
 #include "gather.h"
 #include "ops.h"
 #include "prof.h"
@@ -90,10 +89,6 @@ struct ConvArgs {
     int seg_Q, seg_nseg, seg_stages;
     double flops;  // algorithmic work of the launch (measurement tap)
     double hbm_bytes;  // its algorithmic HBM bytes: both activation tensors once + the filter (combined roofline, prof.h)
-    // BatchNorm finalize folded into the launch (fold.h): the block that completes the statistics computes
-    // mean / rstd / scale / shift and the running statistics (fold.ctr == nullptr: the caller launches bn_finalize_train)
-    FoldWs fold;
-    FinTrain fin;
 #ifdef GDL_TIMING
     unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
 #endif
@@ -500,8 +495,6 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     };
     if (a.stats || a.sacc.acc) {
         tile_sums(ssum, ssq, a.sacc.acc ? nullptr : a.stats);
-        if constexpr (NT == 256)  // (the fold's thread mapping is written for 256-thread blocks)
-            if (a.fold.ctr) fold_finalize(a.stats, a.mtiles, a.OC, n0, BN, mtile, ntile, a.fold, smem, a.fin);
     }
     if (bw) {
         float k1[EPC];
@@ -974,7 +967,6 @@ __global__ __launch_bounds__(256, 2) void conv_stem_pers_kernel(ConvArgs a, int 
             else
                 st_agent(a.stats + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
-        if (a.stats && a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
     }
 }
 
@@ -1730,9 +1722,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
             else
                 st_agent(sdst + ((size_t)blockIdx.x * 64 + c) * 2 + w, s2);
         }
-        // BatchNorm finalize inside the launch (fold.h): with ONE partial row per persistent block the ticket is paid once
-        // per block life (~40 us), not once per tile -- what made the fold lose on the one-tile-per-block kernels
-        if (a.stats && a.fold.ctr) fold_finalize(a.stats, (int)gridDim.x, 64, 0, 64, (int)blockIdx.x, 0, a.fold, smem, a.fin);
     }
     GDL_STAMP(3);
 }
@@ -1771,16 +1760,8 @@ static TileCfg pick_cfg(int M, int OC, int dtype) {
     // Measured on MI355X (tools/bench_conv.py, CREMA-D B=64 shapes): 256x64 wins whenever it still
     // yields >= ~160 blocks, also for wide layers (the A panel re-read per N-tile is served by L2);
     // below that the smaller M-tiles fill the chip better.
-    // 128x128 (wide layers): 8 DMA pieces per wave and K-step instead of 256x64's 10 for the same 32 MFMAs, each A row
-    // gathered for half as many N-tiles.  Measured: the stride-2 convolutions are 10 % faster ALONE (visual forward
-    // 44 / 44 / 41 -> 40 / 39 / 36 us, data gradients 58 / 64 -> 52 / 58 us) and the step is 0.4 % slower with it (two
-    // A/B pairs, 6.05 vs 6.075 ms): off by default
-    static int bn128 = -1;
-    if (bn128 < 0) {
-        const char* e = tune_env("GDL_FLAT_BN128");  // tuning aid: the minimum block count for 128x128 tiles (0 = never)
-        bn128 = e ? atoi(e) : 0;
-    }
-    if (bn128 > 0 && OC % 128 == 0 && (long)((M + 127) / 128) * (OC / 128) >= bn128) return {128, 128};
+    // (a 128 x 128 flat tile for the wide stride-2 layers -- 10 % faster alone, 0.4 % slower in the step -- was removed in round 4:
+    // tools/experiments/r4_pruned_knobs.diff.txt)
     const long b256 = (long)((M + 255) / 256) * (OC / 64);
     if (b256 >= 160) return {256, 64};
     const long b128 = (long)((M + 127) / 128) * (OC / 64);
@@ -1820,7 +1801,6 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_slab)");
         attr_set = true;
     }
-    if (NWV != 4) GDL_REQUIRE(!a.fold.ctr, "conv: the in-launch BatchNorm finalize needs a 256-thread tile configuration");
     const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / BN) * (a.ksplit > 1 ? a.ksplit : 1);
     static char pname[96] = "";
     if (!pname[0])
@@ -2113,12 +2093,6 @@ int conv_dgrad_bm(int dtype, int N, int H, int W, int C, int K, int R, int S, in
     return plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad).bm;
 }
 
-// BatchNorm finalize arguments -> the device functor (fold.h); `count` = GEMM rows
-static FinTrain make_fin(const BnFinTrain& b, float eps, float momentum) {
-    return FinTrain{b.gamma, b.beta, b.running_mean, b.running_var, b.nbt, b.save_mean, b.save_rstd, b.scale, b.shift, b.count,
-                    eps, momentum};
-}
-
 // ---------------------------------------------------------------- split-K finish
 // One block per M-tile of the producing launch (so the per-tile statistics rows keep their count): out[row][c] = what
 // conv_epilogue would have stored from the sum of the `nsplit` fp32 partial tensors, folded in split order (deterministic):
@@ -2271,7 +2245,7 @@ size_t conv_split_ws_bytes(int dtype, int N, int H, int W, int C, int K, int R, 
 
 static int run_conv(int mode, int dtype, const void* in, const void* wt, void* out, const void* addend, float* stats,
                     const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                    hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
+                    hipStream_t st,
                     const uint8_t* relu_bits = nullptr, const void* dy_ds = nullptr, const void* w_ds = nullptr,
                     const float* bias = nullptr, void* gelu_out = nullptr, const BwdStats* bw = nullptr,
                     const BnAcc* sacc = nullptr, const void* gelu_u = nullptr, const SplitWs* split = nullptr) {
@@ -2329,17 +2303,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
     // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
     ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
-    if (pl.nwv8 && fold && fold->ctr) pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad, false);  // (the fold is written for 256 threads)
     a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction
     {
         const double esz = dtype == GDL_BF16 ? 2.0 : 4.0;
         a.hbm_bytes = esz * ((double)N * H * W * C + (double)N * P * Q * K + (double)K * C * R * S);
-    }
-    if (fold && fold->ctr) {
-        GDL_REQUIRE(stats && bn && mode == GATHER_FWD && fold_fits(pl.c64 ? C64_GRID : ceil_div(a.M, pl.bm), a.OC) && a.OC / pl.bn <= FOLD_NCG,
-                    "conv: bad fold arguments");
-        a.fold = *fold;
-        a.fin = make_fin(*bn, 1e-5f, 0.1f);
     }
     if (dy_ds) {
         GDL_REQUIRE(mode == GATHER_DGRAD && stride == 2 && R == 3 && S == 3 && pad == 1 && w_ds && !pl.slab,
@@ -2365,7 +2332,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
             for (int s2 = 0; s2 < 3; ++s2)
                 a.pshift[r * 3 + s2] = mode == GATHER_FWD ? (r - 1) * W + (s2 - 1) : (1 - r) * W + (1 - s2);
     }
-    const int ks = (split && split->ptr && !fold && !bias && !gelu_out && !gelu_u && !dy_ds) ? plan_ksplit(pl, dtype, a.M, a.OC, a.IC) : 1;
+    const int ks = (split && split->ptr && !bias && !gelu_out && !gelu_u && !dy_ds) ? plan_ksplit(pl, dtype, a.M, a.OC, a.IC) : 1;
     if (ks > 1) {
         GDL_REQUIRE(split->bytes >= (size_t)ks * a.M * a.OC * sizeof(float), "conv: split-K workspace of %zu bytes, need %zu",
                     split->bytes, (size_t)ks * a.M * a.OC * sizeof(float));
@@ -2392,9 +2359,8 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
 }
 
 int conv_fwd(int dtype, const void* x, const void* w, void* y, float* bn_partial, const void* table, int N, int H, int W,
-             int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn,
-             const BnAcc* sacc, const SplitWs* split) {
-    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st, fold, bn, nullptr,
+             int C, int K, int R, int S, int stride, int pad, hipStream_t st, const BnAcc* sacc, const SplitWs* split) {
+    return run_conv(GATHER_FWD, dtype, x, w, y, nullptr, bn_partial, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
                     nullptr, nullptr, nullptr, nullptr, nullptr, sacc, nullptr, split);
 }
 
@@ -2426,7 +2392,7 @@ int conv_stem_tiles_m(int dtype, int n_img, int H, int W) {
     return ceil_div(M, pick_cfg(M, 64, dtype).bm);
 }
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
-                  int W, int Cin, hipStream_t st, const FoldWs* fold, const BnFinTrain* bn, const BnAcc* sacc) {
+                  int W, int Cin, hipStream_t st, const BnAcc* sacc) {
     GDL_REQUIRE(dtype == GDL_BF16 || dtype == GDL_F32, "stem: bad dtype %d", dtype);
     GDL_REQUIRE(xp && wp && y && table, "stem: null pointer");
     const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
@@ -2462,11 +2428,6 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     GDL_REQUIRE(a.M < (1 << 24), "stem: M = %d exceeds 2^24", a.M);
     a.flops = 2.0 * (double)a.M * 64 * 49 * Cin;  // what the layer is worth, not the zero padding of the K-steps
     a.hbm_bytes = (dtype == GDL_BF16 ? 2.0 : 4.0) * ((double)a.M * 64 + (double)n_img * H * W * Cin + 64.0 * 49 * Cin);
-    if (fold && fold->ctr) {
-        GDL_REQUIRE(bn_partial && bn && fold_fits(conv_stem_tiles_m(dtype, n_img, H, W), 64), "stem: bad fold arguments");
-        a.fold = *fold;
-        a.fin = make_fin(*bn, 1e-5f, 0.1f);
-    }
     if (stem_rows(dtype, W)) {
         a.seg_Q = Q;
         a.seg_nseg = ceil_div(Q, 64);
@@ -2512,8 +2473,8 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
 int conv_dgrad(int dtype, const void* dy, const void* w_crsk, void* dx, const void* addend, const void* table, int N, int H,
                int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const uint8_t* relu_bits,
                const BwdStats* bw, const SplitWs* split) {
-    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
-                    nullptr, relu_bits, nullptr, nullptr, nullptr, nullptr, bw, nullptr, nullptr, split);
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st,
+                    relu_bits, nullptr, nullptr, nullptr, nullptr, bw, nullptr, nullptr, split);
 }
 
 // dx = dgrad(dy) * gelu'(u), elementwise in the epilogue (u laid out like dx), and the column sums of dx as stored added to
@@ -2524,14 +2485,14 @@ int conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, con
     GDL_REQUIRE(u, "conv_dgrad_gelu: null pointer");
     const ConvPlan pl = plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad);
     GDL_REQUIRE(!pl.c64, "conv_dgrad_gelu: not available on the 64-channel persistent kernel");
-    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
-                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, acc, u);
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, R, S, stride, pad, st,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, acc, u);
 }
 
 // forward with the epilogue's bias / residual: y = conv(x, w) + bias (+ addend), each optional (the Swin Linears)
 int conv_fwd_bias(int dtype, const void* x, const void* w, void* y, const float* bias, const void* addend, void* gelu_out,
                   const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st) {
-    return run_conv(GATHER_FWD, dtype, x, w, y, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr, nullptr, nullptr,
+    return run_conv(GATHER_FWD, dtype, x, w, y, addend, nullptr, table, N, H, W, C, K, R, S, stride, pad, st, nullptr,
                     nullptr, nullptr, bias, gelu_out);
 }
 
@@ -2539,7 +2500,7 @@ int conv_dgrad_ds(int dtype, const void* dy, const void* w_crsk, const void* dy_
                   const void* table, int N, int H, int W, int C, int K, hipStream_t st, const uint8_t* relu_bits,
                   const BwdStats* bw) {
     GDL_REQUIRE(dy_ds && w_ds_ck, "conv_dgrad_ds: null pointer");
-    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, 3, 3, 2, 1, st, nullptr, nullptr,
+    return run_conv(GATHER_DGRAD, dtype, dy, w_crsk, dx, nullptr, nullptr, table, N, H, W, C, K, 3, 3, 2, 1, st,
                     relu_bits, dy_ds, w_ds_ck, nullptr, nullptr, bw);
 }
 

@@ -104,7 +104,6 @@ struct gdl_encoder {
     size_t acc_bytes = 0;
     void* wg_ws = nullptr;
     size_t wg_ws_bytes = 0, bn_partial_floats = 0, bnb_partial_floats = 0;
-    FoldWs fold{nullptr, nullptr};  // in-launch BatchNorm finalize (fold.h): counters + group rows, used on the caller's stream
     size_t ws_bytes = 0;
     void* ws = nullptr;
     // bound tables
@@ -279,8 +278,6 @@ size_t gdl_encoder::plan(unsigned char* base) {
         sk.bytes = need;
         sk.ptr = need ? b.take(need) : nullptr;
     }
-    fold.ctr = (unsigned*)b.take(fold_ctr_bytes());
-    fold.gpart = (double*)b.take(fold_gpart_bytes());
     return align_up(b.off, 256);
 }
 
@@ -514,31 +511,9 @@ static bool wgrad_late() {
     return v != 0;
 }
 
-// In-launch BatchNorm finalize (fold.h), GDL_FOLD=1.  OFF by default: measured on MI355X (B=64 bf16 step, same box,
-// 40 steps) 6.69 ms with it against 6.22 ms with the 80 separate finalize launches -- every block pays the drain +
-// ticket round trip at its tail (bn_bwd_reduce 28 -> 58 us, the 3x3 forward +16 us per launch) and the folding block
-// two dependent trips to the memory side, which is more than the ~9 us a finalize launch costs its chain.
-static bool fold_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* env = tune_env("GDL_FOLD");
-        v = env ? atoi(env) : 0;
-    }
-    return v != 0;
-}
-
+// (The in-launch BatchNorm finalize -- "the last block folds", GDL_FOLD / GDL_PERS_FOLD -- lost twice (6.69 vs 6.22 ms in round 1;
+// 5.855 vs 5.841 ms on the persistent kernels in round 2) and was removed in round 4: tools/experiments/r4_pruned_fold.diff.txt.)
 // ReLU mask of a block output applied by the producing data gradient (default on; GDL_PREMASK=0: the block masks itself)
-// The persistent forward kernels (64 -> 64 channel layers, stem) pay the ticket once per block LIFE (512 long-lived blocks, one
-// partial row each) instead of once per tile, and there the fold costs nothing -- but it gains nothing either: 5.855 vs 5.841 ms
-// (three A/B rounds) with the ten finalize launches gone.  The step is throughput-bound, not launch-bound.  Off by default.
-static bool pers_fold_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* env = tune_env("GDL_PERS_FOLD");  // tuning aid: 1 = finalize inside the persistent kernels' launches
-        v = env ? atoi(env) : 0;
-    }
-    return v != 0;
-}
 static bool ds_fold_on() {
     static int v = -1;
     if (v < 0) {
@@ -615,14 +590,8 @@ static int conv_bn(gdl_encoder* e, Conv& c, BN& n, const void* x, void* y, int n
         return bn_finalize(e, n, training, bn_stats_tiles(M), (double)M, st);
     }
     const int tiles = conv_tiles_m(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad);
-    const bool pers = pers_fold_on() && conv_fwd_persistent(e->dtype, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad);
-    if (training && (fold_on() || pers) && fold_fits(tiles, c.cout)) {  // statistics AND finalize inside the convolution's launch
-        const BnFinTrain fin = fin_train_args(e, n, partial, tiles, (double)M);
-        return conv_fwd(e->dtype, x, c.w_krsc, y, partial, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
-                        &e->fold, &fin);
-    }
     RC(conv_fwd(e->dtype, x, c.w_krsc, y, training ? partial : nullptr, c.tab_fwd, nimg, c.h, c.w, c.cin, c.cout, c.r, c.s,
-                c.stride, c.pad, st, nullptr, nullptr, nullptr, &e->sk));
+                c.stride, c.pad, st, nullptr, &e->sk));
     return bn_finalize(e, n, training, tiles, (double)M, st);
 }
 
@@ -643,8 +612,6 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         RC(build_stem_table(dt, e->n_img, e->H, e->W, stem_taps(dt), (GatherEntry*)e->tab_stem, st));
         for (const gdl_encoder::TabJob& j : e->tab_jobs)
             RC(build_gather_table(j.mode, dt, j.N, j.H, j.W, j.C, j.K, j.R, j.S, j.stride, j.pad, (GatherEntry*)j.dst, st));
-        hipError_t he = hipMemsetAsync(e->fold.ctr, 0, fold_ctr_bytes(), st);  // ticket counters: zero once, self-resetting
-        if (he != hipSuccess) return check_hip(he, "encoder_forward: counter reset");
         e->tabs_dirty = false;
     }
     if (e->pack_dirty) {  // (re)build the descriptor table of the batched packing launch
@@ -697,25 +664,19 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         hipError_t he = hipEventRecord(e->ev_join, e->side);
         if (he != hipSuccess) return check_hip(he, "encoder_forward: pack event");
     }
-    const bool acc = training && bn_acc_on() && !fold_on() && !pers_fold_on() && !separate_stats();
+    const bool acc = training && bn_acc_on() && !separate_stats();
     e->acc_last = acc;
     // stem: conv1 (7x7/2) as a direct implicit GEMM over the padded input, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     // (the padding launch also clears the BatchNorm accumulators of this forward)
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st, acc ? e->acc_arena : nullptr, acc ? e->acc_bytes : 0));
     if (acc) {
         const BnAcc pa = acc_producer(e->bn0, e->m0);
-        RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, nullptr, nullptr, &pa));
+        RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, &pa));
     } else {
         const int tiles = conv_stem_tiles_m(dt, e->n_img, e->H, e->W);
-        if (training && (fold_on() || (pers_fold_on() && conv_stem_persistent(dt, e->W))) && fold_fits(tiles, 64)) {
-            const BnFinTrain fin = fin_train_args(e, e->bn0, e->bn_partial, tiles, (double)e->m0);
-            RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, e->bn_partial, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, &e->fold,
-                             &fin));
-        } else {
-            RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, e->n_img, e->H, e->W,
-                             e->cin, st));
-            RC(bn_finalize(e, e->bn0, training, tiles, (double)e->m0, st));
-        }
+        RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, training ? e->bn_partial : nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin,
+                         st));
+        RC(bn_finalize(e, e->bn0, training, tiles, (double)e->m0, st));
     }
     if (!GDL_SKIPPED(128)) {
         const BnAccFin f0 = acc ? acc_consumer(e, e->bn0, e->m0) : BnAccFin{};
@@ -733,7 +694,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
             auto conv = [&](const Conv& c, const BN& n, const void* x, void* y) {
                 const BnAcc pa = acc_producer(n, Mo);
                 return conv_fwd(dt, x, c.w_krsc, y, nullptr, c.tab_fwd, k.n, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
-                                nullptr, nullptr, &pa, &e->sk);
+                                &pa, &e->sk);
             };
             RC(conv(k.c1, k.b1, k.xin, k.y1));
             const BnAccFin f1 = acc_consumer(e, k.b1, Mo), f2 = acc_consumer(e, k.b2, Mo);
@@ -753,7 +714,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         if (!(GDL_SKIPPED(1) || (GDL_SKIPPED(2) && k.cout == 64)))
             RC(bn_act(dt, k.y1, k.b1.scale, k.b1.shift, nullptr, nullptr, nullptr, 1, k.a1, Mo, k.cout, st,
                       (training && bw_fuse_on()) ? k.abits : nullptr));
-        if (k.has_ds && training && !separate_stats() && !fold_on()) {
+        if (k.has_ds && training && !separate_stats()) {
             // bn2 and the downsample BatchNorm are independent: both convolutions first, ONE finalize launch for the two
             // (a finalize kernel costs the chain its whole ~6 us; 80 of them were 0.56 ms of the step)
             auto fin = [&](const Conv& c, BN& n, const float* partial) {
@@ -796,9 +757,6 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
 static int bn_backward_reduce(gdl_encoder* e, BN& n, const void* g, const void* y, int relu_mask, size_t M, double count,
                               float* const* grads, hipStream_t st) {
     const int blocks = bn_bwd_blocks(M, n.c);
-    if (fold_on() && fold_fits(blocks, n.c))
-        return bn_bwd_reduce_fold(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, count,
-                                  grads[n.pidx], grads[n.pidx + 1], n.coef, e->fold, st);
     RC(bn_bwd_reduce(e->dtype, g, y, n.scale, n.shift, n.mean, n.rstd, relu_mask, e->bnb_partial, M, n.c, st));
     return bn_bwd_finalize(e->bnb_partial, blocks, n.c, count, grads[n.pidx], grads[n.pidx + 1], n.coef, st);
 }
@@ -854,7 +812,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
     // ... and with the bn2 / downsample-BatchNorm sums of this block in e->bwB / e->bwB2 (b2_rows partial rows) when the data
     // gradient that produced dz computed them in its epilogue
     int b2_rows = phase == 2 ? e->bw_b2_rows : 0;
-    const bool fuse = bw_fuse_on() && !fold_on();
+    const bool fuse = bw_fuse_on();
     // weight gradients: forked onto the side stream (sw) once their dy exists on st
     hipStream_t sw = e->side ? e->side : st;
     auto fork = [&]() -> int {  // sw waits for everything enqueued on st so far
@@ -881,7 +839,6 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             const BnFinBwd f2{e->bnb_partial, blocks, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef};
             const BnFinBwd fd{e->bnb_partial2, blocks, k.cout, (double)Mo, k.has_ds ? grads[k.bd.pidx] : nullptr,
                               k.has_ds ? grads[k.bd.pidx + 1] : nullptr, k.has_ds ? k.bd.coef : nullptr};
-            const bool fold = fold_on() && fold_fits(blocks, k.cout);
             if (b2_rows > 0) {
                 // the sums came with dz (conv1's data gradient of the block behind this one): only the finalize is left
                 const BnFinBwd g2{e->bwB, b2_rows, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef};
@@ -894,9 +851,8 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                     RC(bn_bwd_finalize(g2.partial, g2.blocks, k.cout, (double)Mo, g2.dgamma, g2.dbeta, g2.coef, st));
             } else
             RC(block_bwd_reduce(dt, dz, k.z, k.y2, k.has_ds ? k.yd : nullptr, k.b2.mean, k.b2.rstd, k.has_ds ? k.bd.mean : nullptr,
-                                k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st,
-                                fold ? &e->fold : nullptr, &f2, &fd, premasked));
-            if (!fold && b2_rows == 0) {
+                                k.has_ds ? k.bd.rstd : nullptr, do2, e->bnb_partial, e->bnb_partial2, Mo, k.cout, st, premasked));
+            if (b2_rows == 0) {
                 if (k.has_ds)  // one finalize launch for bn2 and the downsample BatchNorm
                     RC(bn_bwd_finalize_pair(f2, fd, st));
                 else

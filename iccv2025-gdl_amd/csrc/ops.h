@@ -3,7 +3,6 @@
 #pragma once
 #include "bnacc.h"
 #include "common.h"
-#include "fold.h"
 #include "gather.h"
 
 namespace gdl {
@@ -56,10 +55,9 @@ size_t conv_split_ws_bytes(int dtype, int N, int H, int W, int C, int K, int R, 
 // conv_igemm.hip
 int conv_dgrad_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
-// (fold != nullptr: the BatchNorm finalize of `bn` runs inside the launch, fold.h; bn->partial / tiles are ignored)
 int conv_fwd(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table, int N, int H,
-             int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const FoldWs* fold = nullptr,
-             const BnFinTrain* bn = nullptr, const BnAcc* sacc = nullptr, const SplitWs* split = nullptr);
+             int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st, const BnAcc* sacc = nullptr,
+             const SplitWs* split = nullptr);
 int conv_fwd_bias(int dtype, const void* x, const void* w_krsc, void* y, const float* bias, const void* addend, void* gelu_out,
                   const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, hipStream_t st);
 // relu_bits (optional): sign bits of the tensor whose gradient dx is (bn_act's relu_bits): dx = bit ? dx (+ addend) : 0
@@ -89,8 +87,7 @@ int conv_stem_tiles_m(int dtype, int n_img, int H, int W);
 bool conv_fwd_persistent(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 bool conv_stem_persistent(int dtype, int W);
 int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_partial, const void* table, int n_img, int H,
-                  int W, int Cin, hipStream_t st, const FoldWs* fold = nullptr, const BnFinTrain* bn = nullptr,
-                  const BnAcc* sacc = nullptr);
+                  int W, int Cin, hipStream_t st, const BnAcc* sacc = nullptr);
 size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W);
 int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
                     void* ws, size_t ws_bytes, hipStream_t st);
@@ -132,15 +129,9 @@ int bn_act(int dtype, const void* y, const float* scale, const float* shift, con
 int bn_bwd_blocks(size_t M, int C);
 int bn_bwd_reduce(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
                   const float* rstd, int relu_mask, float* partial, size_t M, int C, hipStream_t st);
-// (fws != nullptr: the finalize of bn2 -- and of the downsample BatchNorm -- is folded into the launch, fold.h; the
-// partial / blocks fields of fin2 / find are ignored)
 int block_bwd_reduce(int dtype, const void* dz, const void* z, const void* y2, const void* yd, const float* mean2,
                      const float* rstd2, const float* meand, const float* rstdd, void* do2, float* partial2,
-                     float* partiald, size_t M, int C, hipStream_t st, const FoldWs* fws = nullptr,
-                     const BnFinBwd* fin2 = nullptr, const BnFinBwd* find = nullptr, bool premasked = false);
-int bn_bwd_reduce_fold(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,
-                       const float* rstd, int relu_mask, float* partial, size_t M, int C, double count, float* dgamma,
-                       float* dbeta, float* coef, const FoldWs& fws, hipStream_t st);
+                     float* partiald, size_t M, int C, hipStream_t st, bool premasked = false);
 int bn_bwd_finalize(const float* partial, int blocks, int C, double count, float* dgamma, float* dbeta, float* coef,
                     hipStream_t st);
 int bn_bwd_apply(int dtype, const void* g, const void* y, const float* scale, const float* shift, const float* mean,

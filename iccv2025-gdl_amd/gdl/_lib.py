@@ -61,10 +61,6 @@ SIGNATURES = {
     "gdl_swin_pack_matrix": ("i", "ippp" + "iiiiii" + "p"),
     "gdl_swin_pack_batched": ("i", "piii" + "p"),
     "gdl_swin_unpack_matrix": ("i", "pp" + "iiiiii" + "p"),
-    "gdl_fold_workspace_bytes": ("z", ""),
-    "gdl_fold_workspace_init": ("i", "pzp"),
-    "gdl_conv_fwd_bn": ("i", "ippppp" + "iiiiiiiii" + "ppppp" + "pppp" + "pp"),
-    "gdl_bn_bwd_reduce_fin": ("i", "ipppppp" + "i" + "p" + "zi" + "d" + "ppp" + "pp"),
     "gdl_conv_wgrad_workspace_bytes": ("z", "iiiiiiiiii"),
     "gdl_conv_wgrad": ("i", "ipppp" + "iiiiiiiii" + "pzp"),
     "gdl_pack_weight": ("i", "ippp" + "iiii" + "p"),

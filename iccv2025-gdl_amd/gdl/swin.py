@@ -223,8 +223,6 @@ class SwinEngine:
         self.fuse_gelu = not (os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_FUSE_GELU") == "0")
         # (tuning aid, OFF by default: measured 26.8 ms either way at 192 frames -- the Linears' three GEMMs are all HBM-bound, beside
         # the weight gradients the data gradients slow down by what the weight gradients would have taken: 4.2 -> 6.4 ms)
-        self.side_wgrad = os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_SIDE_WGRAD") == "1"
-        self._side = None
         tot = 0
         self.fc1_off = []
         for s in self.stages:
@@ -375,11 +373,6 @@ class SwinEngine:
         self.serial += 1
         return out
 
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
-
     def _run(self, key, body):
         """Run `body` (a fixed launch sequence over fixed buffers) -- eagerly the first two times and whenever the
         measurement tap is recording, afterwards as a replay of its captured HIP graph: ~400 launches per pass enqueued from
@@ -498,33 +491,13 @@ class SwinEngine:
         first_si = nst - 2 if phase == 2 else nst - 1
         last_si = nst - 1 if phase == 1 else 0
         fuse = self.fuse_gelu
-        # Weight gradients on a side stream: nothing on the backward chain waits for them (they are only read when the gradients
-        # are unpacked), so the chain is the data gradients / attention / LayerNorm passes alone.  A weight gradient starts once
-        # its gradient operand exists (event from the chain) and the chain waits for it only in front of the launch that
-        # overwrites that operand's buffer: fc2's before norm1's backward rewrites dx, fc1's before the attention backward
-        # reuses g_w, proj's / qkv's before the NEXT block's norm2 backward / fc2 data gradient.  The side stream's launches are
-        # ordered among themselves (they share the split-K workspace).  Part of the captured graph like everything else.
-        cur = torch.cuda.current_stream(self.device)
-        side = self._side_stream() if self.side_wgrad else None
-        pend = {}
-
+        # (round 3 also had the Linears' weight gradients on a side stream with per-buffer reuse events: 26.8 ms either way -- all
+        # three GEMMs of a Linear are HBM-bound -- removed in round 4, tools/experiments/r4_pruned_knobs.diff.txt)
         def wg(lin, dy, x, rows, tag):
-            if side is None:
-                return lin.wgrad(dy, x, rows, st)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                lin.wgrad(dy, x, rows, side.cuda_stream)
-                done = torch.cuda.Event()
-                done.record(side)
-            pend[tag] = done
+            return lin.wgrad(dy, x, rows, st)
 
         def need(tag=None):
-            for t in ([tag] if tag is not None else list(pend)):
-                done = pend.pop(t, None)
-                if done is not None:
-                    cur.wait_event(done)
+            return None
 
         acc_lo = self.fc1_off[last_si - 1] if last_si > 0 else 0
         acc_hi = self.fc1_off[first_si]

@@ -186,8 +186,6 @@ class DGLTrainer:
         # (total norm, clip coefficient) into the next row, device to device on the step's stream
         self.stats_log = None
         self.stats_log_pos = None
-        d_us = os.environ.get("GDL_AUDIO_DELAY_US") if os.environ.get("GDL_TUNING") == "1" else None
-        self._audio_delay = int(float(d_us) * 2100) if d_us else 0  # spin cycles (~2.1 GHz)
 
     def _replica_buffers(self):
         """Every tensor of the replica that is not in the flat arenas: BatchNorm running statistics and counters of
@@ -337,8 +335,6 @@ class DGLTrainer:
                        self.s_v.cuda_stream)
                 ev_v = self.s_v.record_event()
             with torch.cuda.stream(self.s_a):
-                if self._audio_delay:  # tuning aid (GDL_AUDIO_DELAY_US with GDL_TUNING=1): see DESIGN "phase offset"
-                    torch.cuda._sleep(self._audio_delay)
                 self.eng_a.forward(audio, True, feat_out=self.fa)
                 L.call("gdl_head_uni_dfeat", L.ptr(self.fa), wa, ldw, ba, L.ptr(label), self.alpha, L.ptr(self.dfa), B, n,
                        self.s_a.cuda_stream)

@@ -133,23 +133,6 @@ GDL_API int gdl_conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, v
                                 const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                                 void* stream);
 GDL_API int gdl_acc_to_float(const void* acc, int n, double inv_scale, float* out, void* stream);
-/* In-launch BatchNorm finalize ("the last block folds"): the kernel that produces the per-block partial sums also
- * reduces them -- the block that completes them, found by an arrival ticket, folds them in a fixed order and runs
- * the finalize arithmetic -- so no separate finalize launch sits on the chain (backbone.py:45-48,104: conv -> bn).
- * `fold_ws`: gdl_fold_workspace_bytes() bytes, prepared ONCE with gdl_fold_workspace_init and then owned by one
- * stream (the launches that use it must be ordered).  Results are bit-identical from run to run.
- * gdl_conv_fwd_bn = gdl_conv_fwd(bn_partial) + gdl_bn_finalize_train(count = N*P*Q, eps 1e-5, momentum 0.1);
- * gdl_bn_bwd_reduce_fin = gdl_bn_bwd_reduce + gdl_bn_bwd_finalize(count). */
-GDL_API size_t gdl_fold_workspace_bytes(void);
-GDL_API int gdl_fold_workspace_init(void* fold_ws, size_t bytes, void* stream);
-GDL_API int gdl_conv_fwd_bn(int dtype, const void* x, const void* w_krsc, void* y, float* bn_partial, const void* table,
-                            int N, int H, int W, int C, int K, int R, int S, int stride, int pad, const float* gamma,
-                            const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                            float* save_mean, float* save_rstd, float* scale, float* shift, void* fold_ws, void* stream);
-GDL_API int gdl_bn_bwd_reduce_fin(int dtype, const void* g, const void* y, const float* scale, const float* shift,
-                                  const float* save_mean, const float* save_rstd, int relu_mask, float* partial, size_t M,
-                                  int C, double count, float* dgamma, float* dbeta, float* coef, void* fold_ws,
-                                  void* stream);
 GDL_API size_t gdl_conv_wgrad_workspace_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
                                               int pad);
 GDL_API int gdl_conv_wgrad(int dtype, const void* dy, const void* x, float* dw_kcrs, const void* table, int N, int H,

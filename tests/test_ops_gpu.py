@@ -499,124 +499,6 @@ def test_relu_bits_and_masked_dgrad(shape, dt):
     assert np.all(got[zg <= 0] == 0)
 
 
-def _fold_ws():
-    lib = L.load()
-    nb = lib.gdl_fold_workspace_bytes()
-    ws = torch.empty(nb, dtype=torch.uint8, device=DEV).random_()  # garbage everywhere but the counters
-    L.call("gdl_fold_workspace_init", L.ptr(ws), nb, L.cur_stream())
-    return ws
-
-
-FOLD_CONV = [
-    # N, C, H, W, K, R, stride, pad -- rows (M-tiles) x column groups of the fold
-    (2, 64, 17, 13, 64, 3, 1, 1),      # one group, one column group
-    (24, 64, 56, 56, 128, 3, 1, 1),    # several groups, ragged last group
-    (24, 64, 56, 56, 64, 3, 1, 1),     # 64 -> 64 channels: the persistent kernel, 512 partial rows (one per block), 8 groups
-    (16, 128, 28, 28, 256, 3, 1, 1),   # 128-channel tiles: two column groups
-    (16, 64, 65, 47, 128, 3, 2, 1),    # flat kernel, stride 2
-    (48, 512, 7, 7, 512, 3, 1, 1),     # few rows, four column groups
-]
-
-
-@pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape", FOLD_CONV)
-def test_conv_fwd_bn_fold(shape, dt):
-    """gdl_conv_fwd_bn (statistics + finalize inside the convolution's launch, "the last block folds") against
-    gdl_conv_fwd + gdl_bn_finalize_train: same outputs, statistics to double-rounding, bit-identical from run to run,
-    with the consumer-visible arrays poisoned before every run (a stale or early read shows as NaN / a changed bit)."""
-    N, C, H, W, K, R, stride, pad = shape
-    lib = L.load()
-    st = L.cur_stream()
-    td = L.torch_dtype(dt)
-    P, Q = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
-    M = N * P * Q
-    x = torch.randn(N, H, W, C, device=DEV).to(td)
-    wk = (torch.randn(K, R, R, C, device=DEV) * (2.0 / (C * R * R)) ** 0.5).to(td)
-    tab = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, R, R, stride, pad)
-    tiles = lib.gdl_conv_bn_tiles(dt, N, H, W, C, K, R, R, stride, pad)
-    gamma, beta = dev((1 + 0.1 * rng.standard_normal(K)).astype(np.float32)), dev((0.1 * rng.standard_normal(K)).astype(np.float32))
-    rm0, rv0 = (0.05 * rng.standard_normal(K)).astype(np.float32), (1 + 0.1 * np.abs(rng.standard_normal(K))).astype(np.float32)
-    # reference: the two separate launches
-    y0 = torch.empty(N, P, Q, K, device=DEV, dtype=td)
-    part0 = torch.empty(tiles, K, 2, device=DEV)
-    rm, rv, nbt = dev(rm0), dev(rv0), torch.zeros((), dtype=torch.int64, device=DEV)
-    ref = [torch.empty(K, device=DEV) for _ in range(4)]
-    L.call("gdl_conv_fwd", dt, L.ptr(x), L.ptr(wk), L.ptr(y0), L.ptr(part0), L.ptr(tab), N, H, W, C, K, R, R, stride, pad, st)
-    L.call("gdl_bn_finalize_train", L.ptr(part0), tiles, K, float(M), L.ptr(gamma), L.ptr(beta), 1e-5, 0.1, L.ptr(rm), L.ptr(rv),
-           L.ptr(nbt), L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]), L.ptr(ref[3]), st)
-    torch.cuda.synchronize()
-    ws = _fold_ws()
-    first = None
-    filler = torch.randn(1 << 22, device=DEV)
-    for rep in range(6):
-        y = torch.full((N, P, Q, K), float("nan"), device=DEV, dtype=td)
-        part = torch.full((tiles, K, 2), float("nan"), device=DEV)
-        rm2, rv2, nbt2 = dev(rm0), dev(rv0), torch.zeros((), dtype=torch.int64, device=DEV)
-        out = [torch.full((K,), float("nan"), device=DEV) for _ in range(4)]
-        filler.mul_(1.0001)  # other work between the runs
-        L.call("gdl_conv_fwd_bn", dt, L.ptr(x), L.ptr(wk), L.ptr(y), L.ptr(part), L.ptr(tab), N, H, W, C, K, R, R, stride, pad,
-               L.ptr(gamma), L.ptr(beta), L.ptr(rm2), L.ptr(rv2), L.ptr(nbt2), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]),
-               L.ptr(out[3]), L.ptr(ws), st)
-        torch.cuda.synchronize()
-        assert torch.equal(y.view(torch.int16 if dt == L.GDL_BF16 else torch.int32),
-                           y0.view(torch.int16 if dt == L.GDL_BF16 else torch.int32))
-        if shape == (48, 512, 7, 7, 512, 3, 1, 1):
-            # this small layer runs the 8-wave 128 x 128 tile without the fold and 128 x 64 tiles with it (the fold is written
-            # for 256-thread blocks): same rows, same outputs, the row sums in another order
-            np.testing.assert_allclose(part.cpu().numpy(), part0.cpu().numpy(), rtol=2e-5, atol=1e-4)
-        else:
-            assert torch.equal(part, part0)
-        assert int(nbt2.item()) == 1
-        for a, b in zip(out + [rm2, rv2], ref + [rm, rv]):
-            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=1e-7)
-        cur = [t.view(torch.int32).clone() for t in out + [rm2, rv2]]
-        if first is None:
-            first = cur
-        else:
-            for a, b in zip(cur, first):
-                assert torch.equal(a, b)
-    # the counters reset themselves: the workspace's counter area is all zero again
-    assert int(ws[: (1 + 256) * 8 * 4].view(torch.int32).abs().sum().item()) == 0
-
-
-@pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("M,C", [(300, 64), (37632, 256), (602112, 64), (9408, 512)])
-def test_bn_bwd_reduce_fold(M, C, dt):
-    """gdl_bn_bwd_reduce_fin against gdl_bn_bwd_reduce + gdl_bn_bwd_finalize (one block ... 2048 blocks, C up to 512)."""
-    lib = L.load()
-    st = L.cur_stream()
-    td = L.torch_dtype(dt)
-    g = torch.randn(M, C, device=DEV).to(td)
-    y = torch.randn(M, C, device=DEV).to(td)
-    sc, sh = dev((1 + 0.1 * rng.standard_normal(C)).astype(np.float32)), dev((0.1 * rng.standard_normal(C)).astype(np.float32))
-    mu, rs = dev((0.1 * rng.standard_normal(C)).astype(np.float32)), dev((1 + 0.1 * np.abs(rng.standard_normal(C))).astype(np.float32))
-    blocks = lib.gdl_bn_bwd_blocks(M, C)
-    part0 = torch.empty(blocks, C, 2, device=DEV)
-    ref = [torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)]
-    L.call("gdl_bn_bwd_reduce", dt, L.ptr(g), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(rs), 1, L.ptr(part0), M, C, st)
-    L.call("gdl_bn_bwd_finalize", L.ptr(part0), blocks, C, float(M), L.ptr(ref[0]), L.ptr(ref[1]), L.ptr(ref[2]), st)
-    torch.cuda.synchronize()
-    ws = _fold_ws()
-    first = None
-    for rep in range(6):
-        part = torch.full((blocks, C, 2), float("nan"), device=DEV)
-        out = [torch.full((C,), float("nan"), device=DEV), torch.full((C,), float("nan"), device=DEV),
-               torch.full((2 * C,), float("nan"), device=DEV)]
-        L.call("gdl_bn_bwd_reduce_fin", dt, L.ptr(g), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mu), L.ptr(rs), 1, L.ptr(part), M, C,
-               float(M), L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(ws), st)
-        torch.cuda.synchronize()
-        assert torch.equal(part, part0)
-        for a, b in zip(out, ref):
-            scale = float(b.abs().max().item())
-            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-6, atol=2e-6 * scale)
-        cur = [t.view(torch.int32).clone() for t in out]
-        if first is None:
-            first = cur
-        else:
-            for a, b in zip(cur, first):
-                assert torch.equal(a, b)
-
-
 def test_conv_run_to_run_determinism():
     """Race screen (found a real one once: packed-f32 BatchNorm sums): every conv op of a few
     geometries, four runs each with fresh NaN-poisoned outputs and other kernels in between, must be
