@@ -2301,6 +2301,10 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     GDL_REQUIRE(a.IC % bke == 0, "conv: gather channels %d not a multiple of %d", a.IC, bke);
     GDL_REQUIRE(a.OC % 64 == 0, "conv: output channels %d not a multiple of 64", a.OC);
     GDL_REQUIRE(a.M < (1 << 24), "conv: M = %d exceeds 2^24", a.M);
+    // the short-K Linears of the Swin branch (plain GEMM, K = 128 / 192, many rows): the streaming kernel (linear_stream.hip)
+    if (a.plain && !stats && !(sacc && sacc->acc) && !relu_bits && !(bw && bw->y) && !gelu_u && !dy_ds &&
+        linear_stream_ok(dtype, a.M, a.IC, a.OC, addend != nullptr))
+        return linear_stream_fwd(in, wt, out, addend, bias, gelu_out, a.M, a.IC, a.OC, st);
     // the gathered tensor has the output's spatial size for the stride-1 3x3 case the slab kernel serves
     ConvPlan pl = plan_conv(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad);
     a.flops = 2.0 * (double)N * P * Q * K * C * R * S;  // the convolution's multiply-adds, whatever the direction

@@ -52,6 +52,10 @@ struct SplitWs {
     size_t bytes;
 };
 size_t conv_split_ws_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad);
+// linear_stream.hip: out[M][N] = A[M][K] W[N][K]^T (+ bias) (+ addend), optional gelu_out -- bf16, K = 128 / 192 (Swin Linears)
+bool linear_stream_ok(int dtype, int M, int K, int N, bool has_addend);
+int linear_stream_fwd(const void* A, const void* W, void* out, const void* addend, const float* bias, void* gelu_out, int M, int K,
+                      int N, hipStream_t st);
 // conv_igemm.hip
 int conv_dgrad_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad);

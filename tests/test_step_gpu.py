@@ -351,7 +351,12 @@ def _load_state(module, state):
     module.load_state_dict(sd, strict=True)
 
 
-BF16_ENC_GRAD_TOL = 0.6  # measured worst over both tiny encoders: 0.46 (audio) / 0.50 (visual), BN bias / weight of layer 1 (-s prints it)
+# HIP, worst gradient tensor of the tiny encoders (element-wise relative error): 0.46 (audio) / 0.50 (visual), BatchNorm bias / weight of
+# layer 1 (-s prints it).  What the bound is held against (round 4): the float64 encoder with bf16 rounding at exactly the storage points of
+# this library (tools/parity_sources.py --tiny-encoders, profiles/r04_parity_tiny_encoders.txt) deviates by 0.449 (audio, layer1.0.bn1.bias)
+# / 0.560 (visual, layer1.1.bn2.bias) on these fixtures, features 3.8e-2 -- BatchNorm over 16-64 samples makes the ReLU flips of the
+# forward rounding that large.  0.6 = 1.07x the emulated worst: an implementation cannot be much closer, one that is broken is far outside.
+BF16_ENC_GRAD_TOL = 0.6
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -827,6 +832,15 @@ def test_full_size_bf16_against_fp64():
     # per channel that nearly cancel -- the upstream BatchNorm backward makes the unmasked sum zero), NOT the reference's
     # rounding as round 2 had guessed.  Hence: SURVEY's 0.1 holds for 121 of the 122 tensors; ONE BatchNorm parameter may
     # sit between 0.1 and 0.12.
+    # Round 4: (i) the BatchNorm-backward sums of the 64-channel layers now come from the fp32 accumulators
+    # BEFORE the bf16 rounding (conv_epilogue F32ST, conv3x3_c64_kernel<DGRAD, BW>) -- and the worst tensor did not move
+    # (0.1036 -> 0.1048): the gradient storage is not where the deviation comes from.  (ii) tools/parity_sources.py (the float64 step
+    # with bf16 rounding at ONE class of storage points at a time, B = 64, profiles/r04_parity_sources_b64.txt): gradient storage
+    # (dy / dx) <= 0.002; convolution outputs alone 0.086 on this very tensor, activations alone 0.065, weights 0.068 on its
+    # partner; all storage points together: worst tensor 0.097 (audio_net.layer1.1.bn2.weight), logits 2.5e-2.  An idealised
+    # bf16-storage implementation therefore sits AT SURVEY's 0.1 on its worst BatchNorm tensor (ReLU decisions of near-zero
+    # pre-activations flip under the forward rounding; every flip adds or removes a whole gradient element of a sum that has
+    # no other error of that size); 0.105 here is one realisation of that.  Hence the allowance for ONE BatchNorm tensor stays.
     for k in ("out", "out_a", "out_v"):
         assert dbf[k] <= 3e-2, (k, dbf[k])
     over = [(k, v) for k, v in relbf.items() if v > 0.1]

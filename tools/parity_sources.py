@@ -129,11 +129,43 @@ def main():
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 1, 64))
     ap.add_argument("--sources", default="w,in,y,a,dy,dx,all")
     ap.add_argument("--two-steps", action="store_true", help="two consecutive steps with every source on: the deviation of the SECOND step")
+    ap.add_argument("--tiny-encoders", action="store_true",
+                    help="the tiny encoder fixtures of tests/test_step_gpu.py::test_encoder_golden: element-wise relative error of every "
+                         "gradient tensor with all bf16 storage points on (what BF16_ENC_GRAD_TOL bounds)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     P0, Bf0 = fx.model_state(6, "concat_dgl")
     spec, image, label = fx.make_batch(0, args.batch, [257, 188], 3, [224, 224], 6)
     spec, image, label = torch.from_numpy(spec).double(), torch.from_numpy(image).double(), torch.from_numpy(label).long()
+    if args.tiny_encoders:
+        for name, cin in (("enc_audio_tiny", 1), ("enc_visual_tiny", 3)):
+            g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+            Pn = fx.make_state(fx.resnet18_param_shapes("", cin))
+            Bn = fx.make_state(fx.resnet18_buffer_shapes(""))
+            x = torch.from_numpy(g["x"]).double()
+            if x.dim() == 5:  # visual fixture [B, 3, T, H, W] -> frames
+                B, C, T, H, W = x.shape
+                x = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+            res = {}
+            for tag, on in (("none", []), ("all", ["w", "in", "y", "a", "dy", "dx"])):
+                ON.clear()
+                ON.update(on)
+                P = {"n." + k: torch.from_numpy(np.array(v)).double().requires_grad_(True) for k, v in Pn.items()}
+                Bf = {"n." + k: (torch.from_numpy(np.array(v)).double() if np.array(v).dtype.kind == "f" else torch.from_numpy(np.array(v)))
+                      for k, v in Bn.items()}
+                y = encoder(x, P, Bf, "n")
+                dy = torch.from_numpy(g["dy"]).double()
+                if dy.shape != y.shape:  # the visual golden's feature map is [B, 512, T, h, w]
+                    B_, C_, T_, h_, w_ = dy.shape
+                    dy = dy.permute(0, 2, 1, 3, 4).reshape(B_ * T_, C_, h_, w_)
+                y.backward(dy)
+                res[tag] = (y.detach().numpy(), {k: p.grad.numpy() for k, p in P.items()})
+            rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+            r = {k: rel(res["all"][1][k], res["none"][1][k]) for k in res["none"][1]}
+            wk = max(r, key=r.get)
+            print(f"{name}: features relerr {rel(res['all'][0], res['none'][0]):.3e}; gradient tensors, element-wise relerr: worst {r[wk]:.3f} "
+                  f"({wk}), median {np.median(list(r.values())):.3f}", flush=True)
+        return
     if args.two_steps:
         b = [(spec, image, label)]
         s2, i2, l2 = fx.make_batch(1, args.batch, [257, 188], 3, [224, 224], 6)
