@@ -55,6 +55,17 @@ class _SwinAdapter:
         self.eng.backward(self._dfeat, list(grads), phase=phase)
 
 
+_CHAIN_STREAMS = {}
+
+
+def _chain_streams(device):
+    """(audio-chain stream, visual-chain stream) of `device`, created once per process"""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _CHAIN_STREAMS:
+        _CHAIN_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _CHAIN_STREAMS[key]
+
+
 class DGLTrainer:
     def __init__(self, model, lr, alpha=4.0, momentum=0.9, weight_decay=1e-4, max_norm=40.0, mode="dgl", dtype=None,
                  process_group=None, comm_backend="torch", visual_side_stream=None, early_backward=None):
@@ -177,8 +188,11 @@ class DGLTrainer:
         L.call("gdl_optim_bind_workspace", self.opt, L.ptr(self.opt_ws), self.opt_ws_bytes, L.cur_stream())
         self.stats = torch.zeros(self.lib.gdl_optim_stats_len(h), device=self.device)
         self.losses = torch.zeros(3, device=self.device)  # loss_f, loss_a, loss_v
-        self.s_a = torch.cuda.Stream(device=self.device)
-        self.s_v = torch.cuda.Stream(device=self.device)
+        # The two chain streams are shared by every trainer of a process on this device: torch hands out a NEW pool stream per
+        # torch.cuda.Stream() call and never retires one, and once more distinct streams have carried work than the runtime has
+        # hardware queues (four), two chains can end up time-slicing one queue -- the third trainer built in a process ran its step
+        # 15 % slower than the same trainer in a fresh process (bench.py's `extra_workloads.ks`: 7.33 vs 6.36 ms, round 4).
+        self.s_a, self.s_v = _chain_streams(self.device)
         self.eng_a = self.eng_v = None
         self.steps = 0
         self.phase_events = None  # set to [] to record (name, event) marks on the main stream per step
