@@ -265,6 +265,56 @@ def test_linear_with_bias_and_residual(dt):
     assert np.abs(_np(ge) - 0.5 * yy * (1 + np.vectorize(math.erf)(yy / math.sqrt(2)))).max() < _tol(dt, 3e-6, 3e-2)
 
 
+@pytest.mark.parametrize("M,K,N,opts", [
+    (20008, 128, 384, ("bias",)),                 # qkv at stage 1; ragged last 16-row tile
+    (16400, 128, 128, ("bias", "res")),           # proj: residual addend (prefetched one tile ahead)
+    (18000, 128, 384, ("bias", "gelu")),          # fc1: two outputs
+    (17000, 192, 576, ("bias",)),                 # stage 2: 96-column chunks
+    (16384, 192, 768, ("bias", "gelu")),
+    (16500, 192, 192, ()),                        # no epilogue options at all
+])
+def test_linear_stream_kernel(M, K, N, opts):
+    """csrc/linear_stream.hip (round 4): plain GEMMs with K = 128 / 192 and >= 16 384 rows leave gdl_conv_fwd_bias / gdl_conv_fwd on
+    the streaming kernel (weights in registers, a wave per 16-row tile, one memory wait per tile).  Against float64 (nn.Linear,
+    /root/reference/models/swin_transformer.py:30-46, 98-101) -- and BIT-identical to the tile kernel, which the same call runs for
+    the first 4 000 rows alone (below the streaming threshold): same accumulation order, same rounding points."""
+    import math
+
+    from gpu_util import gather_table
+
+    dt = "bf16"
+    dc = L.dtype_code(dt)
+    st = L.cur_stream()
+    x, w = _q(rng.standard_normal((M, K)), dt), _q(rng.standard_normal((N, K)) * 0.1, dt)
+    b = rng.standard_normal(N).astype(np.float32)
+    res = _q(rng.standard_normal((M, N)), dt)
+    xd, wd, rd, bd = _dev(x, dt), _dev(w, dt), _dev(res, dt), torch.from_numpy(b).to(DEV)
+
+    def run(rows):
+        tab = gather_table(L.GATHER_FWD, dc, rows, 1, 1, K, N, 1, 1, 1, 0)
+        y = torch.full((rows, N), float("nan"), device=DEV, dtype=_td(dt))
+        ge = torch.full((rows, N), float("nan"), device=DEV, dtype=_td(dt))
+        L.call("gdl_conv_fwd_bias", dc, L.ptr(xd), L.ptr(wd), L.ptr(y), L.ptr(bd) if "bias" in opts else None,
+               L.ptr(rd) if "res" in opts else None, L.ptr(ge) if "gelu" in opts else None, L.ptr(tab), rows, 1, 1, K, N, 1, 1, 1, 0, st)
+        torch.cuda.synchronize()
+        return y, ge
+
+    y, ge = run(M)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + (b if "bias" in opts else 0.0) + (res if "res" in opts else 0.0)
+    assert not torch.isnan(y).any()
+    assert np.abs(_np(y) - want).max() < 6e-2 * max(1.0, np.abs(want).max() / 4)
+    if "gelu" in opts:
+        yy = _np(y)
+        assert not torch.isnan(ge).any()
+        assert np.abs(_np(ge) - 0.5 * yy * (1 + np.vectorize(math.erf)(yy / math.sqrt(2)))).max() < 3e-2
+    y0, ge0 = run(4000)  # the tile kernel (fewer than 16 384 rows)
+    assert torch.equal(y[:4000].view(torch.int16), y0.view(torch.int16))
+    if "gelu" in opts:
+        assert torch.equal(ge[:4000].view(torch.int16), ge0.view(torch.int16))
+    y2, _ = run(M)  # run to run
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,K,N", [(777, 384, 128), (5000, 768, 192), (300, 3072, 768)])
 def test_linear_dgrad_gelu_colsum(dt, M, K, N):
