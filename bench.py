@@ -242,15 +242,17 @@ def extra_leg(name, a, dev, lib, collect, steps=30, warmup=15):
     table = collect(2)
     dom = table[0]["kernel"]
     lib.gdl_prof_set_filter(dom.encode())
-    lib.gdl_prof_enable(1)
     torch.cuda.synchronize()
+    tapped = 0
     t0 = time.perf_counter()
-    for i in range(steps):
+    for i in range(steps):  # (the tap samples every 4th step, as in the main measurement)
+        lib.gdl_prof_enable(1 if i % 4 == 0 else 0)
+        tapped += i % 4 == 0
         tr.step(*data[i % 4])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     lib.gdl_prof_enable(0)
-    d = [k for k in collect(steps) if k["kernel"] == dom][0]
+    d = [k for k in collect(max(1, tapped)) if k["kernel"] == dom][0]
     lib.gdl_prof_set_filter(None)
     res = tr.read()
     top = [{"kernel": k["kernel"], "ms_per_step": k["ms_per_step"], "frac": k["frac"], "bound": k["bound"]} for k in table[:6]]
@@ -395,12 +397,20 @@ def main():
             dominant = kernels[0]["kernel"]
             lib.gdl_prof_set_filter(dominant.encode())
     barrier()
-    if prof:
-        lib.gdl_prof_enable(1)
+    # The dominant kernel's launches carry HIP event pairs (hipExtLaunchKernelGGL) -- and an event-stamped launch does not pipeline
+    # with its neighbours on the stream the way a plain one does: tapping all 26 launches of every step costs the timed region
+    # ~1.5 % (5.62 vs 5.54 ms on one box).  The tap therefore samples every TAP_EVERY-th step of the timed region (first step
+    # included): the roofline figures are averages over those steps' launches, the other steps run as the job does.
+    TAP_EVERY = 4
+    tapped = 0
     torch.cuda.synchronize()
     tr.stats_log_pos = 0
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if prof:
+            on = i % TAP_EVERY == 0
+            lib.gdl_prof_enable(1 if on else 0)
+            tapped += on
         step()
     torch.cuda.synchronize()
     barrier()
@@ -418,7 +428,7 @@ def main():
     roof = None
     if prof:
         lib.gdl_prof_enable(0)
-        d = [k for k in collect(a.steps) if k["kernel"] == dominant][0]
+        d = [k for k in collect(max(1, tapped)) if k["kernel"] == dominant][0]
         lib.gdl_prof_set_filter(None)
         # HBM bytes per launch from the PMC counters: they need their own rocprofv3 --pmc passes (tools/pmc_kernels.sh
         # over this very command), so the committed measurement is read back -- but only if it was taken on the kernel
@@ -439,7 +449,8 @@ def main():
             pass
         roof = {"bound": d["bound"], "achieved": d["achieved"], "peak": MFMA_PEAK_TFLOPS[a.dtype] if d["bound"] == "mfma"
                 else HBM_PEAK_GBS, "unit": d["unit"], "frac": d["frac"], "traffic": traffic, "kernel": d["kernel"],
-                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"], "frac_of": d["frac_of"]}
+                "avg_launch_us": d["avg_us"], "launches_per_step": d["launches_per_step"], "frac_of": d["frac_of"],
+                "tapped_steps": tapped, "tapped_steps_note": f"every {TAP_EVERY}th step of the timed region carries the event pairs"}
         if "frac_combined" in d:
             roof["combined"] = {"frac": d["frac_combined"], "algorithmic_mbytes_per_launch": d["algorithmic_mbytes_per_launch"],
                                 "note": "sum over the launches of max(flop / MFMA peak, algorithmic bytes / HBM peak) / measured time"}
