@@ -299,7 +299,7 @@ int gdl_head_gated_bwd(const float* x, const float* y, const float* hx, const fl
     return head_gated_bwd(x, y, hx, hy, W1, W2, Wo, g_x_out, g_y_out, g_out, uni_in_dw, dx, dy, dW1, db1, dW2, db2, dWo, dbo, ws, B,
                           n_classes, (hipStream_t)stream);
 }
-size_t gdl_head_film_workspace_bytes(int B) { return (B >= 1 && B <= 64) ? head_film_ws_bytes(B) : 0; }
+size_t gdl_head_film_workspace_bytes(int B) { return head_film_ws_bytes(B); }
 int gdl_head_film_fwd(const float* x, const float* y, const float* Wfc, const float* bfc, const float* Wo, const float* bo,
                       float* hidden, float* out, float* x_out, float* y_out, int B, int n_classes, void* ws, size_t ws_bytes,
                       void* stream) {
@@ -403,7 +403,10 @@ int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out,
     return swin_attn_fwd(dtype, qkv, table, out, n_img, H, W, window, shift, heads, ld, (hipStream_t)stream);
 }
 size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int H, int W, int window, int heads) {
-    return window > 0 ? swin_attn_bwd_ws_bytes(n_img, (H / window) * (W / window), window, heads) : 0;
+    if (window <= 0) return 0;
+    const size_t general = swin_attn_bwd_ws_bytes(n_img, (H / window) * (W / window), window, heads);
+    const size_t seven = window == 7 ? swin_attn7_bwd_ws_bytes(n_img, H, W, heads) : 0;  // either kernel may serve the call
+    return general > seven ? general : seven;
 }
 int gdl_swin_attn_bwd(int dtype, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, void* ws, int n_img,
                       int H, int W, int window, int shift, int heads, int ld, void* stream) {

@@ -23,6 +23,8 @@ namespace gdl {
 constexpr int FD = 512;            // feature width of both modalities and of fc's output
 constexpr int FROWS = FD * FD;     // rows of fc.weight viewed as [FROWS][FD]
 
+// the operand matrices have 2 Bp .. 3 Bp columns of FROWS rows (3 Bp: 1.6 GB at the limit), every index is size_t
+constexpr int FILM_MAX_B = 512;
 static inline int film_bp(int B) { return (B + 31) / 32 * 32; }  // batch padded so that 2*Bp % 64 == 0, 3*Bp % 32 == 0
 
 // ---- V[2*Bp][512]: rows 0..B-1 = x, rows Bp..Bp+B-1 = y, padding rows zero
@@ -33,7 +35,8 @@ __global__ void film_v_kernel(const float* __restrict__ x, const float* __restri
     for (int i = threadIdx.x; i < FD; i += blockDim.x) V[(size_t)r * FD + i] = src ? src[i] : 0.f;
 }
 
-// ---- h[b][k] = bias[k] + sum_i left_b[i] * T[(k,i)][col(b)]     grid = (512 k, 3 forms): 0 = x form, 1 = fused, 2 = y form
+// ---- h[b][k] = bias[k] + sum_i left_b[i] * T[(k,i)][col(b)]     grid = (512 k, 3 forms, ceil(B / 64) sample groups):
+// 0 = x form, 1 = fused, 2 = y form
 __global__ __launch_bounds__(256) void film_h_kernel(const float* __restrict__ T, const float* __restrict__ x,
                                                      const float* __restrict__ y, const float* __restrict__ bias,
                                                      float* __restrict__ hx, float* __restrict__ hf, float* __restrict__ hy,
@@ -43,16 +46,15 @@ __global__ __launch_bounds__(256) void film_h_kernel(const float* __restrict__ T
     const float* left = form == 2 ? y : x;                 // x^T W_k x, x^T W_k y, y^T W_k y
     const int coff = form == 0 ? 0 : Bp;                   // T columns: W_k x_b at b, W_k y_b at Bp + b
     float* h = form == 0 ? hx : (form == 1 ? hf : hy);
-    const int b = threadIdx.x & 63, part = threadIdx.x >> 6;  // 4 slices of i
+    const int bl = threadIdx.x & 63, b = blockIdx.z * 64 + bl, part = threadIdx.x >> 6;  // 4 slices of i
     float s = 0.f;
     if (b < B) {
         const float* Tk = T + (size_t)k * FD * (2 * Bp) + coff + b;
         for (int i = part; i < FD; i += 4) s += left[(size_t)b * FD + i] * Tk[(size_t)i * (2 * Bp)];
     }
-    red[part][b] = s;
+    red[part][bl] = s;
     __syncthreads();
-    if (part == 0 && b < B) h[(size_t)b * FD + k] = ((red[0][b] + red[1][b]) + red[2][b]) + red[3][b] + bias[k];
-    // batches beyond 64 samples: handled by the caller in chunks of 64
+    if (part == 0 && b < B) h[(size_t)b * FD + k] = ((red[0][bl] + red[1][bl]) + red[2][bl]) + red[3][bl] + bias[k];
 }
 
 // ---- logits of the three hidden vectors: grid = B
@@ -241,12 +243,12 @@ static FilmWs film_layout(unsigned char* base, int B) {
     w.total = off;
     return w;
 }
-size_t head_film_ws_bytes(int B) { return film_layout(nullptr, B).total; }
+size_t head_film_ws_bytes(int B) { return (B >= 1 && B <= FILM_MAX_B) ? film_layout(nullptr, B).total : 0; }
 
 // hidden: [3][B][512] = h_x, h_f, h_y (kept by the caller for the backward, together with ws: T is reused)
 int head_film_fwd(const float* x, const float* y, const float* Wfc, const float* bfc, const float* Wo, const float* bo,
                   float* hidden, float* out, float* x_out, float* y_out, int B, int n, void* ws, size_t ws_bytes, hipStream_t st) {
-    GDL_REQUIRE(B >= 1 && B <= 64, "head_film: B=%d (1..64 per call)", B);
+    GDL_REQUIRE(B >= 1 && B <= FILM_MAX_B, "head_film: B=%d (1..%d per call)", B, FILM_MAX_B);
     const FilmWs w = film_layout((unsigned char*)ws, B);
     if (!ws || ws_bytes < w.total) {
         set_error("head_film_fwd: workspace %zu < %zu bytes", ws_bytes, w.total);
@@ -261,7 +263,7 @@ int head_film_fwd(const float* x, const float* y, const float* Wfc, const float*
     // T[(k,i)][col] = sum_j A[(k,i)][j] V[col][j]
     rc = conv_fwd(GDL_F32, Wfc, w.V, w.T, nullptr, w.tab_a, 1, FROWS, 1, FD, 2 * Bp, 1, 1, 1, 0, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(film_h_kernel, dim3(FD, 3), dim3(256), 0, st, w.T, x, y, bfc, hx, hf, hy, B, Bp);
+    hipLaunchKernelGGL(film_h_kernel, dim3(FD, 3, (B + 63) / 64), dim3(256), 0, st, w.T, x, y, bfc, hx, hf, hy, B, Bp);
     GDL_CHECK_LAUNCH("film_h_kernel");
     hipLaunchKernelGGL(film_out_kernel, dim3(B), dim3(256), 0, st, hx, hf, hy, Wo, bo, out, x_out, y_out, n);
     GDL_CHECK_LAUNCH("film_out_kernel");
@@ -274,7 +276,7 @@ int head_film_fwd(const float* x, const float* y, const float* Wfc, const float*
 int head_film_bwd(const float* x, const float* y, const float* Wfc, const float* Wo, const float* hidden,
                   const float* g_x_out, const float* g_y_out, const float* g_out, int uni, float* dx, float* dy, float* dWfc,
                   float* dbfc, float* dWo, float* dbo, int B, int n, void* ws, size_t ws_bytes, hipStream_t st) {
-    GDL_REQUIRE(B >= 1 && B <= 64, "head_film: B=%d (1..64 per call)", B);
+    GDL_REQUIRE(B >= 1 && B <= FILM_MAX_B, "head_film: B=%d (1..%d per call)", B, FILM_MAX_B);
     const FilmWs w = film_layout((unsigned char*)ws, B);
     if (!ws || ws_bytes < w.total) {
         set_error("head_film_bwd: workspace %zu < %zu bytes", ws_bytes, w.total);

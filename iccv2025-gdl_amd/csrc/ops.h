@@ -210,6 +210,12 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
 size_t swin_attn_bwd_ws_bytes(int n_img, int nwin, int ws, int nh);
 int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, void* dqkv, float* dtable, float* tpart, int n_img,
                   int H, int W, int ws, int shift, int nh, int ld, hipStream_t st);
+// window 7, bf16: swin_attn7.hip (swin_attn_fwd / _bwd dispatch to it)
+bool swin_attn7_ok(int dt, int H, int W, int ws, int shift, int nh, int ld, int n_img);
+int swin_attn7_fwd(const void* qkv, const float* table, void* out, int n_img, int H, int W, int shift, int nh, int ld, hipStream_t st);
+size_t swin_attn7_bwd_ws_bytes(int n_img, int H, int W, int nh);
+int swin_attn7_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* tpart, int* nparts, int n_img, int H, int W,
+                   int shift, int nh, int ld, hipStream_t st);
 int swin_merge(int dt, const void* src, void* dst, int N, int H, int W, int C, int ldx, int scatter, hipStream_t st);
 int swin_token_mean(int dt, const void* x, float* y, int N, int L, int C, int ld, hipStream_t st);
 int swin_token_mean_bwd(int dt, const float* dy, void* dx, int N, int L, int C, int ld, hipStream_t st);

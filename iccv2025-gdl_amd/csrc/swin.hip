@@ -531,16 +531,24 @@ __device__ __forceinline__ void sw_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Consecutive block ids land on consecutive XCDs (eight L2s).  The heads of one window read neighbouring 64-byte runs of the same
+// token rows -- two heads per 128-byte line -- so consecutive LOGICAL ids are given to the blocks of one XCD: block b is the
+// (b / 8)-th block of XCD b % 8 and takes the (b / 8)-th id of that XCD's contiguous share.
+__device__ __forceinline__ unsigned sw_xcd_block(unsigned b, unsigned nb, int on) {
+    if (!on) return b;
+    const unsigned q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
+}
 __device__ __forceinline__ bf16x8_t sw_ld_frag(const bf16* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
 __device__ __forceinline__ bf16x8_t sw_zero_frag() { return __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u)); }
 
 __global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
-                                                                 bf16* __restrict__ out, SwinAttnGeom g, int n_img) {
+                                                                 bf16* __restrict__ out, SwinAttnGeom g, int n_img, int xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     SwinMfmaLds& S = ((SwinMfmaLds*)swm_smem)[wave];
     const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
-    const long unit = (long)blockIdx.x * 4 + wave, nunits = (long)n_img * g.nwin * g.nh;
+    const long unit = (long)sw_xcd_block(blockIdx.x, gridDim.x, xcd) * 4 + wave, nunits = (long)n_img * g.nwin * g.nh;
     const bool live = unit < nunits;
     const int h = live ? (int)(unit % g.nh) : 0;
     const int w = live ? (int)((unit / g.nh) % g.nwin) : 0;
@@ -724,14 +732,15 @@ __device__ __forceinline__ void sw_bwd_product(const SwinMfmaBwdLds& S, const ui
 }
 __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                                    const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
-                                                                   float* __restrict__ tpart, SwinAttnGeom g, int G) {
+                                                                   float* __restrict__ tpart, SwinAttnGeom g, int G, int xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
     SwinMfmaBwdLds& S = *(SwinMfmaBwdLds*)swm_smem;
     const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
     const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
     const int ngrp = (g.nwin + G - 1) / G;
-    const int h = blockIdx.x % g.nh, grp = (blockIdx.x / g.nh) % ngrp;
-    const size_t img_row0 = (size_t)(blockIdx.x / (g.nh * ngrp)) * L;
+    const unsigned bid = sw_xcd_block(blockIdx.x, gridDim.x, xcd);
+    const int h = bid % g.nh, grp = (bid / g.nh) % ngrp;
+    const size_t img_row0 = (size_t)(bid / (g.nh * ngrp)) * L;
     const float scale = 0.17677669529663687f;
     for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
     // d(bias): table entry (dh, dw) collects dS_ij over the pairs with (ri - rj, ci - cj) = (dh, dw), gathered from the dS^T tile
@@ -911,7 +920,7 @@ __global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* _
                 for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
     }
     __syncthreads();
-    float* tp = tpart + (size_t)blockIdx.x * tw * tw;
+    float* tp = tpart + (size_t)bid * tw * tw;
     if (lane < Tn) {  // entries (dh0 [+ ws], dw0 [+ ws]); the partners past the table's edge (dh0 = 0 or dw0 = 0) do not exist
         const int dh0 = lane / g.ws - (g.ws - 1), dw0 = lane % g.ws - (g.ws - 1);
         const int e0 = (dh0 + g.ws - 1) * tw + (dw0 + g.ws - 1);
@@ -1457,6 +1466,14 @@ static bool swin_mfma_on() {
     }
     return v != 0;
 }
+static int swin_xcd_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_SWIN_XCD");  // tuning aid: 0 = block id -> (window, head) without the XCD grouping
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
 static int attn_geom(SwinAttnGeom* g, int H, int W, int ws, int shift, int nh, int ld) {
     GDL_REQUIRE(ws >= 1 && ws * ws <= SW_MAXT && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws && nh * SW_HD <= ld,
                 "swin_attn: window %d (shift %d) on %dx%d tokens, %d heads in %d channels", ws, shift, H, W, nh, ld);
@@ -1469,6 +1486,7 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
     SwinAttnGeom g;
     int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
     if (rc) return rc;
+    if (swin_attn7_ok(dt, H, W, ws, shift, nh, ld, n_img)) return swin_attn7_fwd(qkv, table, out, n_img, H, W, shift, nh, ld, st);
     const long units = (long)n_img * g.nwin * nh;
     if (dt == GDL_BF16 && swin_mfma_on()) {  // matrix-core form (bf16 storage only: the f32 mode stays an fp32 FMA chain)
         const size_t lds = 4 * sizeof(SwinMfmaLds);
@@ -1479,7 +1497,7 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
             attr = true;
         }
         ProfScope prof("gdl::swin_attn_fwd_mfma_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 4);
-        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, (const bf16*)qkv, table, (bf16*)out, g, n_img);
+        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, (const bf16*)qkv, table, (bf16*)out, g, n_img, swin_xcd_on());
         GDL_CHECK_LAUNCH("swin_attn_fwd_mfma_kernel");
         return GDL_OK;
     }
@@ -1501,6 +1519,15 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
     int rc = attn_geom(&g, H, W, ws, shift, nh, ld);
     if (rc) return rc;
     GDL_REQUIRE(tpart && dtable, "swin_attn_bwd: null workspace");
+    const int tt = (2 * ws - 1) * (2 * ws - 1);
+    if (swin_attn7_ok(dt, H, W, ws, shift, nh, ld, n_img)) {
+        int nparts = 0;
+        rc = swin_attn7_bwd(qkv, table, dout, dqkv, tpart, &nparts, n_img, H, W, shift, nh, ld, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(swin_table_reduce_kernel, dim3((nh * tt + 3) / 4), dim3(256), 0, st, tpart, dtable, nparts, nh, tt);
+        GDL_CHECK_LAUNCH("swin_table_reduce_kernel");
+        return GDL_OK;
+    }
     const size_t lds = (size_t)4 * SW_MAXT * SW_PD * 4 + (size_t)SW_MAXT * (SW_MAXT + 1) * 4 + 3 * SW_MAXT * 4 + 169 * 4 + SW_MAXT * 4;
     const int G = attn_bwd_group(g.nwin), ngrp = (g.nwin + G - 1) / G;
     static bool attr[2] = {false, false};
@@ -1521,7 +1548,7 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
         }
         ProfScope prof("gdl::swin_attn_bwd_mfma_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 7);
         hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(n_img * ngrp * nh), dim3(64), ldsm, st, (const bf16*)qkv, table, (const bf16*)dout,
-                           (bf16*)dqkv, tpart, g, G);
+                           (bf16*)dqkv, tpart, g, G, swin_xcd_on());
         GDL_CHECK_LAUNCH("swin_attn_bwd_mfma_kernel");
     } else {
         ProfScope prof("gdl::swin_attn_bwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 7);
@@ -1529,7 +1556,6 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
                     hipLaunchKernelGGL(swin_attn_bwd_kernel<bf16>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, tpart, g, G));
         GDL_CHECK_LAUNCH("swin_attn_bwd_kernel");
     }
-    const int tt = (2 * ws - 1) * (2 * ws - 1);
     hipLaunchKernelGGL(swin_table_reduce_kernel, dim3((nh * tt + 3) / 4), dim3(256), 0, st, tpart, dtable, n_img * ngrp, nh, tt);
     GDL_CHECK_LAUNCH("swin_table_reduce_kernel");
     return GDL_OK;

@@ -278,8 +278,8 @@ class DGLTrainer:
         self.dfa, self.dfv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
         self.dscr_a, self.dscr_v = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
         if self.head == "film":
-            if B > 64:
-                raise L.GdlError("DGLTrainer: the FiLM head handles at most 64 samples per step")
+            if B > 512:
+                raise L.GdlError("DGLTrainer: the FiLM head handles at most 512 samples per step")
             self.hidden = torch.empty((3, B, 512), device=d)
             self.head_ws = torch.empty(self.lib.gdl_head_film_workspace_bytes(B), dtype=torch.uint8, device=d)
         if self.head == "gated":  # hidden vectors (saved for the backward) + its scratch

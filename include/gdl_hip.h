@@ -277,7 +277,8 @@ GDL_API int gdl_head_concat_xy_bwd(const float* x, const float* y, const float* 
  * form per output, h[b][k] = u_b^T W_k v_b + bias_k -- and fc_out: Linear(512, n):
  *   out = fc_out(fc(x.detach() (x) y.detach())),  x_out = fc_out(fc(x (x) x)),  y_out = fc_out(fc(y (x) y)).
  * The outer products are never materialised; the contractions over fc.weight (537 MB) run as 1x1 convolutions /
- * weight gradients of this library in exact-f32 mode.  B <= 64 per call.  hidden: [3][B][512] float32 (h_x, h_f,
+ * weight gradients of this library in exact-f32 mode.  B <= 512 per call (the workspace grows with B: 0.47 GiB at 64,
+ * 3.5 GiB at 512; gdl_head_film_workspace_bytes returns 0 beyond).  hidden: [3][B][512] float32 (h_x, h_f,
  * h_y), produced by fwd and consumed, with the SAME untouched workspace, by bwd.  bwd: any upstream gradient may
  * be NULL; dx/dy, dWfc/dbfc, dWo/dbo are optional pairs; uni_in_dw as for the other heads (0 in the DGL step). */
 GDL_API size_t gdl_head_film_workspace_bytes(int B);

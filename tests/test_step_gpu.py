@@ -230,6 +230,54 @@ def test_head_film_dgl_golden():
         close(G[k], "f." + k)
 
 
+def test_head_film_beyond_64_samples():
+    """FiLM_DGL at B = 80 (the head refused more than 64 samples): forward, the DGL step's two
+    backward calls (unimodal gradients to the features, loss_f to fc / fc_out) against the CPU oracle on the same
+    seeded inputs.  f32 with MFMA f32 products: the same 1e-3 as the golden test."""
+    B, n = 80, 6
+    lib = L.load()
+    rng = np.random.default_rng(7)
+    Wfc = (rng.standard_normal((512, 512 * 512), dtype=np.float32) * np.float32(2e-3))
+    bfc = rng.standard_normal(512, dtype=np.float32) * np.float32(0.1)
+    Wo = rng.standard_normal((n, 512), dtype=np.float32) * np.float32(0.05)
+    bo = rng.standard_normal(n, dtype=np.float32) * np.float32(0.1)
+    x = np.maximum(rng.standard_normal((B, 512), dtype=np.float32), 0)
+    y = np.maximum(rng.standard_normal((B, 512), dtype=np.float32), 0)
+    gx, gy, go = (rng.standard_normal((B, n), dtype=np.float32) / np.float32(B) for _ in range(3))
+    ox, oy, oo, hid = orc.film_dgl_fwd(x, y, Wfc, bfc, Wo, bo)
+    dWfc, dbfc, dWo, dbo = (dev(a) for a in (Wfc, bfc, Wo, bo))
+    dx_, dy_ = dev(x), dev(y)
+    nb = lib.gdl_head_film_workspace_bytes(B)
+    assert nb > 0 and lib.gdl_head_film_workspace_bytes(513) == 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hidden = torch.empty(3, B, 512, device=DEV)
+    out, xo, yo = (torch.empty(B, n, device=DEV) for _ in range(3))
+    s = L.cur_stream()
+    L.call("gdl_head_film_fwd", L.ptr(dx_), L.ptr(dy_), L.ptr(dWfc), L.ptr(dbfc), L.ptr(dWo), L.ptr(dbo), L.ptr(hidden),
+           L.ptr(out), L.ptr(xo), L.ptr(yo), B, n, L.ptr(ws), nb, s)
+    torch.cuda.synchronize()
+    for a, ref, k in ((xo, ox, "x_out"), (yo, oy, "y_out"), (out, oo, "out")):
+        np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=1e-3, atol=1e-3, err_msg=k)
+    for i, k in enumerate(("hx", "hf", "hy")):
+        np.testing.assert_allclose(hidden[i].cpu().numpy(), hid[i], rtol=1e-3, atol=1e-3, err_msg=k)
+    # DGL phase 1: the unimodal losses reach the features (head gradients are dropped by the script: not requested)
+    rdx, rdy, _ = orc.film_dgl_bwd(x, y, Wfc, Wo, hid, gx, gy, None, want_fc=False)
+    ddx, ddy = torch.empty_like(dx_), torch.empty_like(dy_)
+    G = [torch.empty_like(t) for t in (dWfc, dbfc, dWo, dbo)]
+    dgx, dgy, dgo = dev(gx), dev(gy), dev(go)  # (named: a temporary's memory would be reused by the next one)
+    L.call("gdl_head_film_bwd", L.ptr(dx_), L.ptr(dy_), L.ptr(dWfc), L.ptr(dWo), L.ptr(hidden), L.ptr(dgx), L.ptr(dgy),
+           L.ptr(dgo), 0, L.ptr(ddx), L.ptr(ddy), L.ptr(G[0]), L.ptr(G[1]), L.ptr(G[2]), L.ptr(G[3]), B, n, L.ptr(ws), nb, s)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ddx.cpu().numpy(), rdx, rtol=1e-3, atol=1e-3, err_msg="dx")
+    np.testing.assert_allclose(ddy.cpu().numpy(), rdy, rtol=1e-3, atol=1e-3, err_msg="dy")
+    # phase 2: loss_f on detached features -> fc, fc_out
+    _, _, RG = orc.film_dgl_bwd(x, y, Wfc, Wo, hid, None, None, go)
+    for t, k in zip(G, ("fc.weight", "fc.bias", "fc_out.weight", "fc_out.bias")):
+        got, ref = t.cpu().numpy(), RG[k]
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) <= 1e-3 * scale + 1e-6, k
+
+
 def test_head_concat_golden():
     g = _gold("head_concat_c6")
     st_ = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})
