@@ -30,6 +30,9 @@
 #include "prof.h"
 
 namespace gdl {
+#ifdef GDL_TIMING
+extern unsigned long long* g_timing_buf;
+#endif
 namespace {
 
 constexpr int A7_T = 49;     // tokens per window
@@ -47,7 +50,29 @@ struct A7Geom {
     int total;         // n_img * wpr * wpc windows per head
     int chunk;         // windows per block (the block's four waves take them round-robin)
     int xcd;
+#ifdef GDL_TIMING
+    unsigned long long* dbg;  // [block][wave][8]: clocks per phase summed over the wave's windows, [6] = windows (tools/probe_attn7.py)
+#endif
 };
+#ifdef GDL_TIMING
+#define A7_STAMP(k)                                         \
+    do {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        tacc[k] += t_ - tprev;                              \
+        tprev = t_;                                         \
+        __builtin_amdgcn_sched_barrier(0);                  \
+    } while (0)
+#define A7_STAMP0()                                  \
+    do {                                             \
+        __builtin_amdgcn_sched_barrier(0);           \
+        tprev = __builtin_amdgcn_s_memtime();        \
+        __builtin_amdgcn_sched_barrier(0);           \
+    } while (0)
+#else
+#define A7_STAMP(k)
+#define A7_STAMP0()
+#endif
 struct A7Wave {
     unsigned char tile[64 * A7_TP];  // P, then dS: [query][key]
     unsigned char opnd[64 * A7_XP];  // V (forward) / dO, K, Q in turn (backward): [token][channel]
@@ -331,7 +356,15 @@ template <bool MASK>
 __device__ __forceinline__ void a7_bwd_window(const A7Geom& g, A7Lds& S, A7Wave& Wv, const A7Lane& c, __amdgpu_buffer_rsrc_t rq,
                                               __amdgpu_buffer_rsrc_t ro, __amdgpu_buffer_rsrc_t rd, const unsigned (&qoff)[4],
                                               const unsigned (&ooff)[4], unsigned lastrow, unsigned lastcol, f32x4_t (&D)[4][3],
-                                              float (&dcol)[4], int lane, int l16, int lq) {
+                                              float (&dcol)[4], int lane, int l16, int lq
+#ifdef GDL_TIMING
+                                              , unsigned long long (&tacc)[6]
+#endif
+) {
+#ifdef GDL_TIMING
+    unsigned long long tprev;
+#endif
+    A7_STAMP0();
     bf16x8_t qf[4], kf[4];
     uint2 pkd[4][4];  // dS of (strip it, key tile jt): keys 16 jt + 4 lq .. + 3 of query 16 it + l16
     {
@@ -350,6 +383,7 @@ __device__ __forceinline__ void a7_bwd_window(const A7Geom& g, A7Lds& S, A7Wave&
             a7_rows_to_lds(Wv.opnd, of, l16, lq);
         }
         a7_wave_sync();
+        A7_STAMP(0);  // offsets, loads issued and landed, dO rows in LDS
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             f32x4_t s[4], dp[4];
@@ -381,10 +415,12 @@ __device__ __forceinline__ void a7_bwd_window(const A7Geom& g, A7Lds& S, A7Wave&
             }
         }
     }
+    A7_STAMP(1);  // the four strips
     // dV = P^T dO
     a7_wave_sync();
     a7_product<true>(Wv.tile, Wv.opnd, rd, qoff, 4 * g.ld, 1.f, l16, lq);
     a7_wave_sync();
+    A7_STAMP(2);
     // dQ = scale dS K, and the window's dS added to the block's D on the matrix cores (D += dS . I)
 #pragma unroll
     for (int it = 0; it < 4; ++it)
@@ -423,11 +459,13 @@ __device__ __forceinline__ void a7_bwd_window(const A7Geom& g, A7Lds& S, A7Wave&
         }
     }
     a7_wave_sync();
+    A7_STAMP(3);
     // dK = scale dS^T Q
     a7_rows_to_lds(Wv.opnd, qf, l16, lq);
     a7_wave_sync();
     a7_product<true>(Wv.tile, Wv.opnd, rd, qoff, 2 * g.ld, A7_SCALE, l16, lq);
     a7_wave_sync();
+    A7_STAMP(4);
 }
 
 __global__ __launch_bounds__(256, 2) void swin_attn7_bwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
@@ -450,6 +488,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn7_bwd_kernel(const bf16* __re
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) D[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifdef GDL_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#define A7_TACC , tacc
+#else
+#define A7_TACC
+#endif
     __syncthreads();
     A7Wave& Wv = S.w[wave];
     const int nwin = g.wpr * g.wpc, L = g.H * g.W;
@@ -465,13 +510,21 @@ __global__ __launch_bounds__(256, 2) void swin_attn7_bwd_kernel(const bf16* __re
         a7_offsets(g, c, wy, wx, l16, cl, qoff, ooff);
         const bool lr = g.shift && wy == g.wpc - 1, lc = g.shift && wx == g.wpr - 1;
         if (lr || lc)
-            a7_bwd_window<true>(g, S, Wv, c, rq, ro, rd, qoff, ooff, lr ? 0xffffffffu : 0u, lc ? 0xffffffffu : 0u, D, dcol, lane, l16, lq);
+            a7_bwd_window<true>(g, S, Wv, c, rq, ro, rd, qoff, ooff, lr ? 0xffffffffu : 0u, lc ? 0xffffffffu : 0u, D, dcol, lane, l16, lq A7_TACC);
         else
-            a7_bwd_window<false>(g, S, Wv, c, rq, ro, rd, qoff, ooff, 0u, 0u, D, dcol, lane, l16, lq);
+            a7_bwd_window<false>(g, S, Wv, c, rq, ro, rd, qoff, ooff, 0u, 0u, D, dcol, lane, l16, lq A7_TACC);
         if (h == 0 && g.ld > 32 * g.nh)
             for (int sgm = 0; sgm < 3; ++sgm) a7_zero_pad(g, rd, 6 * g.ld, wy, wx, lane, sgm * 2 * g.ld);
         a7_advance(g, n, wy, wx);
     }
+#ifdef GDL_TIMING
+    if (g.dbg && lane == 0 && bid < 4096) {
+        unsigned long long* d = g.dbg + ((size_t)bid * 4 + wave) * 8;
+        for (int k = 0; k < 5; ++k) d[k] = tacc[k];
+        d[5] = __builtin_amdgcn_s_memtime() - tk0;  // the wave's life so far (its windows; the bias tile came before)
+        d[6] = (unsigned long long)((gw_end - (chunk * g.chunk + wave) + 3) / 4);
+    }
+#endif
     // d(table) of the block: D of the four waves summed in wave order (a lane owns the same elements in every wave), then entry
     // (dh, dw) = sum of D[i][j] over the pairs with (ri - rj, ci - cj) = (dh, dw), rows ascending
     float* area = S.bias;
@@ -531,6 +584,9 @@ void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int ld, bool
     static int xcd = -1;
     if (xcd < 0) xcd = a7_knob("GDL_SWIN_XCD", 1);
     g->xcd = xcd;
+#ifdef GDL_TIMING
+    g->dbg = g_timing_buf;
+#endif
 }
 template <typename K>
 int a7_attr(K kernel, bool* done) {

@@ -157,7 +157,7 @@ def _attn_ref(qkv, table, n_img, H, W, ws, shift, nh, ld):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("H,ws,shift,nh", [(14, 7, 0, 3), (14, 7, 3, 3), (7, 7, 0, 6), (28, 7, 3, 3), (56, 7, 3, 3), (4, 2, 1, 2)])
+@pytest.mark.parametrize("H,ws,shift,nh", [(14, 7, 0, 3), (14, 7, 3, 3), (7, 7, 0, 6), (28, 7, 3, 3), (35, 7, 3, 3), (56, 7, 3, 3), (4, 2, 1, 2)])
 def test_window_attention(dt, H, ws, shift, nh):
     dc = L.dtype_code(dt)
     n_img, W, ld = 3, H, 128 if nh * 32 <= 128 else 192
