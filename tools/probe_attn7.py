@@ -47,7 +47,7 @@ d = dbg.cpu().numpy()
 d = d[d[:, 6] > 0]
 nwin = d[:, 6].sum()
 print(f"stage {stage} shift {shift}: {e0.elapsed_time(e1) * 1e3:.0f} us; {len(d)} waves stamped, {nwin / len(d):.1f} windows each; "
-      f"wave life {d[:, 5].mean():.0f} s_memtime ticks"))
+      f"wave life {d[:, 5].mean():.0f} s_memtime ticks")
 names = ("offsets + loads issued + landed, dO rows -> LDS", "four strips: S, dP, softmax, dS, P -> tile", "dV = P^T dO (+ stores)",
          "dS -> tile, K rows, dQ = dS K, D += dS . I", "Q rows, dK = dS^T Q")
 tot = d[:, :5].sum()
