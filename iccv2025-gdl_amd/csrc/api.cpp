@@ -377,6 +377,10 @@ int gdl_swin_bias_act(int dtype, void* y, const float* bias, void* u, const void
     GDL_REQUIRE(dt_ok(dtype) && y && bias, "swin_bias_act: bad arguments");
     return swin_bias_act(dtype, y, bias, u, res, M, ld, mode, (hipStream_t)stream);
 }
+int gdl_swin_drop_path(int dtype, const void* y, const void* res, const float* scale, void* out, size_t M, int L, int ld, void* stream) {
+    GDL_REQUIRE(dt_ok(dtype), "swin_drop_path: bad dtype");
+    return swin_drop_path(dtype, y, res, scale, out, M, L, ld, (hipStream_t)stream);
+}
 int gdl_swin_ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
                     void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && x && gamma && beta && y && stats, "swin_ln_fwd: bad arguments");

@@ -199,6 +199,7 @@ int head_concat_xy_bwd(const float* x, const float* y, const float* W, const flo
 // ---- Swin visual encoder, non-GEMM operators (swin.hip; the Linears run on conv_fwd / conv_dgrad / conv_wgrad as 1x1)
 int swin_patch_gather(int dt, const float* x, void* a, int B, int T, int H, int W, int p, hipStream_t st);
 int swin_bias_act(int dt, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode, hipStream_t st);
+int swin_drop_path(int dt, const void* y, const void* res, const float* scale, void* out, size_t M, int L, int ld, hipStream_t st);
 int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M, int C, int ld,
                 hipStream_t st);
 size_t swin_partial_bytes(int ld);

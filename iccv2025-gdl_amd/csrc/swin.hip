@@ -97,6 +97,30 @@ __global__ __launch_bounds__(256) void swin_bias_act_kernel(T* __restrict__ y, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stochastic depth
+// DropPath (timm.models.layers.drop_path as the reference's blocks use it, swin_transformer.py:218, 290, 293): the residual
+// branch of frame n is multiplied by scale[n] (0, or 1 / keep_prob) before it joins the stream.
+//   out[row][c] = (res ? res[row][c] : 0) + scale[row / L] * y[row][c]        (fp32, rounded once; out may be y)
+// The forward uses it with the residual, the backward without (the branch's share of the stream's gradient).  Only models with
+// drop_path_rate > 0 in training mode come here: the Linears' epilogues add the residual themselves otherwise.
+template <typename T>
+__global__ __launch_bounds__(256) void swin_drop_path_kernel(const T* __restrict__ y, const T* __restrict__ res,
+                                                             const float* __restrict__ scale, T* __restrict__ out, size_t M, int L,
+                                                             int ld) {
+    constexpr int EPC = TT<T>::EPC;
+    const int vpr = ld / EPC;
+    const size_t total = M * vpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float s = scale[(i / vpr) / L];
+        float f[EPC], r[EPC];
+        unpack16<T>(((const uint4*)y)[i], f);
+        if (res) unpack16<T>(((const uint4*)res)[i], r);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) f[e] = res ? fmaf(s, f[e], r[e]) : s * f[e];
+        ((uint4*)out)[i] = pack16<T>(f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // A row is ld / EPC 16-byte vectors; `lpr` lanes (a power of two <= 64, host-chosen: the next one >= the vector count)
 // share a row, 64 / lpr rows per wave, each lane up to SW_MAXVPL vectors (vector sub + lpr*i).  A 128-channel bf16 row is
@@ -1328,6 +1352,21 @@ int swin_bias_act(int dt, void* y, const float* bias, void* u, const void* res, 
     ProfScope prof("gdl::swin_bias_act_kernel", PROF_HBM, st, (double)M * ld * esz * (mode == 0 ? 2 : 3));
     if (dt == GDL_F32) return bias_act_t<float>((float*)y, bias, (float*)u, (const float*)res, M, ld, mode, st);
     return bias_act_t<bf16>((bf16*)y, bias, (bf16*)u, (const bf16*)res, M, ld, mode, st);
+}
+
+int swin_drop_path(int dt, const void* y, const void* res, const float* scale, void* out, size_t M, int L, int ld, hipStream_t st) {
+    GDL_REQUIRE(y && scale && out && ld % 64 == 0 && L >= 1 && M % (size_t)L == 0, "swin_drop_path: bad arguments (M=%zu, L=%d, ld=%d)", M, L, ld);
+    const double esz = dt == GDL_F32 ? 4 : 2;
+    ProfScope prof("gdl::swin_drop_path_kernel", PROF_HBM, st, (double)M * ld * esz * (res ? 3 : 2));
+    if (dt == GDL_F32) {
+        const int g = sw_grid(M * (ld / 4));
+        hipLaunchKernelGGL(swin_drop_path_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y, (const float*)res, scale, (float*)out, M, L, ld);
+    } else {
+        const int g = sw_grid(M * (ld / 8));
+        hipLaunchKernelGGL(swin_drop_path_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)y, (const bf16*)res, scale, (bf16*)out, M, L, ld);
+    }
+    GDL_CHECK_LAUNCH("swin_drop_path_kernel");
+    return GDL_OK;
 }
 
 // lanes per row of the LayerNorm kernels: the power of two >= the row's 16-byte vectors, at most 64

@@ -47,6 +47,7 @@ SIGNATURES = {
     "gdl_head_concat_xy_bwd": ("i", "pppppp" + "ii" + "pppp" + "iiii" + "p"),
     "gdl_swin_patch_gather": ("i", "ipp" + "iiiii" + "p"),
     "gdl_swin_bias_act": ("i", "ipppp" + "zii" + "p"),
+    "gdl_swin_drop_path": ("i", "ipppp" + "zii" + "p"),
     "gdl_swin_ln_fwd": ("i", "ippppp" + "zii" + "p"),
     "gdl_swin_partial_bytes": ("z", "i"),
     "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),

@@ -174,7 +174,7 @@ class SwinEngine:
             blocks = []
             for j in range(depth):
                 pre = f"layers.{i}.blocks.{j}."
-                b = {"shift": 0 if (j % 2 == 0 or r <= cfg["window"]) else cfg["window"] // 2}
+                b = {"shift": 0 if (j % 2 == 0 or r <= cfg["window"]) else cfg["window"] // 2, "k": sum(cfg["depths"][:i]) + j}
                 b["norm1"] = _Norm(self, reg(pre + "norm1.weight", (C,)), reg(pre + "norm1.bias", (C,)), C)
                 b["table_idx"] = reg(pre + "attn.relative_position_bias_table", ((2 * ws - 1) ** 2, nh))
                 b["qkv"] = _Linear(self, reg(pre + "attn.qkv.weight", (3 * C, C)), reg(pre + "attn.qkv.bias", (3 * C,)), 3 * C, C, nseg=C)
@@ -269,6 +269,11 @@ class SwinEngine:
         self._wg = torch.empty(nb, dtype=torch.uint8, device=dev)
         self._params = None
         self.have_fwd = False
+        # stochastic depth (swin_transformer.py:218, 290, 293): per-frame scales of the two residual branches of every block, copied
+        # here from the caller's tensor by a forward that is given one (fixed address: the launch sequences may be graph replays)
+        self.nblocks = sum(cfg["depths"])
+        self.drop_buf = torch.ones((self.nblocks, 2, N), dtype=torch.float32, device=dev)
+        self._drop = False  # the last forward ran with DropPath: its backward scales the branch gradients the same way
 
     # ------------------------------------------------------------------ plumbing
     def param_shapes(self):
@@ -352,9 +357,12 @@ class SwinEngine:
         return flat[:rows * cols].view(rows, cols)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, pool_frames=False, out=None):
+    def forward(self, x, pool_frames=False, out=None, drop_scales=None):
         """-> float32 [B*T, C_last] (the reference's contract), or [B, C_last] averaged over the frames of a sample
-        (pool_frames: what basic_model.py:77-80 does for the ResNet branch -- the samples' frames are consecutive rows)."""
+        (pool_frames: what basic_model.py:77-80 does for the ResNet branch -- the samples' frames are consecutive rows).
+        drop_scales: None (DropPath is the identity: eval mode, or drop_path_rate = 0) or a float32 [blocks][2][B*T] tensor on
+        the device -- the factor each frame's attention / Mlp branch is multiplied with before it joins the residual stream, 0
+        or 1 / keep_prob (timm's drop_path with scale_by_keep; the caller draws them: `models.swin_transformer.drop_path_scales`)."""
         if self._params is None:
             raise L.GdlError("SwinEngine.forward: parameters not set")
         cfg, dt, N, st = self.cfg, self.dt, self.N, L.cur_stream()
@@ -366,9 +374,16 @@ class SwinEngine:
             out = self.feat_b if pool_frames else self.feat
         elif tuple(out.shape) != ((B if pool_frames else N), self.C_out) or out.dtype != torch.float32 or not out.is_contiguous():
             raise L.GdlError("SwinEngine.forward: `out` must be a contiguous float32 [B*T or B, C_last] tensor")
+        drop = drop_scales is not None
+        if drop:
+            if tuple(drop_scales.shape) != tuple(self.drop_buf.shape) or drop_scales.dtype != torch.float32 or \
+                    drop_scales.device != self.device:
+                raise L.GdlError(f"SwinEngine.forward: drop_scales must be a float32 {list(self.drop_buf.shape)} tensor on the engine's device")
+            self.drop_buf.copy_(drop_scales, non_blocking=True)
+        self._drop = drop
         L.call("gdl_swin_patch_gather", dt, L.ptr(x), L.ptr(self.pe_rows), B, T, cfg["img"], cfg["img"], cfg["patch"], st)
-        key = ("f", out.data_ptr(), bool(pool_frames)) + tuple(p.data_ptr() for p in self._params)
-        self._run(key, lambda: self._forward_body(out, pool_frames))
+        key = ("f", out.data_ptr(), bool(pool_frames), drop) + tuple(p.data_ptr() for p in self._params)
+        self._run(key, lambda: self._forward_body(out, pool_frames, drop))
         self.have_fwd = True
         self.serial += 1
         return out
@@ -404,7 +419,12 @@ class SwinEngine:
         ent["g"] = g
         g.replay()
 
-    def _forward_body(self, out, pool_frames):
+    def _drop_path(self, y, res, k, branch, out, M, ld, st):
+        """out = (res or 0) + drop_buf[k][branch][frame of the row] * y"""
+        L.call("gdl_swin_drop_path", self.dt, L.ptr(y), L.ptr(res) if res is not None else None, L.ptr(self.drop_buf[k, branch]),
+               L.ptr(out), M, M // self.N, ld, st)
+
+    def _forward_body(self, out, pool_frames, drop=False):
         cfg, dt, N, st = self.cfg, self.dt, self.N, L.cur_stream()
         B, T = self.B, self.T
         P = self._params
@@ -421,10 +441,19 @@ class SwinEngine:
                 b["qkv"].fwd_bias(b["h"], b["qkv_a"], None, M, st)
                 L.call("gdl_swin_attn_fwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(b["attn"]), N, r, r, s["ws"],
                        b["shift"], s["nh"], ld, st)
-                b["proj"].fwd_bias(b["attn"], b["x_mid"], xcur, M, st)
+                if drop:  # the branch without the residual, then x_mid = x_in + scale[frame] * branch (g_c: free during a forward)
+                    br = self._v(self.g_c, M, ld)
+                    b["proj"].fwd_bias(b["attn"], br, None, M, st)
+                    self._drop_path(br, xcur, b["k"], 0, b["x_mid"], M, ld, st)
+                else:
+                    b["proj"].fwd_bias(b["attn"], b["x_mid"], xcur, M, st)
                 b["norm2"].fwd(b["x_mid"], b["m"], b["stats2"], M, st)
                 b["fc1"].fwd_bias(b["m"], b["u"], None, M, st, gelu_out=b["a"])  # u = fc1(m) + b, a = gelu(u)
-                b["fc2"].fwd_bias(b["a"], b["x_out"], b["x_mid"], M, st)
+                if drop:
+                    b["fc2"].fwd_bias(b["a"], br, None, M, st)
+                    self._drop_path(br, b["x_mid"], b["k"], 1, b["x_out"], M, ld, st)
+                else:
+                    b["fc2"].fwd_bias(b["a"], b["x_out"], b["x_mid"], M, st)
                 xcur = b["x_out"]
             if "red" in s:
                 L.call("gdl_swin_merge", dt, L.ptr(xcur), L.ptr(s["cat"]), N, r, r, s["C"], ld, 0, st)
@@ -468,12 +497,12 @@ class SwinEngine:
         if phase == 1:
             self._bw_phase1_serial = self.serial
         grads = list(grads)
-        key = ("b", phase, dfeat.data_ptr(), pooled) + tuple(t.data_ptr() for t in grads) + tuple(p.data_ptr() for p in self._params)
-        self._run(key, lambda: self._backward_body(dfeat, grads, pooled, phase))
+        key = ("b", phase, dfeat.data_ptr(), pooled, self._drop) + tuple(t.data_ptr() for t in grads) + tuple(p.data_ptr() for p in self._params)
+        self._run(key, lambda: self._backward_body(dfeat, grads, pooled, phase, self._drop))
         if phase == 2:
             self._bw_phase1_serial = None
 
-    def _backward_body(self, dfeat, grads, pooled, phase=0):
+    def _backward_body(self, dfeat, grads, pooled, phase=0, drop=False):
         dt, N, st = self.dt, self.N, L.cur_stream()
         P = self._params
         last = self.stages[-1]
@@ -523,24 +552,34 @@ class SwinEngine:
                 hid_ld = b["fc1"].np
                 gw = self._v(self.g_w, M, hid_ld)
                 # x_out = x_mid + fc2(gelu(fc1(norm2(x_mid)))) ; dx = d x_out
-                if b["cs_dx"] is None:
-                    L.call("gdl_swin_colsum", dt, L.ptr(dx), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
-                wg(b["fc2"], dx, b["a"], M, "fc2")
+                # DropPath: the Mlp branch sees g2 = scale[frame] * dx (in gtok until d m is written there); its bias gradient is a
+                # column sum of g2 -- the row the LayerNorm backward left for it sums the unscaled dx
+                g2 = dx
+                if drop:
+                    g2 = gtok
+                    self._drop_path(dx, None, b["k"], 1, g2, M, ld, st)
+                if b["cs_dx"] is None or drop:
+                    L.call("gdl_swin_colsum", dt, L.ptr(g2), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
+                wg(b["fc2"], g2, b["a"], M, "fc2")
                 need("qkv")  # (the previous block's: it reads g_w)
                 if fuse:  # d u = (dx . W2) * gelu'(u) and fc1's bias gradient in the GEMM's epilogue
-                    b["fc2"].dgrad_gelu(dx, gw, b["u"], self.fc1_acc[b["fc1_off"]:], self.fc1_scale, M, st)
+                    b["fc2"].dgrad_gelu(g2, gw, b["u"], self.fc1_acc[b["fc1_off"]:], self.fc1_scale, M, st)
                 else:
-                    b["fc2"].dgrad(dx, gw, M, st)                                 # d a
+                    b["fc2"].dgrad(g2, gw, M, st)                                 # d a
                     L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
                 wg(b["fc1"], gw, b["m"], M, "fc1")
                 b["fc1"].dgrad(gw, gtok, M, st)                                   # d m
                 need("proj")  # (the previous block's: it reads `spare`)
                 b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st, colsum=self.fuse_ln)   # spare = d x_mid
                 # x_mid = x_in + proj(attn(qkv(norm1(x_in))))
-                if not self.fuse_ln:
-                    L.call("gdl_swin_colsum", dt, L.ptr(spare), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
-                wg(b["proj"], spare, b["attn"], M, "proj")
-                b["proj"].dgrad(spare, gtok, M, st)                               # d attention output
+                g1 = spare
+                if drop:  # g1 = scale[frame] * d x_mid, in g_w (free between fc1's data gradient and the attention backward)
+                    g1 = self._v(self.g_w, M, ld)
+                    self._drop_path(spare, None, b["k"], 0, g1, M, ld, st)
+                if not self.fuse_ln or drop:
+                    L.call("gdl_swin_colsum", dt, L.ptr(g1), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
+                wg(b["proj"], g1, b["attn"], M, "proj")
+                b["proj"].dgrad(g1, gtok, M, st)                               # d attention output
                 gq = self._v(self.g_w, M, 3 * ld)
                 need("fc1")
                 L.call("gdl_swin_attn_bwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(gtok), L.ptr(gq),

@@ -36,10 +36,11 @@ class _SwinAdapter:
     """gdl.swin.SwinEngine behind the EncoderEngine calls the trainer makes (features averaged over the T frames of a
     sample; no BatchNorm state; phase 1 = upstream gradient + final norm + last stage, phase 2 = the rest)."""
 
-    def __init__(self, cfg, dtype, B, T, device):
+    def __init__(self, cfg, dtype, B, T, device, net=None):
         from .swin import SwinEngine
 
         self.eng = SwinEngine(cfg, dtype, B, T, device)
+        self.net = net  # the mirror module: drop_path_rate, drop_scales_override / last_drop_scales (stochastic depth)
 
     def set_params(self, params):
         self.eng.set_params(params)
@@ -47,7 +48,15 @@ class _SwinAdapter:
     def forward(self, x, training, feat_out=None):
         if x.dtype != torch.float32 or not x.is_contiguous():
             raise L.GdlError("DGLTrainer: frames must be a contiguous float32 [B, 3, T, H, W] tensor")
-        return self.eng.forward(x, pool_frames=True, out=feat_out)
+        drop = None
+        if training and self.net is not None and self.net.drop_path_rate > 0:  # a training step draws the DropPath masks
+            import sys
+
+            drop_path_scales = sys.modules[type(self.net).__module__].drop_path_scales  # (models.swin_transformer, as imported by the caller)
+            drop = self.net.drop_scales_override if self.net.drop_scales_override is not None else \
+                drop_path_scales(self.eng.cfg, self.net.drop_path_rate, self.eng.N, self.eng.device)
+            self.net.last_drop_scales = drop
+        return self.eng.forward(x, pool_frames=True, out=feat_out, drop_scales=drop)
 
     def backward(self, grads, dfeat=None, phase=0):
         if phase != 2:
@@ -129,8 +138,6 @@ class DGLTrainer:
         # the visual branch: ResNet18 (60 tensors, 512 features) or the Swin composition of SURVEY row N4
         # (models.basic_model.AVClassifier_DGL_Swin: gdl.swin.SwinEngine, num_features wide)
         self.vis_swin = hasattr(model.visual_net, "cfg") and hasattr(model.visual_net, "num_features")
-        if self.vis_swin and getattr(model.visual_net, "drop_path_rate", 0.0) > 0:
-            raise L.GdlError("DGLTrainer: the Swin branch trains with drop_path_rate = 0 only (stochastic depth is random per sample)")
         self.nv = len(named) - nf - 60
         self.dv = int(model.visual_net.num_features) if self.vis_swin else 512
         if self.vis_swin and (self.head != "concat" or mode != "dgl"):
@@ -261,7 +268,7 @@ class DGLTrainer:
             cfg = self.model.visual_net.cfg
             if H != cfg["img"] or W != cfg["img"]:
                 raise L.GdlError(f"DGLTrainer.step: the Swin branch was built for {cfg['img']} x {cfg['img']} frames")
-            self.eng_v = _SwinAdapter(cfg, self.dtype, B, T, self.device)
+            self.eng_v = _SwinAdapter(cfg, self.dtype, B, T, self.device, self.model.visual_net)
         else:
             self.eng_v = EncoderEngine("visual", self.dtype, B, T, H, W, self.device)
         # A fourth stream for the visual (critical-path) encoder's weight gradients -- but never a fifth:

@@ -7,9 +7,10 @@ mlp.{fc1, fc2}}, attn_mask of the shifted blocks, layers.i.downsample.{reduction
 convolution) and the same forward contract: `forward(x [B, 3, T, H, W]) -> [B*T, num_features]` pooled features.  The
 `torch.nn` layers are parameter containers; the arithmetic is one autograd node over `gdl.swin.SwinEngine`.
 
-Supported: `args.pe = 0` (the DUL branch of :577-586 is not built), `ape = False`, `patch_norm = True`, dropouts 0 and
-`drop_path_rate = 0` (the reference's default 0.1 draws random per-sample masks; the engine computes the deterministic
-function), head dimension 32 (every published Swin size).  Anything else raises.
+Supported: `args.pe = 0` (the DUL branch of :577-586 is not built), `ape = False`, `patch_norm = True`, dropouts 0, head
+dimension 32 (every published Swin size); anything else raises.  Stochastic depth (`drop_path_rate`, default 0.1 like the
+reference's): the identity in eval mode; a training forward draws the per-frame masks with torch's generator on the input's
+device, in the reference's order (`drop_path_scales`), and the engine applies them (`gdl_swin_drop_path`).
 """
 import numpy as np
 import torch
@@ -103,12 +104,32 @@ class PatchEmbed(nn.Module):
         self.norm = nn.LayerNorm(embed_dim)
 
 
+def drop_path_scales(cfg, rate, n_frames, device, generator=None):
+    """float32 [blocks][2][n_frames]: what timm's `drop_path(x, p, training=True, scale_by_keep=True)` multiplies the attention /
+    Mlp branch of every block with in a training forward (swin_transformer.py:218, 290, 293): block k of sum(depths) drops a frame
+    with probability linspace(0, rate, sum(depths))[k] (:546) -- Bernoulli(keep) / keep per frame, a fresh draw per branch,
+    attention branch first, blocks in network order; a block of probability 0 is nn.Identity and draws nothing."""
+    nb = sum(cfg["depths"])
+    out = torch.ones((nb, 2, n_frames), dtype=torch.float32, device=device)
+    for k, p in enumerate(torch.linspace(0, rate, nb).tolist()):
+        if p > 0:
+            for br in range(2):
+                m = torch.empty(n_frames, dtype=torch.float32, device=device).bernoulli_(1.0 - p, generator=generator)
+                out[k, br] = m / (1.0 - p) if p < 1.0 else m
+    return out
+
+
 class _SwinFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, pooled, x, *params):
         eng = net._engine(x)
         eng.set_params([p.detach() for p in params])
-        feat = eng.forward(x.float().contiguous(), pool_frames=pooled).clone()
+        drop = None
+        if net.training and net.drop_path_rate > 0:
+            drop = net.drop_scales_override if net.drop_scales_override is not None else \
+                drop_path_scales(net.cfg, net.drop_path_rate, x.shape[0] * x.shape[2], x.device)
+            net.last_drop_scales = drop
+        feat = eng.forward(x.float().contiguous(), pool_frames=pooled, drop_scales=drop).clone()
         ctx.net, ctx.eng, ctx.n = net, eng, len(params)
         ctx.serial = eng.serial  # the engine is shared by every forward of this shape (train and eval): see backward
         ctx.set_materialize_grads(False)
@@ -136,10 +157,13 @@ class SwinTransformer(nn.Module):
                 norm_layer is not nn.LayerNorm or not qkv_bias or modality != 'visual':
             raise NotImplementedError("gdl: SwinTransformer supports modality='visual', ape=False, patch_norm=True, qkv_bias=True, "
                                       "in_chans=3 and drop_rate = attn_drop_rate = 0")
-        # Stochastic depth (the reference constructor's default is 0.1, swin_transformer.py:516): DropPath is the identity in
-        # eval mode (:546 via timm), so a default-constructed model evaluates here; a TRAINING forward with a rate > 0 draws
-        # random per-sample masks, which the engine does not -- forward() refuses that combination (pass drop_path_rate=0.).
+        # Stochastic depth (the reference constructor's default is 0.1, swin_transformer.py:516): the identity in eval mode; a
+        # training forward draws per-frame masks (drop_path_scales).  `drop_scales_override`: a [blocks][2][frames] tensor used
+        # instead of a fresh draw (tests, replaying a recorded run); `last_drop_scales`: what the last training forward used.
         self.drop_path_rate = float(drop_path_rate)
+        if not 0.0 <= self.drop_path_rate < 1.0:
+            raise ValueError("gdl: drop_path_rate must be in [0, 1)")
+        self.drop_scales_override, self.last_drop_scales = None, None
         if any(embed_dim * 2 ** i != 32 * h for i, h in enumerate(num_heads)) or mlp_ratio != int(mlp_ratio):
             raise NotImplementedError("gdl: SwinTransformer needs head dimension 32 and an integer mlp_ratio")
         self.num_classes, self.num_layers, self.embed_dim = num_classes, len(depths), embed_dim
@@ -192,17 +216,10 @@ class SwinTransformer(nn.Module):
     def forward_features(self, x):
         raise NotImplementedError("gdl: the token map is internal to the engine; use forward()")
 
-    def _check_mode(self):
-        if self.training and self.drop_path_rate > 0:
-            raise NotImplementedError("gdl: SwinTransformer in training mode needs drop_path_rate=0. (stochastic depth is random per "
-                                      f"sample; this model was built with {self.drop_path_rate}); eval mode is fine")
-
     def forward(self, x):
-        self._check_mode()
         return _SwinFn.apply(self, False, x, *self.parameters())
 
     def forward_pooled(self, x):
         """[B, 3, T, H, W] -> [B, num_features]: the features averaged over the T frames of a sample (not a method of the
         reference class; the counterpart of the pooling basic_model.py:77-80 applies to the ResNet branch)."""
-        self._check_mode()
         return _SwinFn.apply(self, x.shape[2] > 1, x, *self.parameters())

@@ -459,6 +459,9 @@ GDL_API int gdl_prof_collect_floor(double* floor_ms, double* bytes);
  * are float32 in the padded layout.
  *   gdl_swin_patch_gather   frames [B,3,T,H,W] f32 -> GEMM rows [B*T*(H/p)*(W/p)][64], columns (c,kh,kw)  (:463,:480)
  *   gdl_swin_bias_act       mode 0: y += b;  1: u = y + b, y = gelu(u);  2: y = y + b + res               (:26-42,:287-290)
+ *   gdl_swin_drop_path      DropPath of a residual branch (timm.models.layers.drop_path, scale_by_keep; :218,:290,:293):
+ *                           out = (res ? res : 0) + scale[row / L] * y, scale[frame] = 0 or 1 / keep_prob (drawn by the caller:
+ *                           the reference draws them from torch's generator); forward with res, backward without; out may be y
  *   gdl_swin_ln_fwd / _bwd  nn.LayerNorm(eps 1e-5) over the C real channels; stats [M][2] = (mean, rstd); the backward
  *                           adds `add` (the residual branch's gradient) and returns [2][ld] = (d gamma, d beta)
  *   gdl_swin_colsum         db[ld] = column sums of g; with u != NULL first g <- g * gelu'(u) (in place)
@@ -472,6 +475,8 @@ GDL_API int gdl_prof_collect_floor(double* floor_ms, double* bytes);
  *   gdl_swin_unpack_matrix  float32 padded [np][kp] -> float32 real [n][k] (weight gradients back to parameter shape)
  * ------------------------------------------------------------------------------------------------------------------- */
 GDL_API int gdl_swin_patch_gather(int dtype, const float* x, void* a, int B, int T, int H, int W, int patch, void* stream);
+GDL_API int gdl_swin_drop_path(int dtype, const void* y, const void* res, const float* scale, void* out, size_t M, int L, int ld,
+                               void* stream);
 GDL_API int gdl_swin_bias_act(int dtype, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode,
                               void* stream);
 GDL_API int gdl_swin_ln_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* stats, size_t M,

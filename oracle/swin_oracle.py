@@ -62,8 +62,10 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def block(x, P, pre, H, W, nh, ws, shift):
-    """x [N, H*W, C] -> same (swin_transformer.py:256-295)."""
+def block(x, P, pre, H, W, nh, ws, shift, drop=None):
+    """x [N, H*W, C] -> same (swin_transformer.py:256-295).  drop: None (DropPath is the identity: eval mode or rate 0) or two
+    [N] tensors of per-frame scales (0 or 1 / keep_prob) for the attention and the Mlp branch -- what timm's
+    `drop_path(x, p, training, scale_by_keep=True)` multiplies the branch with (:290, :293)."""
     N, L, C = x.shape
     hd = C // nh
     idx = window_tokens(H, W, ws, shift)  # [nW, T]
@@ -84,10 +86,11 @@ def block(x, P, pre, H, W, nh, ws, shift):
     o = o.permute(0, 1, 3, 2, 4).reshape(N, nW * T, C)
     o = o @ P[pre + "attn.proj.weight"].t() + P[pre + "attn.proj.bias"]
     back = torch.zeros_like(x).index_add(1, idx.reshape(-1), o)  # idx is a permutation of the tokens
-    x = x + back
+    x = x + (back if drop is None else back * drop[0][:, None, None])
     m = layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
     m = gelu(m @ P[pre + "mlp.fc1.weight"].t() + P[pre + "mlp.fc1.bias"])
-    return x + (m @ P[pre + "mlp.fc2.weight"].t() + P[pre + "mlp.fc2.bias"])
+    m = m @ P[pre + "mlp.fc2.weight"].t() + P[pre + "mlp.fc2.bias"]
+    return x + (m if drop is None else m * drop[1][:, None, None])
 
 
 def merge(x, P, pre, H, W):
@@ -100,8 +103,9 @@ def merge(x, P, pre, H, W):
     return cat @ P[pre + "reduction.weight"].t()
 
 
-def forward(x, P, cfg):
-    """x [B, 3, T, img, img] -> pooled features [B*T, C_last]   (swin_transformer.py:596-634, args.pe = 0)"""
+def forward(x, P, cfg, drop=None):
+    """x [B, 3, T, img, img] -> pooled features [B*T, C_last]   (swin_transformer.py:596-634, args.pe = 0).
+    drop: None or a [blocks][2][B*T] tensor of DropPath scales, blocks in network order (see `block`)."""
     B, Cin, T, Hi, Wi = x.shape
     p, E = cfg["patch"], cfg["embed"]
     x = x.permute(0, 2, 1, 3, 4).reshape(B * T, Cin, Hi, Wi)
@@ -110,11 +114,13 @@ def forward(x, P, cfg):
     t = pat @ P["patch_embed.proj.weight"].reshape(E, -1).t() + P["patch_embed.proj.bias"]
     t = layer_norm(t, P["patch_embed.norm.weight"], P["patch_embed.norm.bias"])
     nl = len(cfg["depths"])
+    kb = 0
     for i, (depth, nh) in enumerate(zip(cfg["depths"], cfg["heads"])):
         ws = min(cfg["window"], H)
         for j in range(depth):
             shift = 0 if (j % 2 == 0 or H <= cfg["window"]) else cfg["window"] // 2
-            t = block(t, P, f"layers.{i}.blocks.{j}.", H, W, nh, ws, shift)
+            t = block(t, P, f"layers.{i}.blocks.{j}.", H, W, nh, ws, shift, None if drop is None else drop[kb])
+            kb += 1
         if i < nl - 1:
             t = merge(t, P, f"layers.{i}.downsample.", H, W)
             H, W = H // 2, W // 2
@@ -122,9 +128,23 @@ def forward(x, P, cfg):
     return t.mean(1)
 
 
-def forward_backward(x, params, cfg, dy):
+def drop_path_scales(cfg, rate, n_frames, generator=None):
+    """[blocks][2][n_frames] float32 DropPath scales as the reference's training forward draws them: block k of sum(depths) drops
+    with probability linspace(0, rate, sum(depths))[k] (swin_transformer.py:546), a fresh Bernoulli(keep) / keep per branch and
+    frame, attention branch first; a block with probability 0 is nn.Identity (:218) and draws nothing."""
+    nb = sum(cfg["depths"])
+    dpr = torch.linspace(0, rate, nb).tolist()
+    out = torch.ones((nb, 2, n_frames), dtype=torch.float32)
+    for k, p in enumerate(dpr):
+        if p > 0:
+            for br in range(2):
+                out[k, br] = torch.empty(n_frames).bernoulli_(1.0 - p, generator=generator) / (1.0 - p)
+    return out
+
+
+def forward_backward(x, params, cfg, dy, drop=None):
     """numpy in / numpy out: (y, {name: grad}) for the loss sum(y * dy)."""
     P = {k: torch.from_numpy(np.array(v)).clone().requires_grad_(True) for k, v in params.items()}
-    y = forward(torch.from_numpy(np.asarray(x)), P, cfg)
+    y = forward(torch.from_numpy(np.asarray(x)), P, cfg, None if drop is None else torch.from_numpy(np.asarray(drop, dtype=np.float32)))
     (y * torch.from_numpy(np.asarray(dy))).sum().backward()
     return y.detach().numpy(), {k: v.grad.numpy() for k, v in P.items()}

@@ -25,13 +25,15 @@ class SwinAVModel:
         self.audio = orc.ResNet18(params, buffers, "audio_net.", "audio")
         self.mom = {}
 
-    def _visual(self, image):
-        """-> (features [B, C] float32 numpy, closure dfeat -> {name: grad})"""
+    def _visual(self, image, drop=None):
+        """-> (features [B, C] float32 numpy, closure dfeat -> {name: grad}).  drop: the training forward's DropPath scales
+        ([blocks][2][B*T], swin_oracle.block) or None"""
         pre = "visual_net."
         Pt = {k[len(pre):]: torch.from_numpy(np.array(v)).clone().requires_grad_(True) for k, v in self.P.items()
               if k.startswith(pre)}
         B, T = image.shape[0], image.shape[2]
-        y = so.forward(torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)), Pt, self.cfg)  # [B*T, C]
+        y = so.forward(torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)), Pt, self.cfg,
+                       None if drop is None else torch.from_numpy(np.asarray(drop, dtype=np.float32)))  # [B*T, C]
         fv = y.view(B, T, -1).mean(1)
 
         def backward(dfv):
@@ -40,13 +42,13 @@ class SwinAVModel:
 
         return fv.detach().numpy().astype(np.float32), backward
 
-    def train_step(self, spec, image, label, alpha, lr, momentum=0.9, wd=1e-4, max_norm=40.0):
+    def train_step(self, spec, image, label, alpha, lr, momentum=0.9, wd=1e-4, max_norm=40.0, drop=None):
         P = self.P
         B = image.shape[0]
         audio = np.ascontiguousarray(spec[:, None].astype(np.float32))
         a = self.audio.forward(audio, True)
         fa = orc.avgpool_fwd(a, B, 1)
-        fv, vis_bwd = self._visual(image)
+        fv, vis_bwd = self._visual(image, drop)
         W, b = P["fusion_module.fc_out.weight"], P["fusion_module.fc_out.bias"]
         out_a, out_v, out = orc.concat_dgl_fwd(fa, fv, W, b)
         loss_v, g_v = orc.softmax_ce(out_v, label, alpha)  # main_dgl.py:102,108

@@ -41,11 +41,24 @@ def _import_reference():
     tl = types.ModuleType("timm.models.layers")
 
     class DropPath(nn.Module):
+        """timm 0.x `DropPath` / `drop_path(x, drop_prob, training, scale_by_keep=True)` restated (timm is not in this image):
+        identity in eval mode or at probability 0; otherwise one Bernoulli(keep) per sample of dim 0, divided by keep.  Every
+        drawn mask is appended to `DropPath.record` so that a fixture can hold what the reference's forward multiplied with."""
+        record = []
+
         def __init__(self, p=0.0):
             super().__init__()
+            self.p = float(p)
 
         def forward(self, x):
-            return x
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1.0 - self.p
+            m = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            if keep > 0.0:
+                m.div_(keep)
+            DropPath.record.append(m.reshape(-1).clone())
+            return x * m
 
     tl.DropPath = DropPath
     tl.to_2tuple = lambda x: (x, x)
@@ -274,25 +287,41 @@ def run_encoder_case(name, bb, modality, in_shape, seed=0):
     print(name, d["y"].shape, float(np.abs(d["y"]).mean()))
 
 
-def run_swin_case(name, cfg, batch, frames, seed=0):
+def run_swin_case(name, cfg, batch, frames, seed=0, drop_path_rate=0.0):
     """Pooled features + parameter gradients of the imported `SwinTransformer` (swin_transformer.py:486-674, through the
-    3-symbol timm stub above; drop_path_rate = 0 makes the identity DropPath exact) for a fixed upstream gradient."""
+    3-symbol timm stub above; drop_path_rate = 0 makes the identity DropPath exact) for a fixed upstream gradient.
+    drop_path_rate > 0: the training forward under torch.manual_seed(seed); the fixture keeps the masks the blocks drew
+    (`drop_scales` [blocks][2][frames]; a block of probability 0 is nn.Identity and keeps scale 1)."""
     import models.swin_transformer as sw
+    from timm.models.layers import DropPath
 
     args = argparse.Namespace(pe=0)
     net = sw.SwinTransformer(args, "visual", img_size=cfg["img"], patch_size=cfg["patch"], in_chans=3, embed_dim=cfg["embed"],
                              depths=list(cfg["depths"]), num_heads=list(cfg["heads"]), window_size=cfg["window"],
-                             mlp_ratio=float(cfg["mlp"]), drop_path_rate=0.0)
+                             mlp_ratio=float(cfg["mlp"]), drop_path_rate=float(drop_path_rate))
     ps = fx.make_state(fx.swin_param_shapes(cfg))
     assert [n for n, _ in net.named_parameters()] == list(ps), "parameter order differs from the reference's"
     missing = net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in ps.items()}, strict=False)
     assert not missing.unexpected_keys and all("relative_position_index" in k or "attn_mask" in k for k in missing.missing_keys)
     x = fx.swin_input(cfg, batch, frames, seed)
     net.train()
+    DropPath.record.clear()
+    torch.manual_seed(seed)
     y = net(torch.from_numpy(x))
     dy = np.random.default_rng([79, seed]).standard_normal(tuple(y.shape), dtype=np.float32)
     y.backward(torch.from_numpy(dy))
     d = {"config": np.array(json.dumps(dict(cfg, batch=batch, frames=frames, seed=seed))), "y": y.detach().numpy(), "dy": dy}
+    if drop_path_rate > 0:
+        nb, nf = sum(cfg["depths"]), batch * frames
+        probs = torch.linspace(0, drop_path_rate, nb).tolist()  # swin_transformer.py:546
+        scales = np.ones((nb, 2, nf), np.float32)
+        rec = iter(DropPath.record)
+        for k, pk in enumerate(probs):
+            if pk > 0:  # (:218: probability 0 -> nn.Identity, nothing drawn)
+                scales[k, 0], scales[k, 1] = next(rec).numpy(), next(rec).numpy()
+        assert next(rec, None) is None and (scales == 0).any(), "the masks of this seed drop nothing: pick another"
+        d["drop_scales"] = scales
+        d["config"] = np.array(json.dumps(dict(cfg, batch=batch, frames=frames, seed=seed, drop_path_rate=drop_path_rate)))
     for n, p in net.named_parameters():
         g = p.grad.numpy()
         d["gradstat." + n] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum()), np.abs(g).mean()])
@@ -526,6 +555,7 @@ def main():
                                                   swin_cfg=fx.SWIN_TINY2),
         "swin_tiny2_b2": lambda: run_swin_case("swin_tiny2_b2", fx.SWIN_TINY2, 2, 2),
         "swin_t_b1": lambda: run_swin_case("swin_t_b1", fx.SWIN_T, 1, 2),
+        "swin_tiny2_drop_b3": lambda: run_swin_case("swin_tiny2_drop_b3", fx.SWIN_TINY2, 3, 2, seed=1, drop_path_rate=0.3),
         "concat_cremad_b2": lambda: run_step_case("concat_cremad_b2", bm, bb, fm, "CREMAD", (257, 188), 3, (224, 224),
                                                   2, 0.0, 1, mode="concat"),
     }

@@ -198,13 +198,25 @@ def test_swin_mirror_matches_reference_layout():
         assert "layers.0.blocks.0.attn.relative_position_index" in bufs and "layers.0.blocks.1.attn_mask" in bufs
         assert "layers.0.blocks.0.attn_mask" not in bufs  # un-shifted blocks have none (a None buffer is not in the state)
         assert net.num_features == cfg["embed"] << (len(cfg["depths"]) - 1)
-    # the reference's default drop_path_rate = 0.1 (swin_transformer.py:516): DropPath is the identity in eval mode, so the model
-    # is constructible and evaluates; a TRAINING forward (random per-sample masks) is refused before anything touches the GPU
+    # the reference's default drop_path_rate = 0.1 (swin_transformer.py:516): constructible, and no mode is refused any more
+    # (round 4: a training forward draws the DropPath masks); a CPU tensor is -- there is no CPU path
     dflt = SwinTransformer(args, "visual", embed_dim=96, depths=[2, 2], num_heads=[3, 6])
     assert dflt.drop_path_rate == pytest.approx(0.1)
     dflt.train()
-    with pytest.raises(NotImplementedError):
-        dflt(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        dflt(torch.zeros(1, 3, 1, 224, 224))
+    # the masks: drawn like the reference's blocks draw them (same generator, same order: attention branch then Mlp branch, block
+    # by block; probability linspace(0, rate, blocks); the first block is nn.Identity and draws nothing)
+    from models.swin_transformer import drop_path_scales
+    from oracle import swin_oracle as so
+
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    sc = drop_path_scales(fx.SWIN_T, 0.4, 64, "cpu", generator=g1)
+    assert tuple(sc.shape) == (12, 2, 64) and bool((sc[0] == 1).all()) and torch.equal(sc, so.drop_path_scales(fx.SWIN_T, 0.4, 64, generator=g2))
+    keep = 1.0 - torch.linspace(0, 0.4, 12)
+    for k in range(1, 12):
+        vals = set(sc[k].reshape(-1).tolist())
+        assert vals <= {0.0, float(torch.tensor(1.0) / keep[k])} and (k < 6 or 0.0 in vals)
     with pytest.raises(NotImplementedError):
         SwinTransformer(argparse.Namespace(pe=1), "visual", drop_path_rate=0.)
     m = AVClassifier_DGL_Swin(argparse.Namespace(fusion_method="concat", dataset="VGGSound", modality="full", pe=0))

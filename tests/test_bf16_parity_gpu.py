@@ -97,7 +97,7 @@ def test_bf16_heads_b16_two_steps_vs_oracle(fusion):
     assert not bad, bad
 
 
-def _swin_model(ncls, sc, dtype, B):
+def _swin_model(ncls, sc, dtype, B, drop_path_rate=0.):
     from models.basic_model import AVClassifier_DGL_Swin
 
     args = argparse.Namespace(fusion_method="concat", dataset="VGGSound" if ncls == 309 else "CREMAD", modality="full",
@@ -105,7 +105,7 @@ def _swin_model(ncls, sc, dtype, B):
     model = AVClassifier_DGL_Swin(args, swin_kwargs=dict(img_size=sc["img"], patch_size=sc["patch"], embed_dim=sc["embed"],
                                                          depths=list(sc["depths"]), num_heads=list(sc["heads"]),
                                                          window_size=sc["window"], mlp_ratio=float(sc["mlp"]),
-                                                         drop_path_rate=0.))
+                                                         drop_path_rate=drop_path_rate))
     P, Bf = fx.swin_dgl_state(ncls, sc)
     assert [n for n, _ in model.named_parameters()] == list(P)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in {**P, **Bf}.items()}, strict=False)
@@ -134,6 +134,38 @@ def test_swin_composition_b16_bf16_two_steps_vs_oracle():
         w = _report(f"Swin composition B=16 bf16 step {st}", tr.read(), want)
         bad += [(st,) + b for b in _check(w, False, st > 0, b16=True)]
     assert not bad, bad
+
+
+def test_swin_composition_stochastic_depth_step_vs_oracle():
+    """DGLTrainer on the Swin composition built with drop_path_rate = 0.4 (the reference's constructor default is 0.1): two f32
+    training steps whose DropPath masks the trainer draws itself (`visual_net.last_drop_scales`), against oracle/swin_step.py
+    run with the SAME masks -- SURVEY 8(c)'s f32 bounds; the masks must matter (the same steps without them are elsewhere)."""
+    from gdl.trainer import DGLTrainer
+    from oracle.swin_step import SwinAVModel
+
+    B, ncls, alpha, lr, sc = 8, 6, 4.0, 2e-3, fx.SWIN_TINY2
+    model, P, Bf = _swin_model(ncls, sc, "f32", B, drop_path_rate=0.4)
+    orc.set_num_threads(64)
+    ref = SwinAVModel({k: v.copy() for k, v in P.items()}, {k: np.array(v) for k, v in Bf.items()}, sc)
+    plain = SwinAVModel({k: v.copy() for k, v in P.items()}, {k: np.array(v) for k, v in Bf.items()}, sc)
+    tr = DGLTrainer(model, lr=lr, alpha=alpha, dtype="f32")
+    torch.manual_seed(3)
+    bad = []
+    for st in range(2):
+        spec, image, label = fx.make_batch(300 + st, B, (65, 47), 2, (sc["img"], sc["img"]), ncls)
+        tr.step(dev(spec), dev(image), torch.from_numpy(label).to(DEV))
+        r = tr.read()
+        scales = model.visual_net.last_drop_scales.cpu().numpy()
+        assert scales.shape == (4, 2, 2 * B) and (scales[0] == 1).all() and (scales == 0).any()
+        want = ref.train_step(spec, image, label, alpha, lr, drop=scales)
+        w = _report(f"Swin composition, stochastic depth, f32 step {st}", r, want)
+        bad += [(st,) + b for b in _check(w, True, st > 0)]
+        if st == 0:
+            off = plain.train_step(spec, image, label, alpha, lr)
+            assert np.abs(off["out_v"] - want["out_v"]).max() > 1e-3
+    assert not bad, bad
+    acc = tr.valid([(dev(spec), dev(image), torch.from_numpy(label).to(DEV))])  # eval: DropPath is the identity, nothing is drawn
+    assert all(0.0 <= a <= 1.0 for a in acc)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

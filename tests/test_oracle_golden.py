@@ -288,10 +288,12 @@ def test_torch_restatement_matches_oracle():
     np.testing.assert_allclose(t["total_norm"], r["total_norm"], rtol=1e-3)
 
 
-@pytest.mark.parametrize("name,cfg_name", [("swin_tiny2_b2", "SWIN_TINY2"), ("swin_t_b1", "SWIN_T")])
+@pytest.mark.parametrize("name,cfg_name", [("swin_tiny2_b2", "SWIN_TINY2"), ("swin_t_b1", "SWIN_T"), ("swin_tiny2_drop_b3", "SWIN_TINY2")])
 def test_swin_oracle_matches_reference_golden(golden_dir, name, cfg_name):
     """oracle/swin_oracle.py (index-list windows, region-id masks; autograd) against features and parameter gradients of
-    the imported reference SwinTransformer (swin_transformer.py:486-674; Swin-T settings and a two-stage 56x56 variant)."""
+    the imported reference SwinTransformer (swin_transformer.py:486-674; Swin-T settings and a two-stage 56x56 variant).
+    `swin_tiny2_drop_b3`: the TRAINING forward with drop_path_rate = 0.3 -- the fixture holds the per-frame DropPath scales
+    the reference's blocks drew (four of the six frames lose the second stage's first Mlp branch)."""
     import json
 
     from oracle import swin_oracle as so
@@ -300,8 +302,12 @@ def test_swin_oracle_matches_reference_golden(golden_dir, name, cfg_name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     c = json.loads(str(g["config"]))
     P = fx.make_state(fx.swin_param_shapes(cfg))
-    y, grads = so.forward_backward(fx.swin_input(cfg, c["batch"], c["frames"], c["seed"]), P, cfg, g["dy"])
+    drop = g["drop_scales"] if "drop_scales" in g.files else None
+    y, grads = so.forward_backward(fx.swin_input(cfg, c["batch"], c["frames"], c["seed"]), P, cfg, g["dy"], drop=drop)
     assert np.abs(y - g["y"]).max() <= 2e-6 * np.abs(g["y"]).max()
+    if drop is not None:  # (the masks matter: without them the features are somewhere else)
+        y0, _ = so.forward_backward(fx.swin_input(cfg, c["batch"], c["frames"], c["seed"]), P, cfg, g["dy"])
+        assert np.abs(y0 - g["y"]).max() > 1e-2 * np.abs(g["y"]).max()
     assert set(grads) == {k[len("gradstat."):] for k in g.files if k.startswith("gradstat.")}
     for k, v in grads.items():
         want_norm = g["gradstat." + k][0]

@@ -15,7 +15,7 @@ from oracle import fixtures as fx
 pytestmark = pytest.mark.gpu
 
 
-def _run(cfg, B, T, seed, dy, dtype):
+def _run(cfg, B, T, seed, dy, dtype, drop=None):
     from gdl.swin import SwinEngine
 
     eng = SwinEngine(cfg, dtype, B, T, DEV)
@@ -24,7 +24,7 @@ def _run(cfg, B, T, seed, dy, dtype):
     params = [torch.from_numpy(v).to(DEV) for v in P.values()]
     eng.set_params(params)
     x = torch.from_numpy(fx.swin_input(cfg, B, T, seed)).to(DEV)
-    y = eng.forward(x).clone()
+    y = eng.forward(x, drop_scales=None if drop is None else torch.from_numpy(np.asarray(drop, np.float32)).to(DEV)).clone()
     grads = [torch.full_like(p, float("nan")) for p in params]
     eng.backward(torch.from_numpy(dy).to(DEV), grads)
     torch.cuda.synchronize()
@@ -36,12 +36,14 @@ def _relerr(a, b):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("name,cfg_name", [("swin_tiny2_b2", "SWIN_TINY2"), ("swin_t_b1", "SWIN_T")])
+@pytest.mark.parametrize("name,cfg_name", [("swin_tiny2_b2", "SWIN_TINY2"), ("swin_t_b1", "SWIN_T"), ("swin_tiny2_drop_b3", "SWIN_TINY2")])
 def test_swin_engine_golden(golden_dir, name, cfg_name, dtype):
+    """`swin_tiny2_drop_b3`: the reference's TRAINING forward / backward with drop_path_rate = 0.3 and the DropPath masks its blocks
+    drew (the fixture holds them): stochastic depth through gdl_swin_drop_path, forward and backward."""
     cfg = getattr(fx, cfg_name)
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     c = json.loads(str(g["config"]))
-    y, grads, _ = _run(cfg, c["batch"], c["frames"], c["seed"], g["dy"], dtype)
+    y, grads, _ = _run(cfg, c["batch"], c["frames"], c["seed"], g["dy"], dtype, g["drop_scales"] if "drop_scales" in g.files else None)
     f32 = dtype == "f32"
     ey = _relerr(y, g["y"])
     worst, worst_k = 0.0, None
@@ -62,6 +64,74 @@ def test_swin_engine_golden(golden_dir, name, cfg_name, dtype):
     # measured: f32 4e-7 / 2.7e-6, bf16 6.7e-3 / 2.4e-2 (Swin-T, 224 x 224), both worst on a relative-position bias table
     assert ey < (5e-6 if f32 else 2e-2), ey
     assert worst < (3e-5 if f32 else 6e-2), (worst_k, worst)
+
+
+def test_swin_drop_path_graph_replays_and_mirror(golden_dir):
+    """Stochastic depth beyond the first eager passes: (i) the engine's forward / backward become HIP-graph replays from the third
+    call on -- new masks must still take effect (they are copied into an engine-owned buffer outside the graph); (ii) the drop-in
+    module in training mode draws masks itself (`last_drop_scales`), the same module with those masks pinned reproduces the
+    pass bit for bit, and its gradients agree with the CPU oracle run on the SAME masks; eval mode ignores the rate."""
+    import argparse
+
+    from models.swin_transformer import SwinTransformer
+    from oracle import swin_oracle as so
+
+    cfg = fx.SWIN_TINY2
+    g = np.load(os.path.join(golden_dir, "swin_tiny2_drop_b3.npz"))
+    c = json.loads(str(g["config"]))
+    B, T = c["batch"], c["frames"]
+    from gdl.swin import SwinEngine
+
+    eng = SwinEngine(cfg, "f32", B, T, DEV)
+    P = fx.make_state(fx.swin_param_shapes(cfg))
+    params = [torch.from_numpy(v).to(DEV) for v in P.values()]
+    eng.set_params(params)
+    x = torch.from_numpy(fx.swin_input(cfg, B, T, c["seed"])).to(DEV)
+    dy = torch.from_numpy(g["dy"]).to(DEV)
+    grads = [torch.empty_like(p) for p in params]
+    ones = torch.ones_like(torch.from_numpy(g["drop_scales"])).to(DEV)
+    rec = torch.from_numpy(g["drop_scales"]).to(DEV)
+    outs = []
+    for it in range(6):  # eager, eager, captured, replays -- alternating all-ones masks and the recorded ones
+        sc = rec if it % 2 else ones
+        y = eng.forward(x, drop_scales=sc).clone()
+        eng.backward(dy, grads)
+        outs.append((y.cpu().numpy(), grads[0].cpu().numpy().copy()))
+    for it in (3, 5):
+        assert _relerr(outs[it][0], g["y"]) < 5e-6
+        np.testing.assert_array_equal(outs[it][0], outs[1][0])
+        np.testing.assert_array_equal(outs[it][1], outs[1][1])
+    y_plain = eng.forward(x).clone().cpu().numpy()  # no DropPath at all = all-ones scales
+    np.testing.assert_allclose(outs[4][0], y_plain, rtol=0, atol=2e-6 * np.abs(y_plain).max())
+    assert _relerr(outs[4][0], g["y"]) > 1e-2
+    # (ii) the mirror
+    args = argparse.Namespace(pe=0)
+    net = SwinTransformer(args, "visual", img_size=cfg["img"], patch_size=cfg["patch"], embed_dim=cfg["embed"], depths=list(cfg["depths"]),
+                          num_heads=list(cfg["heads"]), window_size=cfg["window"], mlp_ratio=float(cfg["mlp"]), drop_path_rate=0.5).to(DEV)
+    net.gdl_dtype = "f32"
+    res = net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in P.items()}, strict=False)
+    assert not res.unexpected_keys
+    net.train()
+    torch.manual_seed(11)
+    y1 = net(x)
+    sc1 = net.last_drop_scales.clone()
+    assert tuple(sc1.shape) == (4, 2, B * T) and bool((sc1[0] == 1).all()) and bool((sc1 == 0).any())
+    (y1 * dy).sum().backward()
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad()
+    net.drop_scales_override = sc1
+    y2 = net(x)
+    (y2 * dy).sum().backward()
+    assert torch.equal(y1, y2) and all(torch.equal(g1[n], p.grad) for n, p in net.named_parameters())
+    yo, go = so.forward_backward(fx.swin_input(cfg, B, T, c["seed"]), P, cfg, g["dy"], drop=sc1.cpu().numpy())
+    assert _relerr(y1.detach().cpu().numpy(), yo) < 5e-6
+    worst = max(_relerr(g1[n].cpu().numpy(), go[n]) for n in go)
+    assert worst < 3e-5, worst
+    net.eval()
+    net.drop_scales_override = None
+    with torch.no_grad():
+        ye = net(x)
+    np.testing.assert_allclose(ye.cpu().numpy(), y_plain, rtol=0, atol=2e-6 * np.abs(y_plain).max())
 
 
 def test_swin_engine_deterministic_and_rebindable():
