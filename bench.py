@@ -82,6 +82,9 @@ def parse():
                     help="the visual weight gradients' own stream: auto = on without a process group, off with one")
     ap.add_argument("--phases", action="store_true", help="also report forward / head / backward / optimizer phase times")
     ap.add_argument("--no-extra", action="store_true", help="skip the short ks / vggsound_swin legs behind extra_workloads")
+    ap.add_argument("--drop-path", type=float, default=0.0,
+                    help="vggsound_swin only: stochastic-depth rate of the Swin branch (the reference constructor's default is 0.1; "
+                         "the committed line is quoted at 0)")
     ap.add_argument("--no-comparator", action="store_true", help="skip comparators.torch_rocm (stock PyTorch-ROCm step)")
     ap.add_argument("--comparator-find", action="store_true",
                     help="comparators.torch_rocm in MIOpen find mode, all variants (minutes of warm-up; profiles/ keeps one such run)")
@@ -206,7 +209,8 @@ def build_model(wl, batch, dev):
     if wl.get("swin"):
         from models.basic_model import AVClassifier_DGL_Swin
 
-        model = AVClassifier_DGL_Swin(args)  # (the Swin branch keeps its own initialisation, swin_transformer.py:568-576:
+        kw = dict(AVClassifier_DGL_Swin.SWIN_T, drop_path_rate=float(wl.get("drop_path", 0.0)))
+        model = AVClassifier_DGL_Swin(args, swin_kwargs=kw)  # (the Swin branch keeps its own initialisation, swin_transformer.py:568-576:
         model.audio_net.apply(weight_init)   #  utils.weight_init would trip over PatchMerging's bias-free Linear)
         model.fusion_module.apply(weight_init)
     else:
@@ -311,6 +315,8 @@ def main():
 
     lib = L.load()
     wl = WORKLOADS[a.workload]
+    if wl.get("swin") and a.drop_path > 0:  # (a different workload from the committed one: said in its name)
+        wl = dict(wl, drop_path=a.drop_path, name=wl["name"].replace("drop_path 0)", f"drop_path {a.drop_path:g})"))
     model, args = build_model(wl, a.batch, dev)
     if wl.get("swin"):
         a.no_f32 = a.no_cpu_baseline = a.no_comparator = True  # (those legs are written for the ResNet18 pair)
