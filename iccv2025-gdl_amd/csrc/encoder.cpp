@@ -81,6 +81,8 @@ struct gdl_encoder {
     // nothing here: the range is {0, -1} and the step time is the same with any assignment.)  The gradient buffers they read alternate
     // with the block parity; ev_side[p] = "the side stream is done with parity p's buffers".
     hipStream_t side = nullptr;
+    bool side_owned = true;  // false: a stream of the caller's (gdl_encoder_borrow_side_stream)
+    bool has_side = false;   // (the borrowed stream may be the null stream)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side[2] = {nullptr, nullptr};
     bool side_pending[2] = {false, false};
     // gdl_encoder_backward_phase: state carried from phase 1 (layer4) to phase 2 (the rest)
@@ -96,7 +98,7 @@ struct gdl_encoder {
         if (ev_join) (void)hipEventDestroy(ev_join);
         for (int p = 0; p < 2; ++p)
             if (ev_side[p]) (void)hipEventDestroy(ev_side[p]);
-        if (side) (void)hipStreamDestroy(side);
+        if (side && side_owned) (void)hipStreamDestroy(side);
     }
     float *bn_partial = nullptr, *bn_partial2 = nullptr, *bnb_partial = nullptr, *bnb_partial2 = nullptr;
     SplitWs sk{nullptr, 0};          // split-K workspace of the slab convolutions (ops.h): forward / data-gradient chain only
@@ -375,20 +377,42 @@ int gdl_encoder_create(gdl_encoder_t** out, int modality, int dtype, int B, int 
 
 void gdl_encoder_destroy(gdl_encoder_t* e) { delete e; }
 
+static int side_events(gdl_encoder_t* e) {  // fork / join / per-parity events, created once
+    hipError_t he = hipSuccess;
+    if (!e->ev_fork) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (he == hipSuccess && !e->ev_join) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+    for (int p = 0; p < 2 && he == hipSuccess; ++p)
+        if (!e->ev_side[p]) he = hipEventCreateWithFlags(&e->ev_side[p], hipEventDisableTiming);
+    return he == hipSuccess ? GDL_OK : check_hip(he, "encoder side stream: events");
+}
+
 int gdl_encoder_side_stream(gdl_encoder_t* e, int enable) {
     GDL_REQUIRE(e, "encoder_side_stream: null");
-    if (enable && !e->side) {
+    if (enable && !e->has_side) {
+        int rc = side_events(e);
+        if (rc) return rc;
         hipError_t he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
-        for (int p = 0; p < 2 && he == hipSuccess; ++p) he = hipEventCreateWithFlags(&e->ev_side[p], hipEventDisableTiming);
         if (he != hipSuccess) return check_hip(he, "encoder_side_stream");
-    } else if (!enable && e->side) {
+        e->side_owned = true;
+        e->has_side = true;
+    } else if (!enable && e->has_side) {
         hipError_t he = hipStreamSynchronize(e->side);
         if (he != hipSuccess) return check_hip(he, "encoder_side_stream: sync");
-        (void)hipStreamDestroy(e->side);
+        if (e->side_owned) (void)hipStreamDestroy(e->side);
         e->side = nullptr;
+        e->side_owned = true;
+        e->has_side = false;
     }
+    return GDL_OK;
+}
+
+int gdl_encoder_borrow_side_stream(gdl_encoder_t* e, void* stream) {
+    GDL_REQUIRE(e && !(e->has_side && e->side_owned), "encoder_borrow_side_stream: null, or the engine owns a side stream");
+    int rc = side_events(e);
+    if (rc) return rc;
+    e->side = (hipStream_t)stream;  // (NULL = the null stream: has_side says whether there is one)
+    e->side_owned = false;
+    e->has_side = true;
     return GDL_OK;
 }
 
@@ -652,7 +676,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         const char* env = tune_env("GDL_PACK_SIDE");
         pack_side = env ? atoi(env) : 0;
     }
-    const bool pack_fork = e->side && pack_side;
+    const bool pack_fork = e->has_side && pack_side;
     if (pack_fork) {
         hipError_t he = hipEventRecord(e->ev_fork, st);
         if (he == hipSuccess) he = hipStreamWaitEvent(e->side, e->ev_fork, 0);
@@ -814,9 +838,9 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
     int b2_rows = phase == 2 ? e->bw_b2_rows : 0;
     const bool fuse = bw_fuse_on();
     // weight gradients: forked onto the side stream (sw) once their dy exists on st
-    hipStream_t sw = e->side ? e->side : st;
+    hipStream_t sw = e->has_side ? e->side : st;
     auto fork = [&]() -> int {  // sw waits for everything enqueued on st so far
-        if (!e->side) return GDL_OK;
+        if (!e->has_side) return GDL_OK;
         hipError_t he = hipEventRecord(e->ev_fork, st);
         if (he == hipSuccess) he = hipStreamWaitEvent(e->side, e->ev_fork, 0);
         return he == hipSuccess ? GDL_OK : check_hip(he, "encoder_backward: fork");
@@ -826,7 +850,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         const size_t Mo = (size_t)k.n * k.p * k.q;
         const int par = bi & 1;
         void *gB = e->gB[par], *gC = e->gC[par], *gD = e->gD[par];
-        if (e->side && e->side_pending[par]) {  // the side stream still reads this parity's buffers (two blocks ago)
+        if (e->has_side && e->side_pending[par]) {  // the side stream still reads this parity's buffers (two blocks ago)
             hipError_t he = hipStreamWaitEvent(st, e->ev_side[par], 0);
             if (he != hipSuccess) return check_hip(he, "encoder_backward: buffer wait");
             e->side_pending[par] = false;
@@ -878,7 +902,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         };
         // late: fork AFTER the data gradient that consumes the same dy, so that the (MFMA-bound) weight gradient runs
         // beside the (HBM-bound) BatchNorm passes that follow rather than beside another MFMA-bound kernel
-        const bool late = e->side && wgrad_late();
+        const bool late = e->has_side && wgrad_late();
         if (!late) RC(wgrad2());
         if (fuse) {
             // gC = da1 * (a1 > 0) (sign bits of a1) with bn1's two sums from the epilogue; then finalize + apply
@@ -903,7 +927,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             RC(fork());
             RC(conv_wgrad(dt, gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
                           k.cin, e->wg_ws, e->wg_ws_bytes, sw));
-            if (e->side) {
+            if (e->has_side) {
                 hipError_t he = hipEventRecord(e->ev_side[par], e->side);
                 if (he != hipSuccess) return check_hip(he, "encoder_backward: side event");
                 e->side_pending[par] = true;
@@ -957,7 +981,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         e->bw_premasked = premasked;
         e->bw_b2_rows = b2_rows;
         e->bw_serial = (long)e->serial;
-        if (e->side) {
+        if (e->has_side) {
             hipError_t he = hipEventRecord(e->ev_join, e->side);
             if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);
             if (he != hipSuccess) return check_hip(he, "encoder_backward: phase join");
@@ -979,7 +1003,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
     }
     RC(fork());
     RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
-    if (e->side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
+    if (e->has_side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
         hipError_t he = hipEventRecord(e->ev_join, e->side);
         if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);
         if (he != hipSuccess) return check_hip(he, "encoder_backward: join");

@@ -118,6 +118,7 @@ SIGNATURES = {
     "gdl_encoder_create": ("i", "piiiiii"),
     "gdl_encoder_destroy": (None, "p"),
     "gdl_encoder_side_stream": ("i", "pi"),
+    "gdl_encoder_borrow_side_stream": ("i", "pp"),
     "gdl_encoder_backward_phase": ("i", "pippp" + "p"),
     "gdl_encoder_workspace_bytes": ("z", "p"),
     "gdl_encoder_param_numel": ("i", "pp"),

@@ -40,6 +40,16 @@ class EncoderEngine:
         L.call("gdl_encoder_side_stream", self.h, 1 if enable else 0)
         self._side = bool(enable)
 
+    def borrow_side_stream(self, stream_handle):
+        """The weight gradients of backward() on a stream of the caller's (gdl_encoder_borrow_side_stream); None: back to none."""
+        if stream_handle is None:
+            L.call("gdl_encoder_side_stream", self.h, 0)
+            self._side, self._borrowed = False, None
+            return
+        if getattr(self, "_borrowed", None) != stream_handle:
+            L.call("gdl_encoder_borrow_side_stream", self.h, stream_handle if stream_handle else None)
+            self._side, self._borrowed = True, stream_handle
+
     def has_side_stream(self):
         return bool(getattr(self, "_side", False))
 

@@ -277,8 +277,14 @@ class DGLTrainer:
         side = os.environ.get("GDL_SIDE_STREAM") if os.environ.get("GDL_TUNING") == "1" else None
         if side == "1":
             self.eng_a.side_stream(True)
+        # The audio engine's weight gradients ride on the stream step() is called on: that stream only orders the step before and
+        # behind, so its hardware queue idles for the whole step -- a fourth lane without a fifth queue (round 4: 5.63 -> 5.43 ms;
+        # the audio chain, a quarter of the arithmetic in ~100 small launches, had been the last to finish: 5.36 ms against the
+        # visual chain's 5.18, tools/chain_timeline.py).  Bound per step (the caller's current stream may change): step().
+        # (tuning aid: GDL_SIDE_STREAM=2 = the round-3 layout, the visual engine's side stream alone)
+        self.audio_on_caller = side not in ("0", "1", "2")
         want_v = self.visual_side_stream if self.visual_side_stream is not None else self.reducer is None
-        if (side in ("1", "2") or (side is None and want_v)) and not self.vis_swin:
+        if (side in ("1", "2") or (side in (None, "3") and want_v)) and not self.vis_swin:
             self.eng_v.side_stream(True)
         n, d = self.n_classes, self.device
         self.fa, self.fv = torch.empty((B, 512), device=d), torch.empty((B, self.dv), device=d)
@@ -323,6 +329,8 @@ class DGLTrainer:
         # before the step and behind it, so the call keeps ordinary stream semantics.
         caller = torch.cuda.current_stream(self.device)
         main = self.s_a
+        if self.audio_on_caller:
+            self.eng_a.borrow_side_stream(caller.cuda_stream)
         main.wait_stream(caller)
         with torch.cuda.stream(main):
             self._step_on(main, spec, image, label)

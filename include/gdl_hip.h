@@ -395,6 +395,14 @@ GDL_API void gdl_encoder_destroy(gdl_encoder_t* e);
  * priority, so a caller running {main, audio, visual} streams enables this for the visual engine only (the
  * critical path) and not at all when a collective's stream is active as well. */
 GDL_API int gdl_encoder_side_stream(gdl_encoder_t* e, int enable);
+/* The same fork / join onto a stream of the CALLER's (NULL = the null stream) instead of an engine-owned one: no new
+ * hardware queue.  Meant for a stream the caller already has and that idles during the step -- DGLTrainer hands the audio
+ * engine the stream `step()` was called on, which only orders the step before and behind (round 4: 5.63 -> 5.43 ms per
+ * step; the audio chain, a quarter of the work in ~100 small launches, had been the last to finish).  The engine enqueues
+ * on that stream only inside gdl_encoder_backward(_phase) (between a wait for the engine's stream and an event the
+ * engine's stream waits for), so work the caller puts there before / after the call is ordered as on one stream.  May be
+ * called again with another stream; gdl_encoder_side_stream(e, 0) returns to none. */
+GDL_API int gdl_encoder_borrow_side_stream(gdl_encoder_t* e, void* stream);
 GDL_API size_t gdl_encoder_workspace_bytes(const gdl_encoder_t* e);
 GDL_API int gdl_encoder_param_numel(const gdl_encoder_t* e, int64_t* numel /*[60]*/);
 GDL_API int gdl_encoder_out_shape(const gdl_encoder_t* e, int* n_img, int* h, int* w);
