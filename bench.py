@@ -560,17 +560,21 @@ def main():
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
                 return round(float(t_.item()), 3)
 
-            side0, early0 = tr.eng_v.has_side_stream(), tr.early_backward
+            side0, early0, lane0 = tr.eng_v.has_side_stream(), tr.early_backward, tr.audio_on_caller
             variants = {}
             for side in (False, True):
                 for early in (False, True):
-                    tr.eng_v.side_stream(side)
-                    tr.early_backward = early
-                    variants[f"side_stream_{'on' if side else 'off'}__early_backward_{'on' if early else 'off'}"] = timed(nn_)
+                    for lane in (False, True):  # the audio engine's weight gradients on the caller's stream
+                        tr.eng_v.side_stream(side)
+                        tr.early_backward = early
+                        tr.audio_on_caller = lane
+                        variants[f"side_stream_{'on' if side else 'off'}__early_backward_{'on' if early else 'off'}"
+                                 f"__audio_lane_{'on' if lane else 'off'}"] = timed(nn_)
             tr.eng_v.side_stream(side0)
-            tr.early_backward = early0
+            tr.early_backward, tr.audio_on_caller = early0, lane0
             comm["schedule_variants_ms"] = variants
-            comm["default_schedule"] = f"side_stream_{'on' if side0 else 'off'}__early_backward_{'on' if early0 is not False else 'off'}"
+            comm["default_schedule"] = (f"side_stream_{'on' if side0 else 'off'}__early_backward_{'on' if early0 is not False else 'off'}"
+                                        f"__audio_lane_{'on' if lane0 else 'off'}")
     if rank == 0:
         # the headline measurement is complete here: leave it on stderr (and in gpurun_out/ when that exists) BEFORE the secondary
         # legs below -- a hard fault in one of them (graph capture, MIOpen, an OOM kill) must not take it along

@@ -33,7 +33,6 @@ namespace gdl {
 #ifdef GDL_TIMING
 extern unsigned long long* g_timing_buf;
 #endif
-namespace {
 
 constexpr int A7_T = 49;     // tokens per window
 constexpr int A7_TP = 144;   // bytes per row of the 64 x 64 bf16 tile (pitch 36 banks: rows 4 banks apart)
@@ -561,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn7_bwd_kernel(const bf16* __re
     }
 }
 
-int a7_knob(const char* name, int dflt) {
+static int a7_knob(const char* name, int dflt) {
     const char* e = tune_env(name);
     return e ? atoi(e) : dflt;
 }
@@ -569,14 +568,14 @@ int a7_knob(const char* name, int dflt) {
 // amortise it.  Measured on MI355X at the four Swin-T stage shapes, 192 frames (forward / backward ms per step, 12 layers): 4 windows
 // 0.80 / 1.74, 8: 0.67 / 1.41, 12: 0.62 / 1.34, 16: 0.65 / 1.40, 32: 0.71 / 1.46 -- three windows per wave, also where that
 // leaves fewer blocks than CU slots (stage 4: 384 blocks).
-int a7_chunk(long total, int nh, bool bwd) {
+static int a7_chunk(long total, int nh, bool bwd) {
     static int forced = -1;
     if (forced < 0) forced = a7_knob("GDL_SWIN_ATTN7_CHUNK", 0);
     if (forced > 0) return forced < 4 ? 4 : forced;  // (the workspace is sized for chunks of >= 4 windows)
     (void)bwd, (void)nh, (void)total;
     return 12;
 }
-void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int ld, bool bwd) {
+static void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int ld, bool bwd) {
     g->H = H, g->W = W, g->nh = nh, g->ld = ld, g->shift = shift;
     g->wpr = W / 7, g->wpc = H / 7;
     g->total = n_img * g->wpr * g->wpc;
@@ -589,15 +588,13 @@ void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int ld, bool
 #endif
 }
 template <typename K>
-int a7_attr(K kernel, bool* done) {
+static int a7_attr(K kernel, bool* done) {
     if (*done) return GDL_OK;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(A7Lds));
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn7)");
     *done = true;
     return GDL_OK;
 }
-
-}  // namespace
 
 bool swin_attn7_ok(int dt, int H, int W, int ws, int shift, int nh, int ld, int n_img) {
     static int on = -1;

@@ -281,8 +281,12 @@ class DGLTrainer:
         # behind, so its hardware queue idles for the whole step -- a fourth lane without a fifth queue (round 4: 5.63 -> 5.43 ms;
         # the audio chain, a quarter of the arithmetic in ~100 small launches, had been the last to finish: 5.36 ms against the
         # visual chain's 5.18, tools/chain_timeline.py).  Bound per step (the caller's current stream may change): step().
-        # (tuning aid: GDL_SIDE_STREAM=2 = the round-3 layout, the visual engine's side stream alone)
-        self.audio_on_caller = side not in ("0", "1", "2")
+        # Not with a process group by default: there the backward runs in two phases without the early start and the visual
+        # engine keeps its weight gradients on its chain, and the one-rank proxy (GDL_BENCH_FORCE_PG=1) reads 5.87 ms with the
+        # borrowed lane against 5.78 without (5.61 with the visual side stream alone) -- `bench.py --gpus N` times the variants on
+        # first contact with real RCCL traffic (`comm.schedule_variants_ms`); `trainer.audio_on_caller` may be set at any time.
+        # (tuning aid: GDL_SIDE_STREAM=2 = the round-3 layout, the visual engine's side stream alone; 3 = the borrowed lane forced)
+        self.audio_on_caller = side == "3" or (side not in ("0", "1", "2") and self.reducer is None)
         want_v = self.visual_side_stream if self.visual_side_stream is not None else self.reducer is None
         if (side in ("1", "2") or (side in (None, "3") and want_v)) and not self.vis_swin:
             self.eng_v.side_stream(True)
@@ -331,6 +335,8 @@ class DGLTrainer:
         main = self.s_a
         if self.audio_on_caller:
             self.eng_a.borrow_side_stream(caller.cuda_stream)
+        elif getattr(self.eng_a, "_borrowed", None) is not None:
+            self.eng_a.borrow_side_stream(None)
         main.wait_stream(caller)
         with torch.cuda.stream(main):
             self._step_on(main, spec, image, label)
