@@ -466,8 +466,9 @@ def main():
         # other streams (what the job pays); this one says what the kernel itself does (`roofline.alone`).
         # (a measurement after the timed region: it advances the BatchNorm running statistics and overwrites the gradient
         # arena; everything reported from the training run -- losses, norms, clip_log -- has been read above)
-        had_side = tr.eng_v.has_side_stream()
+        had_side = tr.eng_v.lane() == "owned"
         tr.eng_v.side_stream(False)
+        tr.eng_a.borrow_side_stream(None)  # (DGLTrainer.step binds the caller's stream again by itself)
         spec, image, _ = data[0]
         nf = tr.nf
         lib.gdl_prof_set_filter(None)
@@ -560,20 +561,25 @@ def main():
                 dist.all_reduce(t_, op=dist.ReduceOp.MAX)
                 return round(float(t_.item()), 3)
 
-            side0, early0, lane0 = tr.eng_v.has_side_stream(), tr.early_backward, tr.audio_on_caller
+            vis0 = "caller" if tr.visual_on_caller else ("owned" if tr.eng_v.lane() == "owned" else "off")
+            early0, lane0 = tr.early_backward, tr.audio_on_caller
             variants = {}
-            for side in (False, True):
+            for vis in ("off", "owned", "caller"):  # where the visual engine's weight gradients run
                 for early in (False, True):
-                    for lane in (False, True):  # the audio engine's weight gradients on the caller's stream (DESIGN section 4)
-                        tr.eng_v.side_stream(side)
+                    for lane in (False, True):  # the audio engine's weight gradients on the caller's stream
+                        if vis == "caller" and lane:
+                            continue  # (one borrowed lane)
+                        tr.visual_on_caller = vis == "caller"
+                        tr.eng_v.side_stream(vis == "owned")
                         tr.early_backward = early
                         tr.audio_on_caller = lane
-                        variants[f"side_stream_{'on' if side else 'off'}__early_backward_{'on' if early else 'off'}"
+                        variants[f"visual_wgrad_{vis}__early_backward_{'on' if early else 'off'}"
                                  f"__audio_lane_{'on' if lane else 'off'}"] = timed(nn_)
-            tr.eng_v.side_stream(side0)
+            tr.visual_on_caller = vis0 == "caller"
+            tr.eng_v.side_stream(vis0 == "owned")
             tr.early_backward, tr.audio_on_caller = early0, lane0
             comm["schedule_variants_ms"] = variants
-            comm["default_schedule"] = (f"side_stream_{'on' if side0 else 'off'}__early_backward_{'on' if early0 is not False else 'off'}"
+            comm["default_schedule"] = (f"visual_wgrad_{vis0}__early_backward_{'on' if early0 is not False else 'off'}"
                                         f"__audio_lane_{'on' if lane0 else 'off'}")
     if rank == 0:
         # the headline measurement is complete here: leave it on stderr (and in gpurun_out/ when that exists) BEFORE the secondary

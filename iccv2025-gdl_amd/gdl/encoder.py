@@ -37,21 +37,34 @@ class EncoderEngine:
 
     def side_stream(self, enable=True):
         """Fork the weight gradients of backward() onto an engine-owned side stream (see include/gdl_hip.h)."""
-        L.call("gdl_encoder_side_stream", self.h, 1 if enable else 0)
-        self._side = bool(enable)
+        if self.lane() is not None and (not enable or self.lane() != "owned"):
+            L.call("gdl_encoder_side_stream", self.h, 0)
+            self._lane = None
+        if enable and self.lane() is None:
+            L.call("gdl_encoder_side_stream", self.h, 1)
+            self._lane = "owned"
 
     def borrow_side_stream(self, stream_handle):
-        """The weight gradients of backward() on a stream of the caller's (gdl_encoder_borrow_side_stream); None: back to none."""
+        """The weight gradients of backward() on a stream of the caller's (gdl_encoder_borrow_side_stream; 0 = the null stream);
+        None: back to no side lane.  An engine-owned side stream is replaced."""
         if stream_handle is None:
-            L.call("gdl_encoder_side_stream", self.h, 0)
-            self._side, self._borrowed = False, None
+            if self.lane() is not None:
+                L.call("gdl_encoder_side_stream", self.h, 0)
+                self._lane = None
             return
-        if getattr(self, "_borrowed", None) != stream_handle:
+        if self.lane() == "owned":
+            L.call("gdl_encoder_side_stream", self.h, 0)
+            self._lane = None
+        if self.lane() != ("borrowed", stream_handle):
             L.call("gdl_encoder_borrow_side_stream", self.h, stream_handle if stream_handle else None)
-            self._side, self._borrowed = True, stream_handle
+            self._lane = ("borrowed", stream_handle)
+
+    def lane(self):
+        """None, "owned" or ("borrowed", stream handle): where backward() puts the weight gradients"""
+        return getattr(self, "_lane", None)
 
     def has_side_stream(self):
-        return bool(getattr(self, "_side", False))
+        return self.lane() is not None
 
     def __del__(self):
         try:

@@ -287,6 +287,9 @@ class DGLTrainer:
         # first contact with real RCCL traffic (`comm.schedule_variants_ms`); `trainer.audio_on_caller` may be set at any time.
         # (tuning aid: GDL_SIDE_STREAM=2 = the round-3 layout, the visual engine's side stream alone; 3 = the borrowed lane forced)
         self.audio_on_caller = side == "3" or (side not in ("0", "1", "2") and self.reducer is None)
+        # The borrowed lane for the VISUAL engine instead (tuning aid "4"; a variant `bench.py --gpus N` times): without a group it
+        # equals an owned side stream (5.57 ms), with a one-rank group it reads 6.57 ms -- not a default anywhere.
+        self.visual_on_caller = side == "4"
         want_v = self.visual_side_stream if self.visual_side_stream is not None else self.reducer is None
         if (side in ("1", "2") or (side in (None, "3") and want_v)) and not self.vis_swin:
             self.eng_v.side_stream(True)
@@ -333,10 +336,16 @@ class DGLTrainer:
         # before the step and behind it, so the call keeps ordinary stream semantics.
         caller = torch.cuda.current_stream(self.device)
         main = self.s_a
+        # the borrowed lane (the stream this call came in on): the audio engine's weight gradients, or the visual engine's
         if self.audio_on_caller:
             self.eng_a.borrow_side_stream(caller.cuda_stream)
-        elif getattr(self.eng_a, "_borrowed", None) is not None:
+        elif isinstance(self.eng_a.lane(), tuple):
             self.eng_a.borrow_side_stream(None)
+        if not self.vis_swin:
+            if self.visual_on_caller and not self.audio_on_caller:
+                self.eng_v.borrow_side_stream(caller.cuda_stream)
+            elif isinstance(self.eng_v.lane(), tuple):
+                self.eng_v.borrow_side_stream(None)
         main.wait_stream(caller)
         with torch.cuda.stream(main):
             self._step_on(main, spec, image, label)
