@@ -19,6 +19,10 @@ from utils.utils import setup_seed, weight_init  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--no-group", action="store_true", help="the same variants without a process group")
+ap.add_argument("--emulate-traffic", type=int, default=0,
+                help="N > 0: every bucket's (no-op, one rank) all-reduce is followed by N in-place passes over the bucket on a stream of "
+                     "its own, behind the producer's event and in front of the optimizer -- a busy fifth hardware queue, ~N x 10-15 us "
+                     "per 33 MB bucket; what a real collective's kernels do to the schedule can only be measured on N > 1 GPUs")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
@@ -49,6 +53,30 @@ def timed(n):
 
 
 tr.step(*data[0])
+if a.emulate_traffic and tr.reducer is not None:
+    red = tr.reducer
+    red.force_comm = True
+    cs = torch.cuda.Stream(device=dev)
+    launch0, wait0 = red.launch, red.wait_all
+    evs = []
+
+    def launch(name):
+        launch0(name)
+        lo, hi = red.buckets[name]
+        cs.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cs):
+            seg = red.flat[lo:hi]
+            for _ in range(a.emulate_traffic):
+                seg.mul_(1.0)
+        evs.append(cs.record_event())
+
+    def wait_all():
+        wait0()
+        for e in evs:
+            torch.cuda.current_stream(dev).wait_event(e)
+        evs.clear()
+
+    red.launch, red.wait_all = launch, wait_all
 print("default:", "visual", "caller" if tr.visual_on_caller else tr.eng_v.lane(), "early", tr.early_backward, "audio lane", tr.audio_on_caller,
       f"{timed(a.steps):.3f} ms")
 for rnd in range(2):
