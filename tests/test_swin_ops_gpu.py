@@ -157,6 +157,21 @@ def _attn_ref(qkv, table, n_img, H, W, ws, shift, nh, ld):
 
 
 @pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,T,H", [(2, 2, 16), (1, 3, 56)])
+def test_patch_gather(dt, B, T, H):
+    """gdl_swin_patch_gather: frames [B, 3, T, H, W] f32 -> GEMM rows [B*T*(H/4)*(W/4)][64], columns (c, kh, kw) of the 4 x 4 patch
+    (the flattened Conv2d weight's order, swin_transformer.py:463, 480), 16 zero columns.  bf16 runs the 16-byte-vector kernel."""
+    x = rng.standard_normal((B, 3, T, H, H)).astype(np.float32)
+    a = torch.full((B * T * (H // 4) ** 2, 64), float("nan"), device=DEV, dtype=_td(dt))
+    xd = torch.from_numpy(x).to(DEV)
+    L.call("gdl_swin_patch_gather", L.dtype_code(dt), L.ptr(xd), L.ptr(a), B, T, H, H, 4, L.cur_stream())
+    g = x.transpose(0, 2, 1, 3, 4).reshape(B * T, 3, H // 4, 4, H // 4, 4).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 48)
+    got = _np(a)
+    np.testing.assert_array_equal(got[:, :48], _q(g, dt))
+    assert np.all(got[:, 48:] == 0)
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("H,ws,shift,nh", [(14, 7, 0, 3), (14, 7, 3, 3), (7, 7, 0, 6), (28, 7, 3, 3), (35, 7, 3, 3), (56, 7, 3, 3), (4, 2, 1, 2)])
 def test_window_attention(dt, H, ws, shift, nh):
     dc = L.dtype_code(dt)
