@@ -494,8 +494,9 @@ def test_bn_accumulator_guard(dtype):
 
 @pytest.mark.parametrize("modality,shape", [("audio", (2, 1, 65, 47)), ("visual", (2, 3, 2, 64, 64))])
 def test_encoder_backward_phases(modality, shape):
-    """gdl_encoder_backward_phase 1 + 2 == gdl_encoder_backward, bit for bit (same kernels, same order), with and
-    without the weight-gradient side stream; phase 2 without phase 1 is refused."""
+    """gdl_encoder_backward_phase 1 + 2 == gdl_encoder_backward, bit for bit (same kernels, same order), without a side lane for
+    the weight gradients, with the engine-owned side stream and with a BORROWED one (gdl_encoder_borrow_side_stream: a stream of
+    the caller's -- here once a stream of the test's and once the null stream -- round 4); phase 2 without phase 1 is refused."""
     from gdl.encoder import EncoderEngine
 
     x = torch.randn(*shape, device=DEV)
@@ -503,10 +504,19 @@ def test_encoder_backward_phases(modality, shape):
     T = shape[2] if modality == "visual" else 1
     H, W = shape[-2], shape[-1]
     res = []
-    for side in (False, True):
+    mine = torch.cuda.Stream(device=DEV)
+    for side in (False, True, "borrowed", "null"):
         eng = EncoderEngine(modality, "bf16", B, T, H, W, DEV)
-        if side:
+        if side is True:
             eng.side_stream(True)
+            assert eng.lane() == "owned"
+        elif side == "borrowed":
+            eng.borrow_side_stream(mine.cuda_stream)
+            assert eng.lane() == ("borrowed", mine.cuda_stream) and eng.has_side_stream()
+        elif side == "null":
+            eng.side_stream(True)
+            eng.borrow_side_stream(0)  # (replaces the owned stream)
+            assert eng.lane() == ("borrowed", 0)
         sh = fx.resnet18_param_shapes("", 1 if modality == "audio" else 3)
         P = [dev(v) for v in fx.make_state(sh).values()]
         bs = fx.make_state(fx.resnet18_buffer_shapes(""))
@@ -525,6 +535,9 @@ def test_encoder_backward_phases(modality, shape):
         with pytest.raises(L.GdlError):
             eng.forward(x, True)
             eng.backward(grads, phase=2)
+        if side in ("borrowed", "null"):
+            eng.borrow_side_stream(None)
+            assert eng.lane() is None and not eng.has_side_stream()
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)
