@@ -288,40 +288,69 @@ __device__ __forceinline__ void a7_advance(const A7Geom& g, int& n, int& wy, int
     while (wy >= g.wpc) wy -= g.wpc, ++n;
 }
 
+// The forward needs no probability tile: O = P V is computed transposed, O^T = V^T P^T, whose second operand has n = query and
+// k = key -- and a lane of the score accumulators already holds one query (n = l16) and eight keys of every 32-key K-step: keys
+// 32 ks + 4 lq + (0 .. 3) from tile 2 ks and 32 ks + 16 + 4 lq + (0 .. 3) from tile 2 ks + 1.  That is a permutation of the K-step's
+// keys among the (lq, element) slots, and a dot product does not care as long as the other operand uses the same one: the V^T
+// fragments take their two transpose reads from token rows 32 ks + 4 lq and 32 ks + 16 + 4 lq.  So P goes from the softmax registers
+// straight into the MFMA -- no LDS round trip, one wave barrier less per window, 9 KB of LDS less per wave: four blocks per CU
+// instead of two.
+struct A7LdsF {
+    float bias[4 * 64 * 16];
+    unsigned char opnd[4][64 * A7_XP];  // per wave: the V rows of its window
+};
+__device__ __forceinline__ void a7_v_frags(const unsigned char* opnd, int l16, int lq, bf16x8_t (&xa)[2][2]) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned char* p = opnd + (32 * ks + 4 * lq + (l16 >> 2)) * A7_XP + (8 * (l16 & 3) + 4 * half) * 2;
+            xa[half][ks] = a7_frag(a7_tr(p), a7_tr(p + 16 * A7_XP));
+        }
+}
 // One window of the forward.  (A software-pipelined form -- the next window's fragments requested before this window's strips,
 // 166 registers -- measured the same or 4 % slower at every stage shape: the kernel is not waiting for its loads.)
 template <bool MASK>
-__device__ __forceinline__ void a7_fwd_window(const A7Geom& g, A7Lds& S, A7Wave& Wv, const A7Lane& c, __amdgpu_buffer_rsrc_t rq,
-                                              __amdgpu_buffer_rsrc_t ro, const unsigned (&qoff)[4], const unsigned (&ooff)[4],
-                                              unsigned lastrow, unsigned lastcol, int lane, int l16, int lq) {
-    bf16x8_t qf[4], kf[4], vf[4];
+__device__ __forceinline__ void a7_fwd_window(const A7Geom& g, const float* bias, unsigned char* opnd, const A7Lane& c,
+                                              __amdgpu_buffer_rsrc_t rq, __amdgpu_buffer_rsrc_t ro, const unsigned (&qoff)[4],
+                                              const unsigned (&ooff)[4], unsigned lastrow, unsigned lastcol, int lane, int l16, int lq) {
+    bf16x8_t qf[4], kf[4];
+    bf16x8_t xa[2][2];
+    {
+        bf16x8_t vf[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        qf[t] = a7_load(rq, qoff[t], 0);
-        kf[t] = a7_load(rq, qoff[t], 2 * g.ld);
-        vf[t] = a7_load(rq, qoff[t], 4 * g.ld);
+        for (int t = 0; t < 4; ++t) {
+            qf[t] = a7_load(rq, qoff[t], 0);
+            kf[t] = a7_load(rq, qoff[t], 2 * g.ld);
+            vf[t] = a7_load(rq, qoff[t], 4 * g.ld);
+        }
+        a7_rows_to_lds(opnd, vf, l16, lq);
     }
-    a7_rows_to_lds(Wv.opnd, vf, l16, lq);
+    a7_wave_sync();
+    a7_v_frags(opnd, l16, lq, xa);
+    a7_wave_sync();  // (the next window's V rows may land once these reads are done)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         f32x4_t s[4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) s[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         const unsigned mb = MASK ? ((c.rowd[it >> 1] & lastrow) | (c.cold[it >> 1] & lastcol)) >> (16 * (it & 1)) : 0u;
-        const float inv = a7_exp_strip<MASK>(s, &S.bias[(it * 64 + lane) * 16], mb);
+        const float inv = a7_exp_strip<MASK>(s, &bias[(it * 64 + lane) * 16], mb);
+        f32x4_t o0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, o1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-            *(uint2*)(Wv.tile + (16 * it + l16) * A7_TP + (16 * jt + 4 * lq) * 2) = a7_pack4(s[jt] * inv);
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t b = __builtin_bit_cast(bf16x8_t, a7_pack8(s[2 * ks], s[2 * ks + 1], inv));  // P of the strip's queries
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[0][ks], b, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[1][ks], b, o1, 0, 0, 0);
+        }
+        a7_store(ro, a7_pack8(o0, o1, 1.f), ooff[it], 0);
     }
-    a7_wave_sync();
-    a7_product<false>(Wv.tile, Wv.opnd, ro, ooff, 0, 1.f, l16, lq);  // O = P V
-    a7_wave_sync();
 }
 
-__global__ __launch_bounds__(256, 2) void swin_attn7_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
+__global__ __launch_bounds__(256, 4) void swin_attn7_fwd_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
                                                                 bf16* __restrict__ out, A7Geom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char a7_smem[];
-    A7Lds& S = *(A7Lds*)a7_smem;
+    A7LdsF& S = *(A7LdsF*)a7_smem;
     const int tid = threadIdx.x, lane = tid & 63, l16 = lane & 15, lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned bid = a7_block(blockIdx.x, gridDim.x, g.xcd);
@@ -330,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn7_fwd_kernel(const bf16* __re
     A7Lane c;
     a7_lane_init(c, l16, lq, g.shift);
     __syncthreads();
-    A7Wave& Wv = S.w[wave];
+    unsigned char* opnd = S.opnd[wave];
     const int nwin = g.wpr * g.wpc, L = g.H * g.W;
     const int gw_end = min(g.total, (chunk + 1) * g.chunk);
     int gw = chunk * g.chunk + wave;
@@ -343,9 +372,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn7_fwd_kernel(const bf16* __re
         a7_offsets(g, c, wy, wx, l16, cl, qoff, ooff);
         const bool lr = g.shift && wy == g.wpc - 1, lc = g.shift && wx == g.wpr - 1;
         if (lr || lc)
-            a7_fwd_window<true>(g, S, Wv, c, rq, ro, qoff, ooff, lr ? 0xffffffffu : 0u, lc ? 0xffffffffu : 0u, lane, l16, lq);
+            a7_fwd_window<true>(g, S.bias, opnd, c, rq, ro, qoff, ooff, lr ? 0xffffffffu : 0u, lc ? 0xffffffffu : 0u, lane, l16, lq);
         else
-            a7_fwd_window<false>(g, S, Wv, c, rq, ro, qoff, ooff, 0u, 0u, lane, l16, lq);
+            a7_fwd_window<false>(g, S.bias, opnd, c, rq, ro, qoff, ooff, 0u, 0u, lane, l16, lq);
         if (h == 0 && g.ld > 32 * g.nh) a7_zero_pad(g, ro, 2 * g.ld, wy, wx, lane, 0);
         a7_advance(g, n, wy, wx);
     }
@@ -588,9 +617,9 @@ static void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int l
 #endif
 }
 template <typename K>
-static int a7_attr(K kernel, bool* done) {
+static int a7_attr(K kernel, bool* done, size_t lds = sizeof(A7Lds)) {
     if (*done) return GDL_OK;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(A7Lds));
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn7)");
     *done = true;
     return GDL_OK;
@@ -606,11 +635,11 @@ int swin_attn7_fwd(const void* qkv, const float* table, void* out, int n_img, in
     A7Geom g;
     a7_geom(&g, n_img, H, W, shift, nh, ld, false);
     static bool attr = false;
-    int rc = a7_attr(swin_attn7_fwd_kernel, &attr);
+    int rc = a7_attr(swin_attn7_fwd_kernel, &attr, sizeof(A7LdsF));
     if (rc) return rc;
     const int nchunks = (g.total + g.chunk - 1) / g.chunk;
     ProfScope prof("gdl::swin_attn7_fwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 4);
-    hipLaunchKernelGGL(swin_attn7_fwd_kernel, dim3(nchunks * nh), dim3(256), sizeof(A7Lds), st, (const bf16*)qkv, table, (bf16*)out, g);
+    hipLaunchKernelGGL(swin_attn7_fwd_kernel, dim3(nchunks * nh), dim3(256), sizeof(A7LdsF), st, (const bf16*)qkv, table, (bf16*)out, g);
     GDL_CHECK_LAUNCH("swin_attn7_fwd_kernel");
     return GDL_OK;
 }
