@@ -67,6 +67,6 @@ L.call("gdl_prof_collect", n_l, n_ms, n_w)
 rows = sorted(((n_ms[s], n_l[s], lib.gdl_prof_slot_name(s).decode()) for s in range(ns) if n_l[s]), reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"kernel time {tot:.2f} ms in {sum(r[1] for r in rows)} launches")
-for ms, n, name in rows[:14]:
+for ms, n, name in rows[:int(os.environ.get("GDL_BENCH_SWIN_ROWS", "14"))]:
     print(f"  {name[:66]:66s} n={n:4d}  {ms:7.3f} ms")
 print("graphs:", {k[0]: (v["n"], v["g"] is not None) for k, v in eng._graphs.items()}, "use_graph", eng.use_graph)
