@@ -601,7 +601,13 @@ static int a7_chunk(long total, int nh, bool bwd) {
     static int forced = -1;
     if (forced < 0) forced = a7_knob("GDL_SWIN_ATTN7_CHUNK", 0);
     if (forced > 0) return forced < 4 ? 4 : forced;  // (the workspace is sized for chunks of >= 4 windows)
-    (void)bwd, (void)nh, (void)total;
+    // ... unless a slightly larger block count fits the launch into ONE round of resident blocks (backward: 2 per CU, forward: 4)
+    // where three windows per wave need a second, half-empty one: stage 3 of Swin-T at 192 frames, 768 windows x 12 heads, is
+    // 768 blocks of 12 windows (1.5 rounds of 512) or 468 blocks of 20 -- backward 64 -> 57 us.
+    const long slots = 256L * (bwd ? 2 : 4);
+    if ((total + 11) / 12 * nh > slots)
+        for (int c = 16; c <= 24; c += 4)
+            if ((total + c - 1) / c * nh <= slots) return c;
     return 12;
 }
 static void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int ld, bool bwd) {
