@@ -48,6 +48,9 @@ SIGNATURES = {
     "gdl_swin_patch_gather": ("i", "ipp" + "iiiii" + "p"),
     "gdl_swin_bias_act": ("i", "ipppp" + "zii" + "p"),
     "gdl_swin_drop_path": ("i", "ipppp" + "zii" + "p"),
+    "gdl_linear_bwd_ok": ("i", "izii"),
+    "gdl_linear_bwd_workspace_bytes": ("z", "zii"),
+    "gdl_linear_bwd": ("i", "ippppp" + "pz" + "zii" + "p"),
     "gdl_swin_ln_fwd": ("i", "ippppp" + "zii" + "p"),
     "gdl_swin_partial_bytes": ("z", "i"),
     "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),

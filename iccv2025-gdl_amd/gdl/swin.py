@@ -85,6 +85,17 @@ class _Linear:
         L.call("gdl_conv_dgrad_gelu", e.dt, L.ptr(dy), L.ptr(self.wT), L.ptr(dx), L.ptr(u), L.ptr(acc), scale,
                L.ptr(e.table(L.GATHER_DGRAD, M, self.kp, self.np)), M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
 
+    # both gradients from one pass over dy (csrc/linear_bwd.hip) where the shape is one of its: dx = dy . w, dw = dy^T . x
+    def bwd_pair(self, dy, x, dx, M, st):
+        e = self.eng
+        if e.lib.gdl_linear_bwd_ok(e.dt, M, self.kp, self.np):
+            ws = e.linear_bwd_ws(M, self.kp, self.np)
+            L.call("gdl_linear_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(self.wT), L.ptr(dx), L.ptr(self.dw), L.ptr(ws), ws.numel(), M,
+                   self.kp, self.np, st)
+        else:
+            self.wgrad(dy, x, M, st)
+            self.dgrad(dy, dx, M, st)
+
     # dw[np][kp] = dy^T . x
     def wgrad(self, dy, x, M, st):
         e = self.eng
@@ -267,6 +278,10 @@ class SwinEngine:
             if "red" in s:
                 nb = max(nb, self.lib.gdl_conv_wgrad_workspace_bytes(self.dt, s["M"] // 4, 1, 1, s["red"].kp, s["red"].np, 1, 1, 1, 0))
         self._wg = torch.empty(nb, dtype=torch.uint8, device=dev)
+        # ... and the partials of the fused data + weight gradient (csrc/linear_bwd.hip; 0 bytes for the shapes it does not take)
+        lb = max([self.lib.gdl_linear_bwd_workspace_bytes(s["M"], b[k].kp, b[k].np) for s in self.stages for b in s["blocks"]
+                  for k in ("qkv", "fc1")] + [16])
+        self._lbws = torch.empty(lb, dtype=torch.uint8, device=dev)
         self._params = None
         self.have_fwd = False
         # stochastic depth (swin_transformer.py:218, 290, 293): per-frame scales of the two residual branches of every block, copied
@@ -288,6 +303,12 @@ class SwinEngine:
             L.call("gdl_conv_build_table", mode, self.dt, M, 1, 1, C, K, 1, 1, 1, 0, L.ptr(t), L.cur_stream())
             self._tables[key] = t
         return t
+
+    def linear_bwd_ws(self, M, K, N):
+        need = self.lib.gdl_linear_bwd_workspace_bytes(M, K, N)
+        if getattr(self, "_lbws", None) is None or self._lbws.numel() < need:
+            self._lbws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._lbws
 
     def wgrad_ws(self, M, C, K):
         nb = self.lib.gdl_conv_wgrad_workspace_bytes(self.dt, M, 1, 1, C, K, 1, 1, 1, 0)
@@ -567,8 +588,7 @@ class SwinEngine:
                 else:
                     b["fc2"].dgrad(g2, gw, M, st)                                 # d a
                     L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
-                wg(b["fc1"], gw, b["m"], M, "fc1")
-                b["fc1"].dgrad(gw, gtok, M, st)                                   # d m
+                b["fc1"].bwd_pair(gw, b["m"], gtok, M, st)                        # fc1's weight gradient and d m
                 need("proj")  # (the previous block's: it reads `spare`)
                 b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st, colsum=self.fuse_ln)   # spare = d x_mid
                 # x_mid = x_in + proj(attn(qkv(norm1(x_in))))
@@ -585,8 +605,7 @@ class SwinEngine:
                 L.call("gdl_swin_attn_bwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(gtok), L.ptr(gq),
                        L.ptr(grads[b["table_idx"]]), L.ptr(self.tpart), N, r, r, s["ws"], b["shift"], s["nh"], ld, st)
                 L.call("gdl_swin_colsum", dt, L.ptr(gq), None, L.ptr(b["qkv"].db), L.ptr(self.partial), M, 3 * ld, st)
-                wg(b["qkv"], gq, b["h"], M, "qkv")
-                b["qkv"].dgrad(gq, gtok, M, st)                                   # d h
+                b["qkv"].bwd_pair(gq, b["h"], gtok, M, st)                        # qkv's weight gradient and d h
                 need("fc2")
                 b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st, colsum=b.get("cs_prev", False))    # dx = d x_in
         need()

@@ -330,6 +330,53 @@ def test_linear_stream_kernel(M, K, N, opts):
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
 
 
+@pytest.mark.parametrize("M", [16384 + 40, 20000])
+def test_linear_bwd_fused(M):
+    """csrc/linear_bwd.hip (round 4): dx = dy . W and dW = dy^T . x of a Linear (K = 128 -> N = 384: stage-1 qkv / Mlp.fc1,
+    swin_transformer.py:26-42, 78-101) from ONE pass over dy, against float64 and against the two GEMMs it replaces (gdl_conv_dgrad +
+    gdl_conv_wgrad; same bf16 inputs, fp32 accumulation in another order); ragged row counts (M not a multiple of the 32-row tile),
+    rows beyond M untouched, run-to-run bit-identical."""
+    from gpu_util import gather_table
+
+    dt, K, N = "bf16", 128, 384
+    dc = L.dtype_code(dt)
+    st = L.cur_stream()
+    assert L.load().gdl_linear_bwd_ok(dc, M, K, N) == 1 and L.load().gdl_linear_bwd_ok(dc, 1000, K, N) == 0
+    dy, x = _q(rng.standard_normal((M, N)), dt), _q(rng.standard_normal((M, K)), dt)
+    w = _q(rng.standard_normal((N, K)) * 0.1, dt)
+    dyd, xd, wT = _dev(dy, dt), _dev(x, dt), _dev(np.ascontiguousarray(w.T), dt)
+    nb = L.load().gdl_linear_bwd_workspace_bytes(M, K, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+
+    def run():
+        dx = torch.full((M + 8, K), float("nan"), device=DEV, dtype=_td(dt))
+        dw = torch.full((N, K), float("nan"), device=DEV)
+        L.call("gdl_linear_bwd", dc, L.ptr(dyd), L.ptr(xd), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(ws), nb, M, K, N, st)
+        torch.cuda.synchronize()
+        return dx, dw
+
+    dx, dw = run()
+    assert torch.isnan(dx[M:]).all() and not torch.isnan(dx[:M]).any() and not torch.isnan(dw).any()
+    want_dx = dy.astype(np.float64) @ w.astype(np.float64)
+    want_dw = dy.astype(np.float64).T @ x.astype(np.float64)
+    assert np.abs(_np(dx[:M]) - want_dx).max() < 3e-2 * max(1.0, np.abs(want_dx).max() / 4)
+    assert np.abs(dw.cpu().numpy().astype(np.float64) - want_dw).max() < 2e-3 * np.abs(want_dw).max()
+    # the pair of GEMMs
+    tab_d = gather_table(L.GATHER_DGRAD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    tab_f = gather_table(L.GATHER_FWD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    dx2 = torch.empty((M, K), device=DEV, dtype=_td(dt))
+    dw2 = torch.empty((N, K), device=DEV)
+    L.call("gdl_conv_dgrad", dc, L.ptr(dyd), L.ptr(wT), L.ptr(dx2), None, L.ptr(tab_d), M, 1, 1, K, N, 1, 1, 1, 0, st)
+    wsb = L.load().gdl_conv_wgrad_workspace_bytes(dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    ws2 = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    L.call("gdl_conv_wgrad", dc, L.ptr(dyd), L.ptr(xd), L.ptr(dw2), L.ptr(tab_f), M, 1, 1, K, N, 1, 1, 1, 0, L.ptr(ws2), wsb, st)
+    torch.cuda.synchronize()
+    assert np.abs(_np(dx[:M]) - _np(dx2)).max() <= 2.0 ** -7 * max(1.0, np.abs(want_dx).max())  # (one bf16 ulp of the largest value)
+    assert np.abs(dw.cpu().numpy() - dw2.cpu().numpy()).max() < 1e-4 * np.abs(want_dw).max()
+    dx3, dw3 = run()
+    assert torch.equal(dx[:M].view(torch.int16), dx3[:M].view(torch.int16)) and torch.equal(dw, dw3)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,K,N", [(777, 384, 128), (5000, 768, 192), (300, 3072, 768)])
 def test_linear_dgrad_gelu_colsum(dt, M, K, N):
