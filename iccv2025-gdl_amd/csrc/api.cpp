@@ -379,10 +379,10 @@ int gdl_swin_bias_act(int dtype, void* y, const float* bias, void* u, const void
 }
 int gdl_linear_bwd_ok(int dtype, size_t M, int K, int N) { return linear_bwd_ok(dtype, M, K, N) ? 1 : 0; }
 size_t gdl_linear_bwd_workspace_bytes(size_t M, int K, int N) { return linear_bwd_ok(GDL_BF16, M, K, N) ? linear_bwd_ws_bytes(M, K, N) : 0; }
-int gdl_linear_bwd(int dtype, const void* dy, const void* x, const void* wT, void* dx, float* dw, void* ws, size_t ws_bytes, size_t M, int K,
-                   int N, void* stream) {
+int gdl_linear_bwd(int dtype, const void* dy, const void* x, const void* wT, void* dx, float* dw, float* db, void* ws, size_t ws_bytes,
+                   size_t M, int K, int Kreal, int N, void* stream) {
     GDL_REQUIRE(dtype == GDL_BF16, "linear_bwd: bf16 only");
-    return linear_bwd(dy, x, wT, dx, dw, ws, ws_bytes, M, K, N, (hipStream_t)stream);
+    return linear_bwd(dy, x, wT, dx, dw, db, ws, ws_bytes, M, K, Kreal, N, (hipStream_t)stream);
 }
 int gdl_swin_drop_path(int dtype, const void* y, const void* res, const float* scale, void* out, size_t M, int L, int ld, void* stream) {
     GDL_REQUIRE(dt_ok(dtype), "swin_drop_path: bad dtype");

@@ -19,6 +19,12 @@
 //     wave's own [32][16] x tile).
 // The dW chunks of the blocks are partials [block][N][K] float, folded in block order by a second kernel (fixed order:
 // run-to-run bit-identical).  Rows beyond M load as zeros and are not stored (raw buffer accesses).
+//
+// Padded input widths (stage 1 of Swin-T: 96 real columns in rows of 128): the 16-column tiles of dW beyond the real width
+// multiply zeros -- they are skipped (KT = 6 of 8 tiles), and with DB the first of them gets an all-ones B operand instead of x
+// columns: its accumulators are then the column sums of dy, i.e. the Linear's bias gradient, from MFMAs that were idle anyway
+// (the separate column-sum pass over dy was 80 us per qkv at 192 frames).  The fold kernel moves that column to db and zeroes
+// the padding columns of dW.
 #include "common.h"
 #include "ops.h"
 #include "prof.h"
@@ -61,7 +67,7 @@ __device__ __forceinline__ int lb_pos(int row, int chunk) {
     return row * (NF * 64) + (((chunk & ~7) | ((chunk & 7) ^ lb_key(row))) << 4);
 }
 
-template <int NF>  // N = 32 NF
+template <int NF, int KT, bool DB>  // N = 32 NF; KT real 16-column tiles of x; DB: tile KT = column sums of dy
 __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_kernel(LbArgs a) {
     constexpr int N = 32 * NF, CPR = N / 8;          // 16-byte chunks per dy row
     constexpr int TILE = LB_ROWS * N * 2;            // bytes of a dy tile
@@ -81,9 +87,11 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_kernel(LbArgs a) {
 #pragma unroll
     for (int ks = 0; ks < NF; ++ks)
         wreg[ks] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(a.wT + (size_t)(16 * wave + l16) * N + 32 * ks + 8 * lq));
-    f32x4_t dw[N / 16];
+    constexpr int KTA = KT + (DB ? 1 : 0);  // tiles with accumulators
+    static_assert(KTA <= 8 && N / 16 == 3 * LB_WAVES, "dW tiles per wave");
+    f32x4_t dw[3 * KTA];
 #pragma unroll
-    for (int nt = 0; nt < N / 16; ++nt) dw[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 3 * KTA; ++nt) dw[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // this thread's chunks of a dy tile: linear chunk p = tid + 512 i -> (row, position in the row); it fetches the source chunk
     // that the swizzle puts there
     // (recomputed at every use instead of kept: nine registers the kernel does not have)
@@ -179,11 +187,16 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_kernel(LbArgs a) {
         }
         const unsigned char* xr = xt + buf * (LB_ROWS * LB_K * 2) + (8 * lq + rho) * (LB_K * 2) + boff;  // x rows 8 lq + rho (and + 4: same key)
 #pragma unroll
-        for (int kt = 0; kt < 8; ++kt) {
+        for (int kt = 0; kt < KT; ++kt) {
             const int xo = ((((2 * kt) & ~7) | (((2 * kt + sub) & 7) ^ (2 * rho))) << 4);
             const bf16x8_t xb = lb_frag(lb_tr(xr + xo), lb_tr(xr + 4 * (LB_K * 2) + xo));
 #pragma unroll
             for (int i = 0; i < 3; ++i) dw[3 * kt + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], xb, dw[3 * kt + i], 0, 0, 0);
+        }
+        if constexpr (DB) {  // sum over the tile's 32 rows of dy[m][n] * 1
+            const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dw[3 * KT + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, dw[3 * KT + i], 0, 0, 0);
         }
 #endif
         park(buf ^ 1, S0{});
@@ -200,19 +213,30 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_kernel(LbArgs a) {
     // dW rows 48 wave .. + 47 -> partial [block][N][K]: dw[3 kt + i][r] of lane (l16, lq) = (row 16 (3 wave + i) + 4 lq + r, column 16 kt + l16)
     float* pp = a.part + (size_t)blockIdx.x * N * LB_K + (size_t)(48 * wave + 4 * lq) * LB_K + l16;
 #pragma unroll
-    for (int kt = 0; kt < 8; ++kt)
+    for (int kt = 0; kt < KTA; ++kt)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) pp[(size_t)(16 * i + r) * LB_K + 16 * kt] = dw[3 * kt + i][r];
 }
 
-// dW[n][k] = sum over the blocks, ascending
-__global__ __launch_bounds__(256) void linear_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int total) {
+// dW[n][k] = sum over the blocks, ascending; columns from kcols on are padding (not written by the blocks): zero, except that
+// with db the partials' column kcols holds the column sums of dy -> db[n]
+__global__ __launch_bounds__(256) void linear_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                                int nblk, int total, int kcols) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
+    const int col = i % LB_K;
+    if (col > kcols || (col == kcols && !db)) {
+        dw[i] = 0.f;
+        return;
+    }
     float s = 0.f;
     for (int b = 0; b < nblk; ++b) s += part[(size_t)b * total + i];
+    if (col == kcols) {
+        db[i / LB_K] = s;
+        s = 0.f;
+    }
     dw[i] = s;
 }
 
@@ -229,27 +253,38 @@ bool linear_bwd_ok(int dtype, size_t M, int K, int N) {
     return on && dtype == GDL_BF16 && K == LB_K && N == 384 && M >= 16384 && M * (size_t)N * 2 < (1ull << 31);
 }
 size_t linear_bwd_ws_bytes(size_t M, int K, int N) { return (size_t)lb_blocks((int)M) * N * K * sizeof(float); }
-int linear_bwd(const void* dy, const void* x, const void* wT, void* dx, float* dw, void* ws, size_t ws_bytes, size_t M, int K, int N,
-               hipStream_t st) {
+int linear_bwd(const void* dy, const void* x, const void* wT, void* dx, float* dw, float* db, void* ws, size_t ws_bytes, size_t M, int K,
+               int Kreal, int N, hipStream_t st) {
     GDL_REQUIRE(dy && x && wT && dx && dw && ws, "linear_bwd: null pointer");
     GDL_REQUIRE(linear_bwd_ok(GDL_BF16, M, K, N), "linear_bwd: unsupported shape M=%zu K=%d N=%d", M, K, N);
+    GDL_REQUIRE(Kreal >= 1 && Kreal <= K, "linear_bwd: %d real columns of %d", Kreal, K);
+    GDL_REQUIRE(!db || Kreal <= 96, "linear_bwd: the bias gradient rides in a padding tile (needs at most 96 real columns, got %d)", Kreal);
     GDL_REQUIRE(ws_bytes >= linear_bwd_ws_bytes(M, K, N), "linear_bwd: workspace %zu < %zu bytes", ws_bytes, linear_bwd_ws_bytes(M, K, N));
     constexpr int NF = 12;
     const size_t lds = 2 * (size_t)LB_ROWS * 32 * NF * 2 + 4 * (size_t)LB_ROWS * LB_K * 2;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)linear_bwd_kernel<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int form = Kreal > 96 ? 0 : (db ? 2 : 1);
+    const void* fn = form == 0 ? (const void*)linear_bwd_kernel<NF, 8, false>
+                               : (form == 1 ? (const void*)linear_bwd_kernel<NF, 6, false> : (const void*)linear_bwd_kernel<NF, 6, true>);
+    static bool attr[3] = {false, false, false};
+    if (!attr[form]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(linear_bwd)");
-        attr = true;
+        attr[form] = true;
     }
     LbArgs a{(const bf16*)dy, (const bf16*)x, (const bf16*)wT, (bf16*)dx, (float*)ws, (int)M, (int)((M + LB_ROWS - 1) / LB_ROWS)};
     const int nblk = lb_blocks((int)M);
     {
         ProfScope prof("gdl::linear_bwd_kernel", PROF_MFMA, st, 4.0 * (double)M * K * N, true, 2.0 * (double)M * (N + 2 * K));
-        hipExtLaunchKernelGGL(linear_bwd_kernel<NF>, dim3(nblk), dim3(64 * LB_WAVES), lds, st, prof.e0(), prof.e1(), 0, a);
+        if (form == 0)
+            hipExtLaunchKernelGGL((linear_bwd_kernel<NF, 8, false>), dim3(nblk), dim3(64 * LB_WAVES), lds, st, prof.e0(), prof.e1(), 0, a);
+        else if (form == 1)
+            hipExtLaunchKernelGGL((linear_bwd_kernel<NF, 6, false>), dim3(nblk), dim3(64 * LB_WAVES), lds, st, prof.e0(), prof.e1(), 0, a);
+        else
+            hipExtLaunchKernelGGL((linear_bwd_kernel<NF, 6, true>), dim3(nblk), dim3(64 * LB_WAVES), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("linear_bwd_kernel");
     }
-    hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, nblk, N * K);
+    hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, db, nblk, N * K,
+                       form == 0 ? LB_K : 96);
     GDL_CHECK_LAUNCH("linear_bwd_reduce_kernel");
     return GDL_OK;
 }

@@ -214,8 +214,8 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
 // both gradients of a short-K Linear from one pass over dy (linear_bwd.hip)
 bool linear_bwd_ok(int dtype, size_t M, int K, int N);
 size_t linear_bwd_ws_bytes(size_t M, int K, int N);
-int linear_bwd(const void* dy, const void* x, const void* wT, void* dx, float* dw, void* ws, size_t ws_bytes, size_t M, int K, int N,
-               hipStream_t st);
+int linear_bwd(const void* dy, const void* x, const void* wT, void* dx, float* dw, float* db, void* ws, size_t ws_bytes, size_t M, int K,
+               int Kreal, int N, hipStream_t st);
 // window 7, bf16: swin_attn7.hip (swin_attn_fwd / _bwd dispatch to it)
 bool swin_attn7_ok(int dt, int H, int W, int ws, int shift, int nh, int ld, int n_img);
 int swin_attn7_fwd(const void* qkv, const float* table, void* out, int n_img, int H, int W, int shift, int nh, int ld, hipStream_t st);

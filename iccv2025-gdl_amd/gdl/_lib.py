@@ -50,7 +50,7 @@ SIGNATURES = {
     "gdl_swin_drop_path": ("i", "ipppp" + "zii" + "p"),
     "gdl_linear_bwd_ok": ("i", "izii"),
     "gdl_linear_bwd_workspace_bytes": ("z", "zii"),
-    "gdl_linear_bwd": ("i", "ippppp" + "pz" + "zii" + "p"),
+    "gdl_linear_bwd": ("i", "ipppppp" + "pz" + "ziii" + "p"),
     "gdl_swin_ln_fwd": ("i", "ippppp" + "zii" + "p"),
     "gdl_swin_partial_bytes": ("z", "i"),
     "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),

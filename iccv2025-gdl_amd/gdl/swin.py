@@ -12,6 +12,7 @@ The host side here only plans buffers and enqueues kernels (PyTorch = device all
 Everything saved for the backward is kept (nothing recomputed except the attention probabilities).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -86,13 +87,20 @@ class _Linear:
                L.ptr(e.table(L.GATHER_DGRAD, M, self.kp, self.np)), M, 1, 1, self.kp, self.np, 1, 1, 1, 0, st)
 
     # both gradients from one pass over dy (csrc/linear_bwd.hip) where the shape is one of its: dx = dy . w, dw = dy^T . x
-    def bwd_pair(self, dy, x, dx, M, st):
+    # bias=True: db = column sums of dy as well -- from the fused kernel where the input width leaves it a padding tile, else by
+    # gdl_swin_colsum
+    def bwd_pair(self, dy, x, dx, M, st, bias=False):
         e = self.eng
-        if e.lib.gdl_linear_bwd_ok(e.dt, M, self.kp, self.np):
+        if e.lib.gdl_linear_bwd_ok(e.dt, M, self.kp, self.np) and self.kseg == self.k:
             ws = e.linear_bwd_ws(M, self.kp, self.np)
-            L.call("gdl_linear_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(self.wT), L.ptr(dx), L.ptr(self.dw), L.ptr(ws), ws.numel(), M,
-                   self.kp, self.np, st)
+            db_in = bias and self.k <= 96
+            L.call("gdl_linear_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(self.wT), L.ptr(dx), L.ptr(self.dw), L.ptr(self.db) if db_in else None,
+                   L.ptr(ws), ws.numel(), M, self.kp, self.k, self.np, st)
+            if bias and not db_in:
+                L.call("gdl_swin_colsum", e.dt, L.ptr(dy), None, L.ptr(self.db), L.ptr(e.partial), M, self.np, st)
         else:
+            if bias:
+                L.call("gdl_swin_colsum", e.dt, L.ptr(dy), None, L.ptr(self.db), L.ptr(e.partial), M, self.np, st)
             self.wgrad(dy, x, M, st)
             self.dgrad(dy, dx, M, st)
 
@@ -604,8 +612,7 @@ class SwinEngine:
                 need("fc1")
                 L.call("gdl_swin_attn_bwd", dt, L.ptr(b["qkv_a"]), L.ptr(P[b["table_idx"]]), L.ptr(gtok), L.ptr(gq),
                        L.ptr(grads[b["table_idx"]]), L.ptr(self.tpart), N, r, r, s["ws"], b["shift"], s["nh"], ld, st)
-                L.call("gdl_swin_colsum", dt, L.ptr(gq), None, L.ptr(b["qkv"].db), L.ptr(self.partial), M, 3 * ld, st)
-                b["qkv"].bwd_pair(gq, b["h"], gtok, M, st)                        # qkv's weight gradient and d h
+                b["qkv"].bwd_pair(gq, b["h"], gtok, M, st, bias=True)            # qkv's weight and bias gradients and d h
                 need("fc2")
                 b["norm1"].bwd(gtok, b["x_in"], b["stats1"], spare, dx, M, st, colsum=b.get("cs_prev", False))    # dx = d x_in
         need()

@@ -486,11 +486,14 @@ GDL_API int gdl_swin_patch_gather(int dtype, const float* x, void* a, int B, int
 /* Both gradients of y[M][N] = x[M][K] W^T (nn.Linear; swin_transformer.py:26-42 Mlp.fc1, :78-157 qkv) from ONE pass over dy:
  * dx[M][K] = dy . W (bf16) and dW[N][K] = dy^T . x (float32), for the shapes gdl_linear_bwd_ok accepts (bf16, K = 128, N = 384,
  * M >= 16384: stage 1 of Swin-T) -- what gdl_conv_dgrad + gdl_conv_wgrad (R = S = 1) compute in two passes over dy.  wT: the
- * weight as [K][N] (the layout gdl_swin_pack_matrix's dstT / gdl_conv_dgrad take).  ws: gdl_linear_bwd_workspace_bytes. */
+ * weight as [K][N] (the layout gdl_swin_pack_matrix's dstT / gdl_conv_dgrad take).  ws: gdl_linear_bwd_workspace_bytes.
+ * Kreal: the real input width (columns Kreal .. K - 1 of x are zero padding; dW gets zeros there).  db (optional, float32 [N]):
+ * the bias gradient = column sums of dy -- only where Kreal <= 96, where it costs nothing (an all-ones operand in a padding
+ * tile's place); an error otherwise (use gdl_swin_colsum). */
 GDL_API int gdl_linear_bwd_ok(int dtype, size_t M, int K, int N);
 GDL_API size_t gdl_linear_bwd_workspace_bytes(size_t M, int K, int N);
-GDL_API int gdl_linear_bwd(int dtype, const void* dy, const void* x, const void* wT, void* dx, float* dw, void* ws, size_t ws_bytes,
-                           size_t M, int K, int N, void* stream);
+GDL_API int gdl_linear_bwd(int dtype, const void* dy, const void* x, const void* wT, void* dx, float* dw, float* db, void* ws,
+                           size_t ws_bytes, size_t M, int K, int Kreal, int N, void* stream);
 GDL_API int gdl_swin_drop_path(int dtype, const void* y, const void* res, const float* scale, void* out, size_t M, int L, int ld,
                                void* stream);
 GDL_API int gdl_swin_bias_act(int dtype, void* y, const float* bias, void* u, const void* res, size_t M, int ld, int mode,

@@ -330,12 +330,13 @@ def test_linear_stream_kernel(M, K, N, opts):
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
 
 
-@pytest.mark.parametrize("M", [16384 + 40, 20000])
-def test_linear_bwd_fused(M):
+@pytest.mark.parametrize("M,kreal,bias", [(16384 + 40, 128, False), (20000, 96, False), (20000, 96, True), (16384 + 71, 80, True)])
+def test_linear_bwd_fused(M, kreal, bias):
     """csrc/linear_bwd.hip (round 4): dx = dy . W and dW = dy^T . x of a Linear (K = 128 -> N = 384: stage-1 qkv / Mlp.fc1,
     swin_transformer.py:26-42, 78-101) from ONE pass over dy, against float64 and against the two GEMMs it replaces (gdl_conv_dgrad +
     gdl_conv_wgrad; same bf16 inputs, fp32 accumulation in another order); ragged row counts (M not a multiple of the 32-row tile),
-    rows beyond M untouched, run-to-run bit-identical."""
+    rows beyond M untouched, run-to-run bit-identical.  kreal < 128: the input's padding columns (zeros) -- their tiles of dW are
+    skipped and come back as zeros; bias: the column sums of dy (the Linear's bias gradient) from the first skipped tile."""
     from gpu_util import gather_table
 
     dt, K, N = "bf16", 128, 384
@@ -344,6 +345,8 @@ def test_linear_bwd_fused(M):
     assert L.load().gdl_linear_bwd_ok(dc, M, K, N) == 1 and L.load().gdl_linear_bwd_ok(dc, 1000, K, N) == 0
     dy, x = _q(rng.standard_normal((M, N)), dt), _q(rng.standard_normal((M, K)), dt)
     w = _q(rng.standard_normal((N, K)) * 0.1, dt)
+    x[:, kreal:] = 0
+    w[:, kreal:] = 0
     dyd, xd, wT = _dev(dy, dt), _dev(x, dt), _dev(np.ascontiguousarray(w.T), dt)
     nb = L.load().gdl_linear_bwd_workspace_bytes(M, K, N)
     ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
@@ -351,12 +354,28 @@ def test_linear_bwd_fused(M):
     def run():
         dx = torch.full((M + 8, K), float("nan"), device=DEV, dtype=_td(dt))
         dw = torch.full((N, K), float("nan"), device=DEV)
-        L.call("gdl_linear_bwd", dc, L.ptr(dyd), L.ptr(xd), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(ws), nb, M, K, N, st)
+        db = torch.full((N,), float("nan"), device=DEV)
+        L.call("gdl_linear_bwd", dc, L.ptr(dyd), L.ptr(xd), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(db) if bias else None, L.ptr(ws), nb, M, K,
+               kreal, N, st)
         torch.cuda.synchronize()
-        return dx, dw
+        return dx, dw, db
 
-    dx, dw = run()
+    dx, dw, db = run()
     assert torch.isnan(dx[M:]).all() and not torch.isnan(dx[:M]).any() and not torch.isnan(dw).any()
+    if kreal <= 96:
+        assert (dw[:, 96:] == 0).all() and (dx[:M, kreal:] == 0).all()
+    if bias:
+        want_db = dy.astype(np.float64).sum(0)
+        assert np.abs(db.cpu().numpy().astype(np.float64) - want_db).max() < 1e-4 * max(1.0, np.abs(want_db).max())
+        cs = torch.empty(N, device=DEV)
+        part = torch.empty(L.load().gdl_swin_partial_bytes(N), dtype=torch.uint8, device=DEV)
+        L.call("gdl_swin_colsum", dc, L.ptr(dyd), None, L.ptr(cs), L.ptr(part), M, N, st)  # (the pass it replaces)
+        torch.cuda.synchronize()
+        assert np.abs(db.cpu().numpy() - cs.cpu().numpy()).max() < 1e-4 * max(1.0, np.abs(want_db).max())
+        with pytest.raises(L.GdlError):  # no padding tile to carry it
+            L.call("gdl_linear_bwd", dc, L.ptr(dyd), L.ptr(xd), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nb, M, K, 128, N, st)
+    else:
+        assert torch.isnan(db).all()
     want_dx = dy.astype(np.float64) @ w.astype(np.float64)
     want_dw = dy.astype(np.float64).T @ x.astype(np.float64)
     assert np.abs(_np(dx[:M]) - want_dx).max() < 3e-2 * max(1.0, np.abs(want_dx).max() / 4)
@@ -373,8 +392,9 @@ def test_linear_bwd_fused(M):
     torch.cuda.synchronize()
     assert np.abs(_np(dx[:M]) - _np(dx2)).max() <= 2.0 ** -7 * max(1.0, np.abs(want_dx).max())  # (one bf16 ulp of the largest value)
     assert np.abs(dw.cpu().numpy() - dw2.cpu().numpy()).max() < 1e-4 * np.abs(want_dw).max()
-    dx3, dw3 = run()
+    dx3, dw3, db3 = run()
     assert torch.equal(dx[:M].view(torch.int16), dx3[:M].view(torch.int16)) and torch.equal(dw, dw3)
+    assert not bias or torch.equal(db, db3)
 
 
 @pytest.mark.parametrize("dt", DTS)

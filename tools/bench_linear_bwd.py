@@ -30,8 +30,19 @@ wsb = lib.gdl_conv_wgrad_workspace_bytes(dc, M, 1, 1, K, N, 1, 1, 1, 0)
 ws2 = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
 
-def fused():
-    L.call("gdl_linear_bwd", dc, L.ptr(dy), L.ptr(x), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(ws), nb, M, K, N, st)
+x[:, 96:] = 0
+wT[96:] = 0
+db = torch.empty(N, device=dev)
+part = torch.empty(lib.gdl_swin_partial_bytes(N), dtype=torch.uint8, device=dev)
+
+
+def fused(kreal=128, bias=False):
+    L.call("gdl_linear_bwd", dc, L.ptr(dy), L.ptr(x), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(db) if bias else None, L.ptr(ws), nb, M, K,
+           kreal, N, st)
+
+
+def colsum():
+    L.call("gdl_swin_colsum", dc, L.ptr(dy), None, L.ptr(db), L.ptr(part), M, N, st)
 
 
 def pair():
@@ -39,7 +50,9 @@ def pair():
     L.call("gdl_conv_wgrad", dc, L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(tab_f), M, 1, 1, K, N, 1, 1, 1, 0, L.ptr(ws2), wsb, st)
 
 
-for name, fn, nbytes in (("fused", fused, 2 * M * (N + 2 * K)), ("pair", pair, 2 * M * (2 * N + 2 * K)), ("fused", fused, 2 * M * (N + 2 * K))):
+for name, fn, nbytes in (("fused", fused, 2 * M * (N + 2 * K)), ("pair", pair, 2 * M * (2 * N + 2 * K)), ("fused", fused, 2 * M * (N + 2 * K)),
+                         ("fused, 96 real columns", lambda: fused(96), 2 * M * (N + 2 * K)),
+                         ("fused, 96 + bias gradient", lambda: fused(96, True), 2 * M * (N + 2 * K)), ("column sums alone", colsum, 2 * M * N)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -50,4 +63,4 @@ for name, fn, nbytes in (("fused", fused, 2 * M * (N + 2 * K)), ("pair", pair, 2
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
-    print(f"{name:6s} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s of {nbytes / 1e6:.0f} MB")
+    print(f"{name:26s} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s of {nbytes / 1e6:.0f} MB")
