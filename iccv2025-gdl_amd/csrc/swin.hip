@@ -208,18 +208,26 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
             bt[i][e] = real ? beta[c] : 0.f;
         }
     const size_t stride = (size_t)gridDim.x * 4 * rpw;
-    for (size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr; base < M; base += stride * U) {
-        uint4 vq[U][VPL];  // (packed until a row group's turn: U x VPL x 4 registers in flight instead of U x VPL x EPC)
+    // the NEXT iteration's rows are requested before this iteration's are reduced and stored: a wave's loads stay in flight through
+    // its reductions (with the request at the top of the iteration it served, three waves per SIMD left the memory pipe idle for
+    // a third of the time: 3.5 TB/s at stage 1)
+    auto request = [&](size_t b, uint4 (&q)[U][VPL]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t row = base + u * stride;
+            const size_t row = b + u * stride;
             if (row < M) {
                 const uint4* xr = (const uint4*)(x + row * ld);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
-                    if (sub + lpr * i < vpr) vq[u][i] = xr[sub + lpr * i];
+                    if (sub + lpr * i < vpr) q[u][i] = xr[sub + lpr * i];
             }
         }
+    };
+    size_t base = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + lane / lpr;
+    uint4 vq[U][VPL], vn[U][VPL];  // (packed until a row group's turn: U x VPL x 4 registers in flight instead of U x VPL x EPC)
+    request(base, vq);
+    for (; base < M; base += stride * U) {
+        request(base + stride * U, vn);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t row = base + u * stride;
@@ -257,6 +265,10 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
                     yr[sub + lpr * i] = pack16<T>(o);
                 }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) vq[u][i] = vn[u][i];
     }
 }
 
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void swin_ln_fwd_kernel(const T* __restrict__ 
 // 4 * (64 / lpr) row groups are folded through LDS in group order.
 // CS: a third partial row, partial[blk][2][c] = sum of dx AS STORED over the rows of the block -- the bias gradient of the
 // Linear whose output gradient dx is (x_out = x_mid + fc2(...) + b: d b = column sums of d x_out), instead of a pass of its own.
-template <typename T, int VPL, int U, bool CS>
+template <typename T, int VPL, int U, bool CS, bool PIPE = true>
 __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float2* __restrict__ stats, const float* __restrict__ gamma,
                                                           const T* __restrict__ add, T* __restrict__ dx,
@@ -289,27 +301,32 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
         }
     }
     const size_t stride = (size_t)gridDim.x * 4 * rpw;
-    for (size_t base = ((size_t)blockIdx.x * 4 + wave) * rpw + lane / lpr; base < M; base += stride * U) {
-        // every vector of the U row groups (dy, x and the addend) is requested before the first is used, and stays packed until
-        // its group's turn: 3 x U x VPL x 4 registers in flight (the unpacked form held 2 x U x VPL x EPC and fetched the
-        // addend behind the reductions)
-        uint4 dq[U][VPL], xq[U][VPL], aq[U][VPL];
-        float2 st[U];
+    // every vector of the U row groups (dy, x and the addend) is requested before the first is used, and stays packed until its
+    // group's turn: 3 x U x VPL x 4 registers in flight (the unpacked form held 2 x U x VPL x EPC and fetched the addend behind the
+    // reductions) -- and, as in the forward, the NEXT iteration's request goes out before this iteration's arithmetic
+    auto request = [&](size_t b, uint4 (&dq_)[U][VPL], uint4 (&xq_)[U][VPL], uint4 (&aq_)[U][VPL], float2 (&st_)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t row = base + u * stride;
+            const size_t row = b + u * stride;
             if (row < M) {
-                st[u] = stats[row];
+                st_[u] = stats[row];
                 const uint4 *dr = (const uint4*)(dy + row * ld), *xr = (const uint4*)(x + row * ld);
 #pragma unroll
                 for (int i = 0; i < VPL; ++i)
                     if (sub + lpr * i < vpr) {
-                        dq[u][i] = dr[sub + lpr * i];
-                        xq[u][i] = xr[sub + lpr * i];
-                        if (add) aq[u][i] = ((const uint4*)(add + row * ld))[sub + lpr * i];
+                        dq_[u][i] = dr[sub + lpr * i];
+                        xq_[u][i] = xr[sub + lpr * i];
+                        if (add) aq_[u][i] = ((const uint4*)(add + row * ld))[sub + lpr * i];
                     }
             }
         }
+    };
+    uint4 dq[U][VPL], xq[U][VPL], aq[U][VPL], dn[U][VPL], xn[U][VPL], an[U][VPL];
+    float2 st[U], sn[U];
+    size_t base = ((size_t)blockIdx.x * 4 + wave) * rpw + lane / lpr;
+    request(base, dq, xq, aq, st);
+    for (; base < M; base += stride * U) {
+        if (PIPE) request(base + stride * U, dn, xn, an, sn);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             __builtin_amdgcn_sched_barrier(0);  // one row group at a time: interleaved, the groups' unpacked values pile up in registers
@@ -357,6 +374,17 @@ __global__ __launch_bounds__(256) void swin_ln_bwd_kernel(const T* __restrict__ 
                     }
                     outr[sub + lpr * i] = pack16<T>(o);
                 }
+        }
+        if (!PIPE) request(base + stride * U, dn, xn, an, sn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            st[u] = sn[u];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                dq[u][i] = dn[u][i];
+                xq[u][i] = xn[u][i];
+                aq[u][i] = an[u][i];
+            }
         }
     }
     // block partials: groups (wave, row group) in order
@@ -1420,7 +1448,7 @@ int swin_ln_fwd(int dt, const void* x, const float* gamma, const float* beta, vo
     static int fcap = -1;
     if (fcap < 0) {
         const char* e = tune_env("GDL_SW_LN_CAP");  // tuning aid: block cap of the LayerNorm forward
-        fcap = e ? atoi(e) : 1024;  // (8192 -> 1024: 44 -> 37 us at stage 2, 65 -> 37 us at the second merge; tools/bench_swin_ln.py)
+        fcap = e ? atoi(e) : 768;  // (one round of resident blocks at 112-135 registers; 8192 -> 1024 -> 768: tools/bench_swin_ln.py)
     }
     const int g = sw_grid(M, 4 * (64 / lpr) * uu, fcap);
     ProfScope prof("gdl::swin_ln_fwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 8 : 4));
@@ -1465,32 +1493,38 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
     const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr, vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
     const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
     const size_t gg = (M + (size_t)4 * rpw * uu - 1) / ((size_t)4 * rpw * uu);
-    // three blocks per CU where there is work for them (the kernel holds ~140 registers: three waves per SIMD): 221 -> 175 us at
-    // stage 1; the small stages keep two (tools/bench_swin_ln.py)
-    const size_t cap = tune_env("GDL_SW_PBLOCKS") ? (size_t)sw_pblocks() : (M >= 30000 ? 768 : 512);
+    // large launches: the pipelined form (next iteration's rows requested before this one's arithmetic; ~250 registers: two blocks
+    // per CU, 512 blocks); the 9 408-row shapes of stage 4 lose with it and keep the plain form (tools/bench_swin_ln.py:
+    // stage 3 44.6 -> 40.0 us, first merge 124 -> 111, stage 4 27.6 -> 30.0)
+    const bool pipe = M >= 30000;
+    const size_t cap = tune_env("GDL_SW_PBLOCKS") ? (size_t)sw_pblocks() : 512;
     const int g = (int)(gg > cap ? cap : gg);
     const int nr = colsum ? 3 : 2;
     const size_t lds = (size_t)4 * rpw * nr * ld * sizeof(float);
     GDL_REQUIRE(lds <= 64 * 1024, "swin_ln_bwd: width %d needs %zu bytes of LDS", ld, lds);
     {
         ProfScope prof("gdl::swin_ln_bwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (add ? 4 : 3));
-#define SW_LN_BWD1(T, V, U_, CS_)                                                                                                   \
+#define SW_LN_BWD1(T, V, U_, CS_, P_)                                                                                                  \
     do {                                                                                                                            \
         static bool attr = false;                                                                                                   \
         if (!attr) {                                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<T, V, U_, CS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
+            hipError_t e = hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<T, V, U_, CS_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
             if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_ln_bwd)");                                          \
             attr = true;                                                                                                            \
         }                                                                                                                           \
-        hipLaunchKernelGGL((swin_ln_bwd_kernel<T, V, U_, CS_>), dim3(g), dim3(256), lds, st, (const T*)dy, (const T*)x, (const float2*)stats, gamma, \
+        hipLaunchKernelGGL((swin_ln_bwd_kernel<T, V, U_, CS_, P_>), dim3(g), dim3(256), lds, st, (const T*)dy, (const T*)x, (const float2*)stats, gamma, \
                            (const T*)add, (T*)dx, partial, M, C, ld, lpr);                                                          \
     } while (0)
 #define SW_LN_BWD(T, V, U_)                \
     do {                                   \
-        if (colsum)                        \
-            SW_LN_BWD1(T, V, U_, true);    \
-        else                               \
-            SW_LN_BWD1(T, V, U_, false);   \
+        if (colsum && pipe)                       \
+            SW_LN_BWD1(T, V, U_, true, true);     \
+        else if (colsum)                          \
+            SW_LN_BWD1(T, V, U_, true, false);    \
+        else if (pipe)                            \
+            SW_LN_BWD1(T, V, U_, false, true);    \
+        else                                      \
+            SW_LN_BWD1(T, V, U_, false, false);   \
     } while (0)
         if (dt == GDL_F32) {
             if (vpl == 1) SW_LN_BWD(float, 1, 4); else if (vpl == 2) SW_LN_BWD(float, 2, 2); else if (vpl == 3) SW_LN_BWD(float, 3, 1); else SW_LN_BWD(float, 6, 1);
