@@ -220,24 +220,43 @@ __global__ __launch_bounds__(64 * LB_WAVES) void linear_bwd_kernel(LbArgs a) {
             for (int r = 0; r < 4; ++r) pp[(size_t)(16 * i + r) * LB_K + 16 * kt] = dw[3 * kt + i][r];
 }
 
-// dW[n][k] = sum over the blocks, ascending; columns from kcols on are padding (not written by the blocks): zero, except that
-// with db the partials' column kcols holds the column sums of dy -> db[n]
+// dW[n][k] = sum over the blocks' partials in a fixed order; columns from kcols on are padding (not written by the blocks): zero,
+// except that with db the partials' column kcols holds the column sums of dy -> db[n].
+// A block = 16 partial groups x 16 float4 columns: thread (g, v) sums the partials g, g + 16, ... of four outputs (all its loads in
+// flight at once), the 16 groups fold through LDS in group order.  (One thread per output walking all 256 partials was a chain of
+// 256 dependent-latency loads: 78 us per launch for 50 MB.)
 __global__ __launch_bounds__(256) void linear_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
                                                                 int nblk, int total, int kcols) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int col = i % LB_K;
-    if (col > kcols || (col == kcols && !db)) {
-        dw[i] = 0.f;
-        return;
+    __shared__ float4 red[16][16];
+    const int v = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int i4 = (blockIdx.x * 16 + v) * 4;  // first of this thread's four outputs (total is a multiple of 64)
+    const int col = i4 % LB_K;
+    const bool live = col < kcols || (db && col == kcols);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        constexpr int UN = 8;
+        for (int b0 = g; b0 < nblk; b0 += 16 * UN) {
+            float4 q[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int b = b0 + 16 * u;
+                q[u] = b < nblk ? *(const float4*)(part + (size_t)b * total + i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) s.x += q[u].x, s.y += q[u].y, s.z += q[u].z, s.w += q[u].w;
+        }
     }
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * total + i];
-    if (col == kcols) {
-        db[i / LB_K] = s;
-        s = 0.f;
+    red[g][v] = s;
+    __syncthreads();
+    if (g != 0) return;
+    float4 t = red[0][v];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t.x += red[k][v].x, t.y += red[k][v].y, t.z += red[k][v].z, t.w += red[k][v].w;
+    if (col == kcols) {  // (only reached with live sums when db is given)
+        if (db) db[i4 / LB_K] = t.x;
+        t = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    dw[i] = s;
+    *(float4*)(dw + i4) = t;
 }
 
 static int lb_blocks(int M) {
@@ -283,7 +302,7 @@ int linear_bwd(const void* dy, const void* x, const void* wT, void* dx, float* d
             hipExtLaunchKernelGGL((linear_bwd_kernel<NF, 6, true>), dim3(nblk), dim3(64 * LB_WAVES), lds, st, prof.e0(), prof.e1(), 0, a);
         GDL_CHECK_LAUNCH("linear_bwd_kernel");
     }
-    hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, db, nblk, N * K,
+    hipLaunchKernelGGL(linear_bwd_reduce_kernel, dim3(N * K / 64), dim3(256), 0, st, (const float*)ws, dw, db, nblk, N * K,
                        form == 0 ? LB_K : 96);
     GDL_CHECK_LAUNCH("linear_bwd_reduce_kernel");
     return GDL_OK;

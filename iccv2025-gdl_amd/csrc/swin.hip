@@ -1340,15 +1340,50 @@ __global__ __launch_bounds__(256) void swin_pack_batched_kernel(const SwinPackDe
     }
     const SwinPackDesc d = descs[lo];
     const SwinSeg s = d.s;
-    const size_t total = dir == 0 ? (size_t)s.np * s.kp : (size_t)s.n * s.k;
+    const int blk = (int)blockIdx.x - d.blk0;
+    // (32-bit index arithmetic throughout: a matrix has fewer than 2^31 elements; the 64-bit divisions of the first form were
+    // half of its time, the 2-byte scattered stores of the transposed copy the other half: 287 us per step for Swin-T)
+    auto real = [&](int pn, int pk) -> float {
+        const int sn = pn / s.nseg_pad, on = pn - sn * s.nseg_pad, sk = pk / s.kseg_pad, ok = pk - sk * s.kseg_pad;
+        const int rn = sn * s.nseg + on, rk = sk * s.kseg + ok;
+        return (on < s.nseg && ok < s.kseg && rn < s.n && rk < s.k) ? d.src[(size_t)rn * s.k + rk] : 0.f;
+    };
+    if (dir == 0 && (s.np & 31) == 0 && (s.kp & 31) == 0) {
+        // a 32 x 32 tile of the padded matrix per block (1024 elements, like the linear form: the caller's block count holds):
+        // rows of 32 elements in, rows of 32 elements out for both copies, the transposed one through LDS
+        __shared__ float tile[32][33];
+        const int tpr = s.kp >> 5, tn = blk / tpr, tk = blk - tn * tpr;
+        const int r = threadIdx.x >> 5, c = threadIdx.x & 31;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pn = 32 * tn + r + 8 * u, pk = 32 * tk + c;
+            const float v = real(pn, pk);
+            tile[r + 8 * u][c] = v;
+            if (d.dt == GDL_F32)
+                ((float*)d.dst)[(size_t)pn * s.kp + pk] = v;
+            else
+                storeT((bf16*)d.dst + (size_t)pn * s.kp + pk, v);
+        }
+        if (!d.dstT) return;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pk = 32 * tk + r + 8 * u, pn = 32 * tn + c;
+            const float v = tile[c][r + 8 * u];
+            if (d.dt == GDL_F32)
+                ((float*)d.dstT)[(size_t)pk * s.np + pn] = v;
+            else
+                storeT((bf16*)d.dstT + (size_t)pk * s.np + pn, v);
+        }
+        return;
+    }
+    const int total = dir == 0 ? s.np * s.kp : s.n * s.k;
     for (int u = 0; u < 4; ++u) {
-        const size_t i = ((size_t)(blockIdx.x - d.blk0) * 4 + u) * 256 + threadIdx.x;
+        const int i = (blk * 4 + u) * 256 + (int)threadIdx.x;
         if (i >= total) return;
         if (dir == 0) {
-            const int pk = (int)(i % s.kp), pn = (int)(i / s.kp);
-            const int sn = pn / s.nseg_pad, on = pn % s.nseg_pad, sk = pk / s.kseg_pad, ok = pk % s.kseg_pad;
-            const int rn = sn * s.nseg + on, rk = sk * s.kseg + ok;
-            const float v = (on < s.nseg && ok < s.kseg && rn < s.n && rk < s.k) ? d.src[(size_t)rn * s.k + rk] : 0.f;
+            const int pn = i / s.kp, pk = i - pn * s.kp;
+            const float v = real(pn, pk);
             if (d.dt == GDL_F32) {
                 ((float*)d.dst)[i] = v;
                 if (d.dstT) ((float*)d.dstT)[(size_t)pk * s.np + pn] = v;
@@ -1357,7 +1392,7 @@ __global__ __launch_bounds__(256) void swin_pack_batched_kernel(const SwinPackDe
                 if (d.dstT) storeT((bf16*)d.dstT + (size_t)pk * s.np + pn, v);
             }
         } else {
-            const int rk = (int)(i % s.k), rn = (int)(i / s.k);
+            const int rn = i / s.k, rk = i - rn * s.k;
             const int pn = (rn / s.nseg) * s.nseg_pad + rn % s.nseg, pk = (rk / s.kseg) * s.kseg_pad + rk % s.kseg;
             ((float*)d.dst)[i] = d.src[(size_t)pn * s.kp + pk];
         }

@@ -134,6 +134,55 @@ def test_swin_drop_path_graph_replays_and_mirror(golden_dir):
     np.testing.assert_allclose(ye.cpu().numpy(), y_plain, rtol=0, atol=2e-6 * np.abs(y_plain).max())
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_swin_batched_pack_equals_single_matrix_calls(dtype):
+    """gdl_swin_pack_batched (one launch per step for every Linear / LayerNorm parameter: 32 x 32 tiles, the transposed copy through
+    LDS) against gdl_swin_pack_matrix per matrix, bit for bit: the [out][in] copy, the transposed copy, the padded biases; and
+    the gradients' way back (gdl_swin_pack_batched dir 1) against gdl_swin_unpack_matrix."""
+    from gdl.swin import SwinEngine, _Linear
+
+    cfg = fx.SWIN_TINY2
+    eng = SwinEngine(cfg, dtype, 2, 2, DEV)
+    P = fx.make_state(fx.swin_param_shapes(cfg))
+    params = [torch.from_numpy(v).to(DEV) for v in P.values()]
+    eng.set_params(params)
+    st = L.cur_stream()
+    eng._pack_all(st)
+    torch.cuda.synchronize()
+    seen = 0
+    for o in eng._linears_norms():
+        if not isinstance(o, _Linear):
+            continue
+        w = torch.full_like(o.w, float("nan"))
+        wT = torch.full_like(o.wT, float("nan"))
+        L.call("gdl_swin_pack_matrix", eng.dt, L.ptr(params[o.w_idx]), L.ptr(w), L.ptr(wT), o.n, o.k, o.nseg, o.nseg_pad, o.kseg, o.kseg_pad, st)
+        torch.cuda.synchronize()
+        assert torch.equal(w.view(torch.uint8), o.w.view(torch.uint8)) and torch.equal(wT.view(torch.uint8), o.wT.view(torch.uint8))
+        assert torch.equal(o.wT, o.w.t())
+        if o.b is not None:
+            want = torch.zeros_like(o.b).view(-1, o.nseg_pad)
+            want[:, :o.nseg] = params[o.b_idx].view(-1, o.nseg)
+            assert torch.equal(o.b, want.view(-1))
+        # the way back: a padded float32 gradient -> the parameter's shape
+        o.dw.copy_(torch.randn(o.dw.shape, device=DEV))
+        seen += 1
+    grads = [torch.full_like(p, float("nan")) for p in params]
+    for o in eng._linears_norms():  # (every bias / LayerNorm gradient buffer defined)
+        for t in (getattr(o, "db", None), getattr(o, "dgb", None)):
+            if t is not None:
+                t.zero_()
+    eng._unpack_all(grads, st)
+    torch.cuda.synchronize()
+    for o in eng._linears_norms():
+        if not isinstance(o, _Linear):
+            continue
+        rt = torch.empty_like(params[o.w_idx])
+        L.call("gdl_swin_unpack_matrix", L.ptr(o.dw), L.ptr(rt), o.n, o.k, o.nseg, o.nseg_pad, o.kseg, o.kseg_pad, st)
+        torch.cuda.synchronize()
+        assert torch.equal(rt, grads[o.w_idx])
+    assert seen >= 9
+
+
 def test_swin_engine_deterministic_and_rebindable():
     cfg = fx.SWIN_TINY2
     dy = np.random.default_rng(5).standard_normal((4, 192), dtype=np.float32)
