@@ -250,7 +250,12 @@ int gdl_avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int H
 int gdl_head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale, float* df,
                        int B, int n_classes, void* stream) {
     GDL_REQUIRE(f && Wp && bp && labels && df && B > 0 && n_classes > 0 && ldw >= 512, "head_uni_dfeat: bad arguments");
-    return head_uni_dfeat(f, Wp, ldw, bp, labels, scale, df, B, n_classes, (hipStream_t)stream);
+    return head_uni_dfeat(f, Wp, ldw, bp, labels, scale, df, B, n_classes, 512, (hipStream_t)stream);
+}
+int gdl_head_uni_dfeat_w(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale, float* df,
+                         int B, int n_classes, int width, void* stream) {
+    GDL_REQUIRE(f && Wp && bp && labels && df && B > 0 && n_classes > 0 && ldw >= width, "head_uni_dfeat_w: bad arguments");
+    return head_uni_dfeat(f, Wp, ldw, bp, labels, scale, df, B, n_classes, width, (hipStream_t)stream);
 }
 int gdl_head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out,
                         float* y_out, int B, int n_classes, void* stream) {

@@ -318,20 +318,22 @@ __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logit
 // (main_dgl.py:102-122), so its backward need not wait for the other encoder's forward: DGLTrainer launches this on the
 // encoder's own stream right behind its forward.  grid = B.  Every sum runs in the order head_fwd_kernel, softmax_ce_block and
 // head_bwd_feat_kernel use: df is bit-identical to the three-launch path.
+template <int ND>  // feature width = 64 ND
 __global__ __launch_bounds__(256) void head_uni_dfeat_kernel(const float* __restrict__ f, const float* __restrict__ Wp, int ldw,
                                                             const float* __restrict__ bp, const int64_t* __restrict__ labels,
                                                             float scale, float* __restrict__ df, int B, int n) {
+    constexpr int D = 64 * ND;
     __shared__ float lg[512], dl[512];
     __shared__ float lse_s;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float fv[8];
+    float fv[ND];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fv[i] = f[(size_t)b * HD + lane + 64 * i];
+    for (int i = 0; i < ND; ++i) fv[i] = f[(size_t)b * D + lane + 64 * i];
     for (int j = wave; j < n; j += 4) {
         const float* w = Wp + (size_t)j * ldw;
         float pa = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pa += w[lane + 64 * i] * fv[i];
+        for (int i = 0; i < ND; ++i) pa += w[lane + 64 * i] * fv[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o);
         if (lane == 0) lg[j] = pa + bp[j];
@@ -349,16 +351,22 @@ __global__ __launch_bounds__(256) void head_uni_dfeat_kernel(const float* __rest
     const int lab = (lab64 >= 0 && lab64 < n) ? (int)lab64 : -1;
     for (int j = threadIdx.x; j < n; j += 256) dl[j] = scale * (expf(lg[j] - lse_s) - (j == lab ? 1.f : 0.f)) / (float)B;
     __syncthreads();
-    for (int i = threadIdx.x; i < HD; i += 256) {
+    for (int i = threadIdx.x; i < D; i += 256) {
         float s2 = 0.f;
         for (int j = 0; j < n; ++j) s2 += dl[j] * Wp[(size_t)j * ldw + i];
-        df[(size_t)b * HD + i] = s2;
+        df[(size_t)b * D + i] = s2;
     }
 }
 int head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale, float* df, int B,
-                   int n, hipStream_t st) {
+                   int n, int width, hipStream_t st) {
     GDL_REQUIRE(n <= 512, "head_uni_dfeat: at most 512 classes");
-    hipLaunchKernelGGL(head_uni_dfeat_kernel, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+    GDL_REQUIRE(width == 512 || width == 768 || width == 1024, "head_uni_dfeat: feature width %d (512, 768 or 1024)", width);
+    if (width == 512)
+        hipLaunchKernelGGL(head_uni_dfeat_kernel<8>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+    else if (width == 768)
+        hipLaunchKernelGGL(head_uni_dfeat_kernel<12>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+    else
+        hipLaunchKernelGGL(head_uni_dfeat_kernel<16>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
     GDL_CHECK_LAUNCH("head_uni_dfeat_kernel");
     return GDL_OK;
 }

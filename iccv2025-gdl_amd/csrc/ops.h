@@ -153,7 +153,7 @@ int avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int
 int avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, int C, hipStream_t st);
 // head.hip
 int head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale, float* df, int B,
-                   int n, hipStream_t st);
+                   int n, int width, hipStream_t st);
 int head_concat_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out,
                     int B, int n, hipStream_t st);
 int head_concat_bwd(const float* x, const float* y, const float* W, const float* g_x_out, const float* g_y_out,

@@ -96,6 +96,7 @@ SIGNATURES = {
     "gdl_avgpool_fwd": ("i", "ipp" + "iiii" + "p"),
     "gdl_avgpool_bwd": ("i", "ipp" + "iiii" + "p"),
     "gdl_head_uni_dfeat": ("i", "pp" + "i" + "pp" + "f" + "p" + "ii" + "p"),
+    "gdl_head_uni_dfeat_w": ("i", "pp" + "i" + "pp" + "f" + "p" + "iii" + "p"),
     "gdl_head_concat_fwd": ("i", "ppppppp" + "ii" + "p"),
     "gdl_head_concat_bwd": ("i", "pppppp" + "ii" + "pppp" + "ii" + "p"),
     "gdl_softmax_ce": ("i", "ppf" + "pp" + "ii" + "p"),

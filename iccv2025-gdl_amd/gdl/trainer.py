@@ -363,20 +363,20 @@ class DGLTrainer:
         # the visual encoder is the critical path (3x the audio work): enqueue it first so the single
         # host thread's ~100 launches per encoder pass do not delay it
         dgl = self.mode == "dgl"
-        early = (dgl and self.head in ("concat", "sum") and self.dv == 512 and not self.vis_swin and n <= 512
-                 and self.early_backward is not False)
+        early = (dgl and self.head in ("concat", "sum") and n <= 512 and self.early_backward is not False
+                 and (self.dv == 512 or (self.head == "concat" and self.dv in (768, 1024))))
         red = self.reducer
         gv, ga = self.gviews[nf + 60:nf + 60 + self.nv], self.gviews[nf:nf + 60]
         if early:
             pv = self.pviews
-            if self.head == "concat":  # fc_out [n][1024] + one bias
-                wa, wv, ldw, ba, bv = L.ptr(pv[0]), pv[0].data_ptr() + 512 * 4, 1024, L.ptr(pv[1]), L.ptr(pv[1])
+            if self.head == "concat":  # fc_out [n][512 + dv] + one bias
+                wa, wv, ldw, ba, bv = L.ptr(pv[0]), pv[0].data_ptr() + 512 * 4, 512 + self.dv, L.ptr(pv[1]), L.ptr(pv[1])
             else:  # fc_x, fc_y [n][512] with their biases
                 wa, wv, ldw, ba, bv = L.ptr(pv[0]), L.ptr(pv[2]), 512, L.ptr(pv[1]), L.ptr(pv[3])
             with torch.cuda.stream(self.s_v):
                 self.eng_v.forward(image, True, feat_out=self.fv)
-                L.call("gdl_head_uni_dfeat", L.ptr(self.fv), wv, ldw, bv, L.ptr(label), self.alpha, L.ptr(self.dfv), B, n,
-                       self.s_v.cuda_stream)
+                L.call("gdl_head_uni_dfeat_w", L.ptr(self.fv), wv, ldw, bv, L.ptr(label), self.alpha, L.ptr(self.dfv), B, n,
+                       self.dv, self.s_v.cuda_stream)
                 ev_v = self.s_v.record_event()
             with torch.cuda.stream(self.s_a):
                 self.eng_a.forward(audio, True, feat_out=self.fa)
@@ -414,6 +414,10 @@ class DGLTrainer:
                 L.call("gdl_head_sum_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(pv[2]), L.ptr(self.g_a),
                        L.ptr(self.g_v), L.ptr(self.g_f), 0, 0, L.ptr(self.dscr_a), L.ptr(self.dscr_v), L.ptr(gvw[0]), L.ptr(gvw[1]),
                        L.ptr(gvw[2]), L.ptr(gvw[3]), B, n, st)
+            elif self.dv != 512:
+                L.call("gdl_head_concat_xy_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(self.g_a), L.ptr(self.g_v),
+                       L.ptr(self.g_f), 0, 0, L.ptr(self.dscr_a), L.ptr(self.dscr_v), L.ptr(gvw[0]), L.ptr(gvw[1]), B, n, 512,
+                       self.dv, st)
             else:
                 L.call("gdl_head_concat_bwd", L.ptr(self.fa), L.ptr(self.fv), L.ptr(pv[0]), L.ptr(self.g_a), L.ptr(self.g_v),
                        L.ptr(self.g_f), 0, 0, L.ptr(self.dscr_a), L.ptr(self.dscr_v), L.ptr(gvw[0]), L.ptr(gvw[1]), B, n, st)

@@ -266,6 +266,10 @@ GDL_API int gdl_head_concat_bwd(const float* x, const float* y, const float* W, 
  * gdl_head_*_bwd's dx / dy with the DGL flags. */
 GDL_API int gdl_head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale,
                                float* df, int B, int n_classes, void* stream);
+/* ... for a modality whose features are `width` wide (512, 768 or 1024: the 768 Swin-T features of ConcatFusion_Swin's DGL form,
+ * Wp = W + 512 with ldw = 512 + 768); df bit-identical to gdl_head_concat_xy_fwd + gdl_softmax_ce3 + gdl_head_concat_xy_bwd. */
+GDL_API int gdl_head_uni_dfeat_w(const float* f, const float* Wp, int ldw, const float* bp, const int64_t* labels, float scale,
+                                 float* df, int B, int n_classes, int width, void* stream);
 /* The same head with unequal feature widths, W [n][x_dim + y_dim] (512 audio + 768 Swin features; the reference's
  * ConcatFusion_Swin, fusion_modules.py:79-88, in its DGL form :45-59): same contract as the two calls above. */
 GDL_API int gdl_head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out,

@@ -255,6 +255,36 @@ def _swin_dgl_model(cfg, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_swin_early_backward_identical(golden_dir, dtype):
+    """The Swin composition's default step form (each encoder's feature gradient from ITS unimodal loss in one launch on its own
+    stream -- gdl_head_uni_dfeat_w for the 768-wide Swin features -- and the backward right behind the forward; the fusion head
+    off the critical path) leaves the SAME parameters, losses, logits and statistics, bit for bit, as forward -> head -> backward
+    (main_dgl.py:97-154)."""
+    from gdl.trainer import DGLTrainer
+    from test_step_gpu import _batch
+
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+    res = []
+    for early in (False, True):
+        model = _swin_dgl_model(cfg, dtype)
+        model.train()
+        tr = DGLTrainer(model, lr=cfg["lr"], alpha=cfg["alpha"], mode="dgl", dtype=dtype, early_backward=early)
+        for st in range(3):
+            spec, image, label = _batch(cfg, st)
+            tr.step(spec, image, label)
+        torch.cuda.synchronize()
+        r = tr.read()
+        res.append((tr.params.clone(), tr.losses.clone(), r["total_norm"], tr.out_a.clone(), tr.out_v.clone(), tr.out.clone(),
+                    tr.dfv.clone()))
+    for a, b in zip(res[0], res[1]):
+        if torch.is_tensor(a):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        else:
+            assert a == b
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_swin_dgl_native_step_golden(golden_dir, dtype):
     """DGLTrainer (flat arenas, fused head / losses / optimizer, two chain streams) with the Swin visual branch, two steps,
     against the golden of the composed reference parts."""
