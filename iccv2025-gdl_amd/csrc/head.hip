@@ -167,16 +167,40 @@ int head_concat_bwd(const float* x, const float* y, const float* W, const float*
 // Concat head with unequal feature widths (the Swin composition: 512 audio + 768 visual; cf. ConcatFusion_Swin,
 // fusion_modules.py:79-88, and ConcatFusion_DGL, :45-59): W [n][dxw + dyw].  Same contract as head_concat_fwd / _bwd.
 // Tiny problems (B x 1280 x n): plain FMA, fixed summation order.
+// grid = (B, ceil(n / HXY_CH)): a block's four waves own HXY_CH classes of one sample (64 blocks walking all 309 classes of
+// ConcatFusion_Swin's head, reloading the sample's features for every class, took 550 us); per class the sums run over
+// i = lane, lane + 64, ... and the xor butterfly as before.
+constexpr int HXY_CH = 32;
 __global__ __launch_bounds__(256) void head_xy_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           float* __restrict__ out, float* __restrict__ x_out,
                                                           float* __restrict__ y_out, int n, int dxw, int dyw) {
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < n; j += 4) {
+    constexpr int MAXV = 16;  // feature values per lane kept in registers (widths up to 1024; beyond: read per class)
+    float xs[MAXV], ys[MAXV];
+    const bool reg = dxw <= 64 * MAXV && dyw <= 64 * MAXV;
+    if (reg) {
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            xs[v] = lane + 64 * v < dxw ? x[(size_t)b * dxw + lane + 64 * v] : 0.f;
+            ys[v] = lane + 64 * v < dyw ? y[(size_t)b * dyw + lane + 64 * v] : 0.f;
+        }
+    }
+    const int j1 = min(n, ((int)blockIdx.y + 1) * HXY_CH);
+    for (int j = blockIdx.y * HXY_CH + wave; j < j1; j += 4) {
         const float* w = W + (size_t)j * (dxw + dyw);
         float pa = 0.f, pv = 0.f;
-        for (int i = lane; i < dxw; i += 64) pa += w[i] * x[(size_t)b * dxw + i];
-        for (int i = lane; i < dyw; i += 64) pv += w[dxw + i] * y[(size_t)b * dyw + i];
+        if (reg) {
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v)
+                if (lane + 64 * v < dxw) pa += w[lane + 64 * v] * xs[v];
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v)
+                if (lane + 64 * v < dyw) pv += w[dxw + lane + 64 * v] * ys[v];
+        } else {
+            for (int i = lane; i < dxw; i += 64) pa += w[i] * x[(size_t)b * dxw + i];
+            for (int i = lane; i < dyw; i += 64) pv += w[dxw + i] * y[(size_t)b * dyw + i];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             pa += __shfl_xor(pa, o);
@@ -189,25 +213,42 @@ __global__ __launch_bounds__(256) void head_xy_fwd_kernel(const float* __restric
         }
     }
 }
+// grid = (B, ceil((dxw + dyw) / 256)): a thread per feature; the sample's class gradients staged in LDS once, the walk over the
+// classes in ascending order with eight weight loads in flight
 __global__ __launch_bounds__(256) void head_xy_bwd_feat_kernel(const float* __restrict__ W, const float* __restrict__ g_x_out,
                                                                const float* __restrict__ g_y_out, const float* __restrict__ g_out,
                                                                int out_reaches_xy, float* __restrict__ dx, float* __restrict__ dy,
                                                                int n, int dxw, int dyw) {
+    extern __shared__ float hxy_g[];  // [2][n]: the x side's and the y side's class gradients of this sample
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < dxw + dyw; i += 256) {
-        const bool is_y = i >= dxw;
-        const float* gu = is_y ? g_y_out : g_x_out;
-        float s = 0.f;
-        for (int j = 0; j < n; ++j) {
-            float g = gu ? gu[(size_t)b * n + j] : 0.f;
-            if (out_reaches_xy && g_out) g += g_out[(size_t)b * n + j];
-            s += g * W[(size_t)j * (dxw + dyw) + i];
-        }
-        if (is_y)
-            dy[(size_t)b * dyw + i - dxw] = s;
-        else
-            dx[(size_t)b * dxw + i] = s;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        const float go = (out_reaches_xy && g_out) ? g_out[(size_t)b * n + j] : 0.f;
+        float gx = g_x_out ? g_x_out[(size_t)b * n + j] : 0.f, gy = g_y_out ? g_y_out[(size_t)b * n + j] : 0.f;
+        if (out_reaches_xy && g_out) gx += go, gy += go;
+        hxy_g[j] = gx;
+        hxy_g[n + j] = gy;
     }
+    __syncthreads();
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= dxw + dyw) return;
+    const bool is_y = i >= dxw;
+    const float* g = hxy_g + (is_y ? n : 0);
+    const float* w = W + i;
+    const int ldw = dxw + dyw;
+    float s = 0.f;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = w[(size_t)(j + u) * ldw];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += g[j + u] * q[u];
+    }
+    for (; j < n; ++j) s += g[j] * w[(size_t)j * ldw];
+    if (is_y)
+        dy[(size_t)b * dyw + i - dxw] = s;
+    else
+        dx[(size_t)b * dxw + i] = s;
 }
 // grid = (n, ceil((dxw + dyw) / 256)); db by the first block row
 __global__ __launch_bounds__(256) void head_xy_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -237,7 +278,7 @@ __global__ __launch_bounds__(256) void head_xy_bwd_w_kernel(const float* __restr
 }
 int head_concat_xy_fwd(const float* x, const float* y, const float* W, const float* b, float* out, float* x_out, float* y_out, int B,
                        int n, int dxw, int dyw, hipStream_t st) {
-    hipLaunchKernelGGL(head_xy_fwd_kernel, dim3(B), dim3(256), 0, st, x, y, W, b, out, x_out, y_out, n, dxw, dyw);
+    hipLaunchKernelGGL(head_xy_fwd_kernel, dim3(B, (n + HXY_CH - 1) / HXY_CH), dim3(256), 0, st, x, y, W, b, out, x_out, y_out, n, dxw, dyw);
     GDL_CHECK_LAUNCH("head_xy_fwd_kernel");
     return GDL_OK;
 }
@@ -245,8 +286,9 @@ int head_concat_xy_bwd(const float* x, const float* y, const float* W, const flo
                        int out_reaches_xy, int uni_in_dw, float* dx, float* dy, float* dW, float* db, int B, int n, int dxw, int dyw,
                        hipStream_t st) {
     if (dx && dy) {
-        hipLaunchKernelGGL(head_xy_bwd_feat_kernel, dim3(B), dim3(256), 0, st, W, g_x_out, g_y_out, g_out, out_reaches_xy, dx, dy, n, dxw,
-                           dyw);
+        GDL_REQUIRE(n <= 4096, "head_concat_xy_bwd: at most 4096 classes");
+        hipLaunchKernelGGL(head_xy_bwd_feat_kernel, dim3(B, (dxw + dyw + 255) / 256), dim3(256), 2 * n * sizeof(float), st, W, g_x_out, g_y_out,
+                           g_out, out_reaches_xy, dx, dy, n, dxw, dyw);
         GDL_CHECK_LAUNCH("head_xy_bwd_feat_kernel");
     }
     if (dW && db) {
@@ -275,29 +317,62 @@ int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* W
 }
 
 // loss = mean_b ( logsumexp(l_b) - l_b[label_b] ); dlogits = scale*(softmax - onehot)/B.  One block.
+// A wave per sample (samples b = wave, wave + 4, ...): the lanes evaluate the exponentials, lane 0 adds them in class order --
+// every sum in the order of the first form of this function (one THREAD per sample walking the classes twice with expf in the
+// dependent chain: 141 us at 64 samples x 309 classes, three blocks busy), so losses and gradients keep their bits.
+constexpr int CE_MAXN = 1024;  // classes the wave form stages in LDS (beyond: the thread-per-sample walk)
 __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                          float scale, float* __restrict__ loss, float* __restrict__ dlogits,
                                                          int B, int n) {
     __shared__ float part[256];
-    float acc = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const float* l = logits + (size_t)b * n;
-        float mx = l[0];
-        for (int j = 1; j < n; ++j) mx = fmaxf(mx, l[j]);
-        float se = 0.f;
-        for (int j = 0; j < n; ++j) se += expf(l[j] - mx);
-        const float lse = mx + logf(se);
-        // a class index outside [0, n) (a device assert in the reference's CrossEntropyLoss) must not become an
-        // out-of-bounds read: the sample contributes NaN to the loss (visible in DGLTrainer.read()) and no one-hot term
-        const long lab64 = (long)labels[b];
-        const bool lab_ok = lab64 >= 0 && lab64 < n;
-        const int lab = lab_ok ? (int)lab64 : -1;
-        acc += lab_ok ? lse - l[lab] : __builtin_nanf("");
-        if (dlogits)
-            for (int j = 0; j < n; ++j)
-                dlogits[(size_t)b * n + j] = scale * (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)B;
+    __shared__ float ex[4][CE_MAXN];
+    part[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (n <= CE_MAXN) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int b = wave; b < B; b += 4) {  // (b, b + 256, ... belong to the same wave, ascending: part[b % 256] sums in the old order)
+            const float* l = logits + (size_t)b * n;
+            float mx = -INFINITY;
+            for (int j = lane; j < n; j += 64) mx = fmaxf(mx, l[j]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            for (int j = lane; j < n; j += 64) ex[wave][j] = expf(l[j] - mx);
+            __builtin_amdgcn_wave_barrier();
+            float se = 0.f;
+            if (lane == 0)
+                for (int j = 0; j < n; ++j) se += ex[wave][j];
+            se = __shfl(se, 0);
+            const float lse = mx + logf(se);
+            const long lab64 = (long)labels[b];
+            const bool lab_ok = lab64 >= 0 && lab64 < n;
+            const int lab = lab_ok ? (int)lab64 : -1;
+            if (lane == 0) part[b & 255] += lab_ok ? lse - l[lab] : __builtin_nanf("");
+            if (dlogits)
+                for (int j = lane; j < n; j += 64)
+                    dlogits[(size_t)b * n + j] = scale * (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)B;
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        float acc = 0.f;
+        for (int b = threadIdx.x; b < B; b += 256) {
+            const float* l = logits + (size_t)b * n;
+            float mx = l[0];
+            for (int j = 1; j < n; ++j) mx = fmaxf(mx, l[j]);
+            float se = 0.f;
+            for (int j = 0; j < n; ++j) se += expf(l[j] - mx);
+            const float lse = mx + logf(se);
+            // a class index outside [0, n) (a device assert in the reference's CrossEntropyLoss) must not become an
+            // out-of-bounds read: the sample contributes NaN to the loss (visible in DGLTrainer.read()) and no one-hot term
+            const long lab64 = (long)labels[b];
+            const bool lab_ok = lab64 >= 0 && lab64 < n;
+            const int lab = lab_ok ? (int)lab64 : -1;
+            acc += lab_ok ? lse - l[lab] : __builtin_nanf("");
+            if (dlogits)
+                for (int j = 0; j < n; ++j)
+                    dlogits[(size_t)b * n + j] = scale * (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)B;
+        }
+        part[threadIdx.x] = acc;
     }
-    part[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
