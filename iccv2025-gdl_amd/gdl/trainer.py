@@ -2,7 +2,8 @@
 sequence of gfx950 kernels on two HIP streams (+ a side stream for the visual weight gradients), without an autograd tape.
 
 Per step (all asynchronous, nothing is read back unless `read()` is called).  Default form for the concat / sum DGL heads
-without a process group ("early backward", bit-identical to the junction form below):
+(the Swin composition's 512 + 768 concat head included) without a process group ("early backward", bit-identical to the
+junction form below):
   stream V: visual forward -> gdl_head_uni_dfeat (alpha * dCE(v_out)/d feature) -> visual backward
   stream A: audio  forward -> gdl_head_uni_dfeat (alpha * dCE(a_out)/d feature) -> audio  backward
             -> fusion head forward (all three logit sets), 3x cross-entropy, gradient of fc_out from loss_f alone
