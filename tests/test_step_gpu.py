@@ -296,8 +296,9 @@ def test_head_concat_golden():
         np.testing.assert_allclose(t.cpu().numpy(), g[k], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,n", [(64, 6), (5, 34), (300, 309)])
+@pytest.mark.parametrize("B,n", [(64, 6), (5, 34), (300, 309), (7, 1024), (9, 1500)])
 def test_softmax_ce(B, n):
+    # (a wave per sample up to 1024 classes, 300 samples = more than one pass of a block's 256 loss slots; a thread per sample beyond)
     lg = (3 * rng.standard_normal((B, n))).astype(np.float32)
     lab = rng.integers(0, n, B).astype(np.int64)
     loss_ref, d_ref = orc.softmax_ce(lg, lab, 4.0)
@@ -309,7 +310,7 @@ def test_softmax_ce(B, n):
     np.testing.assert_allclose(d.cpu().numpy(), d_ref, rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("B,n", [(64, 6), (5, 34)])
+@pytest.mark.parametrize("B,n", [(64, 6), (5, 34), (64, 309)])
 def test_softmax_ce3(B, n):
     """The three losses of the DGL step in one launch: each set as gdl_softmax_ce leaves it; a NULL dlogits is allowed."""
     lgs = [(3 * rng.standard_normal((B, n))).astype(np.float32) for _ in range(3)]
