@@ -35,8 +35,12 @@ def _tol(dt, f32, bf16):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("M,C,ld", [(37, 96, 128), (1000, 192, 192), (9000, 384, 384), (70, 768, 768), (33, 1536, 1536)])
+@pytest.mark.parametrize("M,C,ld", [(37, 96, 128), (1000, 192, 192), (9000, 384, 384), (70, 768, 768), (33, 1536, 1536),
+                                    (30011, 96, 128), (30001, 192, 192), (30005, 384, 384), (30002, 768, 768), (30003, 1536, 1536)])
 def test_layernorm_fwd_bwd(dt, M, C, ld):
+    """LayerNorm forward / backward (swin_transformer.py:203, 219, 340, 542) against float64; from 30 000 rows on the backward runs
+    its pipelined form (the next iteration's rows requested before this one's arithmetic) -- one case per vectors-per-lane
+    variant, row counts that are not multiples of a block's rows."""
     dc = L.dtype_code(dt)
     x = np.zeros((M, ld), np.float32)
     x[:, :C] = _q(rng.standard_normal((M, C)) * 1.5 + 0.3, dt)
@@ -395,6 +399,44 @@ def test_linear_bwd_fused(M, kreal, bias):
     dx3, dw3, db3 = run()
     assert torch.equal(dx[:M].view(torch.int16), dx3[:M].view(torch.int16)) and torch.equal(dw, dw3)
     assert not bias or torch.equal(db, db3)
+
+
+@pytest.mark.parametrize("M", [602112, (1 << 31) // 768 - 1])
+def test_linear_bwd_largest_launches(M):
+    """gdl_linear_bwd at config 5's own row count (192 frames x 56 x 56) and at the largest launch it accepts (dy just under
+    2^31 bytes: its buffer descriptors are 32-bit), against the two GEMMs and the column-sum pass it replaces, all on the device."""
+    from gpu_util import gather_table
+
+    K, N, kreal = 128, 384, 96
+    dc = L.dtype_code("bf16")
+    st = L.cur_stream()
+    lib = L.load()
+    assert lib.gdl_linear_bwd_ok(dc, M, K, N) == 1 and lib.gdl_linear_bwd_ok(dc, (1 << 31) // 768 + 1, K, N) == 0
+    g = torch.Generator(device=DEV).manual_seed(M % 1000)
+    dy = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    x[:, kreal:] = 0
+    wT = (torch.randn(K, N, device=DEV, generator=g) * 0.1).bfloat16()
+    wT[kreal:] = 0
+    nb = lib.gdl_linear_bwd_workspace_bytes(M, K, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dx, dw, db = torch.empty(M, K, device=DEV, dtype=torch.bfloat16), torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    L.call("gdl_linear_bwd", dc, L.ptr(dy), L.ptr(x), L.ptr(wT), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nb, M, K, kreal, N, st)
+    tab_d = gather_table(L.GATHER_DGRAD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    tab_f = gather_table(L.GATHER_FWD, dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    dx2, dw2, db2 = torch.empty_like(dx), torch.empty_like(dw), torch.empty_like(db)
+    L.call("gdl_conv_dgrad", dc, L.ptr(dy), L.ptr(wT), L.ptr(dx2), None, L.ptr(tab_d), M, 1, 1, K, N, 1, 1, 1, 0, st)
+    wsb = lib.gdl_conv_wgrad_workspace_bytes(dc, M, 1, 1, K, N, 1, 1, 1, 0)
+    ws2 = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    L.call("gdl_conv_wgrad", dc, L.ptr(dy), L.ptr(x), L.ptr(dw2), L.ptr(tab_f), M, 1, 1, K, N, 1, 1, 1, 0, L.ptr(ws2), wsb, st)
+    part = torch.empty(lib.gdl_swin_partial_bytes(N), dtype=torch.uint8, device=DEV)
+    L.call("gdl_swin_colsum", dc, L.ptr(dy), None, L.ptr(db2), L.ptr(part), M, N, st)
+    torch.cuda.synchronize()
+    assert float((dx.float() - dx2.float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(dx2.float().abs().max()))  # (a bf16 ulp of the largest)
+    assert torch.equal(dx[-1], dx[-1]) and not torch.isnan(dx[-40:].float()).any()  # (the last, partial tile)
+    scale = float(dw2.abs().max())
+    assert float((dw[:, :kreal] - dw2[:, :kreal]).abs().max()) < 2e-4 * scale and bool((dw[:, kreal:] == 0).all())
+    assert float((db - db2).abs().max()) < 2e-4 * max(1.0, float(db2.abs().max()))
 
 
 @pytest.mark.parametrize("dt", DTS)
