@@ -175,6 +175,41 @@ def test_patch_gather(dt, B, T, H):
     assert np.all(got[:, 48:] == 0)
 
 
+@pytest.mark.parametrize("H,nh,ld,shift", [(56, 3, 128, 3), (28, 6, 192, 3), (14, 12, 384, 0), (7, 24, 768, 0)])
+def test_window_attention_config5_size(H, nh, ld, shift):
+    """The bf16 window attention (csrc/swin_attn7.hip) at config 5's own launch sizes -- 192 frames, the four Swin-T stages: the
+    launches whose block count exceeds one round of resident blocks take the larger window chunks -- against the library's float32
+    kernels on the same (bf16-representable) inputs, which the test above pins to the float64 formulas at small sizes."""
+    n_img, ws = 192, 7
+    rows, C = n_img * H * H, nh * 32
+    g = torch.Generator(device=DEV).manual_seed(H)
+    qkv = torch.zeros(rows, 3, ld, device=DEV)
+    qkv[:, :, :C] = torch.randn(rows, 3, C, device=DEV, generator=g).bfloat16().float()
+    qkv = qkv.reshape(rows, 3 * ld)
+    dout = torch.zeros(rows, ld, device=DEV)
+    dout[:, :C] = torch.randn(rows, C, device=DEV, generator=g).bfloat16().float()
+    table = 0.5 * torch.randn((2 * ws - 1) ** 2, nh, device=DEV, generator=g)
+    st = L.cur_stream()
+    res = {}
+    for dt in ("f32", "bf16"):
+        dc, td = L.dtype_code(dt), _td(dt)
+        q, d = qkv.to(td), dout.to(td)
+        out = torch.full((rows, ld), float("nan"), device=DEV, dtype=td)
+        dq = torch.full((rows, 3 * ld), float("nan"), device=DEV, dtype=td)
+        dtab = torch.empty_like(table)
+        wsb = torch.empty(max(L.load().gdl_swin_attn_bwd_workspace_bytes(n_img, H, H, ws, nh), 4), dtype=torch.uint8, device=DEV)
+        L.call("gdl_swin_attn_fwd", dc, L.ptr(q), L.ptr(table), L.ptr(out), n_img, H, H, ws, shift, nh, ld, st)
+        L.call("gdl_swin_attn_bwd", dc, L.ptr(q), L.ptr(table), L.ptr(d), L.ptr(dq), L.ptr(dtab), L.ptr(wsb), n_img, H, H, ws, shift, nh, ld, st)
+        torch.cuda.synchronize()
+        res[dt] = (out.float(), dq.float(), dtab)
+    (o32, q32, t32), (o16, q16, t16) = res["f32"], res["bf16"]
+    assert not torch.isnan(o16).any() and not torch.isnan(q16).any()
+    assert float((o16 - o32).abs().max()) < 3e-2 and bool((o16[:, C:] == 0).all())
+    assert float((q16 - q32).abs().max()) < 4e-2 * max(1.0, float(q32.abs().max()))
+    assert bool((q16.reshape(rows, 3, ld)[:, :, C:] == 0).all())
+    assert float((t16 - t32).abs().max()) < 2e-2 * max(1.0, float(t32.abs().max()))
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("H,ws,shift,nh", [(14, 7, 0, 3), (14, 7, 3, 3), (7, 7, 0, 6), (28, 7, 3, 3), (35, 7, 3, 3), (56, 7, 3, 3), (4, 2, 1, 2)])
 def test_window_attention(dt, H, ws, shift, nh):
