@@ -361,6 +361,34 @@ def test_swin_engine_vs_oracle_16_frames(dtype):
     np.testing.assert_allclose(yp, y.reshape(B, T, -1).mean(1), rtol=0, atol=(1e-6 if f32 else 1e-6) * max(1.0, np.abs(y).max()))
 
 
+def test_swin_engine_config5_size_bf16_vs_f32():
+    """Swin-T at config 5's own size (B = 64, T = 3: 192 frames, 602 112 stage-1 tokens -- every size-gated path of the bf16
+    engine: the streaming and the fused-backward Linears, the pipelined LayerNorm, the larger attention chunks) against the
+    float32 engine on the same parameters and input, which the 16-frame test above pins to the CPU oracle.  Features and every
+    parameter gradient, element-wise relative to the tensor's largest value and norm against norm; the bf16 run twice (graph-free,
+    bit-identical)."""
+    cfg, B, T = fx.SWIN_T, 64, 3
+    dy = np.random.default_rng(13).standard_normal((B * T, 768), dtype=np.float32)
+    y32, g32, _ = _run(cfg, B, T, 9, dy, "f32")
+    torch.cuda.empty_cache()
+    y16, g16, _ = _run(cfg, B, T, 9, dy, "bf16")
+    torch.cuda.empty_cache()
+    ey = _relerr(y16, y32)
+    worst, worst_k = 0.0, None
+    for k, v in g16.items():
+        w = g32[k]
+        e = max(_relerr(v, w), abs(np.linalg.norm(v.astype(np.float64)) - np.linalg.norm(w.astype(np.float64))) / np.linalg.norm(w.astype(np.float64)))
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"swin 192 frames bf16 vs f32: features {ey:.2e}, worst gradient {worst:.2e} ({worst_k})")
+    assert ey < 2e-2, ey
+    assert worst < 8e-2, (worst_k, worst)
+    y16b, g16b, _ = _run(cfg, B, T, 9, dy, "bf16")
+    np.testing.assert_array_equal(y16, y16b)
+    for k in g16:
+        np.testing.assert_array_equal(g16[k], g16b[k], err_msg=k)
+
+
 def test_swin_trainer_graph_replay_equals_eager(golden_dir):
     """From the third step on SwinEngine replays captured HIP graphs of its forward / backward launch sequences: five steps
     with the replay must be bit-identical to five steps launched eagerly."""
