@@ -389,6 +389,39 @@ def test_swin_engine_config5_size_bf16_vs_f32():
         np.testing.assert_array_equal(g16[k], g16b[k], err_msg=k)
 
 
+def test_swin_dgl_step_config5_size_bf16_vs_f32():
+    """BASELINE config 5 as bench.py --workload vggsound_swin times it (B = 64, 129 x 626 spectrograms, 3 frames of 224 x 224,
+    309 classes, ResNet18 audio + Swin-T visual + the 512 + 768 concat DGL head): two DGLTrainer steps in bf16 against the same
+    two steps in the float32 exact-parity mode -- logits, the three losses, the clip's total norm, the per-encoder gradient sums."""
+    import bench
+    from gdl.trainer import DGLTrainer
+
+    wl = bench.WORKLOADS["vggsound_swin"]
+    B = 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    data = [(torch.randn(B, *wl["spec"], generator=g).to(DEV), torch.randn(B, 3, 3, 224, 224, generator=g).to(DEV),
+             torch.randint(0, wl["n_classes"], (B,), generator=g).to(DEV)) for _ in range(2)]
+    res = {}
+    for dt in ("f32", "bf16"):
+        model, _ = bench.build_model(wl, B, torch.device(DEV))
+        tr = DGLTrainer(model, lr=2e-3, alpha=wl["alpha"], momentum=0.9, weight_decay=1e-4, max_norm=40.0, dtype=dt)
+        out = []
+        for d in data:
+            tr.step(*d)
+            out.append(tr.read())
+        res[dt] = out
+        del tr, model
+        torch.cuda.empty_cache()
+    for st, (a, b) in enumerate(zip(res["f32"], res["bf16"])):
+        for k in ("out", "out_a", "out_v"):
+            np.testing.assert_allclose(b[k], a[k], rtol=0, atol=(3e-2 if st == 0 else 6e-2) * max(1.0, float(np.abs(a[k]).max())), err_msg=f"step {st} {k}")
+        for k in ("loss_f", "loss_a", "loss_v"):
+            assert abs(b[k] - a[k]) < (1e-2 if st == 0 else 3e-2) * max(1.0, abs(a[k])), (st, k, a[k], b[k])
+        assert abs(b["total_norm"] - a["total_norm"]) < 4e-2 * a["total_norm"], (st, a["total_norm"], b["total_norm"])
+        for k in ("audio_grad_sum", "visual_grad_sum"):
+            assert abs(b[k] - a[k]) < 6e-2 * abs(a[k]), (st, k, a[k], b[k])
+
+
 def test_swin_trainer_graph_replay_equals_eager(golden_dir):
     """From the third step on SwinEngine replays captured HIP graphs of its forward / backward launch sequences: five steps
     with the replay must be bit-identical to five steps launched eagerly."""
