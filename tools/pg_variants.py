@@ -90,3 +90,6 @@ for rnd in range(2):
                 tr.early_backward = early
                 tr.audio_on_caller = lane
                 print(f"round {rnd}  visual_wgrad_{vis:6s} early_backward_{'on ' if early else 'off'} audio_lane_{'on ' if lane else 'off'}  {timed(a.steps):.3f} ms")
+if pg is not None:
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
