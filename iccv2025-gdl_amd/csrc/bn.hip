@@ -182,7 +182,8 @@ int bn_finalize_train_pair(const BnFinTrain& a, const BnFinTrain& b, float eps, 
 
 __global__ void acc_to_float_kernel(const long long* __restrict__ acc, int n, double inv_scale, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n) out[c] = (float)((double)acc[2 * c] * inv_scale);
+    // (acc[2c + 1] != 0: a block's sum did not fit the fixed-point range or was NaN / inf -- bnacc.h bn_acc_add without a flag word)
+    if (c < n) out[c] = acc[2 * c + 1] != 0 ? __builtin_nanf("") : (float)((double)acc[2 * c] * inv_scale);
 }
 int acc_to_float(const long long* acc, int n, double inv_scale, float* out, hipStream_t st) {
     hipLaunchKernelGGL(acc_to_float_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, acc, n, inv_scale, out);
@@ -650,6 +651,7 @@ static int launch_fin_bwd(const BnFinBwd& a0, const BnFinBwd& a1, int n, hipStre
     const int ch = fin_ch(a0.C);
     auto kern = ch == 8 ? bn_bwd_finalize_kernel<8>
                         : (ch == 4 ? bn_bwd_finalize_kernel<4> : (ch == 2 ? bn_bwd_finalize_kernel<2> : bn_bwd_finalize_kernel<1>));
+    ProfScope prof("gdl::bn_bwd_finalize_kernel", PROF_HBM, st, (double)n * a0.blocks * a0.C * 8.0);
     hipLaunchKernelGGL(kern, dim3(ceil_div(a0.C, ch), n), dim3(FIN_THREADS), 0, st, a0, a1);
     GDL_CHECK_LAUNCH("bn_bwd_finalize_kernel");
     return GDL_OK;

@@ -79,8 +79,13 @@ __device__ __forceinline__ void bn_acc_channel(const BnAccFin& a, int c, bool pu
 // one tile's (or one persistent block's) sum -> the accumulator
 __device__ __forceinline__ void bn_acc_add(const BnAcc& a, int c, int w, float s) {
     const double v = (double)s * (w ? a.s2 : a.s1);
-    if (!(fabs(v) < 4.6e18 / (double)gridDim.x)) {  // (also NaN / inf) the block's share of 2^62
-        if (a.flag) (void)__hip_atomic_fetch_or((unsigned long long*)a.flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the block's share of 2^62 (gridDim.x = EVERY block of the launch, i.e. m-tiles x n-tiles for the flat kernel: the threshold
+    // per block is 2^62 / that count, conservative by the n-tile factor); also true for NaN / inf
+    if (!(fabs(v) < 4.6e18 / (double)gridDim.x)) {
+        // no flag word (the GELU data gradient's column sums, gdl_conv_dgrad_gelu: s2 = 0, so acc[2c + 1] only ever receives
+        // zeros): the channel's second word is the poison mark, gdl_acc_to_float turns a marked channel into NaN
+        unsigned long long* f = a.flag ? (unsigned long long*)a.flag : (unsigned long long*)a.acc + 2 * c + 1;
+        (void)__hip_atomic_fetch_or(f, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const long long q = __double2ll_rn(v);

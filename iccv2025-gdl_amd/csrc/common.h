@@ -1,5 +1,6 @@
 // common.h -- shared device/host helpers for libgdl_hip (gfx950 / MI355X only).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -150,6 +151,24 @@ __device__ __forceinline__ void storeT<bf16>(bf16* p, float f) {
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
+
+// A "done once" mark kept per DEVICE, used like the `static bool` it replaces (`if (!x) { ...; x = true; }`): the >64 KiB
+// dynamic-LDS opt-in (hipFuncSetAttribute) is a per-device attribute, so a process-wide flag would launch the large-LDS kernels on a
+// second GPU without it; a bit per device ordinal, atomic (the launchers may run on the autograd threads).
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 63;
+    }
+    explicit operator bool() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1ull; }
+    bool operator!() const { return !static_cast<bool>(*this); }
+    DevOnce& operator=(bool v) {
+        if (v) mask.fetch_or(1ull << dev(), std::memory_order_release);
+        return *this;
+    }
+};
 
 #define GDL_CHECK_LAUNCH(name)                                  \
     do {                                                        \

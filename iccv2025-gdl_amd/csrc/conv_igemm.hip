@@ -1774,7 +1774,7 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
     using SM = ConvSmem<BM, BN, T>;
     a.mtiles = ceil_div(a.M, BM);
     auto kfn = conv_igemm_kernel<T, BM, BN, WM, WN, MODE>;
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, SM::BYTES);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_igemm)");
@@ -1795,7 +1795,7 @@ template <typename T, int BM, int BN, int MODE, int NWV = 4>
 static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, BM);
     auto kfn = conv3x3_slab_kernel<T, BM, BN, MODE, NWV>;
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_slab)");
@@ -2034,7 +2034,7 @@ static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
         GDL_REQUIRE(lds <= (size_t)80 * 1024, "conv: LDS of the 64-channel data gradient with BatchNorm sums");
     }
     auto kfn = conv3x3_c64_kernel<MODE, BW, ADD>;
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_c64)");
@@ -2439,7 +2439,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
         a.mtiles = ceil_div(a.seg_stages, 4);
         GDL_REQUIRE((size_t)a.seg_stages * 64 < (1UL << 31), "stem: too many rows");
         if (stem_pers()) {
-            static bool attr_p = false;
+            static DevOnce attr_p;
             if (!attr_p) {
                 hipError_t e = hipFuncSetAttribute((const void*)conv_stem_pers_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    8 * SRF_SLAB);
@@ -2452,7 +2452,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
             GDL_CHECK_LAUNCH("conv_stem_pers_kernel");
             return GDL_OK;
         }
-        static bool attr_set = false;
+        static DevOnce attr_set;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)conv_stem_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                SRF_W + 4 * SRF_SLAB);

@@ -412,7 +412,7 @@ template <typename T, int TK, int TC>
 static int launch_wg(WgradArgs& a, hipStream_t st) {
     constexpr int BYTES = 2 * WG_BP * (TK + TC) * (int)sizeof(T);
     auto kfn = conv_wgrad_kernel<T, TK, TC>;
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad)");

@@ -598,7 +598,7 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
     using KernT = void (*)(Wgrad9Args);
     static const KernT kerns[3] = {conv_wgrad9_kernel<0>, conv_wgrad9_kernel<1>, conv_wgrad9_kernel<2>};
     const KernT kern = kerns[ring];
-    static bool attr_set[3] = {false, false, false};
+    static DevOnce attr_set[3];
     if (!attr_set[ring]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv_wgrad9)");

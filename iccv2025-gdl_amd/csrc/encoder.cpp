@@ -500,7 +500,12 @@ int gdl_encoder_bn_overflow(gdl_encoder_t* e, void* stream) {
 // -- the results are then WRONG; what is measured is the bound on what removing / fusing that pass could return
 // (tools/README.md: "skip bounds").  bits: 1 bn_act of a1 (all layers), 2 the same for 64-channel layers only, 4 bn1's backward
 // apply, 8 bn2's / the downsample BatchNorm's backward apply, 16 forward finalize, 32 backward finalize, 64 the stem's
-// maxpool_bn_bwd_apply, 128 the stem's bn_relu_maxpool, 256 the weight pack
+// maxpool_bn_bwd_apply, 128 the stem's bn_relu_maxpool, 256 the weight pack; round 5, convolution classes (what a rebuilt kernel
+// of that class could return at most): 1024 the stride-2 3x3 data gradients (+ folded shortcut), 2048 layer 4's stride-1 forward
+// convolutions, 4096 layer 4's stride-1 data gradients, 8192 the stride-2 / 1x1 weight gradients, 16384 the 9-tap weight gradients,
+// 32768 the stride-2 / 1x1 forward convolutions, 65536 every stride-1 3x3 forward, 131072 every stride-1 3x3 data gradient,
+// 262144 the backward's BatchNorm finalize launches only (= bit 32), 524288 the stem's forward convolution, 1048576 the stem's
+// weight gradient
 #ifdef GDL_EXPERIMENT
 static unsigned skip_mask() {
     static long v = -1;
@@ -695,6 +700,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st, acc ? e->acc_arena : nullptr, acc ? e->acc_bytes : 0));
     if (acc) {
         const BnAcc pa = acc_producer(e->bn0, e->m0);
+        if (!GDL_SKIPPED(524288))
         RC(conv_stem_fwd(dt, e->col, e->w0p, e->y0, nullptr, e->tab_stem, e->n_img, e->H, e->W, e->cin, st, &pa));
     } else {
         const int tiles = conv_stem_tiles_m(dt, e->n_img, e->H, e->W);
@@ -716,6 +722,8 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         const size_t Mo = (size_t)k.n * k.p * k.q;
         if (acc) {  // convolutions add their tiles' sums to the accumulators; the applies derive the constants themselves
             auto conv = [&](const Conv& c, const BN& n, const void* x, void* y) {
+                if (c.stride == 1 && c.r == 3 && (GDL_SKIPPED(65536) || (GDL_SKIPPED(2048) && c.cout == 512))) return (int)GDL_OK;
+                if ((c.stride == 2 || c.r == 1) && GDL_SKIPPED(32768)) return (int)GDL_OK;
                 const BnAcc pa = acc_producer(n, Mo);
                 return conv_fwd(dt, x, c.w_krsc, y, nullptr, c.tab_fwd, k.n, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
                                 &pa, &e->sk);
@@ -868,7 +876,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                 const BnFinBwd g2{e->bwB, b2_rows, k.cout, (double)Mo, grads[k.b2.pidx], grads[k.b2.pidx + 1], k.b2.coef};
                 const BnFinBwd gd{e->bwB2, b2_rows, k.cout, (double)Mo, k.has_ds ? grads[k.bd.pidx] : nullptr,
                                   k.has_ds ? grads[k.bd.pidx + 1] : nullptr, k.has_ds ? k.bd.coef : nullptr};
-                if (GDL_SKIPPED(32)) {
+                if ((GDL_SKIPPED(32) || GDL_SKIPPED(262144))) {
                 } else if (k.has_ds)
                     RC(bn_bwd_finalize_pair(g2, gd, st));
                 else
@@ -893,9 +901,10 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         }
         auto wgrad2 = [&]() -> int {  // weight gradients of conv2 (and of the downsample convolution): need dy2 (dyd)
             RC(fork());
+            if (!GDL_SKIPPED(16384))
             RC(conv_wgrad(dt, gB, k.a1, grads[k.c2.pidx], k.c2.tab_fwd, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, k.cout,
                           e->wg_ws, e->wg_ws_bytes, sw));
-            if (k.has_ds)
+            if (k.has_ds && !GDL_SKIPPED(8192))
                 RC(conv_wgrad(dt, gD, k.xin, grads[k.cd.pidx], k.cd.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 1, 1, k.cd.stride, 0,
                               k.cin, e->wg_ws, e->wg_ws_bytes, sw));
             return GDL_OK;
@@ -907,11 +916,12 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         if (fuse) {
             // gC = da1 * (a1 > 0) (sign bits of a1) with bn1's two sums from the epilogue; then finalize + apply
             const BwdStats bwa{k.y1, k.b1.mean, k.b1.rstd, e->bwA, nullptr, nullptr, nullptr, nullptr};
+            if (!(GDL_SKIPPED(131072) || (GDL_SKIPPED(4096) && k.cout == 512)))
             RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, st,
                           k.abits, &bwa, &e->sk));
             if (late) RC(wgrad2());
             const int rows = conv_dgrad_tiles_m(dt, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1);
-            if (!GDL_SKIPPED(32))
+            if (!(GDL_SKIPPED(32) || GDL_SKIPPED(262144)))
                 RC(bn_bwd_finalize(e->bwA, rows, k.cout, (double)Mo, grads[k.b1.pidx], grads[k.b1.pidx + 1], k.b1.coef, st));
             if (!GDL_SKIPPED(4))
             RC(bn_bwd_apply(dt, gC, k.y1, k.b1.scale, k.b1.shift, k.b1.mean, k.b1.rstd, e->params[k.b1.pidx], k.b1.coef, 0, gC, Mo,
@@ -925,6 +935,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         }
         auto wgrad1 = [&]() -> int {  // weight gradient of conv1: needs dy1
             RC(fork());
+            if (!(k.c1.stride == 1 ? GDL_SKIPPED(16384) : GDL_SKIPPED(8192)))
             RC(conv_wgrad(dt, gC, k.xin, grads[k.c1.pidx], k.c1.tab_fwd, k.n, k.h, k.w, k.cin, k.cout, 3, 3, k.c1.stride, 1,
                           k.cin, e->wg_ws, e->wg_ws_bytes, sw));
             if (e->has_side) {
@@ -953,6 +964,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         if (k.has_ds && ds_fold_on() && k.c1.stride == 2) {
             // the shortcut's 1x1 stride-2 data gradient rides in the 3x3 one as a tenth tap of the (even, even) pixels:
             // one launch and one tensor write instead of two launches, two writes and a read
+            if (!GDL_SKIPPED(1024))
             RC(conv_dgrad_ds(dt, gC, k.c1.w_crsk, gD, k.cd.w_crsk, spare, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, st,
                              inbits, bwp));
             dxin = spare;
@@ -966,6 +978,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             spare = dz;  // the old dz buffer is free now
         } else {
             // identity shortcut: dx = dgrad(conv1) + do2, accumulated in place over do2
+            if (!(GDL_SKIPPED(131072) || (GDL_SKIPPED(4096) && k.cout == 512)))
             RC(conv_dgrad(dt, gC, k.c1.w_crsk, do2, do2, k.c1.tab_dgrad, k.n, k.h, k.w, k.cin, k.cout, 3, 3, 1, 1, st,
                           inbits, bwp, &e->sk));
             dxin = do2;
@@ -1002,6 +1015,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                                 e->n_img, e->h0, e->w0, 64, st));
     }
     RC(fork());
+    if (!GDL_SKIPPED(1048576))
     RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
     if (e->has_side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
         hipError_t he = hipEventRecord(e->ev_join, e->side);

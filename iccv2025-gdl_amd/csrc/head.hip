@@ -9,6 +9,7 @@
 // W[:, 512:].y, so one launch produces all of them.  Sizes are tiny (B x 1024 x n_classes):
 // latency bound, no MFMA.
 #include "common.h"
+#include "prof.h"
 
 namespace gdl {
 
@@ -436,6 +437,7 @@ int head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, co
                    int n, int width, hipStream_t st) {
     GDL_REQUIRE(n <= 512, "head_uni_dfeat: at most 512 classes");
     GDL_REQUIRE(width == 512 || width == 768 || width == 1024, "head_uni_dfeat: feature width %d (512, 768 or 1024)", width);
+    ProfScope prof("gdl::head_uni_dfeat_kernel", PROF_HBM, st, (double)B * width * 8.0 + (double)n * width * 4.0);
     if (width == 512)
         hipLaunchKernelGGL(head_uni_dfeat_kernel<8>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
     else if (width == 768)

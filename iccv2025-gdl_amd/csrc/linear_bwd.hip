@@ -284,7 +284,7 @@ int linear_bwd(const void* dy, const void* x, const void* wT, void* dx, float* d
     const int form = Kreal > 96 ? 0 : (db ? 2 : 1);
     const void* fn = form == 0 ? (const void*)linear_bwd_kernel<NF, 8, false>
                                : (form == 1 ? (const void*)linear_bwd_kernel<NF, 6, false> : (const void*)linear_bwd_kernel<NF, 6, true>);
-    static bool attr[3] = {false, false, false};
+    static DevOnce attr[3];
     if (!attr[form]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(linear_bwd)");

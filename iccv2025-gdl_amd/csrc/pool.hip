@@ -530,6 +530,7 @@ int avgpool_fwd(int dtype, const void* x, float* feat, int B, int T, int HW, int
     const int cpr = C / epc;
     GDL_REQUIRE(C % epc == 0 && cpr <= 256 && 256 % cpr == 0, "avgpool: C=%d unsupported", C);
     const size_t sh = (size_t)(256 / cpr) * C * sizeof(float);
+    ProfScope prof("gdl::avgpool_fwd_kernel", PROF_HBM, st, (double)B * T * HW * C * (16.0 / epc));
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, dim3(B), dim3(256), sh, st, (const bf16*)x, feat, T, HW, C);
     else
@@ -557,6 +558,7 @@ int avgpool_bwd(int dtype, const float* dfeat, void* dx, int B, int T, int HW, i
     const int epc = dtype == GDL_BF16 ? 8 : 4;
     const size_t nvec = (size_t)B * T * HW * (C / epc);
     const int grid = (int)((nvec + 255) / 256 > 4096 ? 4096 : (nvec + 255) / 256);
+    ProfScope prof("gdl::avgpool_bwd_kernel", PROF_HBM, st, (double)nvec * 16.0);
     if (dtype == GDL_BF16)
         hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, dfeat, (bf16*)dx, T * HW, C, nvec);
     else

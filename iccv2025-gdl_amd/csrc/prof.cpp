@@ -16,6 +16,7 @@ struct Rec {
     hipEvent_t e0, e1;
     double work;
     double bytes;  // MFMA-bound launches: algorithmic HBM bytes (0 = not stated)
+    hipStream_t st;  // the launching stream (gdl_prof_timeline: which lane the launch ran on)
 };
 static std::mutex g_mu;
 static bool g_on = false;
@@ -53,6 +54,7 @@ int prof_begin(const char* name, int bound, hipStream_t st, bool ext) {
     r.slot = slot;
     r.work = 0;
     r.bytes = 0;
+    r.st = st;
     if (!g_pool.empty()) {
         r.e0 = g_pool.back().first;
         r.e1 = g_pool.back().second;
@@ -143,6 +145,41 @@ int gdl_prof_collect(int64_t* launches, double* ms, double* work) {
     }
     g_recs.clear();
     return GDL_OK;
+}
+
+// Per-launch timeline of the records gathered so far (call it BEFORE gdl_prof_collect, which clears them): for record i, in
+// enqueue order, slot[i], lane[i] (index of its stream in order of first appearance), start_ms[i] / end_ms[i] relative to the
+// earliest start among the records, work[i] (flops or bytes, as the slot's bound says) and bytes[i] (algorithmic HBM bytes of an
+// MFMA-bound launch, 0 = not stated).  Synchronises the device.  Returns the number of records (<= cap are written), < 0: error.
+int gdl_prof_timeline(int cap, int32_t* slot, int32_t* lane, double* start_ms, double* end_ms, double* work, double* bytes) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return -check_hip(e, "prof_timeline: hipDeviceSynchronize");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int n = (int)g_recs.size();
+    if (n == 0) return 0;
+    std::vector<hipStream_t> lanes;
+    std::vector<double> s0((size_t)n, 0.0), s1((size_t)n, 0.0);
+    double first = 0.0;
+    for (int i = 0; i < n; ++i) {
+        float a = 0.f, d = 0.f;
+        (void)hipEventElapsedTime(&a, g_recs[0].e0, g_recs[i].e0);  // (negative when record i started before record 0)
+        (void)hipEventElapsedTime(&d, g_recs[i].e0, g_recs[i].e1);
+        s0[i] = (double)a;
+        s1[i] = (double)a + (double)d;
+        if (s0[i] < first) first = s0[i];
+    }
+    for (int i = 0; i < n && i < cap; ++i) {
+        size_t l = 0;
+        while (l < lanes.size() && lanes[l] != g_recs[i].st) ++l;
+        if (l == lanes.size()) lanes.push_back(g_recs[i].st);
+        if (slot) slot[i] = g_recs[i].slot;
+        if (lane) lane[i] = (int32_t)l;
+        if (start_ms) start_ms[i] = s0[i] - first;
+        if (end_ms) end_ms[i] = s1[i] - first;
+        if (work) work[i] = g_recs[i].work;
+        if (bytes) bytes[i] = g_recs[i].bytes;
+    }
+    return n;
 }
 
 // Combined roofline of the launches folded by the LAST gdl_prof_collect: floor_ms[s] = sum over the slot's launches of

@@ -1550,7 +1550,7 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
         ProfScope prof("gdl::swin_ln_bwd_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (add ? 4 : 3));
 #define SW_LN_BWD1(T, V, U_, CS_, P_)                                                                                                  \
     do {                                                                                                                            \
-        static bool attr = false;                                                                                                   \
+        static DevOnce attr;                                                                                                   \
         if (!attr) {                                                                                                                \
             hipError_t e = hipFuncSetAttribute((const void*)swin_ln_bwd_kernel<T, V, U_, CS_, P_>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); \
             if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_ln_bwd)");                                          \
@@ -1638,7 +1638,7 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
     const long units = (long)n_img * g.nwin * nh;
     if (dt == GDL_BF16 && swin_mfma_on()) {  // matrix-core form (bf16 storage only: the f32 mode stays an fp32 FMA chain)
         const size_t lds = 4 * sizeof(SwinMfmaLds);
-        static bool attr = false;
+        static DevOnce attr;
         if (!attr) {
             hipError_t e = hipFuncSetAttribute((const void*)swin_attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_fwd_mfma)");
@@ -1678,7 +1678,7 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
     }
     const size_t lds = (size_t)4 * SW_MAXT * SW_PD * 4 + (size_t)SW_MAXT * (SW_MAXT + 1) * 4 + 3 * SW_MAXT * 4 + 169 * 4 + SW_MAXT * 4;
     const int G = attn_bwd_group(g.nwin), ngrp = (g.nwin + G - 1) / G;
-    static bool attr[2] = {false, false};
+    static DevOnce attr[2];
     const int di = dt == GDL_F32 ? 0 : 1;
     if (!attr[di]) {
         hipError_t e = dt == GDL_F32 ? hipFuncSetAttribute((const void*)swin_attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -1688,7 +1688,7 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
     }
     if (dt == GDL_BF16 && swin_mfma_on()) {
         const size_t ldsm = sizeof(SwinMfmaBwdLds);
-        static bool attrm = false;
+        static DevOnce attrm;
         if (!attrm) {
             hipError_t e = hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
             if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_bwd_mfma)");

@@ -623,7 +623,7 @@ static void a7_geom(A7Geom* g, int n_img, int H, int W, int shift, int nh, int l
 #endif
 }
 template <typename K>
-static int a7_attr(K kernel, bool* done, size_t lds = sizeof(A7Lds)) {
+static int a7_attr(K kernel, DevOnce* done, size_t lds = sizeof(A7Lds)) {
     if (*done) return GDL_OK;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn7)");
@@ -640,7 +640,7 @@ bool swin_attn7_ok(int dt, int H, int W, int ws, int shift, int nh, int ld, int 
 int swin_attn7_fwd(const void* qkv, const float* table, void* out, int n_img, int H, int W, int shift, int nh, int ld, hipStream_t st) {
     A7Geom g;
     a7_geom(&g, n_img, H, W, shift, nh, ld, false);
-    static bool attr = false;
+    static DevOnce attr;
     int rc = a7_attr(swin_attn7_fwd_kernel, &attr, sizeof(A7LdsF));
     if (rc) return rc;
     const int nchunks = (g.total + g.chunk - 1) / g.chunk;
@@ -658,7 +658,7 @@ int swin_attn7_bwd(const void* qkv, const float* table, const void* dout, void* 
                    int shift, int nh, int ld, hipStream_t st) {
     A7Geom g;
     a7_geom(&g, n_img, H, W, shift, nh, ld, true);
-    static bool attr = false;
+    static DevOnce attr;
     int rc = a7_attr(swin_attn7_bwd_kernel, &attr);
     if (rc) return rc;
     const int nchunks = (g.total + g.chunk - 1) / g.chunk;

@@ -143,6 +143,7 @@ SIGNATURES = {
     "gdl_prof_collect": ("i", "ppp"),
     "gdl_prof_set_peaks": ("i", "dd"),
     "gdl_prof_collect_floor": ("i", "pp"),
+    "gdl_prof_timeline": ("i", "ipppppp"),
 }
 
 _lib = None

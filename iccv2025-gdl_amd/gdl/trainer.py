@@ -287,10 +287,11 @@ class DGLTrainer:
         # borrowed lane against 5.78 without (5.61 with the visual side stream alone) -- `bench.py --gpus N` times the variants on
         # first contact with real RCCL traffic (`comm.schedule_variants_ms`); `trainer.audio_on_caller` may be set at any time.
         # (tuning aid: GDL_SIDE_STREAM=2 = the round-3 layout, the visual engine's side stream alone; 3 = the borrowed lane forced)
-        self.audio_on_caller = side == "3" or (side not in ("0", "1", "2") and self.reducer is None)
+        self.audio_on_caller = side == "3" or (side not in ("0", "1", "2", "4") and self.reducer is None)
         # The borrowed lane for the VISUAL engine instead (tuning aid "4"; a variant `bench.py --gpus N` times): without a group it
         # equals an owned side stream (5.57 ms), with a one-rank group it reads 6.57 ms -- not a default anywhere.
         self.visual_on_caller = side == "4"
+        assert not (self.audio_on_caller and self.visual_on_caller), "the caller's stream carries ONE engine's weight gradients"
         want_v = self.visual_side_stream if self.visual_side_stream is not None else self.reducer is None
         if (side in ("1", "2") or (side in (None, "3") and want_v)) and not self.vis_swin:
             self.eng_v.side_stream(True)

@@ -461,6 +461,13 @@ GDL_API int gdl_prof_collect(int64_t* launches, double* ms, double* work);
  * bytes (either pointer may be NULL).  gdl_prof_set_peaks: the two peaks (defaults: 2.5e15 flop/s bf16 MFMA, 8e12 B/s HBM3E). */
 GDL_API int gdl_prof_set_peaks(double peak_flops, double peak_bytes);
 GDL_API int gdl_prof_collect_floor(double* floor_ms, double* bytes);
+/* Utilisation timeline (round 5; measurement only, tools/utilisation_timeline.py): the records the tap holds, in enqueue order,
+ * one per launch -- slot[i], lane[i] (the launching stream, numbered in order of first appearance), start_ms[i] / end_ms[i]
+ * relative to the earliest start among them (HIP events: the kernel's own begin / end for the hipExtLaunchKernelGGL taps),
+ * work[i] (flops or bytes as gdl_prof_slot_bound says) and bytes[i] (algorithmic HBM bytes of an MFMA-bound launch, 0 = not
+ * stated).  Call it BEFORE gdl_prof_collect (which clears the records).  Synchronises the device.  Returns the number of
+ * records held (at most `cap` are written; any pointer may be NULL), < 0 = -error code. */
+GDL_API int gdl_prof_timeline(int cap, int32_t* slot, int32_t* lane, double* start_ms, double* end_ms, double* work, double* bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Swin visual encoder (/root/reference/models/swin_transformer.py, which the DGL script does not

@@ -9,18 +9,31 @@
 # usage: tools/check_isa.sh <build dir with the .o files>     (exit 1 if the form is present)
 set -e
 B=${1:-iccv2025-gdl_amd/csrc/build}
-LLVM=/opt/rocm/lib/llvm/bin
+ROCM=${ROCM_PATH:-$(hipconfig --rocmpath 2>/dev/null || echo /opt/rocm)}
+LLVM=$ROCM/lib/llvm/bin
+[ -x $LLVM/llvm-objdump ] || { echo "check_isa: no llvm-objdump under $LLVM (set ROCM_PATH)"; exit 1; }
 T=$(mktemp -d)
-bad=0; pk=0
+bad=0; pk=0; seen=0; want=0
 for o in "$B"/*.o; do
+  # (objects built from .hip sources carry a fat binary; the plain C++ ones -- errors / api / encoder / prof / comm -- may hold none)
   $LLVM/llvm-objcopy --dump-section .hip_fatbin=$T/fb.bin "$o" 2>/dev/null || continue
+  [ -s $T/fb.bin ] || continue
+  want=$((want + 1))
   $LLVM/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$T/fb.bin --output=$T/dev.co --unbundle 2>/dev/null || continue
-  $LLVM/llvm-objdump -d $T/dev.co > $T/dev.s
+  [ -s $T/dev.co ] || continue
+  $LLVM/llvm-objdump -d $T/dev.co > $T/dev.s || continue
+  grep -q 's_endpgm' $T/dev.s || continue
+  seen=$((seen + 1))
   n=$(grep -c 'v_pk_add_f32.*op_sel:\[0,1\] op_sel_hi:\[1,0\]' $T/dev.s || true)
   p=$(grep -c 'v_pk_\(add\|mul\|fma\)_f32' $T/dev.s || true)
   [ "$n" != "0" ] && echo "$(basename $o): $n cross-half v_pk_add_f32"
   bad=$((bad + n)); pk=$((pk + p))
 done
 rm -rf $T
+nhip=$(ls "$B"/../*.hip 2>/dev/null | wc -l)
+if [ "$seen" = "0" ] || [ "$seen" -lt "$nhip" ]; then
+  echo "check_isa: disassembled $seen device objects of $want with a fat binary ($nhip .hip sources) in $B -- the gate would be vacuous: failing"
+  exit 1
+fi
 echo "check_isa: $bad cross-half v_pk_add_f32 (second source), $pk packed-f32 VALU instructions in $B"
 [ "$bad" = "0" ]
