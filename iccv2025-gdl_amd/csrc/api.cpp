@@ -161,6 +161,14 @@ int gdl_stem_conv_fwd(int dtype, const void* xp, const void* wp, void* y, float*
     return conv_stem_fwd(dtype, xp, wp, y, bn_partial, table, n_img, H, W, Cin, (hipStream_t)stream);
 }
 size_t gdl_stem_conv_wgrad_workspace_bytes(int n_img, int H, int W) { return conv_stem_wgrad_ws_bytes(n_img, H, W); }
+int gdl_stem_bwd_fused_ok(int dtype, int W) { return stem_bwd_fused_ok(dtype, W) ? 1 : 0; }
+int gdl_stem_bwd_fused(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* scale, const float* shift,
+                       const float* save_mean, const float* save_rstd, const float* gamma, const float* coef, const void* xp,
+                       float* dw, int n_img, int H, int W, int Cin, void* ws, size_t ws_bytes, void* stream) {
+    GDL_REQUIRE(stem_bwd_fused_ok(dtype, W), "stem_bwd_fused: bf16 with output rows of at least 64 pixels only (ask gdl_stem_bwd_fused_ok)");
+    return stem_bwd_fused(dout, idx, y, scale, shift, save_mean, save_rstd, gamma, coef, xp, dw, n_img, H, W, Cin, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
 int gdl_stem_conv_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W,
                         int Cin, void* ws, size_t ws_bytes, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && Cin >= 1 && Cin <= 4, "stem_conv_wgrad: bad arguments");

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/gdl_hip.h"
@@ -187,6 +188,18 @@ struct DevOnce {
 // Tuning aids: the GDL_* environment knobs of the kernels' planners are read only when GDL_TUNING=1 is set (tools/ and
 // the A/B runs behind DESIGN.md's numbers); a production process never consults the environment.
 const char* tune_env(const char* name);
+#ifdef GDL_EXPERIMENT
+// timing experiments only (tools/skip_bounds.sh; encoder.cpp documents the bits): GDL_SKIP2 = launches left out inside the
+// kernels' own launchers -- 1 the weight-gradient fold launches (9-tap, per-tap, stem)
+inline unsigned experiment_mask2() {
+    static long v = -1;
+    if (v < 0) {
+        const char* env = getenv("GDL_SKIP2");
+        v = env ? atol(env) : 0;
+    }
+    return (unsigned)v;
+}
+#endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -489,6 +489,9 @@ int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* 
     }
     if (rc) return rc;
     const size_t total = (size_t)K * R * S * C;
+#ifdef GDL_EXPERIMENT
+    if (experiment_mask2() & 1) return GDL_OK;
+#endif
     ProfScope prof(p.nsplit >= 64 ? "gdl::wgrad_reduce_kernel<16>" : (p.nsplit > 8 ? "gdl::wgrad_reduce_kernel<4>" : "gdl::wgrad_reduce_kernel<1>"),
                    PROF_HBM, st, (double)total * 4.0 * (p.nsplit + 1));
     if (p.nsplit >= 64)
@@ -701,6 +704,290 @@ __global__ __launch_bounds__(256) void stem_wgrad_rows_kernel(StemRowsArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) part[((16 * i + g * 4 + e) * 4 + t) * 64 + 16 * wave + li] = acc[t][i][e];
 }
+// ---- fused stem backward (round 5): max-pool gather + ReLU mask + BatchNorm-backward apply + the stem's weight gradient in ONE
+// launch.  The gradient of the stem output, dy0 -- as large as the stem output itself, the largest activation of the network:
+// 308 MB written by maxpool_bn_bwd_apply_kernel and read back by stem_wgrad_rows_kernel for the visual batch -- is never
+// stored: a stage's [64 pixels][64 channels] dy tile is COMPUTED into the LDS image the LDS-DMA used to deposit (same rows, same
+// 32-byte-granule swizzle), from the stem output y0, the pooled gradient dz and the arg-max codes of the (at most four) pooling
+// windows that contain each pixel.  The arithmetic of a tile element is maxpool_bn_bwd_apply_kernel's, in the same order
+// (windows (p, q), (p, q+1), (p+1, q), (p+1, q+1) of the pixel's 2 x 2 patch; A g' + (B y + D)), the stages, the x slab, the
+// MFMA loop and the partial layout are stem_wgrad_rows_kernel's: the weight gradient is bit-identical to the two-launch form.
+// Thread t owns the logical 16-byte chunk t & 7 (channels 8 (t & 7) ..) of tile rows t >> 3 and 32 + (t >> 3): its forty
+// per-channel constants live in registers for the whole launch.  Per stage: the operands of the NEXT stage's two elements are
+// requested behind this stage's tile writes and land under the MFMAs.
+struct StemFusedArgs {
+    const void* y0;      // [n_img*P*Q][64] bf16: the stem convolution's raw output
+    const void* dz;      // [n_img*PP*QQ][64] bf16: gradient of the pooled map
+    const uint8_t* idx;  // [n_img*PP*QQ][64]: arg-max code of every pooling window
+    const float *scale, *shift, *mean, *rstd, *gamma, *coef;
+    const void* xp;
+    float* partial;
+    int P, Q, PP, QQ, Hp, Wp, nseg;
+    int stages, chunk, nsplit;
+    unsigned x_bytes;
+};
+typedef unsigned int sr_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sr_write16(unsigned addr, const uint4& v) {
+    const sr_u32x4_t w = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(w) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int slice = blockIdx.x;
+    const int s_begin = slice * a.chunk, s_end = min(a.stages, s_begin + a.chunk);
+    const int nst = s_end - s_begin;
+    const unsigned smem_base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)smem;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.xp, 0, a.x_bytes, 0x00020000);
+
+    // ---- per-channel constants of this thread's chunk (maxpool_bn_bwd_apply_kernel's three-constant form)
+    const int vc = tid & 7;
+    float sc[8], sf[8], A[8], Bc[8], D[8];
+    {
+        float mu[8], rs[8], gr[8], k1[8], k2[8];
+#pragma unroll
+        for (int q4 = 0; q4 < 2; ++q4) {
+            auto ld = [&](const float* p, float* v) {
+                const float4 t = *(const float4*)(p + vc * 8 + 4 * q4);
+                v[4 * q4 + 0] = t.x, v[4 * q4 + 1] = t.y, v[4 * q4 + 2] = t.z, v[4 * q4 + 3] = t.w;
+            };
+            ld(a.scale, sc), ld(a.shift, sf), ld(a.mean, mu), ld(a.rstd, rs), ld(a.gamma, gr), ld(a.coef, k1), ld(a.coef + 64, k2);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            A[e] = gr[e] * rs[e];
+            Bc[e] = -A[e] * rs[e] * k2[e];
+            D[e] = -A[e] * k1[e] - Bc[e] * mu[e];
+        }
+    }
+    // This thread's two tile elements are the pixels 2j and 2j + 1 of the stage (j = t >> 3), taken so that element 0 is the one
+    // in an EVEN image column and element 1 the one in an ODD column (par = the parity of the stage's first column: odd only in
+    // the last segment of an odd-width row): an even column lies in the windows (p, q) [and (p + 1, q) in odd rows], an odd one in
+    // (p, q), (p, q + 1) [and (p + 1, q), (p + 1, q + 1)] -- the window sets are static per element, the row parity is uniform.
+    // LDS byte offset inside a stage's dy tile: logical chunk vc of row r sits at physical chunk ((vc >> 1) ^ wg_swz<128>(r)) * 2
+    // + (vc & 1), the image the LDS-DMA of stem_wgrad_rows_kernel leaves.
+    const int j2 = (tid >> 3) * 2;
+    unsigned eoffs[2];  // [tile row parity]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) eoffs[i] = (j2 + i) * 128 + ((((vc >> 1) ^ wg_swz<128>(j2 + i)) << 5) | ((vc & 1) << 4));
+
+    // ---- x slab DMA bookkeeping (as stem_wgrad_rows_kernel)
+    int x_rel[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = wave + 4 * i, off = 1024 * p + 16 * lane;
+        const int row = off / SR_PITCH, col = off % SR_PITCH;
+        x_rel[i] = (p < 9 && row < 8 && col < 1072) ? row * a.Wp * 8 + col : -1;
+    }
+    // stage coordinates, advanced incrementally (wave-uniform): segment, output row, image
+    struct Coord {
+        int sg, oh, n;
+    };
+    auto advance = [&](Coord& c) {
+        if (++c.sg == a.nseg) {
+            c.sg = 0;
+            if (++c.oh == a.P) {
+                c.oh = 0;
+                ++c.n;
+            }
+        }
+    };
+    Coord cq;  // of the stage whose operands were requested last (= the next one to emit)
+    {
+        const int R = s_begin / a.nseg;
+        cq.sg = s_begin - R * a.nseg;
+        cq.n = R / a.P;
+        cq.oh = R - cq.n * a.P;
+    }
+    // operands in flight from one stage to the next: the stem output of both pixels, gradient + codes of their windows
+    uint4 y_e, y_o, d_e[2], d_o[4];
+    uint2 i_e[2], i_o[4];
+    bool live_e = false, live_o = false;
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    const uint2 none2 = make_uint2(0xffffffffu, 0xffffffffu);
+    const unsigned char* y0b = (const unsigned char*)a.y0;
+    const unsigned char* dzb = (const unsigned char*)a.dz;
+    auto request = [&](const Coord& c) {  // global loads of the two elements of the stage at c
+        const int ow0 = min(64 * c.sg, a.Q - 64), first = 64 * c.sg - ow0;
+        const int par = ow0 & 1;
+        const int r_e = j2 + par, r_o = j2 + (par ^ 1);  // tile rows of the even- / odd-column pixel
+        live_e = r_e >= first, live_o = r_o >= first;
+        const int p = c.oh >> 1, hb = c.oh & 1;
+        const size_t rowbase = ((size_t)c.n * a.P + c.oh) * a.Q;
+        const int q_e = (ow0 + r_e) >> 1, q_o = (ow0 + r_o) >> 1;
+        y_e = y_o = z4;
+        d_e[0] = d_e[1] = d_o[0] = d_o[1] = d_o[2] = d_o[3] = z4;
+        i_e[0] = i_e[1] = i_o[0] = i_o[1] = i_o[2] = i_o[3] = none2;
+        const size_t w0 = ((size_t)c.n * a.PP + p) * a.QQ;  // pooled row p
+        const bool row1 = hb && p + 1 < a.PP;               // (uniform) the pixels also lie in pooled row p + 1
+        if (live_e) {
+            y_e = *(const uint4*)(y0b + (rowbase + ow0 + r_e) * 128 + vc * 16);
+            d_e[0] = *(const uint4*)(dzb + (w0 + q_e) * 128 + vc * 16);
+            i_e[0] = *(const uint2*)(a.idx + (w0 + q_e) * 64 + vc * 8);
+        }
+        if (live_o) {
+            y_o = *(const uint4*)(y0b + (rowbase + ow0 + r_o) * 128 + vc * 16);
+            d_o[0] = *(const uint4*)(dzb + (w0 + q_o) * 128 + vc * 16);
+            i_o[0] = *(const uint2*)(a.idx + (w0 + q_o) * 64 + vc * 8);
+            if (q_o + 1 < a.QQ) {
+                d_o[1] = *(const uint4*)(dzb + (w0 + q_o + 1) * 128 + vc * 16);
+                i_o[1] = *(const uint2*)(a.idx + (w0 + q_o + 1) * 64 + vc * 8);
+            }
+        }
+        if (row1) {
+            const size_t w1 = w0 + a.QQ;
+            if (live_e) {
+                d_e[1] = *(const uint4*)(dzb + (w1 + q_e) * 128 + vc * 16);
+                i_e[1] = *(const uint2*)(a.idx + (w1 + q_e) * 64 + vc * 8);
+            }
+            if (live_o) {
+                d_o[2] = *(const uint4*)(dzb + (w1 + q_o) * 128 + vc * 16);
+                i_o[2] = *(const uint2*)(a.idx + (w1 + q_o) * 64 + vc * 8);
+                if (q_o + 1 < a.QQ) {
+                    d_o[3] = *(const uint4*)(dzb + (w1 + q_o + 1) * 128 + vc * 16);
+                    i_o[3] = *(const uint2*)(a.idx + (w1 + q_o + 1) * 64 + vc * 8);
+                }
+            }
+        }
+    };
+    // one window's contribution: gsum[c] += dz[c] where the window's arg-max code names this pixel
+    auto window = [&](float (&gsum)[8], const uint4& dq, const uint2& u, uint32_t code) __attribute__((always_inline)) {
+        float d[8];
+        unpack16<bf16>(dq, d);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (((u.x >> (8 * c)) & 0xff) == code) gsum[c] += d[c];
+            if (((u.y >> (8 * c)) & 0xff) == code) gsum[4 + c] += d[4 + c];
+        }
+    };
+    auto finish = [&](float (&gsum)[8], const uint4& yq, bool live, unsigned addr) __attribute__((always_inline)) {
+        float yv[8];
+        unpack16<bf16>(yq, yv);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float gg = (yv[c] * sc[c] + sf[c] > 0.f) ? gsum[c] : 0.f;
+            gsum[c] = A[c] * gg + (Bc[c] * yv[c] + D[c]);
+        }
+        sr_write16(addr, live ? pack16<bf16>(gsum) : z4);
+    };
+    auto emit = [&](const Coord& c, int buf) {  // the dy tile elements of the stage at c (operands: the last request) -> LDS
+        const int ow0 = min(64 * c.sg, a.Q - 64);
+        const int par = ow0 & 1;
+        const uint32_t hb = (uint32_t)(c.oh & 1);
+        const unsigned base = smem_base + buf * SR_STAGE;
+        // codes of a pixel inside the windows of its 2 x 2 patch, in maxpool_bn_bwd_apply_kernel's order: (p, q), (p, q + 1),
+        // (p + 1, q), (p + 1, q + 1); window p covers the rows 2p - 1 .. 2p + 1
+        float ge[8], go[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ge[k] = go[k] = 0.f;
+        window(ge, d_e[0], i_e[0], (1 + hb) * 3 + 1);
+        window(go, d_o[0], i_o[0], (1 + hb) * 3 + 2);
+        window(go, d_o[1], i_o[1], (1 + hb) * 3);
+        if (hb) {
+            window(ge, d_e[1], i_e[1], 1);
+            window(go, d_o[2], i_o[2], 2);
+            window(go, d_o[3], i_o[3], 0);
+        }
+        finish(ge, y_e, live_e, base + eoffs[par]);
+        finish(go, y_o, live_o, base + eoffs[par ^ 1]);
+    };
+    auto load_x = [&](const Coord& c, int buf) {
+        unsigned char* Xs = smem + buf * SR_STAGE + 8192;
+        const int ow0 = min(64 * c.sg, a.Q - 64);
+        const int x_base = ((c.n * a.Hp + 2 * c.oh) * a.Wp + 2 * ow0) * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (wave + 4 * i < 9) wg_dma16(rx, Xs + (wave + 4 * i) * 1024, x_rel[i] >= 0 ? x_base + x_rel[i] : (int)0x80000000);
+    };
+
+    // ---- per-lane LDS read addresses (stage buffer 0), as stem_wgrad_rows_kernel
+    const int lrow = g * 8 + (li >> 2);
+    unsigned aaddr[4][2], baddr[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = lrow + h * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aaddr[i][h] = smem_base + row * 128 + ((i ^ wg_swz<128>(row)) << 5) + (li & 3) * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            baddr[t][h] = smem_base + 8192 + (2 * t + (wave >> 1)) * SR_PITCH + (2 * row + 4 * (wave & 1) + (li & 3)) * 8;
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    if (nst > 0) {
+        request(cq);
+        load_x(cq, 0);
+        emit(cq, 0);  // (the compiler waits for the requested operands here)
+        if (nst > 1) {
+            advance(cq);
+            request(cq);
+        }
+    }
+    for (int st = 0; st < nst; ++st) {
+        // the x slab of stage st (and the operands of stage st + 1) have landed; every wave's tile writes of stage st are visible
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < nst) {
+            emit(cq, (st + 1) & 1);
+            load_x(cq, (st + 1) & 1);
+            if (st + 2 < nst) {
+                advance(cq);
+                request(cq);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint2 af[4][2], bf[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) af[i][h] = ks ? sr_tr<4096>(aaddr[i][h]) : sr_tr<0>(aaddr[i][h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bf[t][h] = ks ? sr_tr<512>(baddr[t][h]) : sr_tr<0>(baddr[t][h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t == 0)
+                    sr_wait<6>();
+                else if (t == 1)
+                    sr_wait<4>();
+                else if (t == 2)
+                    sr_wait<2>();
+                else
+                    sr_wait<0>();
+                const uint4 fb = make_uint4(bf[t][0].x, bf[t][0].y, bf[t][1].x, bf[t][1].y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 fa = make_uint4(af[i][0].x, af[i][0].y, af[i][1].x, af[i][1].y);
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa),
+                                                                       __builtin_bit_cast(bf16x8_t, fb), acc[t][i], 0, 0, 0);
+                }
+            }
+        }
+        const int dlt = (st & 1) ? -SR_STAGE : SR_STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aaddr[i][h] += dlt;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) baddr[t][h] += dlt;
+        }
+    }
+    float* part = a.partial + (size_t)slice * (64 * 4 * 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[((16 * i + g * 4 + e) * 4 + t) * 64 + 16 * wave + li] = acc[t][i][e];
+}
 struct StemRowsPlan {
     int nseg, stages, chunk, nsplit;
 };
@@ -806,6 +1093,50 @@ int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const 
     ProfScope prof("gdl::stem_wgrad_reduce_kernel", PROF_HBM, st, (double)64 * Cin * 49 * 4.0 * (p.nsplit + 1));
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * 4 * 64 / 4 / 16), dim3(256), 0, st, a.partial, dw, p.nsplit,
                        Cin);
+    GDL_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
+    return GDL_OK;
+}
+
+// the fused stem backward (stem_bwd_fused_kernel): bf16, output rows of at least 64 pixels -- where conv_stem_wgrad runs the
+// row-slab kernel
+bool stem_bwd_fused_ok(int dtype, int W) {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = tune_env("GDL_STEM_FUSED");  // tuning aid: 0 = maxpool_bn_bwd_apply + conv_stem_wgrad (two launches, dy0 stored)
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0 && stem_rows_ok(dtype, W);
+}
+int stem_bwd_fused(const void* dz, const uint8_t* idx, const void* y0, const float* scale, const float* shift, const float* mean,
+                   const float* rstd, const float* gamma, const float* coef, const void* xp, float* dw, int n_img, int H, int W,
+                   int Cin, void* ws, size_t ws_bytes, hipStream_t st) {
+    GDL_REQUIRE(dz && idx && y0 && scale && shift && mean && rstd && gamma && coef && xp && dw, "stem_bwd_fused: null pointer");
+    const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1, Hp = H + 6, Wp = W + 8;
+    GDL_REQUIRE(Q >= 64, "stem_bwd_fused: output rows of %d pixels (at least 64)", Q);
+    const StemRowsPlan p = plan_stem_rows(n_img, H, W);
+    const size_t need = (size_t)p.nsplit * 64 * 4 * 64 * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        set_error("stem_bwd_fused: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDL_ERR_WORKSPACE;
+    }
+    GDL_REQUIRE((size_t)n_img * P * Q * 128 < (1UL << 31) && (size_t)n_img * Hp * Wp * 8 < (1UL << 31), "stem_bwd_fused: tensor exceeds 2 GiB");
+    StemFusedArgs r{};
+    r.y0 = y0, r.dz = dz, r.idx = idx;
+    r.scale = scale, r.shift = shift, r.mean = mean, r.rstd = rstd, r.gamma = gamma, r.coef = coef;
+    r.xp = xp;
+    r.partial = (float*)ws;
+    r.P = P, r.Q = Q, r.PP = (P - 1) / 2 + 1, r.QQ = (Q - 1) / 2 + 1, r.Hp = Hp, r.Wp = Wp, r.nseg = p.nseg;
+    r.stages = p.stages, r.chunk = p.chunk, r.nsplit = p.nsplit;
+    r.x_bytes = (unsigned)((size_t)n_img * Hp * Wp * 8);
+    {
+        // (priced as the weight gradient; its algorithmic bytes: y0 + the pooled gradient and codes + the padded input, once)
+        ProfScope prof("gdl::stem_bwd_fused_kernel", PROF_MFMA, st, 2.0 * (double)n_img * P * Q * 64 * 49 * Cin, true,
+                       (double)n_img * P * Q * 128.0 + (double)n_img * r.PP * r.QQ * 192.0 + (double)n_img * Hp * Wp * 8.0);
+        hipExtLaunchKernelGGL(stem_bwd_fused_kernel, dim3(p.nsplit), dim3(256), 2 * SR_STAGE, st, prof.e0(), prof.e1(), 0, r);
+        GDL_CHECK_LAUNCH("stem_bwd_fused_kernel");
+    }
+    ProfScope prof("gdl::stem_wgrad_reduce_kernel", PROF_HBM, st, (double)64 * Cin * 49 * 4.0 * (p.nsplit + 1));
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * 4 * 64 / 4 / 16), dim3(256), 0, st, r.partial, dw, p.nsplit, Cin);
     GDL_CHECK_LAUNCH("stem_wgrad_reduce_kernel");
     return GDL_OK;
 }

@@ -614,6 +614,9 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
         GDL_CHECK_LAUNCH("conv_wgrad9_kernel");
     }
     const size_t total4 = (size_t)K * C * 9 / 4;
+#ifdef GDL_EXPERIMENT
+    if (experiment_mask2() & 1) return GDL_OK;
+#endif
     ProfScope prof("gdl::wgrad9_reduce_kernel", PROF_HBM, st, (double)total4 * 16.0 * (p.nsplit + 1));
     if (p.nsplit <= 4)
         hipLaunchKernelGGL(wgrad9_reduce_rows_kernel, dim3((unsigned)(a.tiles_k * a.tiles_c * 16)), dim3(256), 0, st,

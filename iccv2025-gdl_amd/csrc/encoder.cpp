@@ -724,6 +724,7 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
             auto conv = [&](const Conv& c, const BN& n, const void* x, void* y) {
                 if (c.stride == 1 && c.r == 3 && (GDL_SKIPPED(65536) || (GDL_SKIPPED(2048) && c.cout == 512))) return (int)GDL_OK;
                 if ((c.stride == 2 || c.r == 1) && GDL_SKIPPED(32768)) return (int)GDL_OK;
+                if (c.r == 1 && GDL_SKIPPED(2097152)) return (int)GDL_OK;  // the shortcut's 1x1 convolutions only
                 const BnAcc pa = acc_producer(n, Mo);
                 return conv_fwd(dt, x, c.w_krsc, y, nullptr, c.tab_fwd, k.n, c.h, c.w, c.cin, c.cout, c.r, c.s, c.stride, c.pad, st,
                                 &pa, &e->sk);
@@ -1010,6 +1011,15 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         BN& n = e->bn0;
         const size_t Mp = (size_t)e->n_img * e->h1 * e->w1;
         RC(bn_backward_reduce(e, n, dz, e->ymax, 1, Mp, (double)e->m0, grads, st));
+        if (stem_bwd_fused_ok(dt, e->W)) {
+            // round 5: gather + mask + BatchNorm-backward apply + weight gradient in one launch; the gradient of the stem output
+            // (e->g0: as large as the stem output, the largest activation) is never written (conv_wgrad.hip stem_bwd_fused_kernel)
+            RC(fork());
+            if (!GDL_SKIPPED(64) && !GDL_SKIPPED(1048576))
+            RC(stem_bwd_fused(dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->col, grads[0],
+                              e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
+            goto stem_done;
+        }
         if (!GDL_SKIPPED(64))
         RC(maxpool_bn_bwd_apply(dt, dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->g0,
                                 e->n_img, e->h0, e->w0, 64, st));
@@ -1017,6 +1027,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
     RC(fork());
     if (!GDL_SKIPPED(1048576))
     RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
+stem_done:
     if (e->has_side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
         hipError_t he = hipEventRecord(e->ev_join, e->side);
         if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);

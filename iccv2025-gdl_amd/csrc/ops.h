@@ -95,6 +95,11 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
 size_t conv_stem_wgrad_ws_bytes(int n_img, int H, int W);
 int conv_stem_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H, int W, int Cin,
                     void* ws, size_t ws_bytes, hipStream_t st);
+// fused stem backward (round 5): max-pool gather + ReLU mask + BatchNorm-backward apply + weight gradient, dy0 never stored
+bool stem_bwd_fused_ok(int dtype, int W);
+int stem_bwd_fused(const void* dz, const uint8_t* idx, const void* y0, const float* scale, const float* shift, const float* mean,
+                   const float* rstd, const float* gamma, const float* coef, const void* xp, float* dw, int n_img, int H, int W,
+                   int Cin, void* ws, size_t ws_bytes, hipStream_t st);
 // conv_wgrad.hip
 size_t conv_wgrad_ws_bytes(int M, int C, int K, int RS);
 int conv_wgrad(int dtype, const void* dy, const void* x, float* dw, const void* table, int N, int H, int W, int C, int K,

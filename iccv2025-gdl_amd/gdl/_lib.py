@@ -144,6 +144,8 @@ SIGNATURES = {
     "gdl_prof_set_peaks": ("i", "dd"),
     "gdl_prof_collect_floor": ("i", "pp"),
     "gdl_prof_timeline": ("i", "ipppppp"),
+    "gdl_stem_bwd_fused_ok": ("i", "ii"),
+    "gdl_stem_bwd_fused": ("i", "ipppppppppp" + "p" + "iiii" + "pz" + "p"),
 }
 
 _lib = None

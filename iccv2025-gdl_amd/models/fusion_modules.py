@@ -192,8 +192,8 @@ class _FiLMDGLFn(torch.autograd.Function):
         B, n = x.shape[0], Wo.shape[0]
         if x.shape[1] != 512 or y.shape[1] != 512 or Wfc.shape != (512, 512 * 512) or Wo.shape[1] != 512:
             raise RuntimeError("gdl: FiLM_DGL expects 512-d features and dim = 512")
-        if B > 64:
-            raise RuntimeError("gdl: FiLM_DGL handles at most 64 samples per call")
+        if B > 512:  # (gdl_head_film_workspace_bytes returns 0 beyond; csrc/head_film.hip walks sample groups of 64)
+            raise RuntimeError("gdl: FiLM_DGL handles at most 512 samples per call")
         nb = L.load().gdl_head_film_workspace_bytes(B)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device)  # keeps W_k v_b for the backward
         hidden = torch.empty((3, B, 512), device=x.device)

@@ -165,6 +165,19 @@ GDL_API int gdl_stem_conv_fwd(int dtype, const void* xp, const void* wp, void* y
 GDL_API size_t gdl_stem_conv_wgrad_workspace_bytes(int n_img, int H, int W);
 GDL_API int gdl_stem_conv_wgrad(int dtype, const void* dy, const void* xp, float* dw, const void* table, int n_img, int H,
                                 int W, int Cin, void* ws, size_t ws_bytes, void* stream);
+/* Fused stem backward (round 5): gdl_maxpool_bn_bwd_apply (below) and gdl_stem_conv_wgrad in ONE launch -- the max-pool gather, the
+ * ReLU mask and the BatchNorm-backward apply of /root/reference/models/backbone.py:104-106 reversed, feeding the weight gradient
+ * of the 7x7/2 stem convolution (backbone.py:97-101) tile by tile through LDS: the gradient of the stem output (the largest
+ * activation) is never stored.  dout / idx: gradient and arg-max codes of the POOLED map [n_img*P'*Q'][64] (P' x Q' the pooled
+ * size of the (H-1)/2+1 x (W-1)/2+1 stem output), y: the stem output, scale .. coef as for gdl_maxpool_bn_bwd_apply, xp: the
+ * padded input of gdl_stem_pad, dw [64][Cin][7][7] float32; workspace as gdl_stem_conv_wgrad_workspace_bytes.  bf16 with stem
+ * output rows of at least 64 pixels only (gdl_stem_bwd_fused_ok; other shapes run the two launches).  The result is
+ * bit-identical to the two-launch form (same element arithmetic, same stages, same fold). */
+GDL_API int gdl_stem_bwd_fused_ok(int dtype, int W);
+GDL_API int gdl_stem_bwd_fused(int dtype, const void* dout, const uint8_t* idx, const void* y, const float* scale,
+                               const float* shift, const float* save_mean, const float* save_rstd, const float* gamma,
+                               const float* coef, const void* xp, float* dw, int n_img, int H, int W, int Cin, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* layout conversion at the module boundary: NHWC dtype <-> NCHW float32 */
 GDL_API int gdl_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int N, int H, int W, int C, void* stream);

@@ -219,6 +219,86 @@ def test_stem_direct(case, dt):
     assert relerr(dw.cpu().numpy(), refw) < 2e-5, relerr(dw.cpu().numpy(), refw)
 
 
+@pytest.mark.parametrize("case", [("row64", 1, 3, 2, 12, 128), ("row95_odd_h", 2, 1, 1, 9, 190), ("row135", 2, 3, 1, 7, 270),
+                                  ("cremad_audio_rows", 2, 1, 1, 33, 188), ("visual_rows", 1, 3, 2, 20, 224)])
+def test_stem_bwd_fused(case):
+    """gdl_stem_bwd_fused (round 5): max-pool gather + ReLU mask + BatchNorm-backward apply + the 7x7/2 stem's weight gradient in
+    one launch, the gradient of the stem output never stored -- BIT-IDENTICAL to gdl_maxpool_bn_bwd_apply followed by
+    gdl_stem_conv_wgrad (same element arithmetic and order, same stages, same fold), and against the oracle's
+    maxpool_bwd -> relu_bwd -> bn_bwd -> conv2d_bwd_weight chain (/root/reference/models/backbone.py:97-106 differentiated)."""
+    _, B, Cin, T, H, W = case
+    dt = L.GDL_BF16
+    lib = L.load()
+    assert lib.gdl_stem_bwd_fused_ok(dt, W) == 1
+    C = 64
+    x = rng.standard_normal((B, Cin, T, H, W), dtype=np.float32)
+    w = (rng.standard_normal((64, Cin, 7, 7), dtype=np.float32) * 0.1).astype(np.float32)
+    xq, wq = quant(x, dt), quant(w, dt)
+    x4 = np.ascontiguousarray(xq.transpose(0, 2, 1, 3, 4)).reshape(B * T, Cin, H, W)
+    y = quant(orc.conv2d_fwd(x4, wq, 2, 3), dt)  # the stem output as stored
+    n_img, P, Q = y.shape[0], y.shape[2], y.shape[3]
+    gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    gamma[::7] *= -1
+    beta = (0.2 * rng.standard_normal(C)).astype(np.float32)
+    rm, rv = np.zeros(C, np.float32), np.ones(C, np.float32)
+    _, mean, invstd = orc.bn_fwd_train(y, gamma, beta, rm, rv)
+    sc = (gamma * invstd).astype(np.float32)
+    sh = (beta - mean * gamma * invstd).astype(np.float32)
+    st = L.cur_stream()
+    xp = torch.empty(lib.gdl_stem_pad_bytes(dt, n_img, H, W), dtype=torch.uint8, device=DEV)
+    tab = torch.empty(lib.gdl_stem_table_bytes(n_img, H, W), dtype=torch.uint8, device=DEV)
+    xd = dev(x)
+    L.call("gdl_stem_pad", dt, L.ptr(xd), L.ptr(xp), B, Cin, T, H, W, st)
+    L.call("gdl_stem_build_table", dt, n_img, H, W, L.ptr(tab), st)
+    yd = to_nhwc(y, dt)
+    scd, shd, smd, srd, gd = dev(sc), dev(sh), dev(mean.astype(np.float32)), dev(invstd.astype(np.float32)), dev(gamma)
+    PP, QQ = (P - 1) // 2 + 1, (Q - 1) // 2 + 1
+    out, ym = empty((n_img, PP, QQ, C), dt), empty((n_img, PP, QQ, C), dt)
+    ix = torch.empty((n_img, PP, QQ, C), dtype=torch.uint8, device=DEV)
+    L.call("gdl_bn_relu_maxpool_fwd", dt, L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(out), L.ptr(ix), L.ptr(ym), n_img, P, Q, C, st)
+    dout = quant(rng.standard_normal((n_img, C, PP, QQ), dtype=np.float32), dt)
+    doutd = to_nhwc(dout, dt)
+    Mp, M = n_img * PP * QQ, n_img * P * Q
+    blocks = lib.gdl_bn_bwd_blocks(Mp, C)
+    bpart = torch.empty((blocks, C, 2), device=DEV)
+    dg, db, coef = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2 * C, device=DEV)
+    L.call("gdl_bn_bwd_reduce", dt, L.ptr(doutd), L.ptr(ym), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd), 1, L.ptr(bpart),
+           Mp, C, st)
+    L.call("gdl_bn_bwd_finalize", L.ptr(bpart), blocks, C, float(M), L.ptr(dg), L.ptr(db), L.ptr(coef), st)
+    # two launches: dy0 stored, then the weight gradient
+    dyd = empty((n_img, P, Q, C), dt)
+    L.call("gdl_maxpool_bn_bwd_apply", dt, L.ptr(doutd), L.ptr(ix), L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd),
+           L.ptr(gd), L.ptr(coef), L.ptr(dyd), n_img, P, Q, C, st)
+    nbytes = lib.gdl_stem_conv_wgrad_workspace_bytes(n_img, H, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw2 = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
+    L.call("gdl_stem_conv_wgrad", dt, L.ptr(dyd), L.ptr(xp), L.ptr(dw2), L.ptr(tab), n_img, H, W, Cin, L.ptr(ws), nbytes, st)
+    # one launch
+    ws1 = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    dw1 = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
+    L.call("gdl_stem_bwd_fused", dt, L.ptr(doutd), L.ptr(ix), L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd), L.ptr(gd),
+           L.ptr(coef), L.ptr(xp), L.ptr(dw1), n_img, H, W, Cin, L.ptr(ws1), nbytes, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw1).all()
+    assert torch.equal(dw1.view(torch.int32), dw2.view(torch.int32)), float((dw1 - dw2).abs().max())
+    # run to run
+    dw3 = torch.full((64, Cin, 7, 7), float("nan"), device=DEV)
+    L.call("gdl_stem_bwd_fused", dt, L.ptr(doutd), L.ptr(ix), L.ptr(yd), L.ptr(scd), L.ptr(shd), L.ptr(smd), L.ptr(srd), L.ptr(gd),
+           L.ptr(coef), L.ptr(xp), L.ptr(dw3), n_img, H, W, Cin, L.ptr(ws1), nbytes, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dw1.view(torch.int32), dw3.view(torch.int32))
+    # the oracle's chain on the device's own arg-max codes (bf16 ties may pick another position than the oracle's first maximum)
+    a = quant(np.maximum(y * sc[None, :, None, None] + sh[None, :, None, None], 0).astype(np.float32), dt)
+    code = ix.cpu().numpy().astype(np.int64)  # [n][PP][QQ][C], code = r*3 + s inside the window
+    d_a = np.zeros((n_img, P, Q, C), np.float32)
+    nn_, pp_, qq_, cc_ = np.meshgrid(np.arange(n_img), np.arange(PP), np.arange(QQ), np.arange(C), indexing="ij")
+    np.add.at(d_a, (nn_, 2 * pp_ - 1 + code // 3, 2 * qq_ - 1 + code % 3, cc_), np.transpose(dout, (0, 2, 3, 1)))
+    d_a = np.ascontiguousarray(np.transpose(d_a, (0, 3, 1, 2)))
+    dyref, _, _ = orc.bn_bwd(orc.relu_bwd(d_a, a), y, gamma, mean, invstd)
+    refw = orc.conv2d_bwd_weight(quant(dyref.astype(np.float32), dt), x4, (64, Cin, 7, 7), 2, 3)
+    assert relerr(dw1.cpu().numpy(), refw) < 2e-2, relerr(dw1.cpu().numpy(), refw)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C,N,H,W", [(64, 3, 9, 7), (128, 2, 17, 12), (512, 4, 3, 2)])
 def test_bn_forward_backward(C, N, H, W, dt):

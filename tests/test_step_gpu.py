@@ -278,6 +278,49 @@ def test_head_film_beyond_64_samples():
         assert float(np.abs(got - ref).max()) <= 1e-3 * scale + 1e-6, k
 
 
+def test_film_mirror_beyond_64_samples():
+    """The drop-in FiLM_DGL module at B = 80 (the mirror still refused B > 64 although the kernel and the
+    trainer take 512): the reference's two-phase backward on the autograd path -- unimodal losses with retain_graph, head
+    gradients dropped, then loss_f -- against the CPU oracle (/root/reference/models/fusion_modules.py:126-178,
+    main_dgl.py:110-122)."""
+    from models.fusion_modules import FiLM_DGL
+
+    B, n = 80, 6
+    rng = np.random.default_rng(11)
+    Wfc = (rng.standard_normal((512, 512 * 512), dtype=np.float32) * np.float32(2e-3))
+    bfc = rng.standard_normal(512, dtype=np.float32) * np.float32(0.1)
+    Wo = rng.standard_normal((n, 512), dtype=np.float32) * np.float32(0.05)
+    bo = rng.standard_normal(n, dtype=np.float32) * np.float32(0.1)
+    x = np.maximum(rng.standard_normal((B, 512), dtype=np.float32), 0)
+    y = np.maximum(rng.standard_normal((B, 512), dtype=np.float32), 0)
+    gx, gy, go = (rng.standard_normal((B, n), dtype=np.float32) / np.float32(B) for _ in range(3))
+    ox, oy, oo, hid = orc.film_dgl_fwd(x, y, Wfc, bfc, Wo, bo)
+    m = FiLM_DGL(output_dim=n).to(DEV)
+    with torch.no_grad():
+        m.fc.weight.copy_(dev(Wfc)), m.fc.bias.copy_(dev(bfc)), m.fc_out.weight.copy_(dev(Wo)), m.fc_out.bias.copy_(dev(bo))
+    tx, ty = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    zx, zy, out = m(tx, ty)
+    for a, ref, k in ((zx, ox, "x_out"), (zy, oy, "y_out"), (out, oo, "out")):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), ref, rtol=1e-3, atol=1e-3, err_msg=k)
+    # phase 1 (main_dgl.py:110): the unimodal losses, graph retained; then the head's gradients are dropped (:114-119)
+    torch.autograd.backward([zx, zy], [dev(gx), dev(gy)], retain_graph=True)
+    for p_ in m.parameters():
+        p_.grad = None
+    rdx, rdy, _ = orc.film_dgl_bwd(x, y, Wfc, Wo, hid, gx, gy, None, want_fc=False)
+    np.testing.assert_allclose(tx.grad.cpu().numpy(), rdx, rtol=1e-3, atol=1e-3, err_msg="dx")
+    np.testing.assert_allclose(ty.grad.cpu().numpy(), rdy, rtol=1e-3, atol=1e-3, err_msg="dy")
+    # phase 2 (main_dgl.py:122): loss_f reaches fc / fc_out only (the features are detached)
+    gx0, gy0 = tx.grad.clone(), ty.grad.clone()
+    out.backward(dev(go))
+    assert torch.equal(tx.grad, gx0) and torch.equal(ty.grad, gy0)
+    _, _, RG = orc.film_dgl_bwd(x, y, Wfc, Wo, hid, None, None, go)
+    for t, k in ((m.fc.weight.grad, "fc.weight"), (m.fc.bias.grad, "fc.bias"), (m.fc_out.weight.grad, "fc_out.weight"),
+                 (m.fc_out.bias.grad, "fc_out.bias")):
+        got, ref = t.cpu().numpy(), RG[k]
+        scale = float(np.abs(ref).max())
+        assert float(np.abs(got - ref).max()) <= 1e-3 * scale + 1e-6, k
+
+
 def test_head_concat_golden():
     g = _gold("head_concat_c6")
     st_ = fx.make_state({"fusion_module.fc_out.weight": (6, 1024), "fusion_module.fc_out.bias": (6,)})

@@ -34,7 +34,12 @@ def main():
     pow_in = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or sorted(
         glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
     print("sysfs:", cards, freq_in, pow_in, flush=True)
-    child = subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    # the child's stdout goes to a temporary file (a pipe read only after exit blocks a child that prints more than the pipe
+    # buffer -- bench.py's JSON line can); its stderr is inherited (bench.py's early `headline:` line stays visible)
+    import tempfile
+
+    sink = tempfile.TemporaryFile(mode="w+")
+    child = subprocess.Popen(argv, stdout=sink, stderr=None, text=True)
     sclk, freq, power = [], [], []
     t0 = time.time()
     while child.poll() is None:
@@ -53,7 +58,8 @@ def main():
             if s:
                 power.append((time.time() - t0, int(s) / 1e6))
         time.sleep(period)
-    out = child.stdout.read().strip().splitlines()
+    sink.seek(0)
+    out = sink.read().strip().splitlines()
     print("child rc", child.returncode, "| last line:", (out[-1][:400] if out else ""))
     # per-card view: the busy card is the one that drew the most power
     ncard = max(1, len(pow_in))
