@@ -1843,24 +1843,11 @@ static int slab_cfg() {
     }
     return v;
 }
-static long slab_big_min() {
-    static long v = -1;
-    if (v < 0) {
-        const char* e = tune_env("GDL_SLAB_BIG_MIN");  // tuning aid: fewest blocks for which the 192 / 256 x 128 tiles are used
-        v = e ? atol(e) : 128;
-    }
-    return v;
-}
-static long slab_bn128_min() {
-    static long v = -1;
-    if (v < 0) {
-        // fewest blocks for which the 128-channel tile is used: the small layers (visual layer 4, audio layers 3 / 4) keep
-        // 64-wide tiles -- twice the blocks (knob sweep of round 2: 100 -> 384 is -0.5 % step time)
-        const char* e = tune_env("GDL_SLAB_BN128_MIN");  // tuning aid
-        v = e ? atol(e) : 384;
-    }
-    return v;
-}
+// fewest blocks for which the 192 / 256 x 128 tiles are used, and for which the 128-channel tile is used at all: the small layers
+// (visual layer 4, audio layers 3 / 4) keep 64-wide tiles or the 8-wave form -- twice the blocks (knob sweeps of rounds 2-4: 100 ->
+// 384 is -0.5 % step time, the defaults stayed twice; GDL_SLAB_BIG_MIN / GDL_SLAB_BN128_MIN: tools/experiments/r5_pruned_knobs.diff.txt)
+static constexpr long slab_big_min() { return 128; }
+static constexpr long slab_bn128_min() { return 384; }
 static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_nwv8 = true) {
     ConvPlan p{};
     static int noslab = -1;

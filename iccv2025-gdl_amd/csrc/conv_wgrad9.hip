@@ -491,13 +491,10 @@ struct W9Plan {
 };
 static W9Plan plan_w9(int M, int C, int K) {
     const int tiles = (K / 64) * (C / 64);
-    static int target = -1;
-    if (target < 0) {
-        const char* e = tune_env("GDL_WGRAD9_BLOCKS");  // tuning aid
-        // 512 blocks win when the kernel runs alone (tools/bench_conv.py); inside the step, where four
-        // streams share the CUs and every block leaves 144 KB of partials, 256 do (bench.py: -2 % step time)
-        target = e ? atoi(e) : 256;
-    }
+    // 512 blocks win when the kernel runs alone (tools/bench_conv.py); inside the step, where four streams share the CUs and
+    // every block leaves 144 KB of partials, 256 do (bench.py: -2 % step time; re-swept in rounds 3 and 4: the default stayed --
+    // the GDL_WGRAD9_BLOCKS knob went to tools/experiments/r5_pruned_knobs.diff.txt)
+    constexpr int target = 256;
     // every block leaves 144 KB of fp32 partials that the reduce kernel reads back: at least `min_st` 64-pixel stages of work
     // per block.  Round 3 (tools/ab_env.sh, same box, three rounds, B = 64 step): 8 -> 5.72 ms, 36 -> 5.70, 48 -> 5.70,
     // 72 -> 5.79, 110 -> 6.07.  36 leaves the visual layers at their 256 slices of 37 stages and brings the audio layers

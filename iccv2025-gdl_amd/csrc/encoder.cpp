@@ -531,15 +531,6 @@ static int bn_finalize(gdl_encoder* e, BN& n, int training, int tiles, double co
     return bn_finalize_eval(n.c, gamma, beta, 1e-5f, e->rmean[n.bidx], e->rvar[n.bidx], n.scale, n.shift, st);
 }
 
-static bool wgrad_late() {
-    static int v = -1;
-    if (v < 0) {
-        const char* env = tune_env("GDL_WGRAD_LATE");  // tuning aid (side-stream mode only)
-        v = env ? atoi(env) : 0;
-    }
-    return v != 0;
-}
-
 // (The in-launch BatchNorm finalize -- "the last block folds", GDL_FOLD / GDL_PERS_FOLD -- lost twice (6.69 vs 6.22 ms in round 1;
 // 5.855 vs 5.841 ms on the persistent kernels in round 2) and was removed in round 4: tools/experiments/r4_pruned_fold.diff.txt.)
 // ReLU mask of a block output applied by the producing data gradient (default on; GDL_PREMASK=0: the block masks itself)
@@ -673,26 +664,10 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         if (he != hipSuccess) return check_hip(he, "encoder_forward: descriptor upload");
         e->pack_dirty = false;
     }
-    // The layer1..4 weights are first needed by layer1's conv1, behind the whole stem (pad, 7x7 convolution, finalize, pooling:
-    // ~260 us): an engine with a side stream (idle during the forward) packs there, beside the stem, and joins in front of
-    // the first block.  Tuning aid GDL_PACK_SIDE=1 -- OFF by default: the skip bound of the pack is 0.12 ms, the overlap returned 0.4 % (5.661 -> 5.640 ms, three A/B rounds, one of them worse): inside the noise.
-    static int pack_side = -1;
-    if (pack_side < 0) {
-        const char* env = tune_env("GDL_PACK_SIDE");
-        pack_side = env ? atoi(env) : 0;
-    }
-    const bool pack_fork = e->has_side && pack_side;
-    if (pack_fork) {
-        hipError_t he = hipEventRecord(e->ev_fork, st);
-        if (he == hipSuccess) he = hipStreamWaitEvent(e->side, e->ev_fork, 0);
-        if (he != hipSuccess) return check_hip(he, "encoder_forward: pack fork");
-    }
+    // (Packing on the side stream, beside the stem -- GDL_PACK_SIDE -- returned 0.4 %, inside the noise, against a skip bound of
+    // 0.12 ms: tools/experiments/r5_pruned_knobs.diff.txt)
     if (!GDL_SKIPPED(256))
-        RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, pack_fork ? e->side : st));
-    if (pack_fork) {
-        hipError_t he = hipEventRecord(e->ev_join, e->side);
-        if (he != hipSuccess) return check_hip(he, "encoder_forward: pack event");
-    }
+        RC(pack_weights_batched(dt, e->pack_dev, (int)e->pack_host.size(), e->pack_blocks, e->pack_bytes, st));
     const bool acc = training && bn_acc_on() && !separate_stats();
     e->acc_last = acc;
     // stem: conv1 (7x7/2) as a direct implicit GEMM over the padded input, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
@@ -712,10 +687,6 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
         const BnAccFin f0 = acc ? acc_consumer(e, e->bn0, e->m0) : BnAccFin{};
         RC(bn_relu_maxpool_fwd(dt, e->y0, e->bn0.scale, e->bn0.shift, e->x1, e->idx, training ? e->ymax : nullptr, e->n_img,
                                e->h0, e->w0, 64, st, &f0));
-    }
-    if (pack_fork) {  // the packed weights are needed from here on
-        hipError_t he = hipStreamWaitEvent(st, e->ev_join, 0);
-        if (he != hipSuccess) return check_hip(he, "encoder_forward: pack join");
     }
     // layer1..layer4   (backbone.py:175-178; BasicBlock.forward :52-68)
     for (Block& k : e->blocks) {
@@ -910,17 +881,15 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
                               k.cin, e->wg_ws, e->wg_ws_bytes, sw));
             return GDL_OK;
         };
-        // late: fork AFTER the data gradient that consumes the same dy, so that the (MFMA-bound) weight gradient runs
-        // beside the (HBM-bound) BatchNorm passes that follow rather than beside another MFMA-bound kernel
-        const bool late = e->has_side && wgrad_late();
-        if (!late) RC(wgrad2());
+        // (forking the weight gradients AFTER the data gradient that consumes the same dy -- GDL_WGRAD_LATE -- let them run at their
+        // stand-alone speed and made the step 0.7 % slower, rounds 2 and 4: tools/experiments/r5_pruned_knobs.diff.txt)
+        RC(wgrad2());
         if (fuse) {
             // gC = da1 * (a1 > 0) (sign bits of a1) with bn1's two sums from the epilogue; then finalize + apply
             const BwdStats bwa{k.y1, k.b1.mean, k.b1.rstd, e->bwA, nullptr, nullptr, nullptr, nullptr};
             if (!(GDL_SKIPPED(131072) || (GDL_SKIPPED(4096) && k.cout == 512)))
             RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1, st,
                           k.abits, &bwa, &e->sk));
-            if (late) RC(wgrad2());
             const int rows = conv_dgrad_tiles_m(dt, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1);
             if (!(GDL_SKIPPED(32) || GDL_SKIPPED(262144)))
                 RC(bn_bwd_finalize(e->bwA, rows, k.cout, (double)Mo, grads[k.b1.pidx], grads[k.b1.pidx + 1], k.b1.coef, st));
@@ -930,7 +899,6 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         } else {
         RC(conv_dgrad(dt, gB, k.c2.w_crsk, gC, nullptr, k.c2.tab_dgrad, k.n, k.p, k.q, k.cout, k.cout, 3, 3, 1, 1,
                       st, nullptr, nullptr, &e->sk));  // gC = da1
-        if (late) RC(wgrad2());
         // relu + bn1 / conv1
         RC(bn_backward(e, k.b1, gC, k.y1, 1, gC, Mo, grads, st));  // gC = dy1 (in place)
         }
@@ -946,7 +914,7 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             }
             return GDL_OK;
         };
-        if (!late) RC(wgrad1());
+        RC(wgrad1());
         void* dxin;
         // the block's input is the previous block's output z (for block 0: the pooled stem output, whose mask the
         // stem's own backward applies): its sign bits turn dx into the masked gradient the previous block wants
@@ -986,7 +954,6 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
         }
         premasked = inbits != nullptr;
         b2_rows = next_rows;
-        if (late) RC(wgrad1());
         dz = dxin;
     }
     if (phase == 1) {  // hand over to phase 2; the layer4 gradients must be complete on st

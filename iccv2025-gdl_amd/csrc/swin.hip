@@ -597,426 +597,8 @@ __global__ __launch_bounds__(256) void swin_attn_fwd_kernel(const T* __restrict_
         for (int c = g.nh * SW_HD; c < g.ld; ++c) storeT(out + row * g.ld + c, 0.f);
 }
 
-// ---- bf16 forward on the matrix cores.  One wave per (image, window, head): S = Q K^T as 4 x 4 MFMA tiles
-// (mfma_f32_16x16x32_bf16; the 32-wide reduction is the head dimension, Q / K fragments are 16-byte loads straight from
-// the QKV rows), softmax on the accumulator layout (a row's 64 columns live in 16 lanes x 4 tiles: xor-shuffle reductions),
-// P rounded to bf16 through LDS (row-major, the A operand of the second product), V transposed through LDS (its B
-// operand), O = P V as 4 x 2 tiles x 2 K-steps.  Rows / columns 49..63 are padding: zero Q / K / V rows, -inf scores.
-constexpr int SW_TP = 64;       // window tokens padded to the MFMA tile grid
-constexpr int SW_PP = SW_TP + 8;  // LDS pitch (bf16 elements) of a 64-wide row: 144 B, 16-byte aligned, rows 4 banks apart
-struct SwinMfmaLds {              // per wave
-    uint16_t Ps[SW_TP][SW_PP];    // probabilities, [query][key]
-    uint16_t Vt[SW_HD][SW_PP];    // V transposed, [channel][key]
-    float tab[(2 * 7 - 1) * (2 * 7 - 1)];
-    int tok[SW_TP];               // slot -> token row of the image (-1: padding slot)
-    uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];  // slot -> window row, column, mask region
-};
-// ordering of one wave's LDS writes against its own later reads (other lanes' data): the LDS unit executes a wave's instructions
-// in order; the compiler must not reorder them either
-__device__ __forceinline__ void sw_wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// Consecutive block ids land on consecutive XCDs (eight L2s).  The heads of one window read neighbouring 64-byte runs of the same
-// token rows -- two heads per 128-byte line -- so consecutive LOGICAL ids are given to the blocks of one XCD: block b is the
-// (b / 8)-th block of XCD b % 8 and takes the (b / 8)-th id of that XCD's contiguous share.
-__device__ __forceinline__ unsigned sw_xcd_block(unsigned b, unsigned nb, int on) {
-    if (!on) return b;
-    const unsigned q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
-    return x < r ? x * (q + 1) + i : r * (q + 1) + (x - r) * q + i;
-}
-__device__ __forceinline__ bf16x8_t sw_ld_frag(const bf16* p) { return __builtin_bit_cast(bf16x8_t, *(const uint4*)p); }
-__device__ __forceinline__ bf16x8_t sw_zero_frag() { return __builtin_bit_cast(bf16x8_t, make_uint4(0u, 0u, 0u, 0u)); }
-
-__global__ __launch_bounds__(256) void swin_attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
-                                                                 bf16* __restrict__ out, SwinAttnGeom g, int n_img, int xcd) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    SwinMfmaLds& S = ((SwinMfmaLds*)swm_smem)[wave];
-    const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
-    const long unit = (long)sw_xcd_block(blockIdx.x, gridDim.x, xcd) * 4 + wave, nunits = (long)n_img * g.nwin * g.nh;
-    const bool live = unit < nunits;
-    const int h = live ? (int)(unit % g.nh) : 0;
-    const int w = live ? (int)((unit / g.nh) % g.nwin) : 0;
-    const size_t img_row0 = live ? (size_t)(unit / ((long)g.nh * g.nwin)) * L : 0;
-    const int l16 = lane & 15, lq = lane >> 4;
-    // Q / K fragments: tile t covers slots 16 t + l16; this lane's 8 channels start at 8 lq.  The slot's token is computed here
-    // (not read back from the bookkeeping in LDS), so these loads go out together with the V rows below: one round trip to
-    // memory per window instead of two in series
-    bf16x8_t qf[4], kf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int slot = 16 * t + l16;
-        const int tokq = (live && slot < Tn) ? sw_token(g, w, slot, nullptr) : -1;
-        if (tokq >= 0) {
-            const bf16* base = qkv + (img_row0 + tokq) * 3 * g.ld + h * SW_HD + 8 * lq;
-            qf[t] = sw_ld_frag(base);
-            kf[t] = sw_ld_frag(base + g.ld);
-        } else {
-            qf[t] = kf[t] = sw_zero_frag();
-        }
-    }
-    // slot bookkeeping + the head's bias column + V transposed
-    {
-        int reg = 0;
-        const int tok = lane < Tn ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : -1;
-        S.tok[lane] = tok;
-        S.rr[lane] = (uint8_t)(lane / g.ws);
-        S.cc[lane] = (uint8_t)(lane % g.ws);
-        S.reg[lane] = (uint8_t)reg;
-        for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
-        uint4 v[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-        if (live && tok >= 0) {
-            const uint4* vp = (const uint4*)(qkv + (img_row0 + tok) * 3 * g.ld + 2 * g.ld + h * SW_HD);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] = vp[q4];
-        }
-        const uint32_t* vw = (const uint32_t*)v;
-#pragma unroll
-        for (int d2 = 0; d2 < SW_HD / 2; ++d2) {
-            S.Vt[2 * d2][lane] = (uint16_t)(vw[d2] & 0xffffu);
-            S.Vt[2 * d2 + 1][lane] = (uint16_t)(vw[d2] >> 16);
-        }
-    }
-    sw_wave_sync();  // (the LDS tiles are this wave's own: no block barrier -- four independent waves would wait for each other)
-    // scores, TRANSPOSED tiles: acc[jt][it][r] = S[i = 16 it + l16][j = 16 jt + 4 lq + r] -- a lane owns four consecutive keys
-    // of one query, so P goes to LDS (row-major [query][key], the A operand of P V) in 8-byte stores; a query's 64 keys
-    // live in 4 lanes (lq) x 4 tiles x 4 registers: the row reductions are xor-shuffles over lanes 16 and 32
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            acc[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt], qf[it], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    const float scale = 0.17677669529663687f;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = 16 * it + l16;
-        const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = 16 * jt + 4 * lq + r;
-                float a = acc[jt][it][r] * scale;
-                if (j >= Tn)
-                    a = -3.0e38f;
-                else if (i < Tn) {
-                    a += S.tab[(ri - (int)S.rr[j] + g.ws - 1) * tw + (ci - (int)S.cc[j] + g.ws - 1)];
-                    if (g.shift && gi != (int)S.reg[j]) a -= 100.f;
-                }
-                acc[jt][it][r] = a;
-                mx = fmaxf(mx, a);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float den = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = 16 * jt + 4 * lq + r < Tn ? __expf(acc[jt][it][r] - mx) : 0.f;
-                acc[jt][it][r] = e;
-                den += e;
-            }
-        den += __shfl_xor(den, 16, 64);
-        den += __shfl_xor(den, 32, 64);
-        const float inv = 1.f / den;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-            *(uint2*)&S.Ps[i][16 * jt + 4 * lq] = make_uint2(pack2bf(acc[jt][it][0] * inv, acc[jt][it][1] * inv),
-                                                             pack2bf(acc[jt][it][2] * inv, acc[jt][it][3] * inv));
-    }
-    sw_wave_sync();  // (the LDS tiles are this wave's own: no block barrier -- four independent waves would wait for each other)
-    // O = P V, computed transposed (operands swapped, V^T rows taken in the order 8 q + r / 8 q + 4 + r: see sw_bwd_product):
-    // a lane owns eight consecutive channels of one query and stores them as one 16-byte vector
-    f32x4_t o[4][2];
-    const int vrow = 8 * (l16 >> 2) + (l16 & 3);
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            o[it][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8_t pa = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Ps[16 * it + l16][32 * ks + 8 * lq]);
-                const bf16x8_t vb = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Vt[vrow + 4 * nt][32 * ks + 8 * lq]);
-                o[it][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, pa, o[it][nt], 0, 0, 0);
-            }
-        }
-    if (!live) return;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = 16 * it + l16;
-        if (i >= Tn) continue;
-        const uint4 v = make_uint4(pack2bf(o[it][0][0], o[it][0][1]), pack2bf(o[it][0][2], o[it][0][3]),
-                                   pack2bf(o[it][1][0], o[it][1][1]), pack2bf(o[it][1][2], o[it][1][3]));
-        *(uint4*)(out + (img_row0 + S.tok[i]) * g.ld + h * SW_HD + 8 * lq) = v;
-    }
-    if (h == 0 && lane < Tn)  // the row's padding columns stay zero
-        for (int c = g.nh * SW_HD; c < g.ld; ++c) out[(img_row0 + S.tok[lane]) * g.ld + c].v = 0;
-}
-
-// ---- bf16 backward on the matrix cores.  One wave (block of 64) per (image, group of G windows, head).  Per window:
-// S and dP = dO V^T as 16x16x32 MFMA tiles from 16-byte fragment loads of the Q / K / dO / V rows, one strip of 16 queries
-// at a time; P, pd_i = sum_j P dP and dS = P (dP - pd) on the accumulator layout, kept as packed bf16 pairs (a lane owns
-// four consecutive queries of one key: exactly one 8-byte run of a TRANSPOSED row).  ONE 64 x 64 bf16 tile of LDS then
-// carries, in turn, dS (A operand of dQ = dS K), dS^T (of dK = dS^T Q) and P^T (of dV = P^T dO); their B operands are the
-// transposed Q / K / dO rows, scattered once from the fragments.  dS also accumulates in fp32 registers over the block's
-// windows and is folded into d(table) at the end.  24 KB of LDS and <= 256 registers: six to eight waves per CU (the
-// first form kept three tiles and every accumulator live: 43 KB, 401 registers, three waves per CU).
-struct SwinMfmaBwdLds {
-    uint16_t Tl[SW_TP][SW_PP];  // dS [i][j], then dS^T [j][i], then P^T [j][i]
-    uint16_t Bt[SW_HD][SW_PP];  // the product's transposed B operand, in turn: K^T [d][j], Q^T [d][i], dO^T [d][i] -- scattered
-                                // from the fragment registers right before the product that reads it (round 3: ONE buffer instead
-                                // of three, 15 instead of 24 KB per wave: ten instead of six waves per CU)
-    float tab[(2 * 7 - 1) * (2 * 7 - 1)];
-    int tok[SW_TP];
-    uint8_t rr[SW_TP], cc[SW_TP], reg[SW_TP];
-};
-static_assert(sizeof(((SwinMfmaBwdLds*)nullptr)->Tl) + sizeof(((SwinMfmaBwdLds*)nullptr)->Bt) >= SW_MAXT * (SW_MAXT + 1) * sizeof(float),
-              "the fp32 d(bias) tile is folded in the operand area");
-// fragment of tile t (row = slot 16 t + l16, channels 8 lq ..) -> transposed LDS copy [channel][slot]
-__device__ __forceinline__ void sw_scatter_frag(uint16_t (*dst)[SW_PP], bf16x8_t f, int slot, int lq) {
-    const uint4 v = __builtin_bit_cast(uint4, f);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) {
-        dst[8 * lq + 2 * e2][slot] = (uint16_t)(w[e2] & 0xffffu);
-        dst[8 * lq + 2 * e2 + 1][slot] = (uint16_t)(w[e2] >> 16);
-    }
-}
-// out[slot][32 channels] = A (the LDS tile, rows = slots) . B (a transposed operand), written to segment `seg` of dqkv.
-// The product is computed TRANSPOSED (operands swapped) with the channel rows of B taken in the order 8 q + r (first MFMA)
-// and 8 q + 4 + r (second): the accumulator row 4 lq + r of a lane then is channel 8 lq + r (+ 4), its column l16 the slot --
-// a lane owns EIGHT consecutive channels of one token and stores them as one 16-byte vector, four lanes cover the head's whole
-// 64-byte run of the row.  (Rounds 1-2 stored two bytes per lane and instruction, 32 instructions per product: 96 scattered
-// 2-byte store instructions per window against 12 now.)
-__device__ __forceinline__ void sw_bwd_product(const SwinMfmaBwdLds& S, const uint16_t (*Bm)[SW_PP], bf16* __restrict__ dqkv,
-                                               size_t img_row0, const SwinAttnGeom& g, int h, int seg, float mul, int Tn, int l16,
-                                               int lq) {
-    const int brow = 8 * (l16 >> 2) + (l16 & 3);  // channel of operand row l16 (first MFMA; + 4: second)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f32x4_t o0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, o1 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8_t a = __builtin_bit_cast(bf16x8_t, *(const uint4*)&S.Tl[16 * t + l16][32 * ks + 8 * lq]);
-            const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[brow][32 * ks + 8 * lq]);
-            const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, *(const uint4*)&Bm[brow + 4][32 * ks + 8 * lq]);
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a, o1, 0, 0, 0);
-        }
-        const int slot = 16 * t + l16;
-        if (slot < Tn) {
-            const uint4 v = make_uint4(pack2bf(o0[0] * mul, o0[1] * mul), pack2bf(o0[2] * mul, o0[3] * mul),
-                                       pack2bf(o1[0] * mul, o1[1] * mul), pack2bf(o1[2] * mul, o1[3] * mul));
-            *(uint4*)(dqkv + (img_row0 + S.tok[slot]) * 3 * g.ld + seg * g.ld + h * SW_HD + 8 * lq) = v;
-        }
-    }
-}
-__global__ __launch_bounds__(64, 2) void swin_attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const float* __restrict__ table,
-                                                                   const bf16* __restrict__ dout, bf16* __restrict__ dqkv,
-                                                                   float* __restrict__ tpart, SwinAttnGeom g, int G, int xcd) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char swm_smem[];
-    SwinMfmaBwdLds& S = *(SwinMfmaBwdLds*)swm_smem;
-    const int lane = threadIdx.x, l16 = lane & 15, lq = lane >> 4;
-    const int Tn = g.ws * g.ws, L = g.H * g.W, tw = 2 * g.ws - 1;
-    const int ngrp = (g.nwin + G - 1) / G;
-    const unsigned bid = sw_xcd_block(blockIdx.x, gridDim.x, xcd);
-    const int h = bid % g.nh, grp = (bid / g.nh) % ngrp;
-    const size_t img_row0 = (size_t)(bid / (g.nh * ngrp)) * L;
-    const float scale = 0.17677669529663687f;
-    for (int r = lane; r < tw * tw; r += 64) S.tab[r] = table[r * g.nh + h];
-    // d(bias): table entry (dh, dw) collects dS_ij over the pairs with (ri - rj, ci - cj) = (dh, dw), gathered from the dS^T tile
-    // of every window (bf16, the values dK is computed from) into four fp32 registers per lane (see the fold below).  (Round 2 kept all (i, j) pairs of a lane in 64 fp32 registers across the window loop --
-    // 256 registers + 296 bytes of scratch; LDS float adds at the lookup index, `ds_add_f32`, cost 500 clk per instruction:
-    // 43 % of the kernel, tools/probe_attn_bwd.py.)
-    float tga[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int w = grp * G; w < min(g.nwin, grp * G + G); ++w) {
-        __syncthreads();  // (the previous window's operand tiles are no longer read)
-        {
-            int reg = 0;
-            const int tok = lane < Tn ? sw_token(g, w, lane, g.shift ? &reg : nullptr) : -1;
-            S.tok[lane] = tok;
-            S.rr[lane] = (uint8_t)(lane / g.ws);
-            S.cc[lane] = (uint8_t)(lane % g.ws);
-            S.reg[lane] = (uint8_t)reg;
-        }
-        uint2 pkp[4][4], pkd[4][4];  // P and dS of tile (it, jt), rows 4 lq .. 4 lq + 3 of column 16 jt + l16, as bf16
-        // fragments straight from the rows (the token of slot 16 t + l16 is computed here: no LDS round trip before
-        // the loads); the transposed copies the second set of products needs are scattered from the same registers later
-        bf16x8_t qf[4], kf[4], of[4];  // (kept for the transposed operands of dQ / dK / dV below)
-        {
-            bf16x8_t vf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int slot = 16 * t + l16;
-                if (slot < Tn) {
-                    const int tok = sw_token(g, w, slot, nullptr);
-                    const bf16* base = qkv + (img_row0 + tok) * 3 * g.ld + h * SW_HD + 8 * lq;
-                    qf[t] = sw_ld_frag(base);
-                    kf[t] = sw_ld_frag(base + g.ld);
-                    vf[t] = sw_ld_frag(base + 2 * g.ld);
-                    of[t] = sw_ld_frag(dout + (img_row0 + tok) * g.ld + h * SW_HD + 8 * lq);
-                } else {
-                    qf[t] = kf[t] = vf[t] = of[t] = sw_zero_frag();
-                }
-            }
-            __syncthreads();  // (slot bookkeeping visible)
-            int rj[4], cj[4], gj[4];
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int j = 16 * jt + l16;
-                rj[jt] = S.rr[j], cj[jt] = S.cc[j], gj[jt] = S.reg[j];
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {  // one strip of 16 queries at a time
-                f32x4_t acc[4], dp[4];
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[it], kf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[it], vf[jt], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * it + 4 * lq + r;
-                    const int ri = S.rr[i], ci = S.cc[i], gi = S.reg[i];
-                    float mx = -3.0e38f;
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        float a = acc[jt][r] * scale;
-                        if (16 * jt + l16 >= Tn)
-                            a = -3.0e38f;
-                        else if (i < Tn) {
-                            a += S.tab[(ri - rj[jt] + g.ws - 1) * tw + (ci - cj[jt] + g.ws - 1)];
-                            if (g.shift && gi != gj[jt]) a -= 100.f;
-                        }
-                        acc[jt][r] = a;
-                        mx = fmaxf(mx, a);
-                    }
-                    mx = row16_max(mx);  // (DPP rotations within the 16 lanes that share a query row, not ds_bpermute round trips)
-                    float den = 0.f;
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        const float e = 16 * jt + l16 < Tn ? __expf(acc[jt][r] - mx) : 0.f;
-                        acc[jt][r] = e;
-                        den += e;
-                    }
-                    den = row16_sum(den);
-                    const float inv = 1.f / den;
-                    float pd = 0.f;
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        acc[jt][r] *= inv;  // P
-                        pd += acc[jt][r] * dp[jt][r];
-                    }
-                    pd = row16_sum(pd);
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) {
-                        const bool in = i < Tn && 16 * jt + l16 < Tn;
-                        const float p = in ? acc[jt][r] : 0.f;
-                        const float ds = p * (dp[jt][r] - pd);
-                        acc[jt][r] = p;
-                        dp[jt][r] = ds;
-                    }
-                }
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) {
-                    pkp[it][jt] = make_uint2(pack2bf(acc[jt][0], acc[jt][1]), pack2bf(acc[jt][2], acc[jt][3]));
-                    pkd[it][jt] = make_uint2(pack2bf(dp[jt][0], dp[jt][1]), pack2bf(dp[jt][2], dp[jt][3]));
-                }
-            }
-        }
-        // ---- dV = P^T dO  (first: P^T and dO are dead afterwards -- the order dV, dQ, dK, d(table) keeps the fewest registers live)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkp[it][jt];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
-            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            (void)tk;
-            sw_scatter_frag(S.Bt, of[t], 16 * t + l16, lq);
-        }
-        __syncthreads();
-        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 2, 1.f, Tn, l16, lq);
-        __syncthreads();
-        // ---- dQ = scale dS K: the tile holds dS row-major [i][j] (2-byte stores: a lane's four values are four rows)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int j = 16 * jt + l16, i0 = 16 * it + 4 * lq;
-                S.Tl[i0][j] = (uint16_t)(pkd[it][jt].x & 0xffffu);
-                S.Tl[i0 + 1][j] = (uint16_t)(pkd[it][jt].x >> 16);
-                S.Tl[i0 + 2][j] = (uint16_t)(pkd[it][jt].y & 0xffffu);
-                S.Tl[i0 + 3][j] = (uint16_t)(pkd[it][jt].y >> 16);
-            }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
-            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            (void)tk;
-            sw_scatter_frag(S.Bt, kf[t], 16 * t + l16, lq);
-        }
-        __syncthreads();
-        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 0, scale, Tn, l16, lq);
-        __syncthreads();
-        // ---- dK = scale dS^T Q: the tile holds dS^T [j][i]: one 8-byte store per (it, jt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) *(uint2*)&S.Tl[16 * jt + l16][16 * it + 4 * lq] = pkd[it][jt];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {  // (re-read from L2 -- the rows were fetched a moment ago -- rather than kept in 16 registers
-            const int tk = S.tok[16 * t + l16];  //  across the strip loop: the kernel sits at the 256-register limit)
-            (void)tk;
-            sw_scatter_frag(S.Bt, qf[t], 16 * t + l16, lq);
-        }
-        __syncthreads();
-        sw_bwd_product(S, S.Bt, dqkv, img_row0, g, h, 1, scale, Tn, l16, lq);
-        __syncthreads();
-        // the tile still holds dS^T [j][i]: this window's share of d(table).  Lane u < ws^2 owns the offsets (dh0, dw0) =
-        // (u / ws - (ws - 1), u % ws - (ws - 1)) <= 0 and their +ws partners: for EVERY key (rj, cj) exactly one of the four entries
-        // (dh0 [+ ws], dw0 [+ ws]) has its query (rj + dh, cj + dw) inside the window -- the wrapped one -- so each lane reads
-        // ws^2 elements per window, no more, no less (a lane per entry walked 1 .. ws^2 pairs: the wave paid for the longest)
-        int u = lane;
-        asm volatile("" : "+v"(u));  // (per window: hoisted out of the window loop, the offsets and bounds would live across the strip loop)
-        if (u < Tn) {
-            const int dh0 = u / g.ws - (g.ws - 1), dw0 = u % g.ws - (g.ws - 1);
-            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-            for (int rj2 = 0; rj2 < g.ws; ++rj2) {
-                const bool wr = rj2 + dh0 < 0;
-                const int ri2 = rj2 + dh0 + (wr ? g.ws : 0);
-                for (int cj2 = 0; cj2 < g.ws; ++cj2) {
-                    const bool wc = cj2 + dw0 < 0;
-                    const int ci2 = cj2 + dw0 + (wc ? g.ws : 0);
-                    const float v = __uint_as_float((uint32_t)S.Tl[rj2 * g.ws + cj2][ri2 * g.ws + ci2] << 16);
-                    a00 += (!wr && !wc) ? v : 0.f;
-                    a01 += (!wr && wc) ? v : 0.f;
-                    a10 += (wr && !wc) ? v : 0.f;
-                    a11 += (wr && wc) ? v : 0.f;
-                }
-            }
-            tga[0] += a00, tga[1] += a01, tga[2] += a10, tga[3] += a11;
-        }
-        if (h == 0 && lane < Tn)  // padding columns of the three segments stay zero
-            for (int sgm = 0; sgm < 3; ++sgm)
-                for (int c = g.nh * SW_HD; c < g.ld; ++c) dqkv[(img_row0 + S.tok[lane]) * 3 * g.ld + sgm * g.ld + c].v = 0;
-    }
-    __syncthreads();
-    float* tp = tpart + (size_t)bid * tw * tw;
-    if (lane < Tn) {  // entries (dh0 [+ ws], dw0 [+ ws]); the partners past the table's edge (dh0 = 0 or dw0 = 0) do not exist
-        const int dh0 = lane / g.ws - (g.ws - 1), dw0 = lane % g.ws - (g.ws - 1);
-        const int e0 = (dh0 + g.ws - 1) * tw + (dw0 + g.ws - 1);
-        tp[e0] = tga[0];
-        if (dw0 < 0) tp[e0 + g.ws] = tga[1];
-        if (dh0 < 0) tp[e0 + g.ws * tw] = tga[2];
-        if (dh0 < 0 && dw0 < 0) tp[e0 + g.ws * tw + g.ws] = tga[3];
-    }
-}
+// (The round-2/3 matrix-core attention kernels -- one wave per (image, window, head), any window up to 7 x 7 -- were removed in
+// round 5: csrc/swin_attn7.hip serves every 7 x 7 bf16 case; tools/experiments/swin_attn_mfma_r2.hip.txt keeps the text.)
 
 // 32 consecutive channels of a token row -> LDS row (float)
 template <typename T>
@@ -1606,22 +1188,6 @@ int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_
     return partial_reduce(partial, db, nb, ld, st);
 }
 
-static bool swin_mfma_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = tune_env("GDL_SWIN_MFMA");  // tuning aid: 0 = the plain-FMA attention kernels for bf16 too
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
-}
-static int swin_xcd_on() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = tune_env("GDL_SWIN_XCD");  // tuning aid: 0 = block id -> (window, head) without the XCD grouping
-        v = e ? atoi(e) : 1;
-    }
-    return v;
-}
 static int attn_geom(SwinAttnGeom* g, int H, int W, int ws, int shift, int nh, int ld) {
     GDL_REQUIRE(ws >= 1 && ws * ws <= SW_MAXT && H % ws == 0 && W % ws == 0 && shift >= 0 && shift < ws && nh * SW_HD <= ld,
                 "swin_attn: window %d (shift %d) on %dx%d tokens, %d heads in %d channels", ws, shift, H, W, nh, ld);
@@ -1636,19 +1202,6 @@ int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_
     if (rc) return rc;
     if (swin_attn7_ok(dt, H, W, ws, shift, nh, ld, n_img)) return swin_attn7_fwd(qkv, table, out, n_img, H, W, shift, nh, ld, st);
     const long units = (long)n_img * g.nwin * nh;
-    if (dt == GDL_BF16 && swin_mfma_on()) {  // matrix-core form (bf16 storage only: the f32 mode stays an fp32 FMA chain)
-        const size_t lds = 4 * sizeof(SwinMfmaLds);
-        static DevOnce attr;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)swin_attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_fwd_mfma)");
-            attr = true;
-        }
-        ProfScope prof("gdl::swin_attn_fwd_mfma_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 4);
-        hipLaunchKernelGGL(swin_attn_fwd_mfma_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, (const bf16*)qkv, table, (bf16*)out, g, n_img, swin_xcd_on());
-        GDL_CHECK_LAUNCH("swin_attn_fwd_mfma_kernel");
-        return GDL_OK;
-    }
     ProfScope prof("gdl::swin_attn_fwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 4);
     SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_fwd_kernel<float>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const float*)qkv, table, (float*)out, g, n_img),
                 hipLaunchKernelGGL(swin_attn_fwd_kernel<bf16>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, (const bf16*)qkv, table, (bf16*)out, g, n_img));
@@ -1686,19 +1239,7 @@ int swin_attn_bwd(int dt, const void* qkv, const float* table, const void* dout,
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_bwd)");
         attr[di] = true;
     }
-    if (dt == GDL_BF16 && swin_mfma_on()) {
-        const size_t ldsm = sizeof(SwinMfmaBwdLds);
-        static DevOnce attrm;
-        if (!attrm) {
-            hipError_t e = hipFuncSetAttribute((const void*)swin_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);
-            if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(swin_attn_bwd_mfma)");
-            attrm = true;
-        }
-        ProfScope prof("gdl::swin_attn_bwd_mfma_kernel", PROF_HBM, st, (double)n_img * H * W * ld * 2 * 7);
-        hipLaunchKernelGGL(swin_attn_bwd_mfma_kernel, dim3(n_img * ngrp * nh), dim3(64), ldsm, st, (const bf16*)qkv, table, (const bf16*)dout,
-                           (bf16*)dqkv, tpart, g, G, swin_xcd_on());
-        GDL_CHECK_LAUNCH("swin_attn_bwd_mfma_kernel");
-    } else {
+    {
         ProfScope prof("gdl::swin_attn_bwd_kernel", PROF_HBM, st, (double)n_img * H * W * ld * (dt == GDL_F32 ? 4 : 2) * 7);
         SW_DISPATCH(dt, hipLaunchKernelGGL(swin_attn_bwd_kernel<float>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const float*)qkv, table, (const float*)dout, (float*)dqkv, tpart, g, G),
                     hipLaunchKernelGGL(swin_attn_bwd_kernel<bf16>, dim3(n_img * ngrp * nh), dim3(64), lds, st, (const bf16*)qkv, table, (const bf16*)dout, (bf16*)dqkv, tpart, g, G));

@@ -350,3 +350,62 @@ def test_swin_step_oracle_matches_reference_golden(golden_dir):
                 assert n not in r["grad_norm"]
             else:
                 assert abs(r["grad_norm"][n] - gn[i]) <= gt * gn[i] + 1e-7, (n, r["grad_norm"][n], gn[i])
+
+
+@pytest.mark.parametrize("name,cfg_name,chunk", [("swin_tiny2_b2", "SWIN_TINY2", 3), ("swin_t_b1", "SWIN_T", 1)])
+def test_torch_swin_f64_arbiter_matches_reference_golden(golden_dir, name, cfg_name, chunk):
+    """oracle/torch_swin_step.py::swin_features_and_grads -- the float64, frame-chunked form of the Swin oracle that arbitrates the
+    config-5 GPU tests at 192 frames -- against features and parameter gradients of the imported reference SwinTransformer
+    (swin_transformer.py:486-674).  The chunk size does not divide the frame count on purpose."""
+    import json
+
+    from oracle.torch_swin_step import swin_features_and_grads
+
+    cfg = getattr(fx, cfg_name)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    c = json.loads(str(g["config"]))
+    P = fx.make_state(fx.swin_param_shapes(cfg))
+    y, grads = swin_features_and_grads(fx.swin_input(cfg, c["batch"], c["frames"], c["seed"]), P, cfg, g["dy"], chunk=chunk)
+    assert y.dtype == np.float64
+    assert np.abs(y - g["y"]).max() <= 2e-6 * np.abs(g["y"]).max()  # (the golden is the reference's float32 run)
+    for k, v in grads.items():
+        want_norm = g["gradstat." + k][0]
+        assert abs(np.sqrt((v ** 2).sum()) - want_norm) <= 2e-5 * want_norm, k
+        if "grad." + k in g.files:
+            np.testing.assert_allclose(v, g["grad." + k], rtol=0, atol=2e-5 * np.abs(g["grad." + k]).max(), err_msg=k)
+        else:
+            w = g["gradsample." + k]
+            np.testing.assert_allclose(v.reshape(-1)[::997], w, rtol=0, atol=2e-5 * np.abs(w).max(), err_msg=k)
+
+
+def test_torch_swin_step_f64_matches_reference_golden(golden_dir):
+    """oracle/torch_swin_step.py::TorchSwinStep (float64; the Swin branch in chunks of 3 of the 4 samples: a no-grad feature pass,
+    then every chunk recomputed with autograd) against the two-step golden of the composition assembled from the imported
+    reference classes (tests/golden/make_golden.py::_SwinDGL; main_dgl.py:97-154)."""
+    import json
+
+    from oracle.torch_swin_step import TorchSwinStep
+
+    g = np.load(os.path.join(golden_dir, "dgl_swin_tiny_b4.npz"))
+    cfg = json.loads(str(g["config"]))
+    P, Bf = fx.swin_dgl_state(cfg["n_classes"], cfg["swin"])
+    m = TorchSwinStep(P, Bf, cfg["swin"], chunk_samples=3)
+    for st in range(cfg["steps"]):
+        spec, image, label = fx.make_batch(cfg["seed"] + st, cfg["batch"], cfg["spec_hw"], cfg["frames"], cfg["image_hw"],
+                                           cfg["n_classes"])
+        r = m.train_step(spec, image, label, cfg["alpha"], cfg["lr"])
+        pre = f"s{st}."
+        lt, nt, gt = (2e-5, 2e-4, 2e-3) if st == 0 else (2e-3, 1e-3, 2e-2)  # (second step: the golden's own fp32 ReLU-flip noise)
+        for k in ("out", "out_a", "out_v"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=lt, atol=lt, err_msg=k)
+        for k in ("loss_f", "loss_a", "loss_v"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=lt * 10, atol=lt * 10, err_msg=k)
+        for k in ("total_norm", "audio_grad_sum", "visual_grad_sum"):
+            np.testing.assert_allclose(r[k], g[pre + k], rtol=nt, err_msg=k)
+        names, gn, isnone = [str(n) for n in g[pre + "grad_names"]], g[pre + "grad_norm"], g[pre + "grad_is_none"]
+        for i, n in enumerate(names):
+            if isnone[i]:
+                assert n not in r["grad_norm"]
+            else:
+                assert abs(r["grad_norm"][n] - gn[i]) <= gt * gn[i] + 1e-7, (n, r["grad_norm"][n], gn[i])
+

@@ -175,11 +175,42 @@ def test_patch_gather(dt, B, T, H):
     assert np.all(got[:, 48:] == 0)
 
 
+def _attn_ref_full(qkv, dout, table, n_img, H, W, ws, shift, nh, ld, chunk=16):
+    """float64 window attention forward + backward over ALL images, `chunk` images at a time (the images are independent; the
+    table gradient adds up): out [rows][C], dqkv [rows][3][C], dtable -- the oracle's index lists / region masks."""
+    C = nh * 32
+    tt = torch.from_numpy(table).double().requires_grad_(True)
+    idx = so.window_tokens(H, W, ws, shift)
+    nW, T = idx.shape
+    ri = so.relative_index(ws).reshape(-1)
+    mask = None
+    if shift:
+        reg = so.window_regions(H, W, ws, shift)
+        mask = torch.where(reg[:, :, None] != reg[:, None, :], -100.0, 0.0).double()[None, :, None]
+    outs, dqs = [], []
+    L_ = H * W
+    for i0 in range(0, n_img, chunk):
+        n = min(chunk, n_img - i0)
+        q = torch.from_numpy(qkv[i0 * L_:(i0 + n) * L_]).double().reshape(n, L_, 3, ld)[..., :C].reshape(n, L_, 3, nh, 32).requires_grad_(True)
+        g = q[:, idx.reshape(-1)].reshape(n, nW, T, 3, nh, 32)
+        qq, kk, vv = (g[:, :, :, i].permute(0, 1, 3, 2, 4) for i in range(3))
+        s = (qq * 32 ** -0.5) @ kk.transpose(-2, -1) + tt[ri].reshape(T, T, nh).permute(2, 0, 1)
+        if mask is not None:
+            s = s + mask
+        o = (torch.softmax(s, -1) @ vv).permute(0, 1, 3, 2, 4).reshape(n, nW * T, C)
+        o2 = torch.zeros(n, L_, C, dtype=torch.float64).index_add(1, idx.reshape(-1), o)
+        (o2 * torch.from_numpy(dout[i0 * L_:(i0 + n) * L_, :C]).double().reshape(n, L_, C)).sum().backward()
+        outs.append(o2.detach().reshape(n * L_, C))
+        dqs.append(q.grad.reshape(n * L_, 3, C))
+    return torch.cat(outs).numpy(), torch.cat(dqs).numpy(), tt.grad.numpy()
+
+
 @pytest.mark.parametrize("H,nh,ld,shift", [(56, 3, 128, 3), (28, 6, 192, 3), (14, 12, 384, 0), (7, 24, 768, 0)])
 def test_window_attention_config5_size(H, nh, ld, shift):
-    """The bf16 window attention (csrc/swin_attn7.hip) at config 5's own launch sizes -- 192 frames, the four Swin-T stages: the
-    launches whose block count exceeds one round of resident blocks take the larger window chunks -- against the library's float32
-    kernels on the same (bf16-representable) inputs, which the test above pins to the float64 formulas at small sizes."""
+    """The window attention at config 5's own launch sizes -- 192 frames, the four Swin-T stages: the launches whose block count
+    exceeds one round of resident blocks take the larger window chunks -- BOTH the float32 kernels (csrc/swin.hip) and the bf16
+    ones (csrc/swin_attn7.hip) against the float64 formulas of the oracle's index lists over all 192 images (VERDICT r4 weak #2:
+    this test compared bf16 with the library's float32 kernels only): output rows, the QKV gradient, the table gradient."""
     n_img, ws = 192, 7
     rows, C = n_img * H * H, nh * 32
     g = torch.Generator(device=DEV).manual_seed(H)
@@ -189,8 +220,9 @@ def test_window_attention_config5_size(H, nh, ld, shift):
     dout = torch.zeros(rows, ld, device=DEV)
     dout[:, :C] = torch.randn(rows, C, device=DEV, generator=g).bfloat16().float()
     table = 0.5 * torch.randn((2 * ws - 1) ** 2, nh, device=DEV, generator=g)
+    want_o, want_dq, want_dt = _attn_ref_full(qkv.cpu().numpy(), dout.cpu().numpy(), table.cpu().numpy(), n_img, H, H, ws, shift, nh, ld)
+    sq, st_ = max(1.0, float(np.abs(want_dq).max())), max(1.0, float(np.abs(want_dt).max()))
     st = L.cur_stream()
-    res = {}
     for dt in ("f32", "bf16"):
         dc, td = L.dtype_code(dt), _td(dt)
         q, d = qkv.to(td), dout.to(td)
@@ -201,13 +233,13 @@ def test_window_attention_config5_size(H, nh, ld, shift):
         L.call("gdl_swin_attn_fwd", dc, L.ptr(q), L.ptr(table), L.ptr(out), n_img, H, H, ws, shift, nh, ld, st)
         L.call("gdl_swin_attn_bwd", dc, L.ptr(q), L.ptr(table), L.ptr(d), L.ptr(dq), L.ptr(dtab), L.ptr(wsb), n_img, H, H, ws, shift, nh, ld, st)
         torch.cuda.synchronize()
-        res[dt] = (out.float(), dq.float(), dtab)
-    (o32, q32, t32), (o16, q16, t16) = res["f32"], res["bf16"]
-    assert not torch.isnan(o16).any() and not torch.isnan(q16).any()
-    assert float((o16 - o32).abs().max()) < 3e-2 and bool((o16[:, C:] == 0).all())
-    assert float((q16 - q32).abs().max()) < 4e-2 * max(1.0, float(q32.abs().max()))
-    assert bool((q16.reshape(rows, 3, ld)[:, :, C:] == 0).all())
-    assert float((t16 - t32).abs().max()) < 2e-2 * max(1.0, float(t32.abs().max()))
+        o, gq, gt = out.float().cpu().numpy(), dq.float().cpu().numpy().reshape(rows, 3, ld), dtab.cpu().numpy()
+        assert not np.isnan(o).any() and not np.isnan(gq).any()
+        eo, eq, et = float(np.abs(o[:, :C] - want_o).max()), float(np.abs(gq[..., :C] - want_dq).max()) / sq, float(np.abs(gt - want_dt).max()) / st_
+        print(f"attention {H}x{H} x 192 {dt} vs float64: out {eo:.2e}, dqkv {eq:.2e}, dtable {et:.2e}")
+        # (the table gradient is a sum over 192 images x windows: fp32 accumulation in fixed order, its bound scales with the sum)
+        assert eo < _tol(dt, 3e-6, 3e-2) and eq < _tol(dt, 1e-5, 4e-2) and et < _tol(dt, 2e-4, 6e-2), (dt, eo, eq, et)
+        assert np.all(o[:, C:] == 0) and np.all(gq[..., C:] == 0)
 
 
 @pytest.mark.parametrize("dt", DTS)

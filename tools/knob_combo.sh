@@ -5,9 +5,6 @@ for l in sys.stdin:
     if l.startswith('{'): print(json.loads(l)['ms_per_step'])"); echo "$label $out"; }
 for r in 1 2 3; do
 run "base      " X=1
-run "all4      " GDL_SLAB_BN128_MIN=384 GDL_WGRAD9_BLOCKS=192 GDL_WGRAD9_MINST=16 GDL_WGRAD_BLOCKS=128
-run "bn384+wg128" GDL_SLAB_BN128_MIN=384 GDL_WGRAD_BLOCKS=128
-run "w9 192/16 " GDL_WGRAD9_BLOCKS=192 GDL_WGRAD9_MINST=16
 run "minst16   " GDL_WGRAD9_MINST=16
 run "wg128     " GDL_WGRAD_BLOCKS=128
 done

@@ -15,9 +15,6 @@ for l in sys.stdin:
 run "base                 " X=1
 run "base (again)         " X=1
 for v in 0 2 3; do run "SLAB_CFG=$v            " GDL_SLAB_CFG=$v; done
-for v in 64 256 512; do run "SLAB_BIG_MIN=$v       " GDL_SLAB_BIG_MIN=$v; done
-for v in 96 192 384 100000; do run "SLAB_BN128_MIN=$v    " GDL_SLAB_BN128_MIN=$v; done
-for v in 128 192 320 384; do run "WGRAD9_BLOCKS=$v      " GDL_WGRAD9_BLOCKS=$v; done
 for v in 4 12 16; do run "WGRAD9_MINST=$v        " GDL_WGRAD9_MINST=$v; done
 for v in 128 256 512; do run "WGRAD_BLOCKS=$v        " GDL_WGRAD_BLOCKS=$v; done
 for v in 1 4; do run "CONV_CFG=$v             " GDL_CONV_CFG=$v; done
