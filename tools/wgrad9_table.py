@@ -76,9 +76,13 @@ def main():
         k_us = us.get("gdl::conv_wgrad9_kernel", float("nan"))
         f_us = us.get("gdl::wgrad9_reduce_kernel", float("nan"))
         tiles = (K // 64) * (C // 64)
-        slices = nb // (K * 9 * C * 4)
+        # csrc/conv_wgrad9.hip plan_w9 restated (256 blocks aimed at, at least 36 stages per slice); the workspace query above is
+        # the larger of this and the per-tap kernel's need
+        ns = max(1, min((256 + tiles - 1) // tiles, (M + 36 * 64 - 1) // (36 * 64)))
+        chunk = ((M + ns - 1) // ns + 63) // 64 * 64
+        slices = (M + chunk - 1) // chunk
         stages = (M + 63) // 64
-        per = (stages + slices - 1) // slices
+        per = chunk // 64
         last = stages - per * (slices - 1)
         blocks = tiles * slices
         flops = 2.0 * M * K * C * 9
