@@ -82,16 +82,18 @@ __global__ __launch_bounds__(256) void grad_stats_kernel(const float* __restrict
 
 // stats[0] total_norm (pre-clip, after grad_scale), [1] clip_coef, [2] audio_sum, [3] visual_sum,
 // [4+s] post-clip L2 norm of segment s, [4+nseg+s] post-clip mean|g| of segment s.
-__global__ __launch_bounds__(256) void grad_stats_final_kernel(const double* __restrict__ partial,
+constexpr int FIN_NT = 1024;
+__global__ __launch_bounds__(FIN_NT) void grad_stats_final_kernel(const double* __restrict__ partial,
                                                                const int32_t* __restrict__ segrange,
                                                                const double* __restrict__ segnumel, int nseg,
                                                                float max_norm, float grad_scale, float* __restrict__ stats,
                                                                double* __restrict__ segsum /*[nseg][2] scratch*/) {
-    __shared__ double sh[3][256];
+    __shared__ double sh[3][FIN_NT];
     // A 16-lane group per segment (a layer-4 convolution has 288 chunk partials: one thread adding them serially
-    // took 47 us): lane l adds chunks l, l+16, ..., the 16 lanes are folded in a fixed order.
+    // took 47 us): lane l adds chunks l, l+16, ..., the 16 lanes are folded in a fixed order.  Round 5: 1024 threads = 64 groups
+    // (the 122 segments in two rounds instead of eight: this launch sits alone between the last gradient and the update, 18 us).
     const int grp16 = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-    for (int s = grp16; s < nseg; s += 16) {
+    for (int s = grp16; s < nseg; s += FIN_NT / 16) {
         const int first = segrange[s * 4 + 0], cnt = segrange[s * 4 + 1];
         double a = 0.0, b = 0.0;
         for (int k = l16; k < cnt; k += 16) {
@@ -110,10 +112,10 @@ __global__ __launch_bounds__(256) void grad_stats_final_kernel(const double* __r
     }
     __syncthreads();  // (segsum is global memory written and read by this one block)
     double tot = 0.0;
-    for (int s = threadIdx.x; s < nseg; s += 256) tot += segsum[s * 2 + 0];
+    for (int s = threadIdx.x; s < nseg; s += FIN_NT) tot += segsum[s * 2 + 0];
     sh[0][threadIdx.x] = tot;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = FIN_NT / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
         __syncthreads();
     }
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void grad_stats_final_kernel(const double* __r
     if (coef > 1.0) coef = 1.0;
     __syncthreads();
     double au = 0.0, vi = 0.0;
-    for (int s = threadIdx.x; s < nseg; s += 256) {
+    for (int s = threadIdx.x; s < nseg; s += FIN_NT) {
         const double l2 = sqrt(segsum[s * 2 + 0]) * (double)grad_scale * coef;
         const double am = segsum[s * 2 + 1] / segnumel[s] * (double)grad_scale * coef;
         stats[4 + s] = (float)l2;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void grad_stats_final_kernel(const double* __r
     sh[1][threadIdx.x] = au;
     sh[2][threadIdx.x] = vi;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = FIN_NT / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
             sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
@@ -281,7 +283,7 @@ int gdl_optim_grad_stats(gdl_optim_t* o, const float* grads, float max_norm, flo
         hipLaunchKernelGGL(grad_stats_kernel, dim3(o->nchunks), dim3(256), 0, st, grads, (const ChunkDesc*)w, partial);
     }
     GDL_CHECK_LAUNCH("grad_stats_kernel");
-    hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial,
+    hipLaunchKernelGGL(grad_stats_final_kernel, dim3(1), dim3(FIN_NT), 0, st, (const double*)partial,
                        (const int32_t*)(w + o->off_segrange), (const double*)(w + o->off_segnumel), o->nseg, max_norm, grad_scale,
                        stats, segsum);
     GDL_CHECK_LAUNCH("grad_stats_final_kernel");

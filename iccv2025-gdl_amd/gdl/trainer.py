@@ -98,11 +98,13 @@ class DGLTrainer:
         # own stream right behind its forward and the backward starts without waiting for the other encoder; the fusion
         # head (logits of all three sets, the losses, fc_out's gradient) follows on the audio stream behind the audio backward.
         # Same numbers bit for bit (tests/test_step_gpu.py::test_early_backward_identical), no forward -> head -> backward junction.
-        # With a process group None means OFF: the early form issues the collectives in a different order (audio_l4, visual_l4,
-        # audio_rest, fusion, visual_rest over two streams) that no multi-GPU run has exercised yet -- opt in with True.
+        # With a process group the early form issues the collectives in the order audio_l4, visual_l4, audio_rest, fusion,
+        # visual_rest (over two streams; the same host code, hence the same order, on every rank).  Round 5: it is the default
+        # there too -- the one-rank proxy reads 5.85 against 5.92 ms (round 4), with emulated collective traffic on a stream of
+        # its own 6.18-6.19 against 6.30-6.31 ms (tools/pg_variants.py --emulate-traffic 16, profiles/r05_pg_variants.txt); the
+        # two- and four-rank step tests (tests/test_ddp_gpu.py) run both forms against the oracle.  `bench.py --gpus N` still
+        # times every variant on first contact with real RCCL traffic (comm.schedule_variants_ms); early_backward=False opts out.
         self.early_backward = early_backward
-        if early_backward is None and process_group is not None:
-            self.early_backward = False
         if early_backward is None and os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_EARLY_BWD") == "0":
             self.early_backward = False  # tuning aid (A/B)
         self.dtype = dtype if dtype is not None else model.audio_net.gdl_dtype
