@@ -171,6 +171,18 @@ struct DevOnce {
     }
 };
 
+// XCD-aware linear work index.  Block b runs on XCD b % 8; the `total` work items of a launch are cut into 8 consecutive runs of
+// ceil(total / 8), one per XCD, so neighbours in the linear order (the tiles of one pixel slice or M-tile) share an L2 AND every XCD
+// gets its share when the outer count is small or does not divide by 8 (round 5: the 512-channel weight gradients have 4 / 2 pixel
+// slices of 64 tiles -- cut by slices they ran two blocks per CU on 4 / 2 XCDs and none on the others).  -1: no work for this
+// block.  Grid = xcd_grid(total).
+__device__ __forceinline__ int xcd_linear(int total) {
+    const int per = (total + 7) >> 3;
+    const int L = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    return L < total ? L : -1;
+}
+static inline int xcd_grid(int total) { return ((total + 7) / 8) * 8; }
+
 #define GDL_CHECK_LAUNCH(name)                                  \
     do {                                                        \
         hipError_t e__ = hipGetLastError();                     \

@@ -529,11 +529,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // ---- tile mapping: consecutive M-tiles stay on one XCD (block b runs on XCD b%8), all
     // N-tiles of an M-tile are neighbours on that XCD, so the input halo and the A panel hit L2
     const int ntn = a.OC / BN;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int mt_per_xcd = (a.mtiles + 7) >> 3;
-    const int slot = xcd * mt_per_xcd + j / ntn;
-    const int ntile = j % ntn;
-    if (slot >= a.mtiles) return;
+    const int L = xcd_linear(a.mtiles * ntn);  // (common.h: every XCD gets an eighth of the tiles)
+    if (L < 0) return;
+    const int slot = L / ntn, ntile = L - slot * ntn;
     const int mtile = a.tile_order ? a.tile_order[slot] : slot;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
@@ -1027,12 +1025,10 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 2 : ((BM >= 192 && BN == 128
     const int wm = wave & 3, wn = wave >> 2;
     const int ntn = a.OC / BN;
     const int nsplit = a.ksplit > 1 ? a.ksplit : 1;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int mt_per_xcd = (a.mtiles + 7) >> 3;
-    const int mtile = xcd * mt_per_xcd + j / (ntn * nsplit);
-    const int jr = j % (ntn * nsplit);
+    const int L = xcd_linear(a.mtiles * ntn * nsplit);
+    if (L < 0) return;
+    const int mtile = L / (ntn * nsplit), jr = L - mtile * (ntn * nsplit);
     const int ntile = jr % ntn, split = jr / ntn;  // (the splits of a tile are neighbours on one XCD)
-    if (mtile >= a.mtiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
     GDL_STAMP(0);
 #ifdef GDL_TIMING
@@ -1781,7 +1777,7 @@ static int launch_one(ConvArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int ntn = a.OC / BN;
-    const int grid = ((a.mtiles + 7) / 8) * 8 * ntn;
+    const int grid = xcd_grid(a.mtiles * ntn);
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv_igemm_kernel<%s, %d, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, WM, WN, MODE);
@@ -1801,7 +1797,7 @@ static int launch_slab(ConvArgs& a, size_t lds, hipStream_t st) {
         if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_slab)");
         attr_set = true;
     }
-    const int grid = ((a.mtiles + 7) / 8) * 8 * (a.OC / BN) * (a.ksplit > 1 ? a.ksplit : 1);
+    const int grid = xcd_grid(a.mtiles * (a.OC / BN) * (a.ksplit > 1 ? a.ksplit : 1));
     static char pname[96] = "";
     if (!pname[0])
         snprintf(pname, sizeof(pname), "gdl::conv3x3_slab_kernel<%s, %d, %d, %d, %d>", prof_tname<T>(), BM, BN, MODE, NWV);

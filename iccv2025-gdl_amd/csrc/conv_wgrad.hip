@@ -108,11 +108,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     // channel tiles of one pixel slice on it
     const int RS = a.RS;
     const int per_slice = RS * a.tiles_k * a.tiles_c;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int slices_per_xcd = (a.nsplit + 7) >> 3;
-    const int slice = xcd * slices_per_xcd + j / per_slice;
-    if (slice >= a.nsplit) return;
-    int rem = j % per_slice;
+    const int L = xcd_linear(a.nsplit * per_slice);
+    if (L < 0) return;
+    const int slice = L / per_slice;
+    int rem = L - slice * per_slice;
     const int tap = rem % RS;
     rem /= RS;
     const int kt = rem % a.tiles_k, ct = rem / a.tiles_k;
@@ -419,7 +418,7 @@ static int launch_wg(WgradArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int per_slice = a.RS * a.tiles_k * a.tiles_c;
-    const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
+    const int grid = xcd_grid(a.nsplit * per_slice);
     static char pname[96] = "";
     if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv_wgrad_kernel<%s, %d, %d>", prof_tname<T>(), TK, TC);
     ProfScope prof(pname, PROF_MFMA, st, 2.0 * (double)a.M * a.K * a.C * a.RS, true,

@@ -109,13 +109,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad9_kernel(Wgrad9Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
 
-    // block -> (slice, ktile, ctile); the tiles of one pixel slice are neighbours on one XCD
+    // block -> (slice, ktile, ctile); the tiles of one pixel slice are neighbours on one XCD (or two / four when there are fewer
+    // slices than XCDs: xcd_linear, common.h)
     const int per_slice = a.tiles_k * a.tiles_c;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int slices_per_xcd = (a.nsplit + 7) >> 3;
-    const int slice = xcd * slices_per_xcd + j / per_slice;
-    if (slice >= a.nsplit) return;
-    const int rem = j % per_slice;
+    const int L = xcd_linear(a.nsplit * per_slice);
+    if (L < 0) return;
+    const int slice = L / per_slice, rem = L - slice * per_slice;
     const int kt = rem % a.tiles_k, ct = rem / a.tiles_k;
     const int k0 = kt * 64, c0 = ct * 64;
     const int m_begin = slice * a.chunk;
@@ -602,7 +601,7 @@ int conv_wgrad9(const void* dy, const void* x, float* dw, const void* table, int
         attr_set[ring] = true;
     }
     const int per_slice = a.tiles_k * a.tiles_c;
-    const int grid = ((a.nsplit + 7) / 8) * 8 * per_slice;
+    const int grid = xcd_grid(a.nsplit * per_slice);
     {
         // (algorithmic bytes: dy and x once + the fp32 result; the partials and their fold are overhead, not algorithm)
         ProfScope prof("gdl::conv_wgrad9_kernel", PROF_MFMA, st, 2.0 * (double)a.M * K * C * 9, true,
