@@ -171,7 +171,7 @@ int head_concat_bwd(const float* x, const float* y, const float* W, const float*
 // grid = (B, ceil(n / HXY_CH)): a block's four waves own HXY_CH classes of one sample (64 blocks walking all 309 classes of
 // ConcatFusion_Swin's head, reloading the sample's features for every class, took 550 us); per class the sums run over
 // i = lane, lane + 64, ... and the xor butterfly as before.
-constexpr int HXY_CH = 32;
+constexpr int HXY_CH = 8;
 __global__ __launch_bounds__(256) void head_xy_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           float* __restrict__ out, float* __restrict__ x_out,
@@ -187,10 +187,14 @@ __global__ __launch_bounds__(256) void head_xy_fwd_kernel(const float* __restric
             ys[v] = lane + 64 * v < dyw ? y[(size_t)b * dyw + lane + 64 * v] : 0.f;
         }
     }
+    // (round 5: two classes per wave at a time -- their loads and butterflies overlap -- and 8 classes per block: 36 us at
+    // 64 x 309 x 1280 against 63 with 32 classes per block walked one by one)
     const int j1 = min(n, ((int)blockIdx.y + 1) * HXY_CH);
-    for (int j = blockIdx.y * HXY_CH + wave; j < j1; j += 4) {
+    for (int j = blockIdx.y * HXY_CH + wave; j < j1; j += 8) {
+        const int j2 = j + 4 < j1 ? j + 4 : j;
         const float* w = W + (size_t)j * (dxw + dyw);
-        float pa = 0.f, pv = 0.f;
+        const float* w2 = W + (size_t)j2 * (dxw + dyw);
+        float pa = 0.f, pv = 0.f, qa = 0.f, qv = 0.f;
         if (reg) {
 #pragma unroll
             for (int v = 0; v < MAXV; ++v)
@@ -198,19 +202,34 @@ __global__ __launch_bounds__(256) void head_xy_fwd_kernel(const float* __restric
 #pragma unroll
             for (int v = 0; v < MAXV; ++v)
                 if (lane + 64 * v < dyw) pv += w[dxw + lane + 64 * v] * ys[v];
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v)
+                if (lane + 64 * v < dxw) qa += w2[lane + 64 * v] * xs[v];
+#pragma unroll
+            for (int v = 0; v < MAXV; ++v)
+                if (lane + 64 * v < dyw) qv += w2[dxw + lane + 64 * v] * ys[v];
         } else {
             for (int i = lane; i < dxw; i += 64) pa += w[i] * x[(size_t)b * dxw + i];
             for (int i = lane; i < dyw; i += 64) pv += w[dxw + i] * y[(size_t)b * dyw + i];
+            for (int i = lane; i < dxw; i += 64) qa += w2[i] * x[(size_t)b * dxw + i];
+            for (int i = lane; i < dyw; i += 64) qv += w2[dxw + i] * y[(size_t)b * dyw + i];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             pa += __shfl_xor(pa, o);
             pv += __shfl_xor(pv, o);
+            qa += __shfl_xor(qa, o);
+            qv += __shfl_xor(qv, o);
         }
         if (lane == 0) {
             out[(size_t)b * n + j] = pa + pv + bias[j];
             if (x_out) x_out[(size_t)b * n + j] = pa + bias[j];
             if (y_out) y_out[(size_t)b * n + j] = pv + bias[j];
+            if (j2 != j) {
+                out[(size_t)b * n + j2] = qa + qv + bias[j2];
+                if (x_out) x_out[(size_t)b * n + j2] = qa + bias[j2];
+                if (y_out) y_out[(size_t)b * n + j2] = qv + bias[j2];
+            }
         }
     }
 }
@@ -321,27 +340,33 @@ int head_sum_bwd(const float* x, const float* y, const float* Wx, const float* W
 // A wave per sample (samples b = wave, wave + 4, ...): the lanes evaluate the exponentials, lane 0 adds them in class order --
 // every sum in the order of the first form of this function (one THREAD per sample walking the classes twice with expf in the
 // dependent chain: 141 us at 64 samples x 309 classes, three blocks busy), so losses and gradients keep their bits.
+// Round 5: the block has 1024 threads and the wave form runs on up to 16 waves (as many as fit the 32 KiB of staged
+// exponentials, a power of two so that samples b and b + 256 stay with one wave): 93 -> 31 us at 64 x 309 on the step's tail.
 constexpr int CE_MAXN = 1024;  // classes the wave form stages in LDS (beyond: the thread-per-sample walk)
+constexpr int CE_EX = 8192;    // floats of staged exponentials
 __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                          float scale, float* __restrict__ loss, float* __restrict__ dlogits,
                                                          int B, int n) {
     __shared__ float part[256];
-    __shared__ float ex[4][CE_MAXN];
-    part[threadIdx.x] = 0.f;
+    __shared__ float ex[CE_EX];
+    if (threadIdx.x < 256) part[threadIdx.x] = 0.f;
     __syncthreads();
     if (n >= 64 && n <= CE_MAXN) {  // (few classes: a thread per sample is the faster walk -- 6 us against 24 at 64 x 6; same bits)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int b = wave; b < B; b += 4) {  // (b, b + 256, ... belong to the same wave, ascending: part[b % 256] sums in the old order)
+        int aw = min((int)(blockDim.x >> 6), CE_EX / n);  // active waves: 16, 8 (n > 512)
+        aw = aw >= 16 ? 16 : (aw >= 8 ? 8 : 4);
+        float* exw = ex + wave * n;
+        for (int b = wave; b < B && wave < aw; b += aw) {  // (b, b + 256, ... belong to the same wave, ascending: part[b % 256] sums in the old order)
             const float* l = logits + (size_t)b * n;
             float mx = -INFINITY;
             for (int j = lane; j < n; j += 64) mx = fmaxf(mx, l[j]);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            for (int j = lane; j < n; j += 64) ex[wave][j] = expf(l[j] - mx);
+            for (int j = lane; j < n; j += 64) exw[j] = expf(l[j] - mx);
             __builtin_amdgcn_wave_barrier();
             float se = 0.f;
             if (lane == 0)
-                for (int j = 0; j < n; ++j) se += ex[wave][j];
+                for (int j = 0; j < n; ++j) se += exw[j];
             se = __shfl(se, 0);
             const float lse = mx + logf(se);
             const long lab64 = (long)labels[b];
@@ -353,7 +378,7 @@ __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logit
                     dlogits[(size_t)b * n + j] = scale * (expf(l[j] - lse) - (j == lab ? 1.f : 0.f)) / (float)B;
             __builtin_amdgcn_wave_barrier();
         }
-    } else {
+    } else if (threadIdx.x < 256) {
         float acc = 0.f;
         for (int b = threadIdx.x; b < B; b += 256) {
             const float* l = logits + (size_t)b * n;
@@ -394,42 +419,79 @@ __device__ __forceinline__ void softmax_ce_block(const float* __restrict__ logit
 // (main_dgl.py:102-122), so its backward need not wait for the other encoder's forward: DGLTrainer launches this on the
 // encoder's own stream right behind its forward.  grid = B.  Every sum runs in the order head_fwd_kernel, softmax_ce_block and
 // head_bwd_feat_kernel use: df is bit-identical to the three-launch path.
+// Round 5: 16 waves per sample and no serial walk beyond the sums whose order is the contract (at 309 classes x 768 features
+// the four-wave form -- 78 classes per wave one after the other, thread 0 alone through max / exp / sum, 927 dependent
+// loads per thread for df -- took 113-131 us ON the chain between an encoder's forward and its backward): the classes go
+// round the 16 waves two at a time, max and exp are evaluated by all threads (max is exact in any order; the exponentials
+// are the same values) and only their SUM is walked in class order by one thread, df keeps its ascending walk per feature
+// with eight weight loads in flight.  113 -> 28 us there (kernel trace, in the step).
 template <int ND>  // feature width = 64 ND
-__global__ __launch_bounds__(256) void head_uni_dfeat_kernel(const float* __restrict__ f, const float* __restrict__ Wp, int ldw,
-                                                            const float* __restrict__ bp, const int64_t* __restrict__ labels,
-                                                            float scale, float* __restrict__ df, int B, int n) {
-    constexpr int D = 64 * ND;
-    __shared__ float lg[512], dl[512];
+__global__ __launch_bounds__(1024) void head_uni_dfeat_kernel(const float* __restrict__ f, const float* __restrict__ Wp, int ldw,
+                                                             const float* __restrict__ bp, const int64_t* __restrict__ labels,
+                                                             float scale, float* __restrict__ df, int B, int n) {
+    constexpr int D = 64 * ND, NW = 16;
+    __shared__ float lg[512], dl[512], ex[512];
+    __shared__ float wmx[NW];
     __shared__ float lse_s;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float fv[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) fv[i] = f[(size_t)b * D + lane + 64 * i];
-    for (int j = wave; j < n; j += 4) {
+    for (int j = wave; j < n; j += 2 * NW) {
+        const int j2 = j + NW;
         const float* w = Wp + (size_t)j * ldw;
-        float pa = 0.f;
+        const float* w2 = Wp + (size_t)(j2 < n ? j2 : j) * ldw;
+        float pa = 0.f, pb = 0.f;
 #pragma unroll
         for (int i = 0; i < ND; ++i) pa += w[lane + 64 * i] * fv[i];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o);
-        if (lane == 0) lg[j] = pa + bp[j];
+        for (int i = 0; i < ND; ++i) pb += w2[lane + 64 * i] * fv[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            pa += __shfl_xor(pa, o);
+            pb += __shfl_xor(pb, o);
+        }
+        if (lane == 0) {
+            lg[j] = pa + bp[j];
+            if (j2 < n) lg[j2] = pb + bp[j2];
+        }
     }
     __syncthreads();
+    {
+        float mx = -INFINITY;
+        for (int j = threadIdx.x; j < n; j += 1024) mx = fmaxf(mx, lg[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) wmx[wave] = mx;
+    }
+    __syncthreads();
+    float mx = wmx[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, wmx[w]);
+    for (int j = threadIdx.x; j < n; j += 1024) ex[j] = expf(lg[j] - mx);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        float mx = lg[0];
-        for (int j = 1; j < n; ++j) mx = fmaxf(mx, lg[j]);
         float se = 0.f;
-        for (int j = 0; j < n; ++j) se += expf(lg[j] - mx);
+        for (int j = 0; j < n; ++j) se += ex[j];
         lse_s = mx + logf(se);
     }
     __syncthreads();
     const long lab64 = (long)labels[b];
     const int lab = (lab64 >= 0 && lab64 < n) ? (int)lab64 : -1;
-    for (int j = threadIdx.x; j < n; j += 256) dl[j] = scale * (expf(lg[j] - lse_s) - (j == lab ? 1.f : 0.f)) / (float)B;
+    for (int j = threadIdx.x; j < n; j += 1024) dl[j] = scale * (expf(lg[j] - lse_s) - (j == lab ? 1.f : 0.f)) / (float)B;
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256) {
+    for (int i = threadIdx.x; i < D; i += 1024) {
+        const float* w = Wp + i;
         float s2 = 0.f;
-        for (int j = 0; j < n; ++j) s2 += dl[j] * Wp[(size_t)j * ldw + i];
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            float q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = w[(size_t)(j + u) * ldw];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s2 += dl[j + u] * q[u];
+        }
+        for (; j < n; ++j) s2 += dl[j] * w[(size_t)j * ldw];
         df[(size_t)b * D + i] = s2;
     }
 }
@@ -439,11 +501,11 @@ int head_uni_dfeat(const float* f, const float* Wp, int ldw, const float* bp, co
     GDL_REQUIRE(width == 512 || width == 768 || width == 1024, "head_uni_dfeat: feature width %d (512, 768 or 1024)", width);
     ProfScope prof("gdl::head_uni_dfeat_kernel", PROF_HBM, st, (double)B * width * 8.0 + (double)n * width * 4.0);
     if (width == 512)
-        hipLaunchKernelGGL(head_uni_dfeat_kernel<8>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+        hipLaunchKernelGGL(head_uni_dfeat_kernel<8>, dim3(B), dim3(1024), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
     else if (width == 768)
-        hipLaunchKernelGGL(head_uni_dfeat_kernel<12>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+        hipLaunchKernelGGL(head_uni_dfeat_kernel<12>, dim3(B), dim3(1024), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
     else
-        hipLaunchKernelGGL(head_uni_dfeat_kernel<16>, dim3(B), dim3(256), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
+        hipLaunchKernelGGL(head_uni_dfeat_kernel<16>, dim3(B), dim3(1024), 0, st, f, Wp, ldw, bp, labels, scale, df, B, n);
     GDL_CHECK_LAUNCH("head_uni_dfeat_kernel");
     return GDL_OK;
 }
@@ -675,7 +737,7 @@ struct CeSets {
     float* dlogits[4];
     float scale[4];
 };
-__global__ __launch_bounds__(256) void softmax_ce_kernel(CeSets s, const int64_t* __restrict__ labels, float* __restrict__ loss,
+__global__ __launch_bounds__(1024) void softmax_ce_kernel(CeSets s, const int64_t* __restrict__ labels, float* __restrict__ loss,
                                                          int B, int n) {
     const int k = blockIdx.x;
     softmax_ce_block(s.logits[k], labels, s.scale[k], loss + k, s.dlogits[k], B, n);
@@ -688,7 +750,7 @@ int softmax_ce_multi(int nsets, const float* const* logits, const int64_t* label
         s.dlogits[k] = dlogits ? dlogits[k] : nullptr;
         s.scale[k] = scales[k];
     }
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(nsets), dim3(256), 0, st, s, labels, losses, B, n);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(nsets), dim3(n >= 64 && n <= CE_MAXN ? 1024 : 256), 0, st, s, labels, losses, B, n);
     GDL_CHECK_LAUNCH("softmax_ce_kernel");
     return GDL_OK;
 }

@@ -867,6 +867,40 @@ __global__ __launch_bounds__(256) void swin_token_mean_kernel(const T* __restric
         y[(size_t)n * C + c] = s / (float)L;
     }
 }
+// The same mean with 16-byte loads and the tokens spread over the block (round 5: the per-channel walk above is L dependent
+// 2-byte loads per thread on 64 blocks -- 137 us at 64 x 147 x 768, on the Swin chain between its forward and its backward;
+// this form: 5 us).
+// grid = (ceil(C / (8 EPC)), N): thread (tl = tid >> 3, ch = tid & 7) adds tokens tl, tl + 32, ... of its 16-byte chunk in
+// ascending order, then the 32 token lanes are folded in ascending order through LDS: a fixed order, not the walk's.
+template <typename T>
+__global__ __launch_bounds__(256) void swin_token_mean_vec_kernel(const T* __restrict__ x, float* __restrict__ y, int L, int C, int ld) {
+    constexpr int EPC = TT<T>::EPC;
+    __shared__ float red[32][8 * EPC + 1];
+    const int n = blockIdx.y, ch = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    const int c0 = (blockIdx.x * 8 + ch) * EPC;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    if (c0 < C) {
+        const T* p = x + (size_t)n * L * ld + c0;
+        for (int l = tl; l < L; l += 32) {
+            float f[EPC];
+            unpack16<T>(*(const uint4*)(p + (size_t)l * ld), f);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[tl][ch * EPC + e] = acc[e];
+    __syncthreads();
+    const int c = blockIdx.x * 8 * EPC + threadIdx.x;
+    if (threadIdx.x < 8 * EPC && c < C) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 32; ++t) s += red[t][threadIdx.x];
+        y[(size_t)n * C + c] = s / (float)L;
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void swin_token_mean_bwd_kernel(const float* __restrict__ dy, T* __restrict__ dx, int N, int L,
                                                                   int C, int ld) {
@@ -1287,6 +1321,14 @@ int swin_merge(int dt, const void* src, void* dst, int N, int H, int W, int C, i
 }
 
 int swin_token_mean(int dt, const void* x, float* y, int N, int L, int C, int ld, hipStream_t st) {
+    const int epc = dt == GDL_BF16 ? 8 : 4;
+    if (C % epc == 0 && ld % epc == 0 && ((uintptr_t)x & 15) == 0) {  // whole 16-byte chunks: the vector form
+        const dim3 grid((unsigned)((C + 8 * epc - 1) / (8 * epc)), (unsigned)N);
+        SW_DISPATCH(dt, hipLaunchKernelGGL(swin_token_mean_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)x, y, L, C, ld),
+                    hipLaunchKernelGGL(swin_token_mean_vec_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, y, L, C, ld));
+        GDL_CHECK_LAUNCH("swin_token_mean_vec_kernel");
+        return GDL_OK;
+    }
     SW_DISPATCH(dt, hipLaunchKernelGGL(swin_token_mean_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)x, y, L, C, ld),
                 hipLaunchKernelGGL(swin_token_mean_kernel<bf16>, dim3(N), dim3(256), 0, st, (const bf16*)x, y, L, C, ld));
     GDL_CHECK_LAUNCH("swin_token_mean_kernel");

@@ -1,0 +1,7 @@
+#!/bin/bash
+O=gpurun_out/r5q; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --output-format csv -d $O/kt -o kt -- python3 bench.py --workload vggsound_swin --steps 4 --warmup 2 --no-cpu-baseline --no-f32 --no-prof --no-extra --no-comparator > $O/kt_stdout.log 2>&1
+python3 tools/grid_audit.py $O/kt --steps 6 > $O/grid_audit_swin.txt 2>&1
+python3 tools/trace_window.py $O/kt > $O/window_swin.txt 2>&1
+rm -rf $O/kt
