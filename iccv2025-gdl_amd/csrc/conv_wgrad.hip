@@ -375,7 +375,7 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS, bool gemm = false) {
     p.tc = (C % 128 == 0) ? 128 : 64;
     const int tiles = (K / p.tk) * (C / p.tc) * RS;
     // Every block leaves a TKxTC fp32 partial tile, so partial traffic = blocks x 16..64 KB; at least 2 stages of work per
-    // block, split count a multiple of 8 (XCD mapping).  Target block count: 128 inside the ResNet step, where these
+    // block.  Target block count: 128 inside the ResNet step, where these
     // weight gradients (stride-2 3x3, 1x1 downsample) run on the side stream beside the data-gradient chain (knob sweep of
     // round 2: 6.18 -> 6.14 ms against 384); 384 -- one resident wave of blocks -- for the plain GEMMs (1x1, stride 1: the
     // Swin encoder's Linears), which have the device to themselves.  GDL_WGRAD_BLOCKS overrides both (tuning aid).
@@ -389,7 +389,9 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS, bool gemm = false) {
     const int max_ns = (M + 2 * WG_BP - 1) / (2 * WG_BP);
     if (ns > max_ns) ns = max_ns;
     if (ns < 1) ns = 1;
-    ns = (ns + 7) / 8 * 8;
+    // (the split count was rounded up to a multiple of 8 while whole slices were dealt to the XCDs; with the linear mapping --
+    // common.h xcd_linear -- the exact count is 0.5 % faster in the ResNet step and 1.3 % in the Swin composition, whose 36-tile
+    // weight gradients took 16 slices for 11: profiles/r05_ab_wgrad_split.txt)
     int chunk = (M + ns - 1) / ns;
     chunk = (chunk + WG_BP - 1) / WG_BP * WG_BP;
     p.nsplit = (M + chunk - 1) / chunk;
