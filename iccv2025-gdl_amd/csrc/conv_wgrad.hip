@@ -377,14 +377,22 @@ static WgradPlan plan_wgrad(int M, int C, int K, int RS, bool gemm = false) {
     // Every block leaves a TKxTC fp32 partial tile, so partial traffic = blocks x 16..64 KB; at least 2 stages of work per
     // block.  Target block count: 128 inside the ResNet step, where these
     // weight gradients (stride-2 3x3, 1x1 downsample) run on the side stream beside the data-gradient chain (knob sweep of
-    // round 2: 6.18 -> 6.14 ms against 384); 384 -- one resident wave of blocks -- for the plain GEMMs (1x1, stride 1: the
-    // Swin encoder's Linears), which have the device to themselves.  GDL_WGRAD_BLOCKS overrides both (tuning aid).
+    // round 2: 6.18 -> 6.14 ms against 384; round 5 with exact split counts: 96 / 128 / 192 / 256 within 0.3 %); about 400 -- one
+    // resident wave of blocks -- for the plain GEMMs (1x1, stride 1: the Swin encoder's Linears), which have the device to
+    // themselves (round 5, exact split counts, Swin step: 256 -> 20.71 ms, 320 -> 20.50, 352 -> 20.23, 384 -> 20.02, 416 -> 19.89,
+    // 448 -> 20.00, 512 -> 20.39, 768 -> 20.32: profiles/r05_ab_wgrad_split.txt).  GDL_WGRAD_BLOCKS overrides both,
+    // GDL_WGRAD_GEMM_BLOCKS the second (tuning aids).
     static int forced = -1;
     if (forced < 0) {
         const char* e = tune_env("GDL_WGRAD_BLOCKS");
         forced = e ? atoi(e) : 0;
     }
-    const int target = forced > 0 ? forced : (gemm ? 384 : 128);
+    static int forced_gemm = -1;
+    if (forced_gemm < 0) {
+        const char* e = tune_env("GDL_WGRAD_GEMM_BLOCKS");  // tuning aid: the plain GEMMs only
+        forced_gemm = e ? atoi(e) : 0;
+    }
+    const int target = (gemm && forced_gemm > 0) ? forced_gemm : forced > 0 ? forced : (gemm ? 416 : 128);
     int ns = (target + tiles - 1) / tiles;
     const int max_ns = (M + 2 * WG_BP - 1) / (2 * WG_BP);
     if (ns > max_ns) ns = max_ns;
