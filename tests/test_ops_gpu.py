@@ -143,7 +143,8 @@ WGRAD_SHAPES = [
     (1, 128, 40, 47, 64, 3, 1, 1),   # audio layer-1 width: the ring wraps several times per slice
     (1, 64, 9, 157, 64, 3, 1, 1),    # Kinetics-Sounds audio layer-1 width: the 512-row ring
     (2, 64, 3, 191, 128, 3, 1, 1),   # widest 512-row ring geometry (2W+2 = 384)
-    (1, 64, 3, 192, 64, 3, 1, 1),    # just past it: per-tap kernel
+    (1, 64, 3, 192, 64, 3, 1, 1),    # just past it: per-tap kernel    (24, 128, 17, 12, 128, 3, 1, 1), # 3 pixel slices x 4 tiles: fewer slices than XCDs, a slice's tiles on two XCDs (xcd_linear)
+    (40, 256, 9, 6, 256, 3, 1, 1),   # one slice of 16 tiles dealt to eight XCDs
 ]
 
 
