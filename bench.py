@@ -249,7 +249,7 @@ def extra_leg(name, a, dev, lib, collect, steps=30, warmup=15):
     torch.cuda.synchronize()
     tapped = 0
     t0 = time.perf_counter()
-    for i in range(steps):  # (the tap samples every 4th step, as in the main measurement)
+    for i in range(steps):  # (the tap samples every 4th step of these shorter runs)
         lib.gdl_prof_enable(1 if i % 4 == 0 else 0)
         tapped += i % 4 == 0
         tr.step(*data[i % 4])
@@ -407,7 +407,7 @@ def main():
     # with its neighbours on the stream the way a plain one does: tapping all 26 launches of every step costs the timed region
     # ~1.5 % (5.62 vs 5.54 ms on one box).  The tap therefore samples every TAP_EVERY-th step of the timed region (first step
     # included): the roofline figures are averages over those steps' launches, the other steps run as the job does.
-    TAP_EVERY = 4
+    TAP_EVERY = 10  # (260 tapped launches in the default 100-step run; every 4th step until round 5 cost 0.4 % of the timed region)
     tapped = 0
     torch.cuda.synchronize()
     tr.stats_log_pos = 0
