@@ -733,7 +733,10 @@ struct StemFusedArgs {
     float* partial;
     int P, Q, PP, QQ, Hp, Wp, nseg;
     int stages, chunk, nsplit;
-    unsigned x_bytes;
+    unsigned x_bytes, y_bytes, dz_bytes;  // (buffer descriptors: the tensors are below 2 GiB)
+#ifdef GDL_TIMING
+    unsigned long long* dbg;  // [block][wave][8]: entry, prologue, wait (memory + barrier), emit + issue, multiply, epilogue, stages
+#endif
 };
 typedef unsigned int sr_u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void sr_write16(unsigned addr, const uint4& v) {
@@ -814,51 +817,49 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a)
     uint2 i_e[2], i_o[4];
     bool live_e = false, live_o = false;
     const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-    const uint2 none2 = make_uint2(0xffffffffu, 0xffffffffu);
-    const unsigned char* y0b = (const unsigned char*)a.y0;
-    const unsigned char* dzb = (const unsigned char*)a.dz;
-    auto request = [&](const Coord& c) {  // global loads of the two elements of the stage at c
+    // Operand loads through buffer descriptors with 32-bit offsets (round 5, second half: as flat loads under exec-mask branches
+    // they cost ~60 VALU of 64-bit address arithmetic, ~40 moves that preset the operands of windows that do not exist and eight
+    // branches per stage in a VALU-bound kernel): a window that does not exist -- or a pixel outside the stage -- is an offset
+    // outside the descriptor, which reads as zeros: a zero gradient adds +0 whatever its (zero) code matches.  Static VALU count
+    // -18 %, 243 -> 231 us alone at the visual shape, nothing in the step (tools/bench_stem_bwd.py --cycles: a wave's stage is 680 clk of
+    // waiting, 2 850 of emit + issue -- two waves per SIMD taking turns on the VALU -- and 625 of multiplication).
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y0, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ridx = __builtin_amdgcn_make_buffer_rsrc((void*)a.idx, 0, a.dz_bytes >> 1, 0x00020000);
+    auto bl16 = [](__amdgpu_buffer_rsrc_t r, int off) __attribute__((always_inline)) {
+        const sr_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+    typedef unsigned int sr_u32x2_t __attribute__((ext_vector_type(2)));
+    auto bl8 = [](__amdgpu_buffer_rsrc_t r, int off) __attribute__((always_inline)) {
+        const sr_u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        return make_uint2(v.x, v.y);
+    };
+    constexpr int OOB = (int)0x80000000;
+    auto request = [&](const Coord& c) {  // loads of the two elements of the stage at c
         const int ow0 = min(64 * c.sg, a.Q - 64), first = 64 * c.sg - ow0;
         const int par = ow0 & 1;
         const int r_e = j2 + par, r_o = j2 + (par ^ 1);  // tile rows of the even- / odd-column pixel
         live_e = r_e >= first, live_o = r_o >= first;
         const int p = c.oh >> 1, hb = c.oh & 1;
-        const size_t rowbase = ((size_t)c.n * a.P + c.oh) * a.Q;
+        const int rowbase = (c.n * a.P + c.oh) * a.Q + ow0;  // (pixels; the tensor is below 2 GiB: host check)
         const int q_e = (ow0 + r_e) >> 1, q_o = (ow0 + r_o) >> 1;
-        y_e = y_o = z4;
-        d_e[0] = d_e[1] = d_o[0] = d_o[1] = d_o[2] = d_o[3] = z4;
-        i_e[0] = i_e[1] = i_o[0] = i_o[1] = i_o[2] = i_o[3] = none2;
-        const size_t w0 = ((size_t)c.n * a.PP + p) * a.QQ;  // pooled row p
-        const bool row1 = hb && p + 1 < a.PP;               // (uniform) the pixels also lie in pooled row p + 1
-        if (live_e) {
-            y_e = *(const uint4*)(y0b + (rowbase + ow0 + r_e) * 128 + vc * 16);
-            d_e[0] = *(const uint4*)(dzb + (w0 + q_e) * 128 + vc * 16);
-            i_e[0] = *(const uint2*)(a.idx + (w0 + q_e) * 64 + vc * 8);
-        }
-        if (live_o) {
-            y_o = *(const uint4*)(y0b + (rowbase + ow0 + r_o) * 128 + vc * 16);
-            d_o[0] = *(const uint4*)(dzb + (w0 + q_o) * 128 + vc * 16);
-            i_o[0] = *(const uint2*)(a.idx + (w0 + q_o) * 64 + vc * 8);
-            if (q_o + 1 < a.QQ) {
-                d_o[1] = *(const uint4*)(dzb + (w0 + q_o + 1) * 128 + vc * 16);
-                i_o[1] = *(const uint2*)(a.idx + (w0 + q_o + 1) * 64 + vc * 8);
-            }
-        }
-        if (row1) {
-            const size_t w1 = w0 + a.QQ;
-            if (live_e) {
-                d_e[1] = *(const uint4*)(dzb + (w1 + q_e) * 128 + vc * 16);
-                i_e[1] = *(const uint2*)(a.idx + (w1 + q_e) * 64 + vc * 8);
-            }
-            if (live_o) {
-                d_o[2] = *(const uint4*)(dzb + (w1 + q_o) * 128 + vc * 16);
-                i_o[2] = *(const uint2*)(a.idx + (w1 + q_o) * 64 + vc * 8);
-                if (q_o + 1 < a.QQ) {
-                    d_o[3] = *(const uint4*)(dzb + (w1 + q_o + 1) * 128 + vc * 16);
-                    i_o[3] = *(const uint2*)(a.idx + (w1 + q_o + 1) * 64 + vc * 8);
-                }
-            }
-        }
+        const int w0 = (c.n * a.PP + p) * a.QQ;                // pooled row p
+        const bool row1 = hb && p + 1 < a.PP;                  // (uniform) the pixels also lie in pooled row p + 1
+        const int w1 = row1 ? w0 + a.QQ : -1;
+        const bool o1 = live_o && q_o + 1 < a.QQ;
+        y_e = bl16(ry, live_e ? (rowbase + r_e) * 128 + vc * 16 : OOB);
+        y_o = bl16(ry, live_o ? (rowbase + r_o) * 128 + vc * 16 : OOB);
+        const int we = live_e ? (w0 + q_e) * 64 + vc * 8 : OOB, wo = live_o ? (w0 + q_o) * 64 + vc * 8 : OOB;
+        const int wo1 = o1 ? (w0 + q_o + 1) * 64 + vc * 8 : OOB;
+        // (an idx offset is half the dz offset; OOB * 2 wraps to 0: the dz offsets are selected on their own)
+        d_e[0] = bl16(rdz, live_e ? (w0 + q_e) * 128 + vc * 16 : OOB), i_e[0] = bl8(ridx, we);
+        d_o[0] = bl16(rdz, live_o ? (w0 + q_o) * 128 + vc * 16 : OOB), i_o[0] = bl8(ridx, wo);
+        d_o[1] = bl16(rdz, o1 ? (w0 + q_o + 1) * 128 + vc * 16 : OOB), i_o[1] = bl8(ridx, wo1);
+        const bool e2 = live_e && row1, o2 = live_o && row1, o3 = o1 && row1;
+        d_e[1] = bl16(rdz, e2 ? (w1 + q_e) * 128 + vc * 16 : OOB), i_e[1] = bl8(ridx, e2 ? (w1 + q_e) * 64 + vc * 8 : OOB);
+        d_o[2] = bl16(rdz, o2 ? (w1 + q_o) * 128 + vc * 16 : OOB), i_o[2] = bl8(ridx, o2 ? (w1 + q_o) * 64 + vc * 8 : OOB);
+        d_o[3] = bl16(rdz, o3 ? (w1 + q_o + 1) * 128 + vc * 16 : OOB), i_o[3] = bl8(ridx, o3 ? (w1 + q_o + 1) * 64 + vc * 8 : OOB);
     };
     // one window's contribution: gsum[c] += dz[c] where the window's arg-max code names this pixel
     auto window = [&](float (&gsum)[8], const uint4& dq, const uint2& u, uint32_t code) __attribute__((always_inline)) {
@@ -928,6 +929,9 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+#ifdef GDL_TIMING
+    unsigned long long t_entry = __builtin_amdgcn_s_memtime(), t_wait = 0, t_emit = 0, t_mul = 0, t_a, t_b;
+#endif
     if (nst > 0) {
         request(cq);
         load_x(cq, 0);
@@ -937,11 +941,21 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a)
             request(cq);
         }
     }
+#ifdef GDL_TIMING
+    const unsigned long long t_first = __builtin_amdgcn_s_memtime();
+#endif
     for (int st = 0; st < nst; ++st) {
+#ifdef GDL_TIMING
+        t_a = __builtin_amdgcn_s_memtime();
+#endif
         // the x slab of stage st (and the operands of stage st + 1) have landed; every wave's tile writes of stage st are visible
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef GDL_TIMING
+        t_b = __builtin_amdgcn_s_memtime();
+        t_wait += t_b - t_a;
+#endif
         if (st + 1 < nst) {
             emit(cq, (st + 1) & 1);
             load_x(cq, (st + 1) & 1);
@@ -950,6 +964,11 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a)
                 request(cq);
             }
         }
+#ifdef GDL_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile writes: so that the split below is the arithmetic's)
+        t_a = __builtin_amdgcn_s_memtime();
+        t_emit += t_a - t_b;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint2 af[4][2], bf[4][2];
@@ -980,6 +999,9 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a)
                 }
             }
         }
+#ifdef GDL_TIMING
+        t_mul += __builtin_amdgcn_s_memtime() - t_a;
+#endif
         const int dlt = (st & 1) ? -SR_STAGE : SR_STAGE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -989,6 +1011,13 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_fused_kernel(StemFusedArgs a)
             for (int t = 0; t < 4; ++t) baddr[t][h] += dlt;
         }
     }
+#ifdef GDL_TIMING
+    if (a.dbg && lane == 0) {
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        d[0] = t_entry, d[1] = t_first - t_entry, d[2] = t_wait, d[3] = t_emit, d[4] = t_mul;
+        d[5] = __builtin_amdgcn_s_memtime() - t_first, d[6] = nst, d[7] = 0;
+    }
+#endif
     float* part = a.partial + (size_t)slice * (64 * 4 * 64);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -1137,6 +1166,11 @@ int stem_bwd_fused(const void* dz, const uint8_t* idx, const void* y0, const flo
     r.P = P, r.Q = Q, r.PP = (P - 1) / 2 + 1, r.QQ = (Q - 1) / 2 + 1, r.Hp = Hp, r.Wp = Wp, r.nseg = p.nseg;
     r.stages = p.stages, r.chunk = p.chunk, r.nsplit = p.nsplit;
     r.x_bytes = (unsigned)((size_t)n_img * Hp * Wp * 8);
+    r.y_bytes = (unsigned)((size_t)n_img * P * Q * 128);
+#ifdef GDL_TIMING
+    r.dbg = g_timing_buf;
+#endif
+    r.dz_bytes = (unsigned)((size_t)n_img * r.PP * r.QQ * 128);
     {
         // (priced as the weight gradient; its algorithmic bytes: y0 + the pooled gradient and codes + the padded input, once)
         ProfScope prof("gdl::stem_bwd_fused_kernel", PROF_MFMA, st, 2.0 * (double)n_img * P * Q * 64 * 49 * Cin, true,
