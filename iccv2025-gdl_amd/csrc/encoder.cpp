@@ -672,6 +672,9 @@ int gdl_encoder_forward(gdl_encoder_t* e, const float* x, int training, float* f
     e->acc_last = acc;
     // stem: conv1 (7x7/2) as a direct implicit GEMM over the padded input, bn1, relu, maxpool   (backbone.py:166-173 / 186-189)
     // (the padding launch also clears the BatchNorm accumulators of this forward)
+    if (GDL_SKIPPED(4194304)) {  // (experiment: the input staging pass -- the bound of staging the next batch behind the previous step)
+        if (acc) (void)hipMemsetAsync(e->acc_arena, 0, e->acc_bytes, st);
+    } else
     RC(stem_pad(dt, x, e->col, e->B, e->cin, e->T, e->H, e->W, st, acc ? e->acc_arena : nullptr, acc ? e->acc_bytes : 0));
     if (acc) {
         const BnAcc pa = acc_producer(e->bn0, e->m0);
