@@ -2,6 +2,7 @@
 """bench.py -- CREMA-D DGL train step on N MI355X (one process per GPU, RCCL over xGMI).
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (starts the launcher below as a child process itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -273,6 +274,26 @@ def extra_leg(name, a, dev, lib, collect, steps=30, warmup=15):
             "top_kernels": top}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...
+    bench.py <the same arguments>` as a CHILD process (one rank per GPU over RCCL, the form the driver contract names), pass
+    its output through -- rank 0's single JSON line included -- and return its exit code.  The parent never initialises the
+    device (no exec of a process that has: the child is a fresh interpreter), so this is safe on the GPU pool."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's cross-process buffers on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {n} without WORLD_SIZE: launching {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,8 +301,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("bench.py: for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed plainly (`python bench.py --gpus N`): launch the N ranks ourselves.  Nothing above this line has touched the GPU
+        sys.exit(self_launch(a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no MI355X visible; the HIP path has no CPU fallback")
     # test plumbing (tests/test_ddp_gpu.py): GDL_BENCH_BACKEND=gloo with GDL_BENCH_ONE_DEVICE=1 runs the N-rank

@@ -91,6 +91,7 @@ struct ConvArgs {
     double hbm_bytes;  // its algorithmic HBM bytes: both activation tensors once + the filter (combined roofline, prof.h)
 #ifdef GDL_TIMING
     unsigned long long* dbg;  // [block][8] s_memtime stamps of wave 0 (tools/timing_probe.py)
+    int dbg_mode;             // conv3x3_pslab_kernel, timing experiments (WRONG results): GDL_PSLAB_DBG bits, see conv_pslab.h
 #endif
 };
 
@@ -1256,6 +1257,8 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 8) ? 2 : ((BM >= 192 && BN == 128
 #endif
 }
 
+#include "conv_pslab.h"
+
 // =====================================================================================================
 // 3x3 stride-1 convolution between 64 and 64 channels (layer 1 of both encoders: forward and data gradient; bf16),
 // persistent, weights in registers.
@@ -1815,6 +1818,8 @@ struct ConvPlan {
     int single;  // slab kernel: one slab buffer
     int c64;     // 1: conv3x3_c64_kernel (persistent; BatchNorm partial rows = C64_GRID)
     int nwv8;    // slab kernel: the 128 x 128 tile on 512 threads (small layers: one block per CU at most)
+    int pslab;   // 1: conv3x3_pslab_kernel (persistent, pipelined; round 6) -- bm / bn / single / lds describe ITS launch
+    int grid;    // pslab: blocks of the launch = BatchNorm partial rows
 };
 static size_t c64_lds_bytes(int W, bool single = false) {
     // slabs, zero KiB, BW: constants (512 B) + accumulator rows (2 KiB)
@@ -1844,7 +1849,7 @@ static int slab_cfg() {
 // 384 is -0.5 % step time, the defaults stayed twice; GDL_SLAB_BIG_MIN / GDL_SLAB_BN128_MIN: tools/experiments/r5_pruned_knobs.diff.txt)
 static constexpr long slab_big_min() { return 128; }
 static constexpr long slab_bn128_min() { return 384; }
-static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_nwv8 = true) {
+static ConvPlan plan_conv_base(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_nwv8 = true) {
     ConvPlan p{};
     static int noslab = -1;
     if (noslab < 0) {
@@ -2001,6 +2006,68 @@ no_c64:
     return p;
 }
 
+// Round 6: the 128-channel-wide slab tiles of 128 / 192 rows (four waves, bf16) run on the persistent pipelined kernel
+// (conv_pslab.h) when its LDS fits: two slab buffers where one block per CU is all the launch can fill anyway (<= 256 items:
+// 160 KiB to itself) or where two still fit into 80 KiB each, else one.
+static int pslab_mode() {
+    static int v = -1;
+    if (v < 0) {
+        // tuning aid: 0 = off (conv3x3_slab_kernel), 1 = the 128 / 192-row tiles, 2 = also in place of the 8-wave 128 x 128 tile
+        const char* e = tune_env("GDL_PSLAB");
+        v = e ? atoi(e) : 1;
+        const char* sk = tune_env("GDL_SPLITK");  // (the split-K alternative path keeps the kernel it was written for)
+        if (sk && atoi(sk)) v = 0;
+    }
+    return v;
+}
+static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S, int stride, int pad, bool allow_nwv8 = true) {
+    ConvPlan p = plan_conv_base(dtype, M, OC, IC, W, R, S, stride, pad, allow_nwv8);
+    if (!pslab_mode() || !p.slab || p.c64 || dtype != GDL_BF16 || p.bn != 128 || (p.bm != 128 && p.bm != 192)) return p;
+    if (p.nwv8 && pslab_mode() < 2) return p;
+    const int items = ceil_div(M, p.bm) * (OC / 128);
+    if ((p.bm + 2 * W + 2 + 7) / 8 > 4 * PS_SLAB_PIECES) return p;  // a slab buffer of at most 32 KiB
+    const size_t budget = items <= 256 ? (size_t)160 * 1024 : (size_t)80 * 1024;
+    int nslab = 0;
+    if (IC > 64 && pslab_lds_bytes(p.bm, W, 2) <= budget)
+        nslab = 2;
+    else if (pslab_lds_bytes(p.bm, W, 1) <= budget)
+        nslab = 1;
+    if (!nslab) return p;
+    // (the 128-row tile of the audio layer 2 -- 396 blocks, two per CU -- had two slab buffers in 80 KiB; with this kernel's staging
+    // and sums rows there is room for one: 23 vs 24 us alone, tools/bench_conv.py -- it keeps the round-5 kernel)
+    if (nslab == 1 && !p.single && IC > 64) return p;
+    p.pslab = 1, p.nwv8 = 0, p.single = nslab == 1, p.lds = pslab_lds_bytes(p.bm, W, nslab), p.grid = pslab_grid(items);
+    return p;
+}
+
+template <int MI, int MODE, bool TWO>
+static int launch_pslab(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
+    a.mtiles = ceil_div(a.M, 64 * MI);
+    GDL_REQUIRE(!a.bias && !a.gelu_out && !a.gelu_u && !a.orow && a.ksplit <= 1 && !a.seg_Q,
+                "conv: unsupported option for the persistent slab kernel");
+    GDL_REQUIRE(MODE == MODE_DGRAD || (!a.addend && !a.relu_bits), "conv: the persistent slab forward has no addend / ReLU bits");
+    GDL_REQUIRE(a.IC % 64 == 0 && a.OC % 128 == 0 && a.ntaps == 9, "conv: persistent slab kernel shape");
+#ifdef GDL_TIMING
+    {
+        const char* e = getenv("GDL_PSLAB_DBG");
+        a.dbg_mode = e ? atoi(e) : 0;
+    }
+#endif
+    auto kfn = conv3x3_pslab_kernel<MI, MODE, TWO>;
+    static DevOnce attr_set;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(conv3x3_pslab)");
+        attr_set = true;
+    }
+    static char pname[64] = "";
+    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_pslab_kernel<%d, %d, %d>", 64 * MI, MODE, TWO ? 2 : 1);
+    ProfScope prof(pname, PROF_MFMA, st, a.flops, true, a.hbm_bytes);
+    hipExtLaunchKernelGGL(kfn, dim3(pl.grid), dim3(256), pl.lds, st, prof.e0(), prof.e1(), 0, a);
+    GDL_CHECK_LAUNCH("conv3x3_pslab_kernel");
+    return GDL_OK;
+}
+
 template <int MODE, bool BW = false, bool ADD = false>
 static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
     a.mtiles = ceil_div(a.M, C64_BM);
@@ -2034,6 +2101,11 @@ static int launch_c64(ConvArgs& a, size_t lds, hipStream_t st) {
 template <typename T, int MODE>
 static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
     if (pl.c64) return launch_c64<MODE>(a, pl.lds, st);
+    if constexpr (std::is_same<T, bf16>::value)
+        if (pl.pslab) {
+            if (pl.single) return pl.bm == 192 ? launch_pslab<3, MODE, false>(a, pl, st) : launch_pslab<2, MODE, false>(a, pl, st);
+            return pl.bm == 192 ? launch_pslab<3, MODE, true>(a, pl, st) : launch_pslab<2, MODE, true>(a, pl, st);
+        }
     if (pl.slab) {
         if constexpr (std::is_same<T, bf16>::value)
             if (pl.bn == 128 && pl.bm == 256) return launch_slab<T, 256, 128, MODE>(a, pl.lds, st);
@@ -2055,19 +2127,21 @@ static int launch_mode(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
 int conv_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
     const ConvPlan pl = plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad);
-    return pl.c64 ? C64_GRID : ceil_div(N * P * Q, pl.bm);
+    return pl.c64 ? C64_GRID : pl.pslab ? pl.grid : ceil_div(N * P * Q, pl.bm);
 }
 
 // true if the forward of this convolution runs on a persistent kernel (one BatchNorm partial row per block): the in-launch
 // finalize costs a ticket per block LIFE there and is used by default
 bool conv_fwd_persistent(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
-    return plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad).c64 != 0;
+    const ConvPlan pl = plan_conv(dtype, N * P * Q, K, C, W, R, S, stride, pad);
+    return pl.c64 != 0 || pl.pslab != 0;
 }
 // partial rows a data gradient with BatchNorm-backward statistics (ops.h BwdStats) writes
 int conv_dgrad_tiles_m(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad) {
     const ConvPlan pl = plan_conv(dtype, N * H * W, C, K, W, R, S, stride, pad);
     if (pl.c64) return C64_GRID;
+    if (pl.pslab) return pl.grid;
     const int rows = stride == 2 ? dgrad_perm_rows(N, H, W, pl.bm) : N * H * W;
     return ceil_div(rows, pl.bm);
 }
@@ -2209,7 +2283,7 @@ static int splitk_threshold() {
     return v;
 }
 static int plan_ksplit(const ConvPlan& pl, int dtype, int M, int OC, int IC) {
-    if (!pl.slab || pl.c64 || dtype != GDL_BF16 || splitk_threshold() <= 0) return 1;
+    if (!pl.slab || pl.c64 || pl.pslab || dtype != GDL_BF16 || splitk_threshold() <= 0) return 1;
     if (OC != 128 && OC != 256 && OC != 512) return 1;
     const long blocks = (long)ceil_div(M, pl.bm) * (OC / pl.bn);
     if (blocks >= splitk_threshold()) return 1;
@@ -2256,6 +2330,9 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
     if (gelu_u) GDL_REQUIRE(mode == GATHER_DGRAD && !(bw && bw->y), "conv: the GELU derivative is a data-gradient option (without BatchNorm sums)");
     if (sacc && sacc->acc) {
         GDL_REQUIRE((mode == GATHER_FWD || gelu_u) && !stats, "conv: integer accumulators belong to the forward statistics and to the GELU data gradient's column sums (without partial rows)");
+        // without a flag word the channel's SECOND accumulator word is the overflow mark (bnacc.h bn_acc_add): such an accumulator
+        // must not also collect sums of squares
+        GDL_REQUIRE(sacc->flag || sacc->s2 == 0.0, "conv: integer accumulators without a flag word take column sums only (s2 = 0)");
         a.sacc = *sacc;
     }
     if (bw && bw->y) {
@@ -2319,7 +2396,7 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
             for (int s2 = 0; s2 < 3; ++s2)
                 a.pshift[r * 3 + s2] = mode == GATHER_FWD ? (r - 1) * W + (s2 - 1) : (1 - r) * W + (1 - s2);
     }
-    const int ks = (split && split->ptr && !bias && !gelu_out && !gelu_u && !dy_ds) ? plan_ksplit(pl, dtype, a.M, a.OC, a.IC) : 1;
+    const int ks = (!pl.pslab && split && split->ptr && !bias && !gelu_out && !gelu_u && !dy_ds) ? plan_ksplit(pl, dtype, a.M, a.OC, a.IC) : 1;
     if (ks > 1) {
         GDL_REQUIRE(split->bytes >= (size_t)ks * a.M * a.OC * sizeof(float), "conv: split-K workspace of %zu bytes, need %zu",
                     split->bytes, (size_t)ks * a.M * a.OC * sizeof(float));
@@ -2394,6 +2471,7 @@ int conv_stem_fwd(int dtype, const void* xp, const void* wp, void* y, float* bn_
     a.stats = bn_partial;
     if (sacc && sacc->acc) {
         GDL_REQUIRE(!bn_partial, "stem: integer statistics accumulators exclude partial rows");
+        GDL_REQUIRE(sacc->flag || sacc->s2 == 0.0, "stem: integer accumulators without a flag word take column sums only (s2 = 0)");
         a.sacc = *sacc;
     }
     a.table = (const GatherEntry*)table;

@@ -247,7 +247,9 @@ size_t gdl_encoder::plan(unsigned char* base) {
         gD[p] = b.take(max_act * e);
     }
     gE = b.take(max_act * e);
-    g0 = b.take((size_t)m0 * 64 * e);
+    // the gradient of the stem output exists only on the two-launch stem backward; the fused one (bf16, output rows of at least 64
+    // pixels: the benchmark shapes) never stores it -- 308 + 99 MB of workspace less at B = 64
+    g0 = stem_bwd_fused_ok(dtype, W) ? nullptr : b.take((size_t)m0 * 64 * e);
     bn_partial_floats = max_tiles_c * 2;
     bnb_partial_floats = max_bnb * 2;
     bn_partial = (float*)b.take(bn_partial_floats * sizeof(float));
@@ -988,16 +990,16 @@ static int encoder_backward_impl(gdl_encoder* e, const float* dfeat, const float
             if (!GDL_SKIPPED(64) && !GDL_SKIPPED(1048576))
             RC(stem_bwd_fused(dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->col, grads[0],
                               e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
-            goto stem_done;
+        } else {
+            // two launches (f32, or output rows under 64 pixels): the gathered gradient goes through e->g0
+            if (!GDL_SKIPPED(64))
+            RC(maxpool_bn_bwd_apply(dt, dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->g0,
+                                    e->n_img, e->h0, e->w0, 64, st));
+            RC(fork());
+            if (!GDL_SKIPPED(1048576))
+            RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
         }
-        if (!GDL_SKIPPED(64))
-        RC(maxpool_bn_bwd_apply(dt, dz, e->idx, e->y0, n.scale, n.shift, n.mean, n.rstd, e->params[n.pidx], n.coef, e->g0,
-                                e->n_img, e->h0, e->w0, 64, st));
     }
-    RC(fork());
-    if (!GDL_SKIPPED(1048576))
-    RC(conv_stem_wgrad(dt, e->g0, e->col, grads[0], e->tab_stem, e->n_img, e->H, e->W, e->cin, e->wg_ws, e->wg_ws_bytes, sw));
-stem_done:
     if (e->has_side) {  // join: everything the caller enqueues on st after this call sees all 60 gradients
         hipError_t he = hipEventRecord(e->ev_join, e->side);
         if (he == hipSuccess) he = hipStreamWaitEvent(st, e->ev_join, 0);

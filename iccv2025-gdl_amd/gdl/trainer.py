@@ -517,9 +517,6 @@ class DGLTrainer:
             red.wait_all()
         self._mark(main, "bwd_done")
         gs = 1.0 / self.world
-        if os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_NO_OPT") == "1":  # timing experiment only (WRONG results):
-            self.steps += 1                                                               # the bound of hiding the optimizer
-            return
         L.call("gdl_optim_grad_stats", self.opt, L.ptr(self.grads), self.max_norm, gs, L.ptr(self.stats),
                L.ptr(self.opt_ws), self.opt_ws_bytes, st)
         L.call("gdl_optim_sgd_step", self.opt, L.ptr(self.params), L.ptr(self.grads), L.ptr(self.momentum),

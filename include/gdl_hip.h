@@ -126,8 +126,8 @@ GDL_API int gdl_conv_dgrad_bn_split(int dtype, const void* dy, const void* w_crs
  * fc1 -> act -> fc2 through autograd): gdl_conv_dgrad_gelu = gdl_conv_dgrad whose epilogue multiplies the stored value by
  * gelu'(u[row][c]) (u laid out like dx: fc1's biased output, as gdl_conv_fwd_bias left it) and adds the column sums of dx AS
  * STORED -- fc1's bias gradient -- to `acc`, int64 [C][2] fixed-point accumulators the caller zeroes: acc[2c] += round(sum *
- * scale) per M-tile with device-scope integer atomics (associative: bit-identical from run to run; acc[2c + 1] is not used).  Choose scale = 2^(62 - h - ceil(log2(rows))) for |mean| < 2^h.
- * gdl_acc_to_float: out[c] = acc[2c] * inv_scale.  Replaces gdl_swin_colsum(g, u): three passes over the widest tensor of a
+ * scale) per M-tile with device-scope integer atomics (associative: bit-identical from run to run).  acc[2c + 1] is the channel's overflow / NaN MARK and must be zeroed with the rest: a tile sum that does not fit the channel's share of 2^62 (or is NaN / inf) sets it instead of being added.  Choose scale = 2^(62 - h - ceil(log2(rows))) for |mean| < 2^h.
+ * gdl_acc_to_float: out[c] = acc[2c] * inv_scale, or NaN when acc[2c + 1] != 0 (a marked channel) -- not a reader of [sum, sumsq] pairs.  Replaces gdl_swin_colsum(g, u): three passes over the widest tensor of a
  * block. */
 GDL_API int gdl_conv_dgrad_gelu(int dtype, const void* dy, const void* w_crsk, void* dx, const void* u, void* acc, double scale,
                                 const void* table, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,

@@ -133,17 +133,25 @@ def test_two_rank_rccl_step_matches_oracle(comm_backend, early, side):
     _two_rank_vs_oracle("nccl", comm_backend, early, side)
 
 
-def test_bench_two_rank_control_flow():
-    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"):
-    every rank must take part in every collective-bearing step (warm-up, calibration, timed region) -- a rank-0-only
-    step would hang here.  Two ranks on the one device over gloo (test plumbing of bench.py); the number is meaningless."""
+@pytest.mark.parametrize("form", ["launcher", "plain"])
+def test_bench_two_rank_control_flow(form):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"), and typed
+    plainly (`python bench.py --gpus 2`: it starts that launcher as a child process itself, before any GPU call -- VERDICT r5
+    next #4): every rank must take part in every collective-bearing step (warm-up, calibration, timed region) -- a
+    rank-0-only step would hang here.  Two ranks on the one device over gloo (test plumbing of bench.py); the number is
+    meaningless."""
     import json
     import subprocess
 
     env = dict(os.environ, GDL_BENCH_BACKEND="gloo", GDL_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "4"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    if form == "launcher":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

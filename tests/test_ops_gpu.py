@@ -37,7 +37,33 @@ CONV_SHAPES = [
     (4, 64, 56, 56, 64, 3, 1, 1),     # 64 -> 64 channels: the weights-stationary persistent kernel (bf16), 98 tiles
     (3, 64, 65, 47, 64, 3, 1, 1),     # the same with odd spatial dims and a ragged last tile (M = 9165)
     (2, 64, 33, 157, 64, 3, 1, 1),    # the same on a wide image (Kinetics-Sounds audio layer 1): ONE slab buffer
+    # xcd_linear (common.h) with fewer outer units than XCDs -- the stride-1 forward / data-gradient counterparts of the
+    # weight-gradient shapes below, on the slab kernel (>= 128 channels) and on the flat kernel
+    (24, 128, 17, 12, 128, 3, 1, 1),  # slab kernel: 26 M-tiles of 192 x one N-tile
+    (40, 256, 9, 6, 256, 3, 1, 1),    # slab kernel: 12 M-tiles x 2 N-tiles (a tile's two N-tiles straddle an XCD boundary)
+    (3, 256, 9, 6, 512, 3, 1, 1),     # slab kernel: ONE ragged M-tile x 4 N-tiles -- fewer tiles than XCDs
+    (1, 128, 17, 12, 256, 1, 2, 0),   # flat kernel: one M-tile, four N-tiles
+    (64, 128, 28, 28, 128, 3, 1, 1),  # slab kernel, several tiles per persistent block (round 6), 262 tiles
+    (20, 256, 14, 14, 256, 3, 1, 1),  # the same with two N-tiles per M-tile and three channel chunks' slab reloads
 ]
+
+
+def _check_shape_list(name, shapes):
+    """Collection-time guard: a tuple that slipped into the trailing comment of the line above it is silently never run
+    (round 5 lost a weight-gradient shape that way).  Every source line of the list must carry exactly one tuple, in code."""
+    import inspect
+    import re
+    import sys
+    body = inspect.getsource(sys.modules[__name__]).split(name + " = [", 1)[1].split("\n]\n", 1)[0]
+    code_rows = 0
+    for ln in body.splitlines():
+        code, _, comment = ln.partition("#")
+        code_rows += code.count("(")
+        assert not re.search(r"\(\s*\d+\s*,\s*\d+\s*,\s*\d+\s*,", comment), f"{name}: a shape tuple inside a comment: {ln.strip()}"
+    assert code_rows == len(shapes), f"{name}: {code_rows} tuples in the source, {len(shapes)} parsed"
+
+
+_check_shape_list("CONV_SHAPES", CONV_SHAPES)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -96,6 +122,7 @@ DS_SHAPES = [
     (2, 256, 14, 14, 512),  # four K-steps per tap
     (5, 128, 7, 9, 256),    # tiny planes, ragged classes
 ]
+_check_shape_list("DS_SHAPES", DS_SHAPES)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -143,9 +170,13 @@ WGRAD_SHAPES = [
     (1, 128, 40, 47, 64, 3, 1, 1),   # audio layer-1 width: the ring wraps several times per slice
     (1, 64, 9, 157, 64, 3, 1, 1),    # Kinetics-Sounds audio layer-1 width: the 512-row ring
     (2, 64, 3, 191, 128, 3, 1, 1),   # widest 512-row ring geometry (2W+2 = 384)
-    (1, 64, 3, 192, 64, 3, 1, 1),    # just past it: per-tap kernel    (24, 128, 17, 12, 128, 3, 1, 1), # 3 pixel slices x 4 tiles: fewer slices than XCDs, a slice's tiles on two XCDs (xcd_linear)
+    (1, 64, 3, 192, 64, 3, 1, 1),    # just past it: per-tap kernel
+    (24, 128, 17, 12, 128, 3, 1, 1), # 3 pixel slices x 4 tiles: fewer slices than XCDs, a slice's tiles on two XCDs (xcd_linear)
     (40, 256, 9, 6, 256, 3, 1, 1),   # one slice of 16 tiles dealt to eight XCDs
+    (24, 128, 17, 12, 256, 1, 2, 0), # per-tap kernel (1x1 stride 2), split count not a multiple of 8 (the round-up went in round 5)
+    (6, 128, 17, 12, 256, 3, 2, 1),  # per-tap kernel (3x3 stride 2) with fewer pixel slices than XCDs
 ]
+_check_shape_list("WGRAD_SHAPES", WGRAD_SHAPES)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -690,8 +721,12 @@ BW_SHAPES = [
     (8, 128, 28, 28, 128, 3, 1, 1, "bits", True),     # 128-channel slab tiles, two BatchNorms fed by the same gradient
     (16, 64, 33, 24, 128, 3, 2, 1, "bits", False),    # permuted stride-2 data gradient (rows scattered through orow)
     (48, 512, 7, 7, 512, 3, 1, 1, "bits", True),      # the 8-wave 128 x 128 tile
+    (64, 128, 28, 28, 128, 3, 1, 1, "bits", True),    # persistent slab kernel (round 6), 192-row tiles: 262 tiles, one N-tile
+    (40, 256, 14, 14, 256, 3, 1, 1, "bits", False),   # the same with two N-tiles (a block keeps its channels) and four chunks
+    (30, 128, 33, 24, 128, 3, 1, 1, None, False),     # its 128-row tiles, ragged last tile, no ReLU mask
     (2, 64, 9, 6, 128, 1, 2, 0, None, False),         # 1x1 stride 2
 ]
+_check_shape_list("BW_SHAPES", BW_SHAPES)
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -771,6 +806,7 @@ SPLIT_SHAPES = [
     (16, 256, 17, 12, 256),   # audio layer 3 at B = 16
     (5, 512, 9, 6, 512),      # ragged last M-tile
 ]
+_check_shape_list("SPLIT_SHAPES", SPLIT_SHAPES)
 
 
 @pytest.mark.parametrize("shape", SPLIT_SHAPES)
@@ -853,3 +889,75 @@ def test_conv_split_k(shape):
     np.testing.assert_allclose(a2[:, 0], g64.sum((0, 2, 3)), rtol=1e-4, atol=2e-6 * sc_)
     np.testing.assert_allclose(a2[:, 1], (g64 * (y2.astype(np.float64) - bc(mean2)) * bc(rstd2)).sum((0, 2, 3)), rtol=1e-4, atol=1e-5 * sc_)
     assert relerr(got, from_nhwc(res[0][0])) < 6e-3
+
+
+@pytest.mark.parametrize("knobs", ["GDL_PSLAB_GRID=32", "GDL_PSLAB_GRID=64,GDL_PSLAB=2", "GDL_PSLAB=0"])
+def test_persistent_slab_kernel_alternate_grids(knobs):
+    """conv3x3_pslab_kernel (round 6) with SEVERAL tiles per block at test sizes -- the grid capped to 32 / 64 blocks, so the
+    weight stream's wrap, the next tile's slab / mask prefetch, the per-block statistics rows and the N-tile-preserving stride
+    are all exercised against the oracle -- and in place of the 8-wave tile (GDL_PSLAB=2); GDL_PSLAB=0 keeps the round-5 kernels
+    under test.  Tuning knobs are read once per process, hence a child process running this file's convolution tests."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GDL_TUNING="1", **dict(kv.split("=") for kv in knobs.split(",")))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "test_conv_fwd or test_conv_dgrad or test_relu_bits_and_masked_dgrad or test_conv_run_to_run_determinism",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout
+
+
+_DUMP_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/iccv2025-gdl_amd"); sys.path.insert(0, {root!r} + "/tests")
+from gdl import _lib as L
+from gpu_util import DEV, empty, gather_table, pack_weight, quant, to_nhwc
+rng = np.random.default_rng(7)
+out = {{}}
+for (N, C, H, W, K) in [(64, 128, 28, 28, 128), (40, 256, 14, 14, 256), (48, 512, 7, 7, 512)]:
+    dt = L.GDL_BF16
+    x = quant(rng.standard_normal((N, C, H, W), dtype=np.float32), dt)
+    w = quant((rng.standard_normal((K, C, 3, 3), dtype=np.float32) * np.sqrt(2.0 / (C * 9))).astype(np.float32), dt)
+    dy = quant(rng.standard_normal((N, K, H, W), dtype=np.float32), dt)
+    krsc, crsk = pack_weight(w, dt)
+    xd, dyd = to_nhwc(x, dt), to_nhwc(dy, dt)
+    y, dx = empty((N, H, W, K), dt), empty((N, H, W, C), dt)
+    tiles = L.load().gdl_conv_bn_tiles(dt, N, H, W, C, K, 3, 3, 1, 1)
+    part = torch.zeros((tiles, K, 2), device=DEV)
+    tf, tb = gather_table(L.GATHER_FWD, dt, N, H, W, C, K, 3, 3, 1, 1), gather_table(L.GATHER_DGRAD, dt, N, H, W, C, K, 3, 3, 1, 1)
+    L.call("gdl_conv_fwd", dt, L.ptr(xd), L.ptr(krsc), L.ptr(y), L.ptr(part), L.ptr(tf), N, H, W, C, K, 3, 3, 1, 1, L.cur_stream())
+    L.call("gdl_conv_dgrad", dt, L.ptr(dyd), L.ptr(crsk), L.ptr(dx), None, L.ptr(tb), N, H, W, C, K, 3, 3, 1, 1, L.cur_stream())
+    torch.cuda.synchronize()
+    out["y%d" % C] = y.view(torch.int16).cpu().numpy()
+    out["dx%d" % C] = dx.view(torch.int16).cpu().numpy()
+    out["sum%d" % C] = part.double().sum(0).cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_persistent_slab_kernel_bit_identical_to_round5_kernel(tmp_path):
+    """conv3x3_pslab_kernel multiplies in the order conv3x3_slab_kernel does (chunk, tap, 32-channel half; fp32 MFMA accumulators,
+    one rounding): its stored outputs must be BIT-identical to the round-5 kernel's (GDL_PSLAB=0) at all three channel counts, forward
+    and data gradient -- only the per-channel statistics are summed in another order (per wave and block instead of per tile), and
+    those must agree to fp32 rounding.  This is what separates "a different rounding order of the BatchNorm sums" from "a different
+    convolution" when a step-level bf16 bound moves (tests/test_step_gpu.py::test_full_size_oracle_parity)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = []
+    for knob in ("1", "0"):
+        f = str(tmp_path / f"pslab{knob}.npz")
+        env = dict(os.environ, GDL_TUNING="1", GDL_PSLAB=knob)
+        r = subprocess.run([sys.executable, "-c", _DUMP_SNIPPET.format(root=root), f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files.append(np.load(f))
+    new, old = files
+    for k in new.files:
+        if k.startswith("sum"):
+            np.testing.assert_allclose(new[k], old[k], rtol=2e-6, atol=1e-3)
+        else:
+            assert np.array_equal(new[k], old[k]), (k, int((new[k] != old[k]).sum()))

@@ -6,7 +6,7 @@
 # "Toolchain note": re-assembling the compiler's own output with that one instruction replaced by two v_add_f32 -- or by the same
 # packed add with the operands commuted, op_sel:[1,0] op_sel_hi:[0,1] -- is bit-stable; wait states in front of / behind it are not).
 # The library is built with -fno-slp-vectorize, so the count must be 0; a toolchain or flag change that brings it back fails here.
-# usage: tools/check_isa.sh <build dir with the .o files>     (exit 1 if the form is present)
+# usage: tools/check_isa.sh <build dir with the .o files> [number of .hip objects expected]     (exit 1 if the form is present)
 set -e
 B=${1:-iccv2025-gdl_amd/csrc/build}
 ROCM=${ROCM_PATH:-$(hipconfig --rocmpath 2>/dev/null || echo /opt/rocm)}
@@ -30,9 +30,12 @@ for o in "$B"/*.o; do
   bad=$((bad + n)); pk=$((pk + p))
 done
 rm -rf $T
-nhip=$(ls "$B"/../*.hip 2>/dev/null | wc -l)
-if [ "$seen" = "0" ] || [ "$seen" -lt "$nhip" ]; then
-  echo "check_isa: disassembled $seen device objects of $want with a fat binary ($nhip .hip sources) in $B -- the gate would be vacuous: failing"
+# Non-vacuous gate: every object that carries a fat binary must have been disassembled (seen == want), and -- when the caller says
+# how many .hip sources the library has (the Makefile does) -- at least that many.  The build directory may be anywhere
+# (`make BUILD=/tmp/x`): nothing here looks at the directory's neighbours.
+expect=${2:-1}
+if [ "$seen" = "0" ] || [ "$seen" != "$want" ] || [ "$seen" -lt "$expect" ]; then
+  echo "check_isa: disassembled $seen device objects of $want with a fat binary (expected at least $expect) in $B -- the gate would be vacuous: failing"
   exit 1
 fi
 echo "check_isa: $bad cross-half v_pk_add_f32 (second source), $pk packed-f32 VALU instructions in $B"

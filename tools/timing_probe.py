@@ -110,8 +110,11 @@ def main():
             print(f"  per tile {nm:>28s}: {seg[:, i].sum() / max(nt, 1):7.0f}")
     elif seg[:, 5].max() > 0:
         nk = seg[:, 5].mean()
-        for i, nm in enumerate(("wait+barrier", "dma issue", "reads->1st data", "mfma0+2nd data", "mfma1")):
-            print(f"  per K-step {nm:>16s}: {seg[:, i].mean() / nk:7.0f}")
+        names5 = ("wait+barrier", "dma issue", "reads->1st data", "mfma0+2nd data", "mfma1")
+        if (seg[:, 6] == 0x5053).any():  # conv3x3_pslab_kernel (round 6): stamps consumed a step later, nothing waits for them
+            names5 = ("wait for F0", "[A] 24 MFMA+reads", "wait + barrier", "[C] 24 MFMA+DMA+rd", "tail (slab, loop)")
+        for i, nm in enumerate(names5):
+            print(f"  per K-step {nm:>20s}: {seg[:, i].mean() / nk:7.0f}")
     start = d[:, 0] - t0
     print("start-time quantiles:", [int(np.percentile(start, q)) for q in (0, 25, 50, 75, 100)])
 
