@@ -2012,9 +2012,10 @@ no_c64:
 static int pslab_mode() {
     static int v = -1;
     if (v < 0) {
-        // tuning aid: 0 = off (conv3x3_slab_kernel), 1 = the 128 / 192-row tiles, 2 = also in place of the 8-wave 128 x 128 tile
+        // tuning aid: 0 = off (conv3x3_slab_kernel), 1 = the 128 / 192-row tiles, 2 (default) = also in place of the 8-wave 128 x 128
+        // tile of the smallest layers (audio layer 4: 108 blocks; step 5.09 -> 5.05 ms, three A/B rounds, profiles/r06_ab_pslab.txt)
         const char* e = tune_env("GDL_PSLAB");
-        v = e ? atoi(e) : 1;
+        v = e ? atoi(e) : 2;
         const char* sk = tune_env("GDL_SPLITK");  // (the split-K alternative path keeps the kernel it was written for)
         if (sk && atoi(sk)) v = 0;
     }
@@ -2040,8 +2041,11 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     return p;
 }
 
-template <int MI, int MODE, bool TWO>
+template <int MI, int MODE, bool TWO, bool RICH = false>
 static int launch_pslab(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
+    // (data gradients with an addend or a second BatchNorm partner: the instantiation that carries their registers)
+    if constexpr (MODE == MODE_DGRAD && !RICH)
+        if (a.addend || a.bw_y2) return launch_pslab<MI, MODE, TWO, true>(a, pl, st);
     a.mtiles = ceil_div(a.M, 64 * MI);
     GDL_REQUIRE(!a.bias && !a.gelu_out && !a.gelu_u && !a.orow && a.ksplit <= 1 && !a.seg_Q,
                 "conv: unsupported option for the persistent slab kernel");
@@ -2053,7 +2057,7 @@ static int launch_pslab(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
         a.dbg_mode = e ? atoi(e) : 0;
     }
 #endif
-    auto kfn = conv3x3_pslab_kernel<MI, MODE, TWO>;
+    auto kfn = conv3x3_pslab_kernel<MI, MODE, TWO, RICH>;
     static DevOnce attr_set;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2061,7 +2065,7 @@ static int launch_pslab(ConvArgs& a, const ConvPlan& pl, hipStream_t st) {
         attr_set = true;
     }
     static char pname[64] = "";
-    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_pslab_kernel<%d, %d, %d>", 64 * MI, MODE, TWO ? 2 : 1);
+    if (!pname[0]) snprintf(pname, sizeof(pname), "gdl::conv3x3_pslab_kernel<%d, %d, %d, %d>", 64 * MI, MODE, TWO ? 2 : 1, RICH ? 1 : 0);
     ProfScope prof(pname, PROF_MFMA, st, a.flops, true, a.hbm_bytes);
     hipExtLaunchKernelGGL(kfn, dim3(pl.grid), dim3(256), pl.lds, st, prof.e0(), prof.e1(), 0, a);
     GDL_CHECK_LAUNCH("conv3x3_pslab_kernel");
@@ -2295,7 +2299,8 @@ static int plan_ksplit(const ConvPlan& pl, int dtype, int M, int OC, int IC) {
 size_t conv_split_ws_bytes(int dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dgrad) {
     const int P = (H + 2 * pad - R) / stride + 1, Q = (W + 2 * pad - S) / stride + 1;
     const int M = dgrad ? N * H * W : N * P * Q, OC = dgrad ? C : K, IC = dgrad ? K : C;
-    const ConvPlan pl = plan_conv(dtype, M, OC, IC, W, R, S, stride, pad);
+    // (split-K belongs to the round-5 slab kernel: a launch that is given a workspace runs on it, below)
+    const ConvPlan pl = plan_conv_base(dtype, M, OC, IC, W, R, S, stride, pad);
     const int s = plan_ksplit(pl, dtype, M, OC, IC);
     return s > 1 ? (size_t)s * M * OC * sizeof(float) : 0;
 }
@@ -2396,7 +2401,20 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
             for (int s2 = 0; s2 < 3; ++s2)
                 a.pshift[r * 3 + s2] = mode == GATHER_FWD ? (r - 1) * W + (s2 - 1) : (1 - r) * W + (1 - s2);
     }
-    const int ks = (!pl.pslab && split && split->ptr && !bias && !gelu_out && !gelu_u && !dy_ds) ? plan_ksplit(pl, dtype, a.M, a.OC, a.IC) : 1;
+    // split-K (an alternative path, off in the engine by default): a launch that is given a workspace and would split runs on the
+    // round-5 slab kernel (its plan), whatever the unsplit launch of this geometry runs on; the partial-row count stays the unsplit
+    // form's (conv_tiles_m / conv_dgrad_tiles_m): the rows past the split form's M-tiles are zeroed
+    const int rows_unsplit = pl.c64 ? C64_GRID : pl.pslab ? pl.grid : 0;
+    int ks = 1;
+    if (split && split->ptr && !bias && !gelu_out && !gelu_u && !dy_ds && !pl.c64) {
+        const ConvPlan plb = pl.pslab ? plan_conv_base(dtype, a.M, a.OC, a.IC, W, R, S, stride, pad) : pl;
+        ks = plan_ksplit(plb, dtype, a.M, a.OC, a.IC);
+        if (ks > 1 && pl.pslab) {
+            pl = plb;
+            a.single_slab = pl.single;
+            a.slab_rows = pl.bm + 2 * W + 2;
+        }
+    }
     if (ks > 1) {
         GDL_REQUIRE(split->bytes >= (size_t)ks * a.M * a.OC * sizeof(float), "conv: split-K workspace of %zu bytes, need %zu",
                     split->bytes, (size_t)ks * a.M * a.OC * sizeof(float));
@@ -2415,6 +2433,15 @@ static int run_conv(int mode, int dtype, const void* in, const void* wt, void* o
         ProfScope prof("gdl::splitk_finish_kernel", PROF_HBM, st, (double)a.M * a.OC * (4.0 * ks + 2.0 * (1 + (a.addend ? 1 : 0) + (a.bw_y ? 1 : 0) + (a.bw_y2 ? 1 : 0))));
         hipLaunchKernelGGL(splitk_finish_kernel<bf16>, dim3(ceil_div(a.M, pl.bm), a.OC / 64), dim3(256), 0, st, f);
         GDL_CHECK_LAUNCH("splitk_finish_kernel");
+        const int mt = ceil_div(a.M, pl.bm);
+        if (rows_unsplit > mt) {  // the caller sized its partial rows for the unsplit (persistent) form
+            const size_t off = (size_t)mt * a.OC * 2, n = (size_t)(rows_unsplit - mt) * a.OC * 2 * sizeof(float);
+            for (float* p : {a.stats, a.bw_partial, a.bw_y2 ? a.bw_partial2 : (float*)nullptr})
+                if (p) {
+                    hipError_t e = hipMemsetAsync(p + off, 0, n, st);
+                    if (e != hipSuccess) return check_hip(e, "hipMemsetAsync(split-K partial rows)");
+                }
+        }
         return GDL_OK;
     }
     if (dtype == GDL_BF16)

@@ -108,7 +108,7 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t rsrc, unsigned cha
 #define PS_EXP 0
 #endif
 
-template <int MI, int MODE, bool TWO>
+template <int MI, int MODE, bool TWO, bool RICH>
 __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NI = 8, BM = 64 * MI, BN = 128, WTM = 16 * MI, WSTAGE = BN * 128, NQ = NI * MI, NR = MI + NI;
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
     };
 
     bf16* __restrict__ gout = (bf16*)a.out;
-    const bf16* __restrict__ gadd = BWD ? (const bf16*)a.addend : nullptr;
+    const bf16* __restrict__ gadd = (BWD && RICH) ? (const bf16*)a.addend : nullptr;
     const uint8_t* __restrict__ rbits = BWD ? a.relu_bits : nullptr;
-    const bool bw = BWD && a.bw_y != nullptr, bw2 = bw && a.bw_y2 != nullptr;
+    const bool bw = BWD && a.bw_y != nullptr, bw2 = RICH && bw && a.bw_y2 != nullptr;
     const bool fst = !BWD && (a.stats != nullptr || a.sacc.acc != nullptr);
 
     for (int t = 0; t < ntiles; ++t, item += bpx) {
@@ -269,10 +269,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
             const unsigned wb = smem_base + slot * WSTAGE + woff0;
             static_for<0, NR>([&](auto rc) { frag_read(rc, px0, wf0, pb, wb); });
         }
-        struct Pre {  // one round's partner vectors (data gradient), requested a round ahead
-            uint4 g[2], y[2], y2[2];
+        // one round's partner vectors (data gradient).  They come from HBM / the memory-side cache (forward activations last touched
+        // a whole backward ago: ~2 000 clk), a round is ~600 clk of work: requested ONE round ahead -- the first version -- every
+        // round stalled on them (a data gradient took 62 us alone where the bare kernel takes 51).  The common launch (ReLU bits +
+        // one BatchNorm partner: conv2's data gradient, RICH = false) therefore requests ALL its rounds behind the tile's last
+        // MFMAs (10 registers per round); the launches with an addend or a second partner (conv1's: 26 registers per round) keep
+        // two rounds in flight.
+        struct Pre {
+            uint4 y[2];
             unsigned mk[2];
+            uint4 g[RICH ? 2 : 1], y2[RICH ? 2 : 1];
         };
+        constexpr int NRND = 2 * MI, PFD = RICH ? 2 : NRND, NPRE = RICH ? 3 : NRND;  // rounds, prefetch distance, register sets
         auto request = [&](auto rc, Pre& q) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value, m = r >> 1, h = r & 1;
             int ln = lane;
@@ -282,17 +290,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
             for (int p = 0; p < 2; ++p) {
                 const int mrow = rbase + m * 16 + erow + 8 * p;
                 const size_t goff = (size_t)mrow * a.OC + n0 + h * 64 + ec * 8;
-                q.g[p] = q.y[p] = q.y2[p] = make_uint4(0u, 0u, 0u, 0u);
+                q.y[p] = make_uint4(0u, 0u, 0u, 0u);
                 q.mk[p] = 0xffu;
+                if constexpr (RICH) q.g[p] = q.y2[p] = make_uint4(0u, 0u, 0u, 0u);
                 if (mrow < a.M) {
-                    if (gadd) q.g[p] = *(const uint4*)(gadd + goff);
                     if (rbits) q.mk[p] = rbits[goff >> 3];
                     if (bw) q.y[p] = *(const uint4*)((const bf16*)a.bw_y + goff);
-                    if (bw2) q.y2[p] = *(const uint4*)((const bf16*)a.bw_y2 + goff);
+                    if constexpr (RICH) {
+                        if (gadd) q.g[p] = *(const uint4*)(gadd + goff);
+                        if (bw2) q.y2[p] = *(const uint4*)((const bf16*)a.bw_y2 + goff);
+                    }
                 }
             }
         };
-        Pre pre[2];
+        Pre pre[NPRE];
 
         // ---- one K-step (kc = channel chunk, tap); LAST = the tile's last one (peeled: no next step's reads, round 0 of the data
         // gradient's partner vectors requested).  No run-time branch sits between the MFMAs -- they cost ~20 clk each there
@@ -388,7 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
             // pinned) the weight cursor and the slab decision
             const int nslot = slot ^ 1;
             const unsigned wbn = smem_base + nslot * WSTAGE + woff0;
-            if constexpr (LAST && BWD) request(std::integral_constant<int, 0>{}, pre[0]);  // round 0's partner vectors: behind the last MFMAs
+            if constexpr (LAST && BWD)  // the first rounds' partner vectors: behind the last MFMAs
+                static_for<0, PFD>([&](auto rc) { request(rc, pre[decltype(rc)::value % NPRE]); });
             static_for<0, NQ>([&](auto qc) {
                 constexpr int q = decltype(qc)::value, n = q / MI, m = q % MI;
                 Mma<bf16>::run(wf1[n], px1[m], acc[n][m]);
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
                 const uint2 v = make_uint2(pack2bf(acc[n][m][0], acc[n][m][1]), pack2bf(acc[n][m][2], acc[n][m][3]));
                 lds_write8_asm_off<nn * 32>(st_wr, v);
             });
-            if constexpr (BWD && r + 1 < 2 * MI) request(std::integral_constant<int, r + 1>{}, pre[(r + 1) & 1]);
+            if constexpr (BWD && r + PFD < NRND) request(std::integral_constant<int, r + PFD>{}, pre[(r + PFD) % NPRE]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             uint4 q[2];
             q[0] = lds_read16_asm_off<0>(st_rd);
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
                 }
             }
             lds_wait();
-            Pre& pq = pre[r & 1];
+            Pre& pq = pre[r % NPRE];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int mrow = rbase + m * 16 + erow + 8 * p;
