@@ -30,7 +30,7 @@
 constexpr int PS_GRID = 512;              // two blocks per CU
 constexpr int PS_PITCH = 144;             // staged row: 64 bf16 + 16 bytes
 constexpr int PS_STAGE = 16 * PS_PITCH;   // per wave
-constexpr int PS_STAT = 4 * 128 * 3 * 4;  // [wave][channel][3] floats
+constexpr int PS_STAT = 4 * 1536;         // [wave]: [chunk 8][k 2][h 2][e 8] floats of the first two sums + [chunk 8][h 2][e 8] of the third
 constexpr int PS_SLAB_PIECES = 8;         // DMA pieces per wave and slab load (a slab buffer is at most 32 KiB)
 
 static size_t pslab_lds_bytes(int BM, int W, int nslab) {
@@ -59,6 +59,16 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, Q>{});
         static_for<Q + 1, QEND>(f);
     }
+}
+// all-reduce over the eight lanes that hold the same channels in the epilogue's row pass (lane ^ 8, ^ 16, ^ 32), in that order,
+// without the LDS crossbar: a DPP row rotation and the two cross-row swaps of gfx950 (3 + 3 + 2 VALU instructions; the
+// __shfl_xor form -- three ds_bpermute round trips per value, 96 per tile -- cost the forward's epilogue 5 100 of its 11 000 clk)
+__device__ __forceinline__ float ps_fold8(float v) {
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
 }
 template <int OFF>
 __device__ __forceinline__ void lds_write8_asm_off(unsigned addr, const uint2& v) {
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
     const unsigned zrow = spare_row ? slab_base + a.slab_rows * 128 : slab_base + nslab * slab_bytes;
     const unsigned tail = 2 * WSTAGE + nslab * slab_bytes + (spare_row ? 0 : 1024);
     const unsigned stg = smem_base + tail + wave * PS_STAGE;
-    const unsigned statw = smem_base + tail + 4 * PS_STAGE + wave * (BN * 3 * 4);  // [wave][BN][3] floats
+    const unsigned statw = smem_base + tail + 4 * PS_STAGE + wave * 1536;  // this wave's sums row
 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc((void*)a.wt, 0, a.wt_bytes, 0x00020000);
@@ -535,40 +545,76 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
                 *(uint4*)(gout + goff) = v;
             }
         });
-        // this tile's sums -> the wave's LDS row: fold the eight row-lanes that hold the same channels (fixed order), lanes 0-7 add
+        if (t == 0) GDL_STAMP(6);  // (behind the first tile's rounds)
+        // this tile's sums -> the wave's LDS row.  The eight lanes that hold the same channels (lane ^ 8, ^ 16, ^ 32) reduce AND scatter:
+        // every level halves the values a lane carries -- across the wave's halves one v_permlane32_swap of a pair leaves sum 1 in
+        // the lower half and sum 2 in the upper, across rows v_permlane16_swap does the same for the two channel halves, inside a row
+        // a select + DPP rotation for channels e / e + 4 -- 60 VALU instructions instead of the 224 of eight all-reduces per
+        // value (and of the 96 ds_bpermute round trips of the first version: 5 100 clk of an 11 000 clk epilogue).  A lane ends with
+        // the four sums (k = lane bit 5, half h = bit 4, channels 4 * bit 3 .. + 3 of its chunk) and adds them into its OWN 16 bytes
+        // of the wave's row, [chunk 8][k 2][h 2][e 8] floats: one LDS read, one write, every lane.  Fixed order: bit-identical from
+        // run to run.
         if (fst || bw) {
+            auto scatter = [&](float (&lo)[2][8], float (&hi)[2][8], unsigned ad) __attribute__((always_inline)) {
+                float r[2][8], q[8], res[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    for (int msk = 8; msk < 64; msk <<= 1) {
-                        s1[h][e] += __shfl_xor(s1[h][e], msk);
-                        s2[h][e] += __shfl_xor(s2[h][e], msk);
-                        if constexpr (BWD)
-                            if (bw2) s3[h][e] += __shfl_xor(s3[h][e], msk);
+                    for (int e = 0; e < 8; ++e) {  // lower half of the wave: lo summed over lane ^ 32; upper half: hi
+                        auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo[h][e]), __float_as_uint(hi[h][e]), false, false);
+                        r[h][e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
                     }
-            if (eln < 8) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    // [channel][3] floats: 8 channels = 24 floats = six 16-byte vectors
-                    const unsigned ad = statw + (h * 64 + eln * 8) * 12;
-                    f32x4_t v[6];
+                for (int e = 0; e < 8; ++e) {  // even rows: half 0 summed over lane ^ 16; odd rows: half 1
+                    auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[0][e]), __float_as_uint(r[1][e]), false, false);
+                    q[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+                }
+                const bool up = (eln & 8) != 0;
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) v[j] = lds_read_f4_asm(ad + 16 * j);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(v[j]));
+                for (int e = 0; e < 4; ++e) {  // lanes 0-7 of a row: channels e summed over lane ^ 8; lanes 8-15: channels e + 4
+                    const float keep = up ? q[e + 4] : q[e], give = up ? q[e] : q[e + 4];
+                    res[e] = keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(give), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+                }
+                f32x4_t v = lds_read_f4_asm(ad);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(v));
+                v[0] += res[0], v[1] += res[1], v[2] += res[2], v[3] += res[3];
+                lds_write_f4_asm(ad, v);
+            };
+            // the lane's 16 bytes: chunk ec = lane & 7, then (k, h, e >> 2) = lane bits 5, 4, 3
+            scatter(s1, s2, statw + (eln & 7) * 128 + (eln >> 3) * 16);
+            if constexpr (BWD && RICH) {
+                if (bw2) {
+                    // the second partner's sum, 16 values: halves across the wave's halves, channels e / e + 4 across rows, e / e + 2 inside
+                    // a row: a lane ends with two, [chunk 8][h 2][e 8] floats behind the first 1 KiB
+                    float r[8], q[4], res[2];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        v[(3 * e) >> 2][(3 * e) & 3] += s1[h][e];
-                        v[(3 * e + 1) >> 2][(3 * e + 1) & 3] += s2[h][e];
-                        if constexpr (BWD) v[(3 * e + 2) >> 2][(3 * e + 2) & 3] += s3[h][e];
+                        auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s3[0][e]), __float_as_uint(s3[1][e]), false, false);
+                        r[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
                     }
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) lds_write_f4_asm(ad + 16 * j, v[j]);
+                    for (int e = 0; e < 4; ++e) {
+                        auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[e]), __float_as_uint(r[e + 4]), false, false);
+                        q[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+                    }
+                    const bool up = (eln & 8) != 0;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float keep = up ? q[e + 2] : q[e], give = up ? q[e] : q[e + 2];
+                        res[e] = keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(give), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+                    }
+                    const unsigned ad = statw + 1024 + (eln & 7) * 64 + (eln >> 3) * 8;
+                    uint2 v;
+                    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(ad));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("" : "+v"(v));
+                    v.x = __float_as_uint(__uint_as_float(v.x) + res[0]), v.y = __float_as_uint(__uint_as_float(v.y) + res[1]);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(v) : "memory");
                 }
             }
         }
+        if (t == 0) GDL_STAMP(7);  // (behind its fold)
 #pragma unroll
         for (int n = 0; n < NI; ++n)
 #pragma unroll
@@ -580,7 +626,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_pslab_kernel(ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const float* sr = (const float*)(smem + tail + 4 * PS_STAGE);
-    auto fold4 = [&](int c, int w) { return ((sr[(0 * BN + c) * 3 + w] + sr[(1 * BN + c) * 3 + w]) + sr[(2 * BN + c) * 3 + w]) + sr[(3 * BN + c) * 3 + w]; };
+    // a wave's row (1 536 B): [chunk 8][k 2][h 2][e 8] floats of sums 0 / 1, then [chunk 8][h 2][e 8] of sum 2; channel c = h * 64 + chunk * 8 + e
+    auto fold4 = [&](int c, int w) {
+        const int ch = (c >> 3) & 7, h = c >> 6, e = c & 7;
+        const int o = w < 2 ? ch * 32 + w * 16 + h * 8 + e : 256 + ch * 16 + h * 8 + e;
+        return ((sr[o] + sr[384 + o]) + sr[768 + o]) + sr[1152 + o];
+    };
     if (fst) {
         if (a.sacc.acc) {
             if (ntiles > 0) bn_acc_add(a.sacc, n0 + (tid >> 1), tid & 1, fold4(tid >> 1, tid & 1));

@@ -21,7 +21,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="192,64,56,56,64,3,1,1")
     ap.add_argument("--op", default="fwd")
-    ap.add_argument("--names", default="entry,issued,landed,kloop_end,kloop_end2,end")
+    ap.add_argument("--names", default="entry,issued,landed,kloop_end,kloop_end2,end",
+                    help="conv3x3_pslab_kernel also leaves stamps 6 / 7 (behind the first tile's epilogue rounds / behind its fold): "
+                         "--names entry,issued,landed,kloop_end,kloop_end2,end,rounds,fold prints them relative to kloop_end2")
     ap.add_argument("--c64", action="store_true", help="the 64-channel persistent kernel's per-tile phases (use --names entry,loop,loop_end,end)")
     a = ap.parse_args()
     N, C, H, W, K, R, stride, pad = [int(v) for v in a.shape.split(",")]
@@ -82,13 +84,14 @@ def main():
     print(f"{a.op} {a.shape}: {e0.elapsed_time(e1) * 1e3:.1f} us, {len(d)} blocks stamped")
     # s_memtime counters are per XCD (block b runs on XCD b % 8) and not synchronised with each other: spans per XCD
     bid = np.nonzero(live)[0]
-    life = d[:, ns - 1] - d[:, 0]
+    last = 5 if ns == 8 else ns - 1
+    life = d[:, last] - d[:, 0]
     spans, resid = [], []
     for x in range(8):
         sel = (bid & 7) == x
         if not sel.any():
             continue
-        sp = d[sel, ns - 1].max() - d[sel, 0].min()
+        sp = d[sel, last].max() - d[sel, 0].min()
         spans.append(sp)
         resid.append(life[sel].sum() / sp)
     span = float(np.mean(spans))
@@ -97,10 +100,14 @@ def main():
           f"-> {span / wall_us / 1e3:.2f} ticks/ns; blocks resident per XCD: {np.mean(resid):.1f} (= {np.mean(resid) / 32:.2f} per CU)")
     t0 = d[:, 0].min()
     print(f"block life: mean {life.mean():.0f} p10 {np.percentile(life, 10):.0f} p90 {np.percentile(life, 90):.0f}")
-    for i in range(ns - 1):
+    for i in range(last):
         seg = d[:, i + 1] - d[:, i]
         print(f"  {names[i]:>10s} -> {names[i + 1]:<10s} mean {seg.mean():8.0f}  p10 {np.percentile(seg, 10):8.0f}  p90 "
               f"{np.percentile(seg, 90):8.0f}")
+    if ns == 8:  # (stamps 6 / 7 were taken between stamps 4 and 5)
+        for nm, i in (("kloop_end2 -> rounds done", 6), ("rounds done -> fold done", 7)):
+            seg = d[:, i] - d[:, 4 if i == 6 else 6]
+            print(f"  {nm:>28s} mean {seg.mean():8.0f}  p10 {np.percentile(seg, 10):8.0f}  p90 {np.percentile(seg, 90):8.0f}")
     seg = full[(1 << 15):][live]
     if a.c64:  # conv3x3_c64_kernel: per-tile phase times of wave 0
         nt = seg[:, 7].sum()
