@@ -463,21 +463,49 @@ __device__ __forceinline__ void conv_epilogue(f32x4_t (&acc)[BN / WN / 16][BM / 
     // per-channel sums of the block's rows -> one partial row [OC][2] per M-tile: lanes with equal (lane % CH) hold the same
     // channels: fold them, then fold the waves in fixed order (deterministic)
     auto tile_sums = [&](float (&s1)[EPC], float (&s2)[EPC], float* dst) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            for (int msk = CH; msk < 64; msk <<= 1) {
-                s1[e] += __shfl_xor(s1[e], msk);
-                s2[e] += __shfl_xor(s2[e], msk);
-            }
-        }
         float* red = (float*)(smem + (f32st ? BM * PITCH32 : SM::CS));  // [waves][BN][2]
-        if (CH >= 64 || lane < CH) {
-            // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
-            const int c = (lane % CH) * EPC;
+        if constexpr (CH == 8 && EPC == 8) {
+            // Round 6 (from conv_pslab.h; the 64-channel-wide bf16 tiles: every stride-2 / 1x1 launch): the eight row-lanes that hold
+            // the same channels reduce AND scatter -- the wave's halves split the two sums (v_permlane32_swap of the pair), the rows
+            // channels e / e + 4 (v_permlane16_swap), a row's halves e / e + 2 (select + DPP rotation): 30 VALU instructions for what
+            // took 48 ds_bpermute round trips per call; a lane ends with two values of the wave's row.
+            float r[8], q[4], res[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1[e]), __float_as_uint(s2[e]), false, false);
+                r[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[e]), __float_as_uint(r[e + 4]), false, false);
+                q[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+            }
+            const bool up = (lane & 8) != 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float keep = up ? q[e + 2] : q[e], give = up ? q[e] : q[e + 2];
+                res[e] = keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(give), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+            }
+            // sum k = lane bit 5, channel = 8 * (lane & 7) + 4 * bit 4 + 2 * bit 3 (+ 0 / 1)
+            const int c = (lane & 7) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2, k = (lane >> 5) & 1;
+            red[(wave * BN + c) * 2 + k] = res[0];
+            red[(wave * BN + c + 1) * 2 + k] = res[1];
+        } else {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
-                red[(wave * BN + c + e) * 2 + 0] = s1[e];
-                red[(wave * BN + c + e) * 2 + 1] = s2[e];
+                for (int msk = CH; msk < 64; msk <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], msk);
+                    s2[e] += __shfl_xor(s2[e], msk);
+                }
+            }
+            if (CH >= 64 || lane < CH) {
+                // when CH < 64 every wave covers all CH chunks; lane < CH holds chunk `lane`
+                const int c = (lane % CH) * EPC;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    red[(wave * BN + c + e) * 2 + 0] = s1[e];
+                    red[(wave * BN + c + e) * 2 + 1] = s2[e];
+                }
             }
         }
         __syncthreads();
@@ -1633,21 +1661,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
                 *(float4*)&rs[0] = cn[16 + ec * 2], *(float4*)&rs[4] = cn[16 + ec * 2 + 1];
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ssq[e] *= rs[e];
-                for (int msk = 8; msk < 64; msk <<= 1) {
-                    ssum[e] += __shfl_xor(ssum[e], msk);
-                    ssq[e] += __shfl_xor(ssq[e], msk);
-                }
-            }
-            if (lane < 8) {
-                float4* ar = (float4*)(smem + nbuf * slab_bytes + 1536) + (wave * 64 + lane * 8) / 2;  // [wave][64][2] floats
+            for (int e = 0; e < 8; ++e) ssq[e] *= rs[e];
+            // Round 6 (from conv_pslab.h): the eight row-lanes that hold the same channels reduce AND scatter -- the wave's halves
+            // split the two sums (v_permlane32_swap of the pair), the rows channels e / e + 4 (v_permlane16_swap), the row's halves
+            // e / e + 2 (select + DPP rotation) -- 30 VALU instructions; a lane ends with two values and adds them into its own 8
+            // bytes of the wave's row, [k 2][64 channels] floats.  (Before: 48 ds_bpermute round trips per 128 x 64 tile -- as long as
+            // the tile's 144 MFMAs -- and a 16-float read-modify-write by eight lanes.)
+            {
+                float r[8], q[4], res[2];
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    float4 t = ar[e2];
-                    t.x += ssum[2 * e2], t.y += ssq[2 * e2], t.z += ssum[2 * e2 + 1], t.w += ssq[2 * e2 + 1];
-                    ar[e2] = t;
+                for (int e = 0; e < 8; ++e) {
+                    auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(ssum[e]), __float_as_uint(ssq[e]), false, false);
+                    r[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[e]), __float_as_uint(r[e + 4]), false, false);
+                    q[e] = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+                }
+                const bool up = (lane & 8) != 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float keep = up ? q[e + 2] : q[e], give = up ? q[e] : q[e + 2];
+                    res[e] = keep + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(give), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+                }
+                // k = lane bit 5, channel = 8 * (lane & 7) + 4 * bit 4 + 2 * bit 3 (+ 0 / 1)
+                const unsigned ad = smem_base + nbuf * slab_bytes + 1536 + wave * 512 +
+                                    (((lane >> 5) & 1) * 64 + (lane & 7) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2) * 4;
+                uint2 v;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(ad));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("" : "+v"(v));
+                v.x = __float_as_uint(__uint_as_float(v.x) + res[0]), v.y = __float_as_uint(__uint_as_float(v.y) + res[1]);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(ad), "v"(v) : "memory");
             }
         }
         // the four stores back to back (a load between two stores would wait for the first)
@@ -1683,9 +1729,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(ConvArgs a) {
 #endif
     if constexpr (BW) {
         __syncthreads();
-        if (tid < 128) {  // the four waves' rows in fixed order
-            const float* ar = (const float*)(smem + nbuf * slab_bytes + 1536);
-            st_agent(a.bw_partial + (size_t)blockIdx.x * 128 + tid, ((ar[tid] + ar[128 + tid]) + ar[256 + tid]) + ar[384 + tid]);
+        if (tid < 128) {  // the four waves' rows ([k][64] floats each) in fixed order -> the partial row's [64][2]
+            const float* ar = (const float*)(smem + nbuf * slab_bytes + 1536) + (tid & 1) * 64 + (tid >> 1);
+            st_agent(a.bw_partial + (size_t)blockIdx.x * 128 + tid, ((ar[0] + ar[128]) + ar[256]) + ar[384]);
         }
     }
     if (MODE == MODE_FWD && (a.stats || a.sacc.acc)) {
