@@ -190,6 +190,16 @@ __device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
 
+// compile-time loop: f(std::integral_constant<int, Q>{}) for Q in [Q0, QEND) -- instruction offsets, register-array indices and the
+// slots of a hand-interleaved MFMA / LDS / DMA stream need constants
+template <int Q, int QEND, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (Q < QEND) {
+        f(std::integral_constant<int, Q>{});
+        static_for<Q + 1, QEND>(f);
+    }
+}
+
 template <int BM, int BN, typename T>
 struct ConvSmem {
     static constexpr int STAGE = (BM + BN) * 128;
@@ -2082,7 +2092,7 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     if (!nslab) return p;
     // (the 128-row tile of the audio layer 2 -- 396 blocks, two per CU -- had two slab buffers in 80 KiB; with this kernel's staging
     // and sums rows there is room for one: 23 vs 24 us alone, tools/bench_conv.py -- it keeps the round-5 kernel)
-    if (nslab == 1 && !p.single && IC > 64) return p;
+    if (nslab == 1 && !p.single && IC > 64 && pslab_mode() < 3) return p;  // (GDL_PSLAB=3, tuning aid: the persistent kernel there too -- a tie in the step)
     p.pslab = 1, p.nwv8 = 0, p.single = nslab == 1, p.lds = pslab_lds_bytes(p.bm, W, nslab), p.grid = pslab_grid(items);
     return p;
 }

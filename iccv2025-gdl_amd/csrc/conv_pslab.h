@@ -53,13 +53,6 @@ static int pslab_grid(int items) {
     return 8 * (per <= cap / 8 ? per : cap / 8);
 }
 
-template <int Q, int QEND, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (Q < QEND) {
-        f(std::integral_constant<int, Q>{});
-        static_for<Q + 1, QEND>(f);
-    }
-}
 // all-reduce over the eight lanes that hold the same channels in the epilogue's row pass (lane ^ 8, ^ 16, ^ 32), in that order,
 // without the LDS crossbar: a DPP row rotation and the two cross-row swaps of gfx950 (3 + 3 + 2 VALU instructions; the
 // __shfl_xor form -- three ds_bpermute round trips per value, 96 per tile -- cost the forward's epilogue 5 100 of its 11 000 clk)
