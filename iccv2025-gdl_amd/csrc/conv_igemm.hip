@@ -2063,8 +2063,9 @@ no_c64:
 }
 
 // Round 6: the 128-channel-wide slab tiles of 128 / 192 rows (four waves, bf16) run on the persistent pipelined kernel
-// (conv_pslab.h) when its LDS fits: two slab buffers where one block per CU is all the launch can fill anyway (<= 256 items:
-// 160 KiB to itself) or where two still fit into 80 KiB each, else one.
+// (conv_pslab.h) when its LDS fits: two slab buffers where they fit into 80 KiB (two blocks per CU) -- 96 KiB for a launch that
+// cannot fill two blocks per CU anyway (<= 256 items) --, else one.  (A launch of <= 256 blocks could take 160 KiB for itself; in
+// the step the LDS it leaves to the CU's other kernels is worth more than the slab reloads it saves: profiles/r06_ab_pslab.txt.)
 static int pslab_mode() {
     static int v = -1;
     if (v < 0) {
@@ -2083,7 +2084,14 @@ static ConvPlan plan_conv(int dtype, int M, int OC, int IC, int W, int R, int S,
     if (p.nwv8 && pslab_mode() < 2) return p;
     const int items = ceil_div(M, p.bm) * (OC / 128);
     if ((p.bm + 2 * W + 2 + 7) / 8 > 4 * PS_SLAB_PIECES) return p;  // a slab buffer of at most 32 KiB
-    const size_t budget = items <= 256 ? (size_t)160 * 1024 : (size_t)80 * 1024;
+    static int big_kb = -1;
+    if (big_kb < 0) {
+        // tuning aid: LDS budget (KiB) of a launch that cannot fill two blocks per CU anyway -- with 160 it takes two slab buffers
+        // (~100 KiB) and leaves the CU's other kernels 60 KiB; 80 = one slab buffer there too
+        const char* e = tune_env("GDL_PSLAB_LDS");
+        big_kb = e ? atoi(e) : 96;  // (step: 160 -> 4.98 ms, 80 -> 4.94, 96 -- two buffers for the 128-row tile of the audio layer 4 only -> 4.92; three A/B rounds)
+    }
+    const size_t budget = items <= 256 ? (size_t)big_kb * 1024 : (size_t)80 * 1024;
     int nslab = 0;
     if (IC > 64 && pslab_lds_bytes(p.bm, W, 2) <= budget)
         nslab = 2;
