@@ -432,9 +432,12 @@ def test_swin_dgl_step_config5_size_vs_f64_arbiter():
         torch.cuda.empty_cache()
     # (the arbiter's step costs ~3 min of host time at this size: it runs the FIRST step; the second step's bf16 results are held
     # against the float32 engine's, which the first step ties to the arbiter -- measured in round 5 with the arbiter on both steps:
-    # f32 logits 3.0e-6 / 1.6e-4, worst gradient tensor 1.8e-3 / 1.2e-2; bf16 1.7e-2 / 3.1e-2, 0.115 / 0.061)
+    # f32 logits 3.0e-6 / 1.6e-4, worst gradient tensor 1.8e-3 / 1.2e-2; bf16 1.7e-2 / 3.1e-2, 0.115 / 0.061;
+    # GDL_TEST_ARBITER_STEP2=1 reproduces that: the loop below then judges both steps, the second with doubled bounds)
     arb = TorchSwinStep(ref_state[0], ref_state[1], fx.SWIN_T, chunk_samples=4)
     want = [arb.train_step(host[0][0].numpy(), host[0][1].numpy(), host[0][2].numpy(), wl["alpha"], 2e-3)]
+    if os.environ.get("GDL_TEST_ARBITER_STEP2") == "1":  # opt-in (3 more minutes of host time): the second step against the arbiter too
+        want.append(arb.train_step(host[1][0].numpy(), host[1][1].numpy(), host[1][2].numpy(), wl["alpha"], 2e-3))
     a, b = res["f32"][1], res["bf16"][1]
     for k in ("out", "out_a", "out_v"):
         np.testing.assert_allclose(b[k], a[k], rtol=0, atol=6e-2 * max(1.0, float(np.abs(a[k]).max())), err_msg=f"step 1 {k}")
