@@ -13,16 +13,21 @@
 //    between them;  [B] wait + ONE barrier (every wave holds step k's fragments in registers: ring slot k % 2 is free; every
 //    wave's pieces of weight tile k + 1 have landed);  [C] MFMAs on F1, with the DMA pieces of weight tile k + 2 -> slot k % 2
 //    and the reads of (k + 1, channels 0-31) -> F0 slipped between them.  Every LDS read has >= 200 clk of MFMAs to land behind,
-//    a DMA piece a whole K-step; the order is pinned with sched_barriers.
+//    a DMA piece a whole K-step; the order is pinned with sched_barriers; there is no run-time branch inside an MFMA stream
+//    (tools/micro/kstep.hip: ~20 clk each there).  With two slab buffers (template parameter TWO) the next chunk's slab arrives
+//    ONE piece per step; with one, its request follows the MFMAs of the chunk's last step and is waited for at once.
 //  * Persistent: <= 512 blocks walk the (M-tile, N-tile) items in XCD-linear order; the weight stream simply continues across
 //    a block's tiles (the N-tile of a block is constant), the next tile's first slab chunk and tap masks are requested in
 //    the last step of the current one and land behind its epilogue.
 //  * Epilogue without block barriers and without touching the slab / ring: a wave stages 16 pixels x 64 channels at a time
-//    through its OWN 2.25 KiB of LDS (accumulator layout -> rows), 2 * MI rounds; the data gradient's partner vectors
-//    (ReLU bits, addend, one or two BatchNorm partners) are requested one round ahead, round 0's before the last MFMAs.
-//  * Statistics (forward: sum / sum of squares; data gradient: the BatchNorm-backward sums of ops.h BwdStats) are folded per
-//    tile into the wave's LDS row and leave the block ONCE, as one partial row per block (conv_tiles_m / conv_dgrad_tiles_m
-//    report the grid) or as one set of integer atomics (bnacc.h).  Every sum has a fixed order: run-to-run bit-identical.
+//    through its OWN 2.25 KiB of LDS (accumulator layout -> rows), 2 * MI rounds; the data gradient's partner vectors are
+//    requested behind the tile's last MFMAs -- all rounds' for the common launch (ReLU bits + one BatchNorm partner), two rounds
+//    ahead for the launches with an addend / second partner (template parameter RICH).
+//  * Statistics (forward: sum / sum of squares; data gradient: the BatchNorm-backward sums of ops.h BwdStats) are reduced AND
+//    scattered across the eight lanes that hold the same channels (v_permlane32/16_swap of value pairs + a DPP rotation), added
+//    per tile into the wave's LDS row -- every lane its own 16 bytes -- and leave the block ONCE, as one partial row per block
+//    (conv_tiles_m / conv_dgrad_tiles_m report the grid) or as one set of integer atomics (bnacc.h).  Every sum has a fixed
+//    order: run-to-run bit-identical.
 // LDS: [weight ring 2 x 16 KiB][slab x 1 or 2][1 KiB of zeros unless the slab has spare rows][staging 4 x 2 304 B][sums 6 KiB]
 // = 80 128 B for the 28-pixel-wide visual layer 2 with one slab buffer: two blocks per CU.
 #pragma once
@@ -53,16 +58,6 @@ static int pslab_grid(int items) {
     return 8 * (per <= cap / 8 ? per : cap / 8);
 }
 
-// all-reduce over the eight lanes that hold the same channels in the epilogue's row pass (lane ^ 8, ^ 16, ^ 32), in that order,
-// without the LDS crossbar: a DPP row rotation and the two cross-row swaps of gfx950 (3 + 3 + 2 VALU instructions; the
-// __shfl_xor form -- three ds_bpermute round trips per value, 96 per tile -- cost the forward's epilogue 5 100 of its 11 000 clk)
-__device__ __forceinline__ float ps_fold8(float v) {
-    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-    auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
-    auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(c[0]) + __uint_as_float(c[1]);
-}
 template <int OFF>
 __device__ __forceinline__ void lds_write8_asm_off(unsigned addr, const uint2& v) {
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");

@@ -502,8 +502,14 @@ static W9Plan plan_w9(int M, int C, int K) {
     // then runs on three quarters of the CUs: 94 instead of 84 us per launch in the step, 53 instead of 39 us alone.)
     static int min_st = -1;
     if (min_st < 0) {
+        // Round 6, re-swept after the chains' kernels got shorter (conv_pslab.h; same box, ms per step, three rounds each):
+        // 36 -> 4.96, 48 -> 4.96, 52 -> 4.88, 56 -> 4.88, 60 -> 4.88, 64 -> 4.92, 72 -> 4.91, 90 -> 4.97.  56: the visual layers run
+        // 168-192 blocks of 56 stages (two thirds of the CUs; the chains get the rest), 0.45 GB less of partials written and read
+        // back per step -- the kernel's HBM traffic falls from 1.53x to 1.35x of its algorithmic bytes -- and a launch takes 92
+        // instead of 81 us in the step (53 instead of 40 alone): the PER-LAUNCH roofline fraction bench.py reports for this kernel
+        // goes DOWN (0.146 -> 0.129) while the step gets faster.  The step is what is optimised.
         const char* e = tune_env("GDL_WGRAD9_MINST");  // tuning aid
-        min_st = e ? atoi(e) : 36;
+        min_st = e ? atoi(e) : 56;
     }
     int ns = (target + tiles - 1) / tiles;
     const int max_ns = (M + min_st * W9_BP - 1) / (min_st * W9_BP);
