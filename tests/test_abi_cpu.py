@@ -60,6 +60,27 @@ def test_host_queries_need_no_gpu():
     assert lib.gdl_bn_bwd_blocks(1 << 20, 64) <= 2048 and lib.gdl_bn_bwd_blocks(1024, 64) >= 1
 
 
+def test_slab_planner_at_the_benchmark_shapes():
+    """Which kernel the >= 128-channel 3x3 stride-1 layers of the B = 64 CREMA-D step run on, read off
+    the BatchNorm partial-row counts the C ABI reports -- forward and data gradient must agree (the engine sizes one buffer for
+    both): the persistent slab kernel writes one row per BLOCK (its grid: at most 512, eight equal XCD shares), the round-5 kernel
+    one per M-tile.  f32 (the exact-parity mode) never uses the persistent kernel.  No GPU needed: the planner is host code."""
+    lib = L.load()
+    bf16, f32 = L.dtype_code("bf16"), L.dtype_code("f32")
+    want = {  # (images, channels, H, W): rows
+        (192, 128, 28, 28): 512,  # visual layer 2: 784 tiles of 192 rows on 512 persistent blocks
+        (192, 256, 14, 14): 392,  # visual layer 3: 196 M-tiles x 2 N-tiles, one tile per block
+        (192, 512, 7, 7): 200,    # visual layer 4: 49 x 4 = 196 items -> 8 x 25 blocks
+        (64, 128, 33, 24): 396,   # audio layer 2: the round-5 kernel (128-row tiles, two slab buffers): its M-tiles
+        (64, 256, 17, 12): 136,   # audio layer 3: 68 x 2
+        (64, 512, 9, 6): 112,     # audio layer 4: 128-row tiles, 27 x 4 = 108 items -> 8 x 14 blocks
+    }
+    for (N, C, H, W), rows in want.items():
+        assert lib.gdl_conv_bn_tiles(bf16, N, H, W, C, C, 3, 3, 1, 1) == rows, (N, C, H, W)
+        assert lib.gdl_conv_dgrad_bn_tiles(bf16, N, H, W, C, C, 3, 3, 1, 1) == rows, (N, C, H, W)
+        assert lib.gdl_conv_bn_tiles(f32, N, H, W, C, C, 3, 3, 1, 1) == -(-N * H * W // 128), (N, C, H, W)
+
+
 def test_engine_plans_without_gpu_and_reports_errors():
     lib = L.load()
     h = ctypes.c_void_p()
