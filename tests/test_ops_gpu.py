@@ -45,6 +45,8 @@ CONV_SHAPES = [
     (1, 128, 17, 12, 256, 1, 2, 0),   # flat kernel: one M-tile, four N-tiles
     (64, 128, 28, 28, 128, 3, 1, 1),  # slab kernel, several tiles per persistent block (round 6), 262 tiles
     (20, 256, 14, 14, 256, 3, 1, 1),  # the same with two N-tiles per M-tile and three channel chunks' slab reloads
+    (7, 256, 13, 11, 256, 3, 1, 1),   # odd height and width, M = 1001 (ragged last tile), two N-tiles
+    (5, 128, 31, 29, 128, 3, 1, 1),   # odd dims at the widest slab of the 192-row tile that still fits 32 KiB (W = 29: 252 rows)
 ]
 
 
@@ -724,6 +726,7 @@ BW_SHAPES = [
     (64, 128, 28, 28, 128, 3, 1, 1, "bits", True),    # persistent slab kernel (round 6), 192-row tiles: 262 tiles, one N-tile
     (40, 256, 14, 14, 256, 3, 1, 1, "bits", False),   # the same with two N-tiles (a block keeps its channels) and four chunks
     (30, 128, 33, 24, 128, 3, 1, 1, None, False),     # its 128-row tiles, ragged last tile, no ReLU mask
+    (7, 256, 13, 11, 256, 3, 1, 1, "bits", True),      # odd dims, ragged last tile, two partners (the RICH instantiation)
     (2, 64, 9, 6, 128, 1, 2, 0, None, False),         # 1x1 stride 2
 ]
 _check_shape_list("BW_SHAPES", BW_SHAPES)
