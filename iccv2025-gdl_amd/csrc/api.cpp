@@ -409,16 +409,16 @@ int gdl_swin_ln_fwd(int dtype, const void* x, const float* gamma, const float* b
 size_t gdl_swin_partial_bytes(int ld) { return swin_partial_bytes(ld); }
 int gdl_swin_ln_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
                     float* dgamma_dbeta, void* partial, size_t M, int C, int ld, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx && dgamma_dbeta, "swin_ln_bwd: bad arguments");
+    GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx, "swin_ln_bwd: bad arguments");
     return swin_ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma_dbeta, (float*)partial, M, C, ld, (hipStream_t)stream);
 }
 int gdl_swin_ln_bwd_colsum(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, const void* add,
                            void* dx, float* dgamma_dbeta_colsum, void* partial, size_t M, int C, int ld, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx && dgamma_dbeta_colsum, "swin_ln_bwd_colsum: bad arguments");
+    GDL_REQUIRE(dt_ok(dtype) && dy && x && stats && gamma && dx, "swin_ln_bwd_colsum: bad arguments");
     return swin_ln_bwd(dtype, dy, x, stats, gamma, add, dx, dgamma_dbeta_colsum, (float*)partial, M, C, ld, (hipStream_t)stream, true);
 }
 int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream) {
-    GDL_REQUIRE(dt_ok(dtype) && g && db, "swin_colsum: bad arguments");
+    GDL_REQUIRE(dt_ok(dtype) && g, "swin_colsum: bad arguments");
     return swin_colsum(dtype, g, u, db, (float*)partial, M, ld, (hipStream_t)stream);
 }
 int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out, int n_img, int H, int W, int window, int shift,
@@ -453,6 +453,17 @@ int gdl_swin_pack_matrix(int dtype, const float* src, void* dst, void* dstT, int
                          int kseg_pad, void* stream) {
     GDL_REQUIRE(dt_ok(dtype) && src && dst, "swin_pack_matrix: bad arguments");
     return swin_pack_matrix(dtype, src, dst, dstT, n, k, nseg, nseg_pad, kseg, kseg_pad, (hipStream_t)stream);
+}
+int gdl_swin_ln_bwd_rows(int dtype, size_t M, int ld) {
+    if (!dt_ok(dtype) || ld <= 0 || ld % 64 != 0 || M == 0) return 0;  // (a count, not a status: 0 = bad arguments)
+    return swin_ln_bwd_rows(dtype, M, ld);
+}
+int gdl_swin_colsum_rows(int dtype, size_t M, int ld) {
+    if (!dt_ok(dtype) || ld <= 0 || ld % 64 != 0 || M == 0) return 0;
+    return swin_colsum_rows(dtype, M, ld);
+}
+int gdl_swin_partial_reduce_batched(const void* descs, int n_desc, int total_blocks, void* stream) {
+    return swin_partial_reduce_batched(descs, n_desc, total_blocks, (hipStream_t)stream);
 }
 int gdl_swin_pack_batched(const void* descs, int n_desc, int total_blocks, int dir, void* stream) {
     return swin_pack_batched(descs, n_desc, total_blocks, dir, (hipStream_t)stream);

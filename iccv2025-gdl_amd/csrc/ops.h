@@ -211,6 +211,9 @@ size_t swin_partial_bytes(int ld);
 int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
                 float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st, bool colsum = false);
 int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st);
+int swin_ln_bwd_rows(int dt, size_t M, int ld);
+int swin_colsum_rows(int dt, size_t M, int ld);
+int swin_partial_reduce_batched(const void* descs, int nd, int total_blocks, hipStream_t st);
 int swin_attn_fwd(int dt, const void* qkv, const float* table, void* out, int n_img, int H, int W, int ws, int shift, int nh, int ld,
                   hipStream_t st);
 size_t swin_attn_bwd_ws_bytes(int n_img, int nwin, int ws, int nh);

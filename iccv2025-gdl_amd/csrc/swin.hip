@@ -438,6 +438,53 @@ __global__ __launch_bounds__(256) void swin_partial_reduce_kernel(const float* _
     }
 }
 
+// Round 6: every fold of a backward in ONE launch.  The LayerNorm backwards and column-sum passes of a Swin backward (42 for
+// Swin-T) each left `nblk` partial rows and were followed by a fold launch of their own on the branch's only chain -- but their
+// results are parameter gradients nobody reads before the optimizer.  With a partial buffer per call site the folds wait until the
+// end of the backward: a descriptor per job, block b serves the job whose [blk0, next blk0) holds b (16 columns per block as
+// above), the arithmetic -- and therefore every bit of the result -- is swin_partial_reduce_kernel's.
+struct SwinRedDesc {
+    const float* partial;
+    float* out;
+    int nblk, width, blk0, stride;  // stride: floats between partial rows (>= width)
+};
+static_assert(sizeof(SwinRedDesc) == 32, "SwinRedDesc layout (mirrored by gdl/swin.py)");
+__global__ __launch_bounds__(256) void swin_partial_reduce_batched_kernel(const SwinRedDesc* __restrict__ descs, int nd) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {  // last descriptor with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk0 <= (int)blockIdx.x)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const SwinRedDesc d = descs[lo];
+    const float* __restrict__ partial = d.partial;
+    const int nblk = d.nblk, width = d.width, stride = d.stride;
+    const int j = ((int)blockIdx.x - d.blk0) * 16 + (threadIdx.x & 15), k = threadIdx.x >> 4;
+    __shared__ float red[16][17];
+    float s = 0.f;
+    if (j < width) {
+        constexpr int UN = 8;
+        for (int b0 = k; b0 < nblk; b0 += 16 * UN) {
+            float q[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) q[u] = b0 + 16 * u < nblk ? partial[(size_t)(b0 + 16 * u) * stride + j] : 0.f;
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (b0 + 16 * u < nblk) s += q[u];
+        }
+    }
+    red[k][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (k == 0 && j < width) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[q][threadIdx.x];
+        d.out[j] = t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ column sums (+ GELU')
 // GELU = 1: g <- g * gelu'(u) in place first.  partial[blk][c] = sum over the block's rows, fixed order.  A thread owns one
 // 16-byte column vector of one of the block's `rpb` = 256 / (vectors per row) concurrent rows (a 128-channel bf16 row is
@@ -1146,19 +1193,26 @@ static int partial_reduce(const float* partial, float* out, int nblk, int width,
     return GDL_OK;
 }
 
-// dgamma_dbeta: [2][ld] (padded layout); colsum: [3][ld], row 2 = column sums of dx as stored
+// partial rows (= blocks) a LayerNorm backward over M rows of width ld leaves
+int swin_ln_bwd_rows(int dt, size_t M, int ld) {
+    const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr, vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
+    const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
+    const size_t gg = (M + (size_t)4 * rpw * uu - 1) / ((size_t)4 * rpw * uu);
+    const size_t cap = tune_env("GDL_SW_PBLOCKS") ? (size_t)sw_pblocks() : 512;
+    return (int)(gg > cap ? cap : gg);
+}
+
+// dgamma_dbeta: [2][ld] (padded layout); colsum: [3][ld], row 2 = column sums of dx as stored.  dgamma_dbeta == nullptr: the
+// partial rows (swin_ln_bwd_rows of them, 2 or 3 * ld wide) stay in `partial` for swin_partial_reduce_batched
 int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const float* gamma, const void* add, void* dx,
                 float* dgamma_dbeta, float* partial, size_t M, int C, int ld, hipStream_t st, bool colsum) {
     GDL_REQUIRE(ld % 64 == 0 && ld <= 64 * SW_MAXV && C <= ld && partial, "swin_ln_bwd: width %d / %d", C, ld);
     const int lpr = ln_lpr(dt, ld), rpw = 64 / lpr, vpl = (ld / (dt == GDL_F32 ? 4 : 8) + lpr - 1) / lpr;
-    const int uu = vpl == 1 ? 4 : (vpl == 2 ? 2 : 1);
-    const size_t gg = (M + (size_t)4 * rpw * uu - 1) / ((size_t)4 * rpw * uu);
     // large launches: the pipelined form (next iteration's rows requested before this one's arithmetic; ~250 registers: two blocks
     // per CU, 512 blocks); the 9 408-row shapes of stage 4 lose with it and keep the plain form (tools/bench_swin_ln.py:
     // stage 3 44.6 -> 40.0 us, first merge 124 -> 111, stage 4 27.6 -> 30.0)
     const bool pipe = M >= 30000;
-    const size_t cap = tune_env("GDL_SW_PBLOCKS") ? (size_t)sw_pblocks() : 512;
-    const int g = (int)(gg > cap ? cap : gg);
+    const int g = swin_ln_bwd_rows(dt, M, ld);
     const int nr = colsum ? 3 : 2;
     const size_t lds = (size_t)4 * rpw * nr * ld * sizeof(float);
     GDL_REQUIRE(lds <= 64 * 1024, "swin_ln_bwd: width %d needs %zu bytes of LDS", ld, lds);
@@ -1195,15 +1249,21 @@ int swin_ln_bwd(int dt, const void* dy, const void* x, const float* stats, const
 #undef SW_LN_BWD1
         GDL_CHECK_LAUNCH("swin_ln_bwd_kernel");
     }
+    if (!dgamma_dbeta) return GDL_OK;
     return partial_reduce(partial, dgamma_dbeta, g, nr * ld, st);
 }
 
-// db[ld] = column sums of g; gelu != 0: g <- g * gelu'(u) first
-int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st) {
-    GDL_REQUIRE(ld % 64 == 0 && partial, "swin_colsum: bad arguments");
+int swin_colsum_rows(int dt, size_t M, int ld) {
     const int vpr = ld / (dt == GDL_F32 ? 4 : 8), rpb = vpr <= 256 ? 256 / vpr : 1;
     const size_t passes = (M + rpb - 1) / rpb;
-    int nb = (int)(passes < (size_t)sw_pblocks() ? passes : (size_t)sw_pblocks());
+    return (int)(passes < (size_t)sw_pblocks() ? passes : (size_t)sw_pblocks());
+}
+
+// db[ld] = column sums of g; gelu != 0: g <- g * gelu'(u) first.  db == nullptr: the partial rows (swin_colsum_rows of them, ld
+// wide) stay in `partial` for swin_partial_reduce_batched
+int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_t M, int ld, hipStream_t st) {
+    GDL_REQUIRE(ld % 64 == 0 && partial, "swin_colsum: bad arguments");
+    const int nb = swin_colsum_rows(dt, M, ld);
     {
         ProfScope prof("gdl::swin_colsum_kernel", PROF_HBM, st, (double)M * ld * (dt == GDL_F32 ? 4 : 2) * (u ? 3 : 1));
         if (dt == GDL_F32) {
@@ -1219,7 +1279,15 @@ int swin_colsum(int dt, void* g, const void* u, float* db, float* partial, size_
         }
         GDL_CHECK_LAUNCH("swin_colsum_kernel");
     }
+    if (!db) return GDL_OK;
     return partial_reduce(partial, db, nb, ld, st);
+}
+
+int swin_partial_reduce_batched(const void* descs, int nd, int total_blocks, hipStream_t st) {
+    GDL_REQUIRE(descs && nd > 0 && total_blocks > 0, "swin_partial_reduce_batched: bad arguments");
+    hipLaunchKernelGGL(swin_partial_reduce_batched_kernel, dim3(total_blocks), dim3(256), 0, st, (const SwinRedDesc*)descs, nd);
+    GDL_CHECK_LAUNCH("swin_partial_reduce_batched_kernel");
+    return GDL_OK;
 }
 
 static int attn_geom(SwinAttnGeom* g, int H, int W, int ws, int shift, int nh, int ld) {

@@ -56,6 +56,9 @@ SIGNATURES = {
     "gdl_swin_ln_bwd": ("i", "ipppppppp" + "zii" + "p"),
     "gdl_swin_ln_bwd_colsum": ("i", "ipppppppp" + "zii" + "p"),
     "gdl_swin_colsum": ("i", "ipppp" + "zi" + "p"),
+    "gdl_swin_ln_bwd_rows": ("i", "izi"),
+    "gdl_swin_colsum_rows": ("i", "izi"),
+    "gdl_swin_partial_reduce_batched": ("i", "pii" + "p"),
     "gdl_swin_attn_fwd": ("i", "ippp" + "iiiiiii" + "p"),
     "gdl_swin_attn_bwd_workspace_bytes": ("z", "iiiii"),
     "gdl_swin_attn_bwd": ("i", "ipppppp" + "iiiiiii" + "p"),

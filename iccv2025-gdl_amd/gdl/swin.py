@@ -28,6 +28,13 @@ class _PackDesc(ctypes.Structure):  # csrc/swin.hip::SwinPackDesc
 assert ctypes.sizeof(_PackDesc) == 64
 
 
+class _RedDesc(ctypes.Structure):  # csrc/swin.hip::SwinRedDesc
+    _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in ("rows", "width", "blk0", "stride")]
+
+
+assert ctypes.sizeof(_RedDesc) == 32
+
+
 def _ld(c):
     return (c + 63) // 64 * 64
 
@@ -97,10 +104,10 @@ class _Linear:
             L.call("gdl_linear_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(self.wT), L.ptr(dx), L.ptr(self.dw), L.ptr(self.db) if db_in else None,
                    L.ptr(ws), ws.numel(), M, self.kp, self.k, self.np, st)
             if bias and not db_in:
-                L.call("gdl_swin_colsum", e.dt, L.ptr(dy), None, L.ptr(self.db), L.ptr(e.partial), M, self.np, st)
+                e.colsum(dy, None, self, M, self.np, st)
         else:
             if bias:
-                L.call("gdl_swin_colsum", e.dt, L.ptr(dy), None, L.ptr(self.db), L.ptr(e.partial), M, self.np, st)
+                e.colsum(dy, None, self, M, self.np, st)
             self.wgrad(dy, x, M, st)
             self.dgrad(dy, dx, M, st)
 
@@ -119,6 +126,7 @@ class _Norm:
         self.g = torch.zeros(self.ld, dtype=torch.float32, device=dev)
         self.b = torch.zeros(self.ld, dtype=torch.float32, device=dev)
         self.dgb = torch.empty((3, self.ld), dtype=torch.float32, device=dev)  # d gamma, d beta, (bwd(colsum=True)) column sums of dx
+        self.partial = None  # (deferred folds: allocated by the first backward)
 
     def pack_descs(self, params):
         return [(params[src], dst, None, self.c, 1, self.c, self.ld, 1, 1, L.GDL_F32) for src, dst in ((self.w_idx, self.g), (self.b_idx, self.b))]
@@ -132,8 +140,22 @@ class _Norm:
     def bwd(self, dy, x, stats, add, dx, M, st, colsum=False):
         """colsum: dgb[2] = column sums of dx -- the bias gradient of the Linear whose output gradient dx is"""
         e = self.eng
-        L.call("gdl_swin_ln_bwd_colsum" if colsum else "gdl_swin_ln_bwd", e.dt, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(self.g),
-               L.ptr(add) if add is not None else None, L.ptr(dx), L.ptr(self.dgb), L.ptr(e.partial), M, self.c, self.ld, st)
+        name = "gdl_swin_ln_bwd_colsum" if colsum else "gdl_swin_ln_bwd"
+        if not e.defer_folds:
+            L.call(name, e.dt, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(self.g), L.ptr(add) if add is not None else None, L.ptr(dx),
+                   L.ptr(self.dgb), L.ptr(e.partial), M, self.c, self.ld, st)
+            return
+        # the partial rows stay in a buffer of this LayerNorm's own; SwinEngine._fold_all folds every call's rows in one launch
+        if self.partial is None:
+            self.rows, self.M = e.lib.gdl_swin_ln_bwd_rows(e.dt, M, self.ld), M
+            if self.rows <= 0:
+                raise L.GdlError("gdl_swin_ln_bwd_rows: bad arguments")
+            self.partial = torch.empty(self.rows * 3 * self.ld, dtype=torch.float32, device=e.device)
+        assert M == self.M
+        L.call(name, e.dt, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(self.g), L.ptr(add) if add is not None else None, L.ptr(dx), None,
+               L.ptr(self.partial), M, self.c, self.ld, st)
+        nr = 3 if colsum else 2
+        e.defer_fold(self.partial, self.dgb, self.rows, nr * self.ld, nr * self.ld)
 
 
 class SwinEngine:
@@ -228,6 +250,12 @@ class SwinEngine:
         self.names = names
         # scratch: LayerNorm / column-sum partials, attention table partials, gradient buffers
         self.partial = torch.empty(self.lib.gdl_swin_partial_bytes(maxld), dtype=torch.uint8, device=dev)
+        # Round 6: the folds of the LayerNorm backwards' and column-sum passes' partial rows (42 launches per Swin-T backward, each
+        # on the branch's only chain, each producing a parameter gradient nobody reads before the optimizer) wait until the end of
+        # the backward and run as ONE launch (gdl_swin_partial_reduce_batched; a partial buffer per call site instead of the shared
+        # one; bit-identical results).  GDL_SWIN_DEFER_FOLDS=0 (tuning aid): a fold launch behind every pass, as before.
+        self.defer_folds = not (os.environ.get("GDL_TUNING") == "1" and os.environ.get("GDL_SWIN_DEFER_FOLDS") == "0")
+        self._fold_jobs, self._fold_key, self._fold_tabs = None, None, {}
         self.tpart = torch.empty(max(maxw, 4), dtype=torch.uint8, device=dev)
         M1, ld1 = self.stages[0]["M"], self.stages[0]["ld"]
         wide = max(max(3 * s["ld"], _ld(s["hid"])) * s["M"] for s in self.stages)
@@ -363,6 +391,57 @@ class SwinEngine:
             cache[part] = self._desc_table(recs, True)
         t, n, blk = cache[part]
         L.call("gdl_swin_pack_batched", L.ptr(t), n, blk, 1, st)
+
+    # ------------------------------------------------------------------ deferred folds of partial rows
+    def colsum(self, g, u, lin, M, ld, st):
+        """lin.db = column sums of g [M][ld] (u given: g <- g * gelu'(u) first)"""
+        if not self.defer_folds:
+            L.call("gdl_swin_colsum", self.dt, L.ptr(g), L.ptr(u) if u is not None else None, L.ptr(lin.db), L.ptr(self.partial), M, ld, st)
+            return
+        if getattr(lin, "cs_partial", None) is None:
+            lin.cs_rows, lin.cs_M = self.lib.gdl_swin_colsum_rows(self.dt, M, ld), M
+            if lin.cs_rows <= 0:
+                raise L.GdlError("gdl_swin_colsum_rows: bad arguments")
+            lin.cs_partial = torch.empty(lin.cs_rows * ld, dtype=torch.float32, device=self.device)
+        assert M == lin.cs_M
+        L.call("gdl_swin_colsum", self.dt, L.ptr(g), L.ptr(u) if u is not None else None, None, L.ptr(lin.cs_partial), M, ld, st)
+        self.defer_fold(lin.cs_partial, lin.db, lin.cs_rows, ld, ld)
+
+    def _fold_begin(self, key):
+        """start of a backward body: its fold jobs are collected once per (phase, DropPath) and kept as a device table"""
+        self._fold_key = key
+        self._fold_jobs = None if key in self._fold_tabs else []
+
+    def defer_fold(self, partial, out, rows, width, stride):
+        if self._fold_jobs is None:  # this body's table exists already (the launch sequence of a body is fixed)
+            return
+        o0, o1 = out.data_ptr(), out.data_ptr() + 4 * width
+        for j in self._fold_jobs:  # a later pass that writes into an earlier job's result takes those columns over (DropPath: the
+            j0, j1 = j[1], j[1] + 4 * j[3]  # column sums of the scaled branch gradient replace the LayerNorm backward's third row)
+            if o0 < j1 and o1 > j0:
+                if not (o0 > j0 and o1 == j1):
+                    raise L.GdlError("SwinEngine: overlapping fold results that are not a replaced last row")
+                j[3] = (o0 - j0) // 4
+        self._fold_jobs.append([partial.data_ptr(), out.data_ptr(), rows, width, stride])
+
+    def _fold_all(self, st):
+        """one launch: every deferred fold of this backward body (before its gradients are unpacked)"""
+        if not self.defer_folds:
+            return
+        tab = self._fold_tabs.get(self._fold_key)
+        if tab is None:
+            jobs = self._fold_jobs
+            arr = (_RedDesc * len(jobs))()
+            blk = 0
+            for d, (partial, out, rows, width, stride) in zip(arr, jobs):
+                d.partial, d.out, d.rows, d.width, d.blk0, d.stride = partial, out, rows, width, blk, stride
+                blk += (width + 15) // 16
+            host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+            tab = self._fold_tabs[self._fold_key] = (host.to(self.device), len(jobs), blk)
+            self._fold_jobs = None
+        t, n, blk = tab
+        if n:
+            L.call("gdl_swin_partial_reduce_batched", L.ptr(t), n, blk, st)
 
     def _linears_norms(self, part=None):
         """part None: every Linear / LayerNorm; "last": the last stage's blocks and the final norm (the parameters whose
@@ -538,6 +617,7 @@ class SwinEngine:
         nst = len(self.stages)
         M, ld = last["M"], last["ld"]
         ga, gb = self._v(self.g_a, M, ld), self._v(self.g_b, M, ld)
+        self._fold_begin((phase, bool(drop), bool(pooled)))
         if phase != 2:
             L.call("gdl_swin_token_mean_bwd", dt, L.ptr(dfeat), L.ptr(ga), self.B if pooled else N,
                    self.L_out * (self.T if pooled else 1), self.C_out, ld, st)
@@ -588,14 +668,14 @@ class SwinEngine:
                     g2 = gtok
                     self._drop_path(dx, None, b["k"], 1, g2, M, ld, st)
                 if b["cs_dx"] is None or drop:
-                    L.call("gdl_swin_colsum", dt, L.ptr(g2), None, L.ptr(b["fc2"].db), L.ptr(self.partial), M, ld, st)
+                    self.colsum(g2, None, b["fc2"], M, ld, st)
                 wg(b["fc2"], g2, b["a"], M, "fc2")
                 need("qkv")  # (the previous block's: it reads g_w)
                 if fuse:  # d u = (dx . W2) * gelu'(u) and fc1's bias gradient in the GEMM's epilogue
                     b["fc2"].dgrad_gelu(g2, gw, b["u"], self.fc1_acc[b["fc1_off"]:], self.fc1_scale, M, st)
                 else:
                     b["fc2"].dgrad(g2, gw, M, st)                                 # d a
-                    L.call("gdl_swin_colsum", dt, L.ptr(gw), L.ptr(b["u"]), L.ptr(b["fc1"].db), L.ptr(self.partial), M, hid_ld, st)  # d u
+                    self.colsum(gw, b["u"], b["fc1"], M, hid_ld, st)  # d u
                 b["fc1"].bwd_pair(gw, b["m"], gtok, M, st)                        # fc1's weight gradient and d m
                 need("proj")  # (the previous block's: it reads `spare`)
                 b["norm2"].bwd(gtok, b["x_mid"], b["stats2"], dx, spare, M, st, colsum=self.fuse_ln)   # spare = d x_mid
@@ -605,7 +685,7 @@ class SwinEngine:
                     g1 = self._v(self.g_w, M, ld)
                     self._drop_path(spare, None, b["k"], 0, g1, M, ld, st)
                 if not self.fuse_ln or drop:
-                    L.call("gdl_swin_colsum", dt, L.ptr(g1), None, L.ptr(b["proj"].db), L.ptr(self.partial), M, ld, st)
+                    self.colsum(g1, None, b["proj"], M, ld, st)
                 wg(b["proj"], g1, b["attn"], M, "proj")
                 b["proj"].dgrad(g1, gtok, M, st)                               # d attention output
                 gq = self._v(self.g_w, M, 3 * ld)
@@ -619,6 +699,7 @@ class SwinEngine:
         if fuse:
             L.call("gdl_acc_to_float", L.ptr(self.fc1_acc[acc_lo:]), acc_hi - acc_lo, 1.0 / self.fc1_scale, L.ptr(self.fc1_db[acc_lo:]), st)
         if phase == 1:
+            self._fold_all(st)
             self._unpack_all(grads, st, "last")  # the last stage's and the final norm's gradients -> the parameters' shapes
             return
         # patch embedding: x0 = norm(conv(x) + b); no input gradient
@@ -626,6 +707,7 @@ class SwinEngine:
         g0 = self._v(spare.reshape(-1), M0, self.pe.np)
         self.pe_norm.bwd(dx, self.pe_out, self.pe_stats, None, g0, M0, st, colsum=self.fuse_ln)
         if not self.fuse_ln:
-            L.call("gdl_swin_colsum", dt, L.ptr(g0), None, L.ptr(self.pe.db), L.ptr(self.partial), M0, self.pe.np, st)
+            self.colsum(g0, None, self.pe, M0, self.pe.np, st)
         self.pe.wgrad(g0, self.pe_rows, M0, st)
+        self._fold_all(st)
         self._unpack_all(grads, st, "rest" if phase == 2 else None)  # padded float32 gradients -> the parameters' shapes, one launch

@@ -534,6 +534,18 @@ GDL_API int gdl_swin_ln_bwd_colsum(int dtype, const void* dy, const void* x, con
                                    const void* add, void* dx, float* dgamma_dbeta_colsum, void* partial, size_t M, int C, int ld,
                                    void* stream);
 GDL_API int gdl_swin_colsum(int dtype, void* g, const void* u, float* db, void* partial, size_t M, int ld, void* stream);
+/* Deferred folds (round 6): gdl_swin_ln_bwd / _colsum with dgamma_dbeta == NULL and gdl_swin_colsum with db == NULL leave their
+ * partial rows in `partial` -- gdl_swin_ln_bwd_rows(dtype, M, ld) rows of 2 * ld (3 * ld: _colsum) floats, gdl_swin_colsum_rows
+ * (dtype, M, ld) rows of ld floats (both counts: 0 for bad arguments) -- and launch no fold; the caller gives every such call a `partial` buffer of its own and
+ * folds all of them with ONE launch before the gradients are read: `descs` = device array of n_desc 32-byte records
+ *   { const float* partial; float* out; int rows, width, blk0, stride; }
+ * (out[j] = sum over the rows of partial[row * stride + j], j < width <= stride, in the order the per-call fold uses: bit-identical results;
+ * blk0 = first block of the record, (width + 15) / 16 blocks per record, ascending; total_blocks = their sum).  The parameter
+ * gradients of the reference's LayerNorms / Linear biases (swin_transformer.py:26-42,:78-157,:176-295) are only read by the
+ * optimizer: 42 fold launches leave the Swin-T backward's chain. */
+GDL_API int gdl_swin_ln_bwd_rows(int dtype, size_t M, int ld);
+GDL_API int gdl_swin_colsum_rows(int dtype, size_t M, int ld);
+GDL_API int gdl_swin_partial_reduce_batched(const void* descs, int n_desc, int total_blocks, void* stream);
 GDL_API int gdl_swin_attn_fwd(int dtype, const void* qkv, const float* table, void* out, int n_img, int H, int W, int window,
                               int shift, int heads, int ld, void* stream);
 GDL_API size_t gdl_swin_attn_bwd_workspace_bytes(int n_img, int H, int W, int window, int heads);

@@ -98,6 +98,63 @@ def test_layernorm_fwd_bwd(dt, M, C, ld):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_deferred_folds_bit_identical(dt):
+    """Round 6: LayerNorm backwards / column-sum passes that leave their partial rows (result pointer NULL) + ONE
+    gdl_swin_partial_reduce_batched over all of them == the per-call folds, bit for bit -- including a job whose third row is
+    taken over by a later column-sum job (DropPath: width 2 * ld at a row pitch of 3 * ld) and row counts on both sides of the
+    512-block cap."""
+    import ctypes
+
+    class Red(ctypes.Structure):
+        _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in ("rows", "width", "blk0", "stride")]
+
+    lib, dc, st = L.load(), L.dtype_code(dt), L.cur_stream()
+    jobs, want, got = [], [], []
+    for M, C, ld, colsum, takeover in ((3000, 96, 128, True, False), (40000, 192, 192, True, True), (777, 384, 384, False, False)):
+        x = _dev(_q(rng.standard_normal((M, ld)), dt), dt)
+        x[:, C:] = 0
+        dy = _dev(_q(rng.standard_normal((M, ld)), dt), dt)
+        dy[:, C:] = 0
+        g = torch.zeros(ld, device=DEV)
+        g[:C] = 1.0
+        b = torch.zeros(ld, device=DEV)
+        y, stats = torch.empty_like(x), torch.empty((M, 2), device=DEV)
+        L.call("gdl_swin_ln_fwd", dc, L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(y), L.ptr(stats), M, C, ld, st)
+        nr = 3 if colsum else 2
+        name = "gdl_swin_ln_bwd_colsum" if colsum else "gdl_swin_ln_bwd"
+        dx, ref = torch.empty_like(x), torch.empty((nr, ld), device=DEV)
+        part = torch.empty(lib.gdl_swin_partial_bytes(2 * ld), dtype=torch.uint8, device=DEV)
+        L.call(name, dc, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(g), None, L.ptr(dx), L.ptr(ref), L.ptr(part), M, C, ld, st)
+        rows = lib.gdl_swin_ln_bwd_rows(dc, M, ld)
+        assert 0 < rows <= 512
+        own = torch.full((rows * nr * ld,), float("nan"), device=DEV)
+        dx2, out = torch.empty_like(x), torch.full((nr, ld), float("nan"), device=DEV)
+        L.call(name, dc, L.ptr(dy), L.ptr(x), L.ptr(stats), L.ptr(g), None, L.ptr(dx2), None, L.ptr(own), M, C, ld, st)
+        assert torch.equal(dx2, dx)
+        jobs.append((own, out, rows, (2 if takeover else nr) * ld, nr * ld))
+        if takeover:  # the column sums of another tensor replace the third row
+            gq = _dev(_q(rng.standard_normal((M, ld)), dt), dt)
+            L.call("gdl_swin_colsum", dc, L.ptr(gq), None, L.ptr(ref[2]), L.ptr(part), M, ld, st)
+            crow = lib.gdl_swin_colsum_rows(dc, M, ld)
+            assert 0 < crow <= 512
+            cown = torch.full((crow * ld,), float("nan"), device=DEV)
+            L.call("gdl_swin_colsum", dc, L.ptr(gq), None, None, L.ptr(cown), M, ld, st)
+            jobs.append((cown, out[2], crow, ld, ld))
+        want.append(ref)
+        got.append(out)
+    arr, blk = (Red * len(jobs))(), 0
+    for d, (partial, out, rows, width, stride) in zip(arr, jobs):
+        d.partial, d.out, d.rows, d.width, d.blk0, d.stride = partial.data_ptr(), out.data_ptr(), rows, width, blk, stride
+        blk += (width + 15) // 16
+    tab = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(DEV)
+    L.call("gdl_swin_partial_reduce_batched", L.ptr(tab), len(jobs), blk, st)
+    torch.cuda.synchronize()
+    for w, o in zip(want, got):
+        assert torch.equal(w, o)
+    assert lib.gdl_swin_ln_bwd_rows(dc, 100, 100) == 0 and lib.gdl_swin_colsum_rows(99, 100, 128) == 0
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,ld", [(50, 128), (3000, 384), (700, 3072)])
 def test_bias_act_and_colsum(dt, M, ld):
     dc = L.dtype_code(dt)

@@ -18,6 +18,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 template <int OFF>
 __device__ __forceinline__ uint4 rd(unsigned addr) {
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(256, 2) void k(const unsigned char* src, unsigned b
         else
             wf[q - 3] = rd<2048 * (q - 3)>(a0 + 8192);
     };
+    u32x4_t stg[4];
+    for (int i = 0; i < 4; ++i) stg[i] = u32x4_t{0u, 0u, 0u, 0u};
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int voff = ((blockIdx.x * 4 + wave) * 4096 + lane * 16) & (bytes - 1);
@@ -101,6 +104,11 @@ __global__ __launch_bounds__(256, 2) void k(const unsigned char* src, unsigned b
             mm(wf1[q / 3], px1[q % 3], acc[q]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (q < 4) {
+                if (MODE & 64) {
+                    // register-staged copy of the same KiB: the piece requested a step ago goes to LDS, the next one is requested
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(base + 32768u + (wave * 4 + q) * 1024 + lane * 16), "v"(stg[q]) : "memory");
+                    stg[q] = __builtin_amdgcn_raw_buffer_load_b128(r, voff, q * 1024, 0);
+                }
                 if (MODE & 4)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + 32768 + (wave * 4 + q) * 1024),
                                                              16, voff, q * 1024, 0, 0);
@@ -159,6 +167,8 @@ int main() {
         run<1 + 2 + 4 + 32>(src, bytes, out, sink, blocks, "+ reads + barrier + DMA, each behind a uniform branch (+ 8 taken)");
         run<2 + 4>(src, bytes, out, sink, blocks, "MFMAs + barrier + 4 LDS-DMA pieces (no reads)");
         run<4>(src, bytes, out, sink, blocks, "MFMAs + 4 LDS-DMA pieces");
+        run<64>(src, bytes, out, sink, blocks, "MFMAs + 4 register-staged KiB (buffer_load_dwordx4 + ds_write_b128)");
+        run<1 + 2 + 64>(src, bytes, out, sink, blocks, "+ reads + barrier + 4 register-staged KiB");
     }
     return 0;
 }
