@@ -76,9 +76,11 @@ def main():
         k_us = us.get("gdl::conv_wgrad9_kernel", float("nan"))
         f_us = us.get("gdl::wgrad9_reduce_kernel", float("nan"))
         tiles = (K // 64) * (C // 64)
-        # csrc/conv_wgrad9.hip plan_w9 restated (256 blocks aimed at, at least 36 stages per slice); the workspace query above is
-        # the larger of this and the per-tap kernel's need
-        ns = max(1, min((256 + tiles - 1) // tiles, (M + 36 * 64 - 1) // (36 * 64)))
+        # csrc/conv_wgrad9.hip plan_w9 restated (256 blocks aimed at, at least MIN_ST stages per slice: 56 since round 6; the
+        # GDL_WGRAD9_MINST tuning knob is honoured like the library honours it); the workspace query above is the larger of this
+        # and the per-tap kernel's need
+        min_st = int(os.environ.get("GDL_WGRAD9_MINST", "56")) if os.environ.get("GDL_TUNING") == "1" else 56
+        ns = max(1, min((256 + tiles - 1) // tiles, (M + min_st * 64 - 1) // (min_st * 64)))
         chunk = ((M + ns - 1) // ns + 63) // 64 * 64
         slices = (M + chunk - 1) // chunk
         stages = (M + 63) // 64
