@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256, 2) void k(const unsigned char* src, unsigned b
     };
     u32x4_t stg[4];
     for (int i = 0; i < 4; ++i) stg[i] = u32x4_t{0u, 0u, 0u, 0u};
+    int sacc[4] = {fa, fb, steps, 1};
+    int vacc[4] = {lane, tid, fg, frow};
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int voff = ((blockIdx.x * 4 + wave) * 4096 + lane * 16) & (bytes - 1);
@@ -81,6 +83,16 @@ __global__ __launch_bounds__(256, 2) void k(const unsigned char* src, unsigned b
         static_for<0, 24>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             mm(wf0[q / 3], px0[q % 3], acc[q]);
+            if (MODE & 128) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_add_u32 %0, %0, %1" : "+s"(sacc[q & 3]) : "s"(steps));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE & 256) {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("v_add_u32 %0, %0, %1" : "+v"(vacc[q & 3]) : "v"(lane));
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (q < 11) {
                 if ((MODE & 1) && !(MODE & 8)) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -103,6 +115,8 @@ __global__ __launch_bounds__(256, 2) void k(const unsigned char* src, unsigned b
             constexpr int q = decltype(qc)::value;
             mm(wf1[q / 3], px1[q % 3], acc[q]);
             __builtin_amdgcn_sched_barrier(0);
+            if (MODE & 128) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sacc[q & 3]) : "s"(steps));
+            if (MODE & 256) asm volatile("v_add_u32 %0, %0, %1" : "+v"(vacc[q & 3]) : "v"(lane));
             if constexpr (q < 4) {
                 if (MODE & 64) {
                     // register-staged copy of the same KiB: the piece requested a step ago goes to LDS, the next one is requested
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void k(const unsigned char* src, unsigned b
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 24; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    if (sum == 12345.f) sink[0] = sum;
+    if (sum == 12345.f) sink[0] = sum + (float)(sacc[0] + sacc[1] + sacc[2] + sacc[3]) + (float)(vacc[0] + vacc[1] + vacc[2] + vacc[3]);
     if (lane == 0) out[blockIdx.x * 4 + wave] = t1 - t0;
 }
 
@@ -167,6 +181,10 @@ int main() {
         run<1 + 2 + 4 + 32>(src, bytes, out, sink, blocks, "+ reads + barrier + DMA, each behind a uniform branch (+ 8 taken)");
         run<2 + 4>(src, bytes, out, sink, blocks, "MFMAs + barrier + 4 LDS-DMA pieces (no reads)");
         run<4>(src, bytes, out, sink, blocks, "MFMAs + 4 LDS-DMA pieces");
+        run<128>(src, bytes, out, sink, blocks, "MFMAs + 48 scalar adds, one behind every MFMA");
+        run<256>(src, bytes, out, sink, blocks, "MFMAs + 48 vector adds, one behind every MFMA");
+        run<1 + 2 + 4 + 128>(src, bytes, out, sink, blocks, "+ reads + barrier + DMA + 48 scalar adds");
+        run<1 + 2 + 4 + 256>(src, bytes, out, sink, blocks, "+ reads + barrier + DMA + 48 vector adds");
         run<64>(src, bytes, out, sink, blocks, "MFMAs + 4 register-staged KiB (buffer_load_dwordx4 + ds_write_b128)");
         run<1 + 2 + 64>(src, bytes, out, sink, blocks, "+ reads + barrier + 4 register-staged KiB");
     }
